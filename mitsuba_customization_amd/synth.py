@@ -1,0 +1,156 @@
+"""Synthetic MERL-layout tables and MERL ``.binary`` file helpers (numpy, host side).
+
+No real MERL file ships with the reference (SURVEY.md §8c "MERL data"), so tests and the bench
+run on seeded synthetic tables written in the real layout: planar R,G,B, and
+inside a plane ``ind = i_pd + n_pd*(i_td + n_td*i_th)``.  Values here are RAW file values,
+i.e. before the 1/1500, 1.15/1500, 1.66/1500 channel scales are applied.
+
+Everything is pure integer hashing / closed-form arithmetic (no numpy RNG streams), so a table
+is a function of (kind, seed, dims) on every host.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+MERL_DIMS = (90, 90, 180)
+MERL_N = 90 * 90 * 180
+MERL_SCALE = (1.0 / 1500.0, 1.15 / 1500.0, 1.66 / 1500.0)
+MERL_FILE_BYTES = 12 + 3 * MERL_N * 8  # 34,992,012
+
+
+def _mix64(z: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on uint64 arrays (wrapping arithmetic)."""
+    z = z.astype(np.uint64, copy=True)
+    with np.errstate(over="ignore"):
+        z += np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def _grid(dims):
+    n_th, n_td, n_pd = dims
+    ith = np.arange(n_th, dtype=np.float64)[:, None, None]
+    itd = np.arange(n_td, dtype=np.float64)[None, :, None]
+    ipd = np.arange(n_pd, dtype=np.float64)[None, None, :]
+    return ith, itd, ipd
+
+
+def constant_table(value=(300.0, 200.0, 100.0), dims=MERL_DIMS) -> np.ndarray:
+    t = np.empty((3,) + tuple(dims), dtype=np.float64)
+    for c in range(3):
+        t[c] = value[c]
+    return t
+
+
+def affine_table(coef=None, dims=MERL_DIMS) -> np.ndarray:
+    """raw[c] = a0 + a1*i_th + a2*i_td + a3*i_pd — trilinear interpolation reproduces it exactly
+    away from the clamped ends and the periodic phi_d seam."""
+    if coef is None:
+        coef = ((50.0, 3.0, 0.5, 0.25), (20.0, 1.0, 2.0, 0.125), (10.0, 0.25, 0.75, 1.5))
+    ith, itd, ipd = _grid(dims)
+    t = np.empty((3,) + tuple(dims), dtype=np.float64)
+    for c in range(3):
+        a0, a1, a2, a3 = coef[c]
+        t[c] = a0 + a1 * ith + a2 * itd + a3 * ipd
+    return t
+
+
+def onehot_table(index=(10, 20, 30), value=1500.0, dims=MERL_DIMS) -> np.ndarray:
+    t = np.zeros((3,) + tuple(dims), dtype=np.float64)
+    t[:, index[0], index[1], index[2]] = value
+    return t
+
+
+def noise_table(seed: int, dims=MERL_DIMS, decades: float = 6.0, negative_fraction: float = 0.02) -> np.ndarray:
+    """Log-uniform hash noise spanning `decades` decades with a sprinkle of negative
+    (below-horizon style) markers; texel-to-texel contrast is O(1) — the worst case for parity."""
+    n = int(np.prod(dims))
+    idx = np.arange(3 * n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        r = _mix64(idx ^ (np.uint64(seed) * np.uint64(0xD1B54A32D192ED03)))
+    u = (r >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    val = 1500.0 * 10.0 ** (-decades / 2 + decades * u) * 1e-2
+    r2 = _mix64(r)
+    neg = (r2 >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53)) < negative_fraction
+    val = np.where(neg, -1.0, val)
+    return val.reshape((3,) + tuple(dims))
+
+
+def ggx_tab_table(seed: int = 0, dims=MERL_DIMS) -> np.ndarray:
+    """Analytic GGX + Lambert BRDF tabulated on the MERL grid ('gold-paint-like'): values span
+    ~6 decades like measured data; alpha and albedo derive from the seed.  Texel (i,j,k) is the
+    BRDF at theta_h=(i/n_th)^2*pi/2, theta_d=j/n_td*pi/2, phi_d=k/n_pd*pi, phi_h=0.
+    Below-horizon directions get MERL's negative marker."""
+    n_th, n_td, n_pd = dims
+    h = _mix64(np.array([seed * 3 + 1, seed * 3 + 2, seed * 3 + 3], dtype=np.uint64))
+    uu = (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    alpha = 0.03 + 0.25 * uu[0]
+    kd = np.array([0.05 + 0.5 * uu[1], 0.04 + 0.3 * uu[2], 0.02 + 0.2 * uu[0]])
+    f0 = np.array([0.9 - 0.3 * uu[2], 0.6 + 0.2 * uu[1], 0.2 + 0.3 * uu[0]])
+    ith, itd, ipd = _grid(dims)
+    th = (ith / n_th) ** 2 * (np.pi / 2)
+    td = itd / n_td * (np.pi / 2)
+    pd = ipd / n_pd * np.pi
+    # in = R_z(phi_h=0) R_y(theta_h) (sin td cos pd, sin td sin pd, cos td); out = reflect about h
+    dx, dy, dz = np.sin(td) * np.cos(pd), np.sin(td) * np.sin(pd), np.cos(td) + 0 * pd
+    ct, st = np.cos(th), np.sin(th)
+    inx, iny, inz = dx * ct + dz * st, dy + 0 * th, -dx * st + dz * ct
+    hx, hz = st, ct
+    dot = inx * hx + inz * hz
+    outz = 2 * dot * hz - inz
+    valid = (inz > 1e-6) & (outz > 1e-6)
+    ci, co = np.maximum(inz, 1e-6), np.maximum(outz, 1e-6)
+    tan2h = (st / np.maximum(ct, 1e-9)) ** 2
+    D = 1.0 / (np.pi * alpha**2 * np.maximum(ct, 1e-9) ** 4 * (1 + tan2h / alpha**2) ** 2)
+
+    def g1(c):
+        t2 = (1 - c * c) / (c * c)
+        return 2.0 / (1.0 + np.sqrt(1.0 + alpha**2 * t2))
+
+    G = g1(ci) * g1(co)
+    spec = D * G / (4 * ci * co)
+    t = np.empty((3,) + tuple(dims), dtype=np.float64)
+    cd = np.cos(td) + 0 * pd + 0 * th
+    for c in range(3):
+        F = f0[c] + (1 - f0[c]) * (1 - cd) ** 5
+        f = kd[c] / np.pi + F * spec
+        t[c] = np.where(valid, f / MERL_SCALE[c], -1.0)
+    return t
+
+
+def make_table(kind: str, seed: int = 0, dims=MERL_DIMS) -> np.ndarray:
+    if kind == "constant":
+        return constant_table(dims=dims)
+    if kind == "affine":
+        return affine_table(dims=dims)
+    if kind == "onehot":
+        return onehot_table(dims=dims)
+    if kind == "noise":
+        return noise_table(seed, dims=dims)
+    if kind == "ggx_tab":
+        return ggx_tab_table(seed, dims=dims)
+    raise ValueError(f"unknown table kind {kind!r}")
+
+
+# ---- MERL .binary file -------------------------------------------------------
+def write_merl_binary(path: str, planar: np.ndarray) -> None:
+    planar = np.ascontiguousarray(planar, dtype="<f8")
+    assert planar.ndim == 4 and planar.shape[0] == 3
+    with open(path, "wb") as f:
+        np.asarray(planar.shape[1:], dtype="<i4").tofile(f)
+        planar.tofile(f)
+
+
+def read_merl_binary(path: str, require_merl_dims: bool = True) -> np.ndarray:
+    with open(path, "rb") as f:
+        dims = np.fromfile(f, dtype="<i4", count=3)
+        if dims.size != 3 or (dims <= 0).any():
+            raise ValueError("bad MERL header")
+        n = int(dims[0]) * int(dims[1]) * int(dims[2])
+        if require_merl_dims and n != MERL_N:
+            raise ValueError(f"dims {tuple(dims)} do not match the MERL grid")
+        data = np.fromfile(f, dtype="<f8", count=3 * n)
+        if data.size != 3 * n:
+            raise ValueError("truncated MERL file")
+    return data.reshape((3,) + tuple(int(d) for d in dims))

@@ -1,0 +1,241 @@
+"""ctypes binding of the CPU oracle (oracle/libmerl_oracle.so).
+
+TEST INFRASTRUCTURE: import this only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg (see merl_oracle.h).  PARITY UNPINNED — the reference ships no source.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmerl_oracle.so")
+
+LOOKUP_NEAREST, LOOKUP_TRILINEAR = 0, 1
+NODE_INTEGER, NODE_CENTER = 0, 1
+DISK_MITSUBA06, DISK_MITSUBA3 = 0, 1
+
+
+class Opts(C.Structure):
+    _fields_ = [("lookup", C.c_int), ("node", C.c_int), ("disk_map", C.c_int)]
+
+
+class Table(C.Structure):
+    _fields_ = [("n_th", C.c_int), ("n_td", C.c_int), ("n_pd", C.c_int),
+                ("data", C.POINTER(C.c_double)), ("scale", C.c_double * 3)]
+
+
+class Ggx(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("eta", C.c_double * 3), ("k", C.c_double * 3)]
+
+
+class Bsdf(C.Structure):
+    _fields_ = [("vtbl", C.c_void_p), ("table", Table), ("ggx", Ggx), ("opts", Opts)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "merl_oracle.c")
+    hdr = os.path.join(_HERE, "merl_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.orc_read_table.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int)]
+        L.orc_write_table.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_half_diff.argtypes = [C.POINTER(C.c_double)] * 2 + [C.POINTER(C.c_double)] * 4
+        for nm in ("orc_theta_half_index", "orc_theta_diff_index", "orc_phi_diff_index"):
+            getattr(L, nm).argtypes = [C.POINTER(Table), C.c_double]
+            getattr(L, nm).restype = C.c_int
+        L.orc_coords.argtypes = [C.POINTER(Table)] + [C.c_double] * 3 + [C.POINTER(C.c_double)] * 3
+        L.orc_lookup.argtypes = [C.POINTER(Table), C.POINTER(Opts)] + [C.c_double] * 3 + [C.POINTER(C.c_double)]
+        L.orc_eval_batch.argtypes = [C.POINTER(Table), C.POINTER(Opts), fp, fp, C.c_size_t, fp]
+        L.orc_pdf_batch.argtypes = [fp, fp, C.c_size_t, fp]
+        L.orc_sample_batch.argtypes = [C.POINTER(Table), C.POINTER(Opts), fp, fp, C.c_size_t, fp, fp, fp]
+        L.orc_eval_sample_batch_multi.argtypes = [C.POINTER(Table), C.c_int, C.POINTER(Opts), fp, fp, fp,
+                                                  C.POINTER(C.c_int32), C.c_size_t, fp, fp, fp, fp, fp]
+        L.orc_square_to_cosine_hemisphere.argtypes = [C.c_int, fp, fp]
+        L.orc_ggx_eval_batch.argtypes = [C.POINTER(Ggx), fp, fp, C.c_size_t, fp]
+        L.orc_ggx_pdf_batch.argtypes = [C.POINTER(Ggx), fp, fp, C.c_size_t, fp]
+        L.orc_ggx_sample_batch.argtypes = [C.POINTER(Ggx), fp, fp, C.c_size_t, fp, fp, fp]
+        L.orc_generate_pairs.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, fp, fp, fp]
+        L.orc_generate_materials.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, C.POINTER(C.c_int32)]
+        L.orc_bsdf_init_merl.argtypes = [C.POINTER(Bsdf), C.POINTER(C.c_double), C.POINTER(Opts)]
+        L.orc_bsdf_init_ggx.argtypes = [C.POINTER(Bsdf), C.POINTER(Ggx)]
+        for nm in ("orc_bench_eval_sample", "orc_bench_eval"):
+            getattr(L, nm).argtypes = [C.POINTER(Bsdf), C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+            getattr(L, nm).restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def make_opts(lookup=LOOKUP_TRILINEAR, node=NODE_INTEGER, disk_map=DISK_MITSUBA06) -> Opts:
+    return Opts(lookup, node, disk_map)
+
+
+class OracleTable:
+    """A planar f64 table (3, n_th, n_td, n_pd) + channel scales, as the oracle sees it."""
+
+    def __init__(self, planar: np.ndarray, scale=None):
+        self.planar = np.ascontiguousarray(planar, dtype=np.float64)
+        assert self.planar.ndim == 4 and self.planar.shape[0] == 3
+        if scale is None:
+            scale = (1.0 / 1500.0, 1.15 / 1500.0, 1.66 / 1500.0)
+        self.c = Table(self.planar.shape[1], self.planar.shape[2], self.planar.shape[3],
+                       _dp(self.planar), (C.c_double * 3)(*scale))
+
+    def eval(self, wi, wo, opts=None):
+        opts = opts or make_opts()
+        wi, pwi = _f32(wi); wo, pwo = _f32(wo)
+        n = wi.shape[0]
+        out = np.empty((n, 3), np.float32)
+        lib().orc_eval_batch(C.byref(self.c), C.byref(opts), pwi, pwo, n, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def sample(self, wi, u, opts=None):
+        opts = opts or make_opts()
+        wi, pwi = _f32(wi); u, pu = _f32(u)
+        n = wi.shape[0]
+        wo = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32); w = np.empty((n, 3), np.float32)
+        fp = C.POINTER(C.c_float)
+        lib().orc_sample_batch(C.byref(self.c), C.byref(opts), pwi, pu, n,
+                               wo.ctypes.data_as(fp), pdf.ctypes.data_as(fp), w.ctypes.data_as(fp))
+        return wo, pdf, w
+
+    def lookup(self, th, td, pd, opts=None):
+        opts = opts or make_opts()
+        out = (C.c_double * 3)()
+        lib().orc_lookup(C.byref(self.c), C.byref(opts), th, td, pd, out)
+        return np.array(out[:])
+
+    def coords(self, th, td, pd):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        lib().orc_coords(C.byref(self.c), th, td, pd, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+
+def pdf(wi, wo):
+    wi, pwi = _f32(wi); wo, pwo = _f32(wo)
+    out = np.empty(wi.shape[0], np.float32)
+    lib().orc_pdf_batch(pwi, pwo, wi.shape[0], out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def eval_sample_multi(tables, wi, wo, u, mat, opts=None):
+    """tables: list[OracleTable]; returns rgb, pdf, wo2, pdf2, weight."""
+    opts = opts or make_opts()
+    arr = (Table * len(tables))(*[t.c for t in tables])
+    wi, pwi = _f32(wi); wo, pwo = _f32(wo); u, pu = _f32(u)
+    n = wi.shape[0]
+    pm = None
+    if mat is not None:
+        mat = np.ascontiguousarray(mat, dtype=np.int32)
+        pm = mat.ctypes.data_as(C.POINTER(C.c_int32))
+    fp = C.POINTER(C.c_float)
+    rgb = np.empty((n, 3), np.float32); p = np.empty(n, np.float32)
+    wo2 = np.empty((n, 3), np.float32); p2 = np.empty(n, np.float32); w = np.empty((n, 3), np.float32)
+    lib().orc_eval_sample_batch_multi(arr, len(tables), C.byref(opts), pwi, pwo, pu, pm, n,
+                                      rgb.ctypes.data_as(fp), p.ctypes.data_as(fp), wo2.ctypes.data_as(fp),
+                                      p2.ctypes.data_as(fp), w.ctypes.data_as(fp))
+    return rgb, p, wo2, p2, w
+
+
+def half_diff(in_vec, out_vec):
+    a = np.ascontiguousarray(in_vec, np.float64); b = np.ascontiguousarray(out_vec, np.float64)
+    r = [C.c_double() for _ in range(4)]
+    lib().orc_half_diff(_dp(a), _dp(b), *[C.byref(x) for x in r])
+    return tuple(x.value for x in r)  # theta_half, phi_half, theta_diff, phi_diff
+
+
+def square_to_cosine_hemisphere(u, disk_map=DISK_MITSUBA06):
+    u = np.ascontiguousarray(u, np.float32).reshape(-1, 2)
+    out = np.empty((u.shape[0], 3), np.float32)
+    fp = C.POINTER(C.c_float)
+    for i in range(u.shape[0]):
+        lib().orc_square_to_cosine_hemisphere(disk_map, u[i].ctypes.data_as(fp), out[i].ctypes.data_as(fp))
+    return out
+
+
+class OracleGgx:
+    def __init__(self, alpha, eta, k):
+        self.c = Ggx(alpha, (C.c_double * 3)(*eta), (C.c_double * 3)(*k))
+
+    def eval(self, wi, wo):
+        wi, pwi = _f32(wi); wo, pwo = _f32(wo)
+        out = np.empty((wi.shape[0], 3), np.float32)
+        lib().orc_ggx_eval_batch(C.byref(self.c), pwi, pwo, wi.shape[0], out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def pdf(self, wi, wo):
+        wi, pwi = _f32(wi); wo, pwo = _f32(wo)
+        out = np.empty(wi.shape[0], np.float32)
+        lib().orc_ggx_pdf_batch(C.byref(self.c), pwi, pwo, wi.shape[0], out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def sample(self, wi, u):
+        wi, pwi = _f32(wi); u, pu = _f32(u)
+        n = wi.shape[0]
+        fp = C.POINTER(C.c_float)
+        wo = np.empty((n, 3), np.float32); pdf_ = np.empty(n, np.float32); w = np.empty((n, 3), np.float32)
+        lib().orc_ggx_sample_batch(C.byref(self.c), pwi, pu, n, wo.ctypes.data_as(fp), pdf_.ctypes.data_as(fp), w.ctypes.data_as(fp))
+        return wo, pdf_, w
+
+
+def generate_pairs(seed, first, n):
+    fp = C.POINTER(C.c_float)
+    wi = np.empty((n, 3), np.float32); wo = np.empty((n, 3), np.float32); u = np.empty((n, 2), np.float32)
+    lib().orc_generate_pairs(seed, first, n, wi.ctypes.data_as(fp), wo.ctypes.data_as(fp), u.ctypes.data_as(fp))
+    return wi, wo, u
+
+
+def generate_materials(seed, first, n, n_materials):
+    mat = np.empty(n, np.int32)
+    lib().orc_generate_materials(seed, first, n, n_materials, mat.ctypes.data_as(C.POINTER(C.c_int32)))
+    return mat
+
+
+def bench_merl(planar, n, n_threads, seed=0x5EED, with_sample=True, opts=None):
+    """Times n units through the Mitsuba-0.6-style virtual bsdf; returns (seconds, checksum)."""
+    opts = opts or make_opts()
+    planar = np.ascontiguousarray(planar, np.float64)
+    b = Bsdf()
+    lib().orc_bsdf_init_merl(C.byref(b), _dp(planar), C.byref(opts))
+    chk = C.c_double()
+    fn = lib().orc_bench_eval_sample if with_sample else lib().orc_bench_eval
+    s = fn(C.byref(b), seed, 0, n, n_threads, C.byref(chk))
+    return s, chk.value
+
+
+def bench_ggx(alpha, eta, k, n, n_threads, seed=0x5EED, with_sample=True):
+    g = Ggx(alpha, (C.c_double * 3)(*eta), (C.c_double * 3)(*k))
+    b = Bsdf()
+    lib().orc_bsdf_init_ggx(C.byref(b), C.byref(g))
+    chk = C.c_double()
+    fn = lib().orc_bench_eval_sample if with_sample else lib().orc_bench_eval
+    s = fn(C.byref(b), seed, 0, n, n_threads, C.byref(chk))
+    return s, chk.value

@@ -1,0 +1,136 @@
+/*
+ * merl_oracle.h — CPU oracle for the MERL / customized_measurement BSDF hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only
+ * as the checker / the timed CPU baseline.  The product (libmerl_hip.so) never links it.
+ *
+ * PARITY UNPINNED.  /root/reference holds no source for this path (README.md:1 names the
+ * plugins; mitsuba/ and mitsuba3/ are empty gitlinks), and ships no golden
+ * vectors.  This file is therefore a plain-C, double-precision restatement of the PUBLIC
+ * algorithm the README names — the MERL distribution's BRDFRead lookup (Matusik et al. 2003)
+ * under upstream Mitsuba 0.6 / Mitsuba 3 BSDF conventions — as specified in SURVEY.md
+ * Appendix A (A.1 file format, A.2 half/diff transform, A.3 index maps, A.4 lookup,
+ * A.5 Mitsuba conventions, A.6 GGX rough conductor).  It is pinned by analytic known-answer
+ * tests and an independent numpy restatement (tests/), not by the reference.
+ */
+#ifndef MERL_ORACLE_H
+#define MERL_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* MERL grid */
+#define ORC_MERL_N_TH 90
+#define ORC_MERL_N_TD 90
+#define ORC_MERL_N_PD 180
+#define ORC_MERL_N (ORC_MERL_N_TH * ORC_MERL_N_TD * ORC_MERL_N_PD) /* 1,458,000 */
+
+enum { ORC_LOOKUP_NEAREST = 0, ORC_LOOKUP_TRILINEAR = 1 };
+enum { ORC_NODE_INTEGER = 0, ORC_NODE_CENTER = 1 };   /* trilinear node position: i or i+1/2 */
+enum { ORC_DISK_MITSUBA06 = 0, ORC_DISK_MITSUBA3 = 1 }; /* concentric-disk flavour (A.5) */
+
+typedef struct orc_opts {
+    int lookup;       /* ORC_LOOKUP_* */
+    int node;         /* ORC_NODE_*   */
+    int disk_map;     /* ORC_DISK_*   */
+} orc_opts;
+
+/* A measured table in MERL parameterisation with free dims (customized_measurement = same
+ * layout, other dims/scales).  data is planar: channel c at data + c*n_th*n_td*n_pd, and
+ * inside a plane ind = i_pd + n_pd*(i_td + n_td*i_th)  (A.1). */
+typedef struct orc_table {
+    int n_th, n_td, n_pd;
+    const double *data;
+    double scale[3];
+} orc_table;
+
+/* ---- a1: file format ---- */
+int  orc_read_table(const char *path, int require_merl_dims, double **out_data, int dims[3]);
+int  orc_write_table(const char *path, const double *planar, const int dims[3]);
+void orc_free(void *p);
+void orc_merl_table(orc_table *t, const double *planar);  /* dims 90/90/180, MERL scales */
+
+/* ---- a2: half/diff transform on unit f64 vectors (Rodrigues form, as BRDFRead) ---- */
+void orc_half_diff(const double in[3], const double out[3],
+                   double *theta_half, double *phi_half, double *theta_diff, double *phi_diff);
+
+/* ---- a3: index maps ---- */
+int orc_theta_half_index(const orc_table *t, double theta_half);
+int orc_theta_diff_index(const orc_table *t, double theta_diff);
+int orc_phi_diff_index(const orc_table *t, double phi_diff);
+/* continuous (pre-truncation) coordinates; phi_diff folded into [0,pi] first */
+void orc_coords(const orc_table *t, double theta_half, double theta_diff, double phi_diff,
+                double *x_th, double *x_td, double *x_pd);
+
+/* ---- a4: lookup (scaled, negatives clamped to 0) ---- */
+void orc_lookup(const orc_table *t, const orc_opts *o,
+                double theta_half, double theta_diff, double phi_diff, double rgb[3]);
+
+/* ---- a5..a7: Mitsuba-convention eval / pdf / sample on f32 directions ---- */
+void  orc_eval(const orc_table *t, const orc_opts *o, const float wi[3], const float wo[3], float rgb[3]);
+float orc_pdf(const float wi[3], const float wo[3]);
+void  orc_square_to_cosine_hemisphere(int disk_map, const float u[2], float wo[3]);
+void  orc_sample(const orc_table *t, const orc_opts *o, const float wi[3], const float u[2],
+                 float wo[3], float *pdf, float weight[3]);
+
+/* batches (AoS f32: xyzxyz…, uvuv…) */
+void orc_eval_batch(const orc_table *t, const orc_opts *o, const float *wi, const float *wo,
+                    size_t n, float *rgb);
+void orc_pdf_batch(const float *wi, const float *wo, size_t n, float *pdf);
+void orc_sample_batch(const orc_table *t, const orc_opts *o, const float *wi, const float *u,
+                      size_t n, float *wo, float *pdf, float *weight);
+/* mixed materials: tables[mat[i]] */
+void orc_eval_sample_batch_multi(const orc_table *tables, int n_tables, const orc_opts *o,
+                                 const float *wi, const float *wo, const float *u, const int32_t *mat,
+                                 size_t n, float *rgb, float *pdf, float *wo2, float *pdf2, float *weight);
+
+/* ---- a9: GGX rough conductor (A.6), isotropic alpha, visible-normal sampling ---- */
+typedef struct orc_ggx {
+    double alpha;
+    double eta[3], k[3];
+} orc_ggx;
+void  orc_ggx_eval(const orc_ggx *g, const float wi[3], const float wo[3], float rgb[3]);
+float orc_ggx_pdf(const orc_ggx *g, const float wi[3], const float wo[3]);
+void  orc_ggx_sample(const orc_ggx *g, const float wi[3], const float u[2],
+                     float wo[3], float *pdf, float weight[3]);
+void  orc_ggx_eval_batch(const orc_ggx *g, const float *wi, const float *wo, size_t n, float *rgb);
+void  orc_ggx_pdf_batch(const orc_ggx *g, const float *wi, const float *wo, size_t n, float *pdf);
+void  orc_ggx_sample_batch(const orc_ggx *g, const float *wi, const float *u, size_t n,
+                           float *wo, float *pdf, float *weight);
+
+/* ---- synthetic inputs: pair i -> splitmix64 -> (wi, wo, u) ---- */
+void orc_generate_pairs(uint64_t seed, uint64_t first, size_t n, float *wi, float *wo, float *u);
+void orc_generate_materials(uint64_t seed, uint64_t first, size_t n, int n_materials, int32_t *mat);
+
+/* ---- CPU baseline: one *virtual* call per pair, Mitsuba-0.6 style ---- */
+typedef struct orc_bsdf orc_bsdf;
+typedef struct orc_bsdf_vtbl {
+    void  (*eval)(const orc_bsdf *self, const float wi[3], const float wo[3], float rgb[3]);
+    float (*pdf)(const orc_bsdf *self, const float wi[3], const float wo[3]);
+    void  (*sample)(const orc_bsdf *self, const float wi[3], const float u[2],
+                    float wo[3], float *pdf, float weight[3]);
+} orc_bsdf_vtbl;
+struct orc_bsdf {
+    const orc_bsdf_vtbl *vtbl;
+    orc_table table;
+    orc_ggx   ggx;
+    orc_opts  opts;
+};
+void orc_bsdf_init_merl(orc_bsdf *b, const double *planar, const orc_opts *o);
+void orc_bsdf_init_ggx(orc_bsdf *b, const orc_ggx *g);
+/* runs n eval+sample units [first, first+n) through the vtable on n_threads pthreads;
+ * returns wall seconds; checksum (sum of all outputs) defeats dead-code elimination */
+double orc_bench_eval_sample(const orc_bsdf *b, uint64_t seed, uint64_t first, size_t n,
+                             int n_threads, double *checksum);
+double orc_bench_eval(const orc_bsdf *b, uint64_t seed, uint64_t first, size_t n,
+                      int n_threads, double *checksum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
