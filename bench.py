@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — BSDF eval+sample throughput on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (mrl_eval_sample_batch: eval rgb + pdf + sample wo'/pdf'/weight')
+over one batch of synthetic (wi, wo, u) that is already resident in HBM.  The workload is
+BASELINE.json configs[1]: single MERL material, 64M pairs per GPU (weak scaling: every rank
+owns the index tile [rank*64M, (rank+1)*64M) and generates it in place, untimed).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B_STREAM = 76           # algorithmic HBM bytes per eval+sample unit: 32 in + 44 out
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW")
+HBM_COPY_GBS = 6290.0   # measured float4 copy on the same chip (same guide)
+SEED = 0x5EED
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--units", type=int, default=64 * (1 << 20), help="eval+sample units per GPU per step")
+    p.add_argument("--table", default="ggx_tab", help="synthetic table kind, or a path to a real MERL .binary")
+    p.add_argument("--lookup", choices=["trilinear", "nearest"], default="trilinear")
+    p.add_argument("--kernel", type=int, default=-1, help="kernel variant (MRL_OPT_KERNEL); -1 = library default")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-units", type=int, default=0, help="units for the CPU baseline sample (0 = auto, ~1-3 s wall)")
+    p.add_argument("--no-gather", action="store_true", help="N>1: skip the separately reported RCCL gather leg")
+    p.add_argument("--parity-sample", type=int, default=4096)
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from mitsuba_customization_amd import host, synth
+
+    gpu = host.MerlHip(local_rank)
+    gpu.use_torch_stream()
+    if args.kernel >= 0:
+        gpu.set_option(host.OPT_KERNEL, args.kernel)
+    gpu.set_option(host.OPT_LOOKUP, 1 if args.lookup == "trilinear" else 0)
+
+    if os.path.exists(args.table):
+        table = synth.read_merl_binary(args.table)
+        table_name = os.path.basename(args.table)
+    else:
+        table = synth.make_table(args.table, 0)
+        table_name = f"synthetic {args.table} seed 0 (MERL layout; no real MERL file offline)"
+    mid = gpu.upload_merl(table)
+
+    n = args.units
+    first = rank * n
+    wi, wo, u = gpu.generate_pairs(SEED, first, n)          # untimed, in place on the device
+    dev = wi.device
+    out = (torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
+           torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
+           torch.empty((n, 3), dtype=torch.float32, device=dev))
+
+    def step():
+        gpu.eval_sample(wi, wo, u, material=mid, out=out)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    gpu.timer_start()                                       # hipEvents on the launch stream (= torch's current)
+    for _ in range(args.steps):
+        step()
+    kernel_ms = gpu.timer_stop() / max(args.steps, 1)       # avg launch duration of the dominant kernel
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    total_units = float(n) * world * args.steps
+    value = total_units / elapsed / 1e6                     # M eval+sample units / s, whole job
+    achieved = B_STREAM * n / (kernel_ms * 1e-3) / 1e9      # GB/s of algorithmic stream bytes, one launch on one GPU
+
+    result = {
+        "metric": "bsdf_eval_sample_throughput",
+        "value": round(value, 3),
+        "unit": "Meval/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: single MERL material, 64M (wi,wo,u) batched eval+sample per GPU",
+            "units_per_gpu_per_step": n,
+            "table": table_name,
+            "lookup": args.lookup,
+            "kernel_variant": gpu.get_option(host.OPT_KERNEL),
+            "sharding": f"index tiles x{world}, tables replicated, no data-path collective",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": None,
+            "kernel": "k_batch<eval_sample>",
+            "kernel_ms": round(kernel_ms, 4),
+            "bytes_per_unit": B_STREAM,
+            "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 5),
+            "note": "algorithmic stream bytes only (32 B in + 44 B out per unit); the 2x8-texel table gather "
+                    "(192 B/unit) is served by L2/Infinity Cache and is not counted (SURVEY.md §8d)",
+        },
+    }
+
+    # ---- N>1: the RCCL result gather, reported beside (never inside) `value` ----
+    if world > 1 and not args.no_gather:
+        try:
+            from mitsuba_customization_amd import shard
+            g = shard.bench_gather(out, steps=max(2, min(args.steps, 5)))
+            if rank == 0:
+                result["gather"] = g
+        except Exception as e:  # the gather leg must never hide the compute number
+            if rank == 0:
+                result["gather"] = {"error": repr(e)}
+
+    # ---- rank 0, N=1: parity sample vs the oracle + CPU baseline on the host cores ----
+    if rank == 0:
+        from oracle import binding as ob                       # checker / cpu_baseline leg only
+        k = min(args.parity_sample, n)
+        if k > 0:
+            idx = torch.linspace(0, n - 1, k, device=dev).long()
+            hin = [x[idx].cpu().numpy() for x in (wi, wo, u)]
+            hout = [x[idx].cpu().numpy() for x in out]
+            lookup = 1 if args.lookup == "trilinear" else 0
+            ref = ob.eval_sample_multi([ob.OracleTable(table)], hin[0], hin[1], hin[2], None, ob.make_opts(lookup=lookup))
+            worst = 0.0
+            for got, want in zip(hout, ref):
+                got = got.astype(np.float64); want = want.astype(np.float64)
+                err = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
+                err = np.where(np.abs(got - want) <= 1e-30, 0.0, err)
+                worst = max(worst, float(np.quantile(err, 0.999) if lookup == 0 else err.max()))
+            result["parity"] = {"sample": k, "max_rel_err_vs_oracle": worst, "tolerance": 1e-6, "pinned": False}
+        if world == 1 and not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except Exception:
+                pass
+            lookup = 1 if args.lookup == "trilinear" else 0
+            s1, _ = ob.bench_merl(table, 1 << 18, 1, SEED, True, ob.make_opts(lookup=lookup))     # calibration, 1 thread
+            rate1 = (1 << 18) / s1
+            cpu_n = args.cpu_units or int(min(16 * (1 << 20), max(1 << 20, rate1 * cores * 2.0)))
+            sN, _ = ob.bench_merl(table, cpu_n, cores, SEED, True, ob.make_opts(lookup=lookup))
+            result["cpu_baseline"] = {
+                "value": round(cpu_n / sN / 1e6, 4),
+                "unit": "Meval/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": f"{cpu_n} eval+sample units of the same workload (pair indices 0..{cpu_n - 1}), "
+                          f"scalar f64 oracle behind a Mitsuba-0.6-style virtual call, {cores} threads; "
+                          f"1-thread rate {rate1 / 1e6:.3f} Meval/s on 2^18 units",
+                "single_thread_value": round(rate1 / 1e6, 4),
+            }
+        print(json.dumps(result), flush=True)
+
+    gpu.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

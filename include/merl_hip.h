@@ -1,0 +1,118 @@
+/*
+ * merl_hip.h — C ABI of libmerl_hip.so: the MI355X (gfx950) implementation of the
+ * MERL / customized_measurement BSDF eval()/sample()/pdf() hot path.
+ *
+ * This is the drop-in boundary.  The reference's own interface for the path is
+ * the Mitsuba BSDF plugin class — /root/reference/README.md:1 names the plugins ("Merl,
+ * customized_measurment brdf pluggin for Mitsuba 0.6 Mitsuba 3.0"); the sources that would
+ * carry file:line (mitsuba/src/bsdfs/<plugin>.cpp, mitsuba3/src/bsdfs/<plugin>.cpp) are empty gitlinks in the
+ * snapshot, so each entry point below cites the public upstream method it stands in for:
+ *
+ *   mrl_material_load_merl / _upload_f64   plugin constructor (Properties "filename" -> table load)
+ *   mrl_material_upload_table / _load_table  customized_measurement constructor (free dims/scales)
+ *   mrl_material_ggx                       upstream roughconductor constructor (BASELINE config 3)
+ *   mrl_eval_batch                         BSDF::eval(bRec, ESolidAngle)   / M3 BSDF::eval
+ *   mrl_pdf_batch                          BSDF::pdf(bRec, ESolidAngle)    / M3 BSDF::pdf
+ *   mrl_sample_batch                       BSDF::sample(bRec, pdf, sample) / M3 BSDF::sample
+ *   mrl_eval_sample_batch                  the fused eval + pdf + sample unit (BASELINE metric)
+ *
+ * Conventions: every function returns 0 on success or a negative mrl_status; no exception
+ * crosses the boundary.  All arrays are f32, direction arrays are xyzxyz… (n x 3), sample
+ * arrays uvuv… (n x 2), directions live in the local shading frame (z = normal).  Pointers
+ * may be device pointers (any allocation of the same HIP runtime, e.g. a torch tensor's
+ * data_ptr) or host pointers; all pointers of one call must be of the same kind.  Device
+ * pointer calls are asynchronous on the context's stream; host pointer calls return when the
+ * outputs are written.  The caller owns every buffer; the context owns tables and streams.
+ * A context is thread-compatible: one caller at a time.
+ *
+ * There is NO CPU fallback: without a usable gfx950 device mrl_init fails.
+ */
+#ifndef MERL_HIP_H
+#define MERL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mrl_ctx mrl_ctx;
+
+enum mrl_status {
+    MRL_OK = 0,
+    MRL_ERR_INVALID = -1,      /* bad argument */
+    MRL_ERR_HIP = -2,          /* a HIP runtime call failed (see mrl_last_error) */
+    MRL_ERR_IO = -3,           /* file could not be opened / read */
+    MRL_ERR_FORMAT = -4,       /* file is not a MERL / table file of the expected dims */
+    MRL_ERR_OOM = -5,
+    MRL_ERR_MATERIAL = -6,     /* unknown material id */
+    MRL_ERR_POINTER_MIX = -7,  /* host and device pointers mixed in one call */
+    MRL_ERR_NO_DEVICE = -8     /* no gfx950 device: there is no CPU fallback */
+};
+
+enum mrl_option {
+    MRL_OPT_LOOKUP = 0,        /* 0 nearest (BRDFRead), 1 trilinear (default) */
+    MRL_OPT_NODE = 1,          /* trilinear node position: 0 integer coordinate (default), 1 texel centre */
+    MRL_OPT_DISK_MAP = 2,      /* concentric disk flavour: 0 Mitsuba 0.6 (default), 1 Mitsuba 3 */
+    MRL_OPT_KERNEL = 3,        /* implementation variant of the table kernels; results identical */
+    MRL_OPT_HOST_CHUNK = 4     /* units per staging chunk for host-pointer calls */
+};
+
+enum mrl_material_kind { MRL_KIND_MERL = 0, MRL_KIND_TABLE = 1, MRL_KIND_GGX = 2 };
+
+/* ---- context ---- */
+int mrl_init(int device_id, mrl_ctx **out);
+int mrl_destroy(mrl_ctx *ctx);
+const char *mrl_strerror(int status);
+const char *mrl_last_error(const mrl_ctx *ctx);
+int mrl_set_option(mrl_ctx *ctx, int option, int value);
+int mrl_get_option(const mrl_ctx *ctx, int option, int *value);
+/* launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own */
+int mrl_set_stream(mrl_ctx *ctx, void *hip_stream);
+int mrl_synchronize(mrl_ctx *ctx);
+int mrl_device_info(const mrl_ctx *ctx, char *name, size_t name_len, int *compute_units, size_t *total_mem);
+
+/* ---- materials (immutable after creation; ids are dense, starting at 0) ---- */
+int mrl_material_load_merl(mrl_ctx *ctx, const char *path, int *out_id);
+/* planar R,G,B doubles in MERL order, 3 x 90*90*180 raw file values (scales applied inside) */
+int mrl_material_upload_f64(mrl_ctx *ctx, const double *planar_rgb, int *out_id);
+/* customized_measurement: MERL parameterisation with free dims and channel scales */
+int mrl_material_upload_table(mrl_ctx *ctx, const double *planar_rgb, const int dims[3],
+                              const double scale[3], int *out_id);
+int mrl_material_load_table(mrl_ctx *ctx, const char *path, const double scale[3], int *out_id);
+int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float k[3], int *out_id);
+int mrl_material_count(const mrl_ctx *ctx);
+int mrl_material_info(const mrl_ctx *ctx, int id, int *kind, int dims[3]);
+
+/* ---- batched hot path.  mat == NULL: every unit uses single_id ---- */
+int mrl_eval_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                   size_t n, float *out_rgb);
+int mrl_pdf_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                  size_t n, float *out_pdf);
+int mrl_sample_batch(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id,
+                     size_t n, float *out_wo, float *out_pdf, float *out_weight);
+/* the benchmarked unit: eval(wi,wo) rgb, pdf(wi,wo), sample(wi,u) -> (wo', pdf', weight') */
+int mrl_eval_sample_batch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u,
+                          const int32_t *mat, int32_t single_id, size_t n,
+                          float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight);
+
+/* ---- synthetic inputs, generated in place on the device; device pointers only ---- */
+int mrl_generate_pairs(mrl_ctx *ctx, uint64_t seed, uint64_t first_index, size_t n,
+                       float *wi, float *wo, float *u);
+int mrl_generate_materials(mrl_ctx *ctx, uint64_t seed, uint64_t first_index, size_t n,
+                           int n_materials, int32_t *mat);
+
+/* ---- device memory + timing helpers for hosts that have no allocator of their own ---- */
+int mrl_device_alloc(mrl_ctx *ctx, size_t bytes, void **out);
+int mrl_device_free(mrl_ctx *ctx, void *ptr);
+int mrl_copy_to_device(mrl_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
+int mrl_copy_to_host(mrl_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+/* hipEvent pair recorded on the stream the kernels are launched on */
+int mrl_timer_start(mrl_ctx *ctx);
+int mrl_timer_stop(mrl_ctx *ctx, float *elapsed_ms);   /* records, synchronises, returns ms */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

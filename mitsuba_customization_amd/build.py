@@ -1,0 +1,73 @@
+"""In-tree build of the native pieces (hipcc cross-compiles gfx950 without a GPU).
+
+    python -m mitsuba_customization_amd.build [--force] [--asm]
+
+Outputs (git-ignored, but shipped to the GPU box by gpurun):
+    mitsuba_customization_amd/lib/libmerl_hip.so     C-ABI library + gfx950 kernels
+    mitsuba_customization_amd/lib/merl.so, customized_measurement.so, ...   plugin adapters (if present)
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "libmerl_hip.so")
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+HIP_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def lib_sources():
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    deps = srcs + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(ROOT, "include", "merl_hip.h")]
+    return srcs, deps
+
+
+def build_lib(force: bool = False, asm: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs, deps = lib_sources()
+    if force or _newer(LIB, deps):
+        cmd = [HIPCC] + HIP_FLAGS + ["-shared", "-o", LIB] + srcs
+        subprocess.check_call(cmd, cwd=PKG)
+    if asm:
+        out = os.path.join(LIBDIR, "asm")
+        os.makedirs(out, exist_ok=True)
+        for s in srcs:
+            if "kernels" not in os.path.basename(s):
+                continue
+            subprocess.check_call([HIPCC] + HIP_FLAGS + ["--cuda-device-only", "-S", "-o",
+                                  os.path.join(out, os.path.basename(s) + ".s"), s], cwd=PKG)
+    return LIB
+
+
+def build_adapters(force: bool = False):
+    """Plugin adapters + their C++ test drivers (see adapters/Makefile-less recipe in adapters/build.py)."""
+    ad = os.path.join(PKG, "adapters", "build.py")
+    if os.path.exists(ad):
+        from .adapters import build as adapters_build
+        return adapters_build.build_all(force=force)
+    return []
+
+
+def build_all(force: bool = False, asm: bool = False):
+    out = [build_lib(force=force, asm=asm)]
+    out += build_adapters(force=force)
+    return out
+
+
+if __name__ == "__main__":
+    print("\n".join(build_all(force="--force" in sys.argv, asm="--asm" in sys.argv)))

@@ -1,0 +1,542 @@
+// merl_abi.hip — the C ABI of libmerl_hip.so (include/merl_hip.h): context, material tables,
+// host/device pointer plumbing, launches.  No CPU evaluation path exists here: every batch
+// entry point ends in a gfx950 kernel launch or an error.
+#include "../../include/merl_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "merl_kernels.hpp"
+
+namespace {
+
+constexpr int kMerlDims[3] = { 90, 90, 180 };
+constexpr double kMerlScale[3] = { 1.0 / 1500.0, 1.15 / 1500.0, 1.66 / 1500.0 };
+
+struct MaterialHost {
+    mrl::MaterialDev dev;
+    float4 *d_texels = nullptr;
+};
+
+} // namespace
+
+struct mrl_ctx {
+    int device = 0;
+    int compute_units = 256;
+    std::string device_name;
+    size_t total_mem = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<MaterialHost> materials;
+    mrl::MaterialDev *d_materials = nullptr;
+    size_t d_materials_cap = 0;
+    mrl::Options opts{ 1, 0, 0 };
+    int kernel_variant = 0;
+    size_t host_chunk = (size_t)1 << 22;
+    void *d_stage = nullptr;
+    size_t d_stage_units = 0;
+    std::string last_error;
+};
+
+namespace {
+
+int fail(mrl_ctx *ctx, int status, const std::string &msg)
+{
+    if (ctx) ctx->last_error = msg;
+    return status;
+}
+
+#define MRL_HIP(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            (void)hipGetLastError();                                                         \
+            return fail((ctx), MRL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+        }                                                                                    \
+    } while (0)
+
+// 1 = the device can dereference it (device, managed or pinned/registered host), 0 = plain host
+int pointer_kind(const void *p)
+{
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    switch (at.type) {
+        case hipMemoryTypeDevice:
+        case hipMemoryTypeManaged:
+        case hipMemoryTypeHost:
+            return 1;
+        default:
+            return 0;
+    }
+}
+
+// all non-null pointers must be of one kind; returns 0/1, or -1 on a mix
+int common_kind(std::initializer_list<const void *> ptrs)
+{
+    int kind = -2;
+    for (const void *p : ptrs) {
+        if (!p) continue;
+        int k = pointer_kind(p);
+        if (kind == -2) kind = k;
+        else if (kind != k) return -1;
+    }
+    return kind == -2 ? 1 : kind;
+}
+
+int sync_material_array(mrl_ctx *ctx)
+{
+    size_t n = ctx->materials.size();
+    if (n > ctx->d_materials_cap) {
+        size_t cap = std::max<size_t>(16, ctx->d_materials_cap * 2);
+        while (cap < n) cap *= 2;
+        mrl::MaterialDev *fresh = nullptr;
+        MRL_HIP(ctx, hipMalloc((void **)&fresh, cap * sizeof(mrl::MaterialDev)));
+        if (ctx->d_materials) {
+            // in-flight launches may still read the old array
+            MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_materials);
+        }
+        ctx->d_materials = fresh;
+        ctx->d_materials_cap = cap;
+    }
+    std::vector<mrl::MaterialDev> host(n);
+    for (size_t i = 0; i < n; ++i) host[i] = ctx->materials[i].dev;
+    MRL_HIP(ctx, hipMemcpy(ctx->d_materials, host.data(), n * sizeof(mrl::MaterialDev), hipMemcpyHostToDevice));
+    return MRL_OK;
+}
+
+// planar f64 (file layout) -> padded, texel-interleaved RGBA f32 in HBM.
+// Row layout [n_th+1][n_td+1][n_pd+1]: the extra theta rows repeat the last row (clamp), the
+// extra phi texel repeats texel 0 (phi_d is periodic with period pi), so the kernel's "+1"
+// neighbours never need a clamp or a wrap.  Scales applied and negatives clamped here, once.
+int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const double scale[3], int kind, int *out_id)
+{
+    if (!ctx || !planar || !dims || !scale || !out_id) return fail(ctx, MRL_ERR_INVALID, "null argument");
+    const int n_th = dims[0], n_td = dims[1], n_pd = dims[2];
+    if (n_th < 1 || n_td < 1 || n_pd < 1 || (long long)n_th * n_td * n_pd > (1LL << 28))
+        return fail(ctx, MRL_ERR_INVALID, "table dims out of range");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1;
+    const size_t plane = (size_t)n_th * n_td * n_pd;
+    std::vector<float4> host;
+    try { host.resize(H * D * P); } catch (const std::bad_alloc &) { return fail(ctx, MRL_ERR_OOM, "host staging for table"); }
+    for (size_t ih = 0; ih < H; ++ih) {
+        size_t sh = std::min<size_t>(ih, n_th - 1);
+        for (size_t id = 0; id < D; ++id) {
+            size_t sd = std::min<size_t>(id, n_td - 1);
+            const size_t src_row = (sh * n_td + sd) * n_pd;
+            float4 *dst = host.data() + (ih * D + id) * P;
+            for (size_t ip = 0; ip < P; ++ip) {
+                size_t sp = ip == (size_t)n_pd ? 0 : ip;
+                double r = planar[src_row + sp] * scale[0];
+                double g = planar[src_row + sp + plane] * scale[1];
+                double b = planar[src_row + sp + 2 * plane] * scale[2];
+                dst[ip] = make_float4(r > 0.0 ? (float)r : 0.0f, g > 0.0 ? (float)g : 0.0f, b > 0.0 ? (float)b : 0.0f, 0.0f);
+            }
+        }
+    }
+    MaterialHost m;
+    MRL_HIP(ctx, hipMalloc((void **)&m.d_texels, host.size() * sizeof(float4)));
+    hipError_t e = hipMemcpy(m.d_texels, host.data(), host.size() * sizeof(float4), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(m.d_texels); return fail(ctx, MRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e)); }
+    std::memset(&m.dev, 0, sizeof m.dev);
+    m.dev.kind = kind;
+    m.dev.n_th = n_th; m.dev.n_td = n_td; m.dev.n_pd = n_pd;
+    m.dev.row_td = (int)P;
+    m.dev.row_th = (int)(D * P);
+    m.dev.texels = m.d_texels;
+    ctx->materials.push_back(m);
+    int rc = sync_material_array(ctx);
+    if (rc != MRL_OK) { ctx->materials.pop_back(); (void)hipFree(m.d_texels); return rc; }
+    *out_id = (int)ctx->materials.size() - 1;
+    return MRL_OK;
+}
+
+// a1: MERL .binary reader: int32 dims[3], then 3*n planar doubles
+int read_table_file(mrl_ctx *ctx, const char *path, bool require_merl, std::vector<double> &data, int dims[3])
+{
+    if (!path) return fail(ctx, MRL_ERR_INVALID, "null path");
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(ctx, MRL_ERR_IO, std::string("cannot open ") + path);
+    int32_t d[3];
+    if (std::fread(d, sizeof(int32_t), 3, f) != 3) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "short header"); }
+    if (d[0] <= 0 || d[1] <= 0 || d[2] <= 0) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "non-positive dims"); }
+    long long n = (long long)d[0] * d[1] * d[2];
+    if (require_merl && n != 90LL * 90 * 180) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "dims do not match the MERL grid (90*90*360/2)"); }
+    if (n > (1LL << 28)) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "table too large"); }
+    try { data.resize(3 * (size_t)n); } catch (const std::bad_alloc &) { std::fclose(f); return fail(ctx, MRL_ERR_OOM, "table buffer"); }
+    size_t got = std::fread(data.data(), sizeof(double), data.size(), f);
+    std::fclose(f);
+    if (got != data.size()) return fail(ctx, MRL_ERR_FORMAT, "truncated table payload");
+    if (require_merl) { dims[0] = kMerlDims[0]; dims[1] = kMerlDims[1]; dims[2] = kMerlDims[2]; }
+    else { dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2]; }
+    return MRL_OK;
+}
+
+int ensure_stage(mrl_ctx *ctx, size_t units)
+{
+    if (units <= ctx->d_stage_units) return MRL_OK;
+    if (ctx->d_stage) { MRL_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_stage); ctx->d_stage = nullptr; ctx->d_stage_units = 0; }
+    MRL_HIP(ctx, hipMalloc(&ctx->d_stage, units * 80));
+    ctx->d_stage_units = units;
+    return MRL_OK;
+}
+
+struct BatchCall {
+    int mode;                                    // 0 eval, 1 pdf, 2 sample, 3 eval+sample
+    const float *wi, *wo, *u;
+    const int32_t *mat;
+    int32_t single_id;
+    size_t n;
+    float *out_rgb, *out_pdf, *out_wo, *out_pdf2, *out_weight;
+};
+
+int launch_device(mrl_ctx *ctx, const BatchCall &c)
+{
+    mrl::BatchArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.wi = c.wi; a.wo = c.wo; a.u = c.u; a.mat = c.mat; a.n = c.n;
+    a.out_rgb = c.out_rgb; a.out_pdf = c.out_pdf; a.out_wo = c.out_wo; a.out_pdf2 = c.out_pdf2; a.out_weight = c.out_weight;
+    a.materials = ctx->d_materials;
+    a.n_materials = (int)ctx->materials.size();
+    a.opts = ctx->opts;
+    bool multi = c.mat != nullptr;
+    if (!multi) a.single = ctx->materials[(size_t)c.single_id].dev;
+    MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->compute_units, ctx->stream));
+    return MRL_OK;
+}
+
+int run_batch(mrl_ctx *ctx, const BatchCall &c)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    if (c.n == 0) return MRL_OK;
+    const bool needs_wo = c.mode != 2, needs_u = c.mode >= 2;
+    const bool has_eval = c.mode == 0 || c.mode == 3, has_pdf = c.mode == 1 || c.mode == 3, has_sample = c.mode >= 2;
+    if (!c.wi || (needs_wo && !c.wo) || (needs_u && !c.u) || (has_eval && !c.out_rgb) || (has_pdf && !c.out_pdf) ||
+        (has_sample && (!c.out_wo || !c.out_pdf2 || !c.out_weight)))
+        return fail(ctx, MRL_ERR_INVALID, "null array argument");
+    if (ctx->materials.empty()) return fail(ctx, MRL_ERR_MATERIAL, "no material loaded");
+    if (!c.mat && (c.single_id < 0 || (size_t)c.single_id >= ctx->materials.size()))
+        return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+
+    int kind = common_kind({ c.wi, needs_wo ? c.wo : nullptr, needs_u ? c.u : nullptr, c.mat,
+                             has_eval ? c.out_rgb : nullptr, has_pdf ? c.out_pdf : nullptr,
+                             has_sample ? c.out_wo : nullptr, has_sample ? c.out_pdf2 : nullptr,
+                             has_sample ? c.out_weight : nullptr });
+    if (kind < 0) return fail(ctx, MRL_ERR_POINTER_MIX, "host and device pointers mixed in one call");
+    if (kind == 1) return launch_device(ctx, c);
+
+    // host pointers: stage through HBM in chunks; returns when the outputs are on the host
+    const size_t chunk = std::min(c.n, ctx->host_chunk);
+    int rc = ensure_stage(ctx, chunk);
+    if (rc != MRL_OK) return rc;
+    char *base = (char *)ctx->d_stage;
+    const size_t cu = ctx->d_stage_units;
+    float *d_wi = (float *)base;               float *d_wo = (float *)(base + 12 * cu);
+    float *d_u = (float *)(base + 24 * cu);    int32_t *d_mat = (int32_t *)(base + 32 * cu);
+    float *d_rgb = (float *)(base + 36 * cu);  float *d_pdf = (float *)(base + 48 * cu);
+    float *d_wo2 = (float *)(base + 52 * cu);  float *d_pdf2 = (float *)(base + 64 * cu);
+    float *d_w = (float *)(base + 68 * cu);
+    for (size_t off = 0; off < c.n; off += chunk) {
+        const size_t m = std::min(chunk, c.n - off);
+        MRL_HIP(ctx, hipMemcpyAsync(d_wi, c.wi + 3 * off, 12 * m, hipMemcpyHostToDevice, ctx->stream));
+        if (needs_wo) MRL_HIP(ctx, hipMemcpyAsync(d_wo, c.wo + 3 * off, 12 * m, hipMemcpyHostToDevice, ctx->stream));
+        if (needs_u) MRL_HIP(ctx, hipMemcpyAsync(d_u, c.u + 2 * off, 8 * m, hipMemcpyHostToDevice, ctx->stream));
+        if (c.mat) MRL_HIP(ctx, hipMemcpyAsync(d_mat, c.mat + off, 4 * m, hipMemcpyHostToDevice, ctx->stream));
+        BatchCall d = c;
+        d.wi = d_wi; d.wo = d_wo; d.u = d_u; d.mat = c.mat ? d_mat : nullptr; d.n = m;
+        d.out_rgb = d_rgb; d.out_pdf = d_pdf; d.out_wo = d_wo2; d.out_pdf2 = d_pdf2; d.out_weight = d_w;
+        rc = launch_device(ctx, d);
+        if (rc != MRL_OK) return rc;
+        if (has_eval) MRL_HIP(ctx, hipMemcpyAsync(c.out_rgb + 3 * off, d_rgb, 12 * m, hipMemcpyDeviceToHost, ctx->stream));
+        if (has_pdf) MRL_HIP(ctx, hipMemcpyAsync(c.out_pdf + off, d_pdf, 4 * m, hipMemcpyDeviceToHost, ctx->stream));
+        if (has_sample) {
+            MRL_HIP(ctx, hipMemcpyAsync(c.out_wo + 3 * off, d_wo2, 12 * m, hipMemcpyDeviceToHost, ctx->stream));
+            MRL_HIP(ctx, hipMemcpyAsync(c.out_pdf2 + off, d_pdf2, 4 * m, hipMemcpyDeviceToHost, ctx->stream));
+            MRL_HIP(ctx, hipMemcpyAsync(c.out_weight + 3 * off, d_w, 12 * m, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MRL_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *mrl_strerror(int status)
+{
+    switch (status) {
+        case MRL_OK: return "ok";
+        case MRL_ERR_INVALID: return "invalid argument";
+        case MRL_ERR_HIP: return "HIP runtime error";
+        case MRL_ERR_IO: return "I/O error";
+        case MRL_ERR_FORMAT: return "bad table file";
+        case MRL_ERR_OOM: return "out of memory";
+        case MRL_ERR_MATERIAL: return "unknown material";
+        case MRL_ERR_POINTER_MIX: return "host and device pointers mixed";
+        case MRL_ERR_NO_DEVICE: return "no gfx950 device (there is no CPU fallback)";
+    }
+    return "unknown status";
+}
+
+const char *mrl_last_error(const mrl_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int mrl_init(int device_id, mrl_ctx **out)
+{
+    if (!out) return MRL_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return MRL_ERR_NO_DEVICE; }
+    if (device_id < 0 || device_id >= count) return MRL_ERR_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { (void)hipGetLastError(); return MRL_ERR_HIP; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MRL_ERR_NO_DEVICE;   // kernels are built for gfx950 only
+    mrl_ctx *ctx = new (std::nothrow) mrl_ctx();
+    if (!ctx) return MRL_ERR_OOM;
+    ctx->device = device_id;
+    ctx->compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->device_name = prop.name;
+    ctx->total_mem = prop.totalGlobalMem;
+    if (hipSetDevice(device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        (void)hipGetLastError();
+        delete ctx;
+        return MRL_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return MRL_OK;
+}
+
+int mrl_destroy(mrl_ctx *ctx)
+{
+    if (!ctx) return MRL_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &m : ctx->materials) if (m.d_texels) (void)hipFree(m.d_texels);
+    if (ctx->d_materials) (void)hipFree(ctx->d_materials);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return MRL_OK;
+}
+
+int mrl_set_option(mrl_ctx *ctx, int option, int value)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    switch (option) {
+        case MRL_OPT_LOOKUP:   if (value < 0 || value > 1) break; ctx->opts.lookup = value; return MRL_OK;
+        case MRL_OPT_NODE:     if (value < 0 || value > 1) break; ctx->opts.node = value; return MRL_OK;
+        case MRL_OPT_DISK_MAP: if (value < 0 || value > 1) break; ctx->opts.disk_map = value; return MRL_OK;
+        case MRL_OPT_KERNEL:   if (value < 0) break; ctx->kernel_variant = value; return MRL_OK;
+        case MRL_OPT_HOST_CHUNK: if (value < 1) break; ctx->host_chunk = (size_t)value; return MRL_OK;
+    }
+    return fail(ctx, MRL_ERR_INVALID, "bad option or value");
+}
+
+int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
+{
+    if (!ctx || !value) return MRL_ERR_INVALID;
+    switch (option) {
+        case MRL_OPT_LOOKUP: *value = ctx->opts.lookup; return MRL_OK;
+        case MRL_OPT_NODE: *value = ctx->opts.node; return MRL_OK;
+        case MRL_OPT_DISK_MAP: *value = ctx->opts.disk_map; return MRL_OK;
+        case MRL_OPT_KERNEL: *value = ctx->kernel_variant; return MRL_OK;
+        case MRL_OPT_HOST_CHUNK: *value = (int)ctx->host_chunk; return MRL_OK;
+    }
+    return MRL_ERR_INVALID;
+}
+
+int mrl_set_stream(mrl_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return MRL_OK;
+}
+
+int mrl_synchronize(mrl_ctx *ctx)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MRL_OK;
+}
+
+int mrl_device_info(const mrl_ctx *ctx, char *name, size_t name_len, int *compute_units, size_t *total_mem)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    if (name && name_len) { std::strncpy(name, ctx->device_name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    if (compute_units) *compute_units = ctx->compute_units;
+    if (total_mem) *total_mem = ctx->total_mem;
+    return MRL_OK;
+}
+
+int mrl_material_load_merl(mrl_ctx *ctx, const char *path, int *out_id)
+{
+    if (!ctx || !out_id) return MRL_ERR_INVALID;
+    std::vector<double> data; int dims[3];
+    int rc = read_table_file(ctx, path, true, data, dims);
+    if (rc != MRL_OK) return rc;
+    return upload_table(ctx, data.data(), dims, kMerlScale, mrl::KIND_MERL, out_id);
+}
+
+int mrl_material_upload_f64(mrl_ctx *ctx, const double *planar_rgb, int *out_id)
+{
+    return upload_table(ctx, planar_rgb, kMerlDims, kMerlScale, mrl::KIND_MERL, out_id);
+}
+
+int mrl_material_upload_table(mrl_ctx *ctx, const double *planar_rgb, const int dims[3], const double scale[3], int *out_id)
+{
+    return upload_table(ctx, planar_rgb, dims, scale, mrl::KIND_TABLE, out_id);
+}
+
+int mrl_material_load_table(mrl_ctx *ctx, const char *path, const double scale[3], int *out_id)
+{
+    if (!ctx || !out_id || !scale) return MRL_ERR_INVALID;
+    std::vector<double> data; int dims[3];
+    int rc = read_table_file(ctx, path, false, data, dims);
+    if (rc != MRL_OK) return rc;
+    return upload_table(ctx, data.data(), dims, scale, mrl::KIND_TABLE, out_id);
+}
+
+int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float k[3], int *out_id)
+{
+    if (!ctx || !eta || !k || !out_id) return MRL_ERR_INVALID;
+    if (!(alpha > 0.0f)) return fail(ctx, MRL_ERR_INVALID, "alpha must be positive");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    MaterialHost m;
+    std::memset(&m.dev, 0, sizeof m.dev);
+    m.dev.kind = mrl::KIND_GGX;
+    m.dev.alpha = (double)alpha;
+    for (int c = 0; c < 3; ++c) { m.dev.eta[c] = (double)eta[c]; m.dev.k[c] = (double)k[c]; }
+    ctx->materials.push_back(m);
+    int rc = sync_material_array(ctx);
+    if (rc != MRL_OK) { ctx->materials.pop_back(); return rc; }
+    *out_id = (int)ctx->materials.size() - 1;
+    return MRL_OK;
+}
+
+int mrl_material_count(const mrl_ctx *ctx) { return ctx ? (int)ctx->materials.size() : MRL_ERR_INVALID; }
+
+int mrl_material_info(const mrl_ctx *ctx, int id, int *kind, int dims[3])
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    if (id < 0 || (size_t)id >= ctx->materials.size()) return MRL_ERR_MATERIAL;
+    const mrl::MaterialDev &d = ctx->materials[(size_t)id].dev;
+    if (kind) *kind = d.kind;
+    if (dims) { dims[0] = d.n_th; dims[1] = d.n_td; dims[2] = d.n_pd; }
+    return MRL_OK;
+}
+
+int mrl_eval_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, float *out_rgb)
+{
+    BatchCall c{ 0, wi, wo, nullptr, mat, single_id, n, out_rgb, nullptr, nullptr, nullptr, nullptr };
+    return run_batch(ctx, c);
+}
+
+int mrl_pdf_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, float *out_pdf)
+{
+    BatchCall c{ 1, wi, wo, nullptr, mat, single_id, n, nullptr, out_pdf, nullptr, nullptr, nullptr };
+    return run_batch(ctx, c);
+}
+
+int mrl_sample_batch(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id, size_t n,
+                     float *out_wo, float *out_pdf, float *out_weight)
+{
+    BatchCall c{ 2, wi, nullptr, u, mat, single_id, n, nullptr, nullptr, out_wo, out_pdf, out_weight };
+    return run_batch(ctx, c);
+}
+
+int mrl_eval_sample_batch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u, const int32_t *mat, int32_t single_id,
+                          size_t n, float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
+{
+    BatchCall c{ 3, wi, wo, u, mat, single_id, n, out_rgb, out_pdf, out_wo, out_pdf2, out_weight };
+    return run_batch(ctx, c);
+}
+
+int mrl_generate_pairs(mrl_ctx *ctx, uint64_t seed, uint64_t first_index, size_t n, float *wi, float *wo, float *u)
+{
+    if (!ctx || !wi || !wo || !u) return fail(ctx, MRL_ERR_INVALID, "null argument");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    if (common_kind({ wi, wo, u }) != 1) return fail(ctx, MRL_ERR_INVALID, "generator needs device pointers");
+    MRL_HIP(ctx, mrl::launch_generate_pairs(seed, first_index, n, wi, wo, u, ctx->compute_units, ctx->stream));
+    return MRL_OK;
+}
+
+int mrl_generate_materials(mrl_ctx *ctx, uint64_t seed, uint64_t first_index, size_t n, int n_materials, int32_t *mat)
+{
+    if (!ctx || !mat || n_materials < 1) return fail(ctx, MRL_ERR_INVALID, "bad argument");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    if (pointer_kind(mat) != 1) return fail(ctx, MRL_ERR_INVALID, "generator needs device pointers");
+    MRL_HIP(ctx, mrl::launch_generate_materials(seed, first_index, n, n_materials, mat, ctx->compute_units, ctx->stream));
+    return MRL_OK;
+}
+
+int mrl_device_alloc(mrl_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out) return MRL_ERR_INVALID;
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    MRL_HIP(ctx, hipMalloc(out, bytes ? bytes : 1));
+    return MRL_OK;
+}
+
+int mrl_device_free(mrl_ctx *ctx, void *ptr)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    if (!ptr) return MRL_OK;
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MRL_HIP(ctx, hipFree(ptr));
+    return MRL_OK;
+}
+
+int mrl_copy_to_device(mrl_ctx *ctx, void *dst_device, const void *src_host, size_t bytes)
+{
+    if (!ctx || (!dst_device && bytes) || (!src_host && bytes)) return MRL_ERR_INVALID;
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    MRL_HIP(ctx, hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MRL_OK;
+}
+
+int mrl_copy_to_host(mrl_ctx *ctx, void *dst_host, const void *src_device, size_t bytes)
+{
+    if (!ctx || (!dst_host && bytes) || (!src_device && bytes)) return MRL_ERR_INVALID;
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    MRL_HIP(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MRL_OK;
+}
+
+int mrl_timer_start(mrl_ctx *ctx)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    MRL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return MRL_OK;
+}
+
+int mrl_timer_stop(mrl_ctx *ctx, float *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms) return MRL_ERR_INVALID;
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    MRL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    MRL_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    MRL_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return MRL_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,376 @@
+// merl_device.hpp — per-lane device math of the MERL / customized_measurement / GGX hot path.
+//
+// Reference rows (reference files absent, /root/reference/README.md:1 names them):
+//   a2 half/diff transform, a3 index maps, a4 table fetch, a5 eval, a6 sample, a7 pdf, a9 GGX.
+//
+// Numerics.  Inputs/outputs are f32 (Mitsuba Float).  The transform runs in f64 VALU: the table
+// coordinate x in [0,180) must be good to ~1e-8 texel for the interpolated value to match an
+// f64 CPU evaluation to 1e-6 relative on high-contrast tables, which f32 (ulp(90) = 7.6e-6)
+// cannot give.  Angles come from atan2 forms that are well conditioned for unit
+// vectors s = in+out, e = in-out:
+//     theta_h = atan2(|s_xy|, s_z)      theta_d = atan2(|e|, |s|)
+//     phi_d   = atan2(e_y s_x - e_x s_y, -e_z |s|)
+// (algebraically the Rodrigues form of BRDFRead; no sin/cos, no acos near 1).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mrl {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kHalfPi = 1.57079632679489661923;
+constexpr float kInvPiF = 0.31830988618379067154f;
+
+enum Kind : int { KIND_MERL = 0, KIND_TABLE = 1, KIND_GGX = 2 };
+
+// One material as the kernels see it (array in device memory; single-material launches get it
+// by value, i.e. in SGPRs).
+struct MaterialDev {
+    int kind;
+    int n_th, n_td, n_pd;        // logical dims
+    int row_td;                  // texels per theta_d row      = n_pd + 1 (phi wrap texel appended)
+    int row_th;                  // texels per theta_h slab     = (n_td + 1) * (n_pd + 1)
+    const float4 *texels;        // [(n_th+1)][(n_td+1)][(n_pd+1)] RGBA f32, scaled, negatives clamped
+    double alpha;                // GGX
+    double eta[3], k[3];
+};
+
+struct Options {
+    int lookup;    // 0 nearest, 1 trilinear
+    int node;      // 0 integer node, 1 texel centre
+    int disk_map;  // 0 Mitsuba 0.6, 1 Mitsuba 3
+};
+
+struct Vec3d { double x, y, z; };
+
+__device__ __forceinline__ Vec3d normalized(float x, float y, float z)
+{
+    double dx = x, dy = y, dz = z;
+    double inv = rsqrt(dx * dx + dy * dy + dz * dz);
+    return { dx * inv, dy * inv, dz * inv };
+}
+
+// ---- a2 + a3: unit in/out -> continuous table coordinates ---------------------------------
+struct Coords { double xh, xd, xp; };
+
+__device__ __forceinline__ Coords half_diff_coords(const Vec3d &in, const Vec3d &out, int n_th, int n_td, int n_pd)
+{
+    const double sx = in.x + out.x, sy = in.y + out.y, sz = in.z + out.z;
+    const double ex = in.x - out.x, ey = in.y - out.y, ez = in.z - out.z;
+    const double rho2 = sx * sx + sy * sy;
+    const double ns = sqrt(rho2 + sz * sz);
+    const double ne = sqrt(ex * ex + ey * ey + ez * ez);
+    const double rho = sqrt(rho2);
+    const double th = atan2(rho, sz);
+    const double td = atan2(ne, ns);
+    double py = ey * sx - ex * sy;
+    double px = -ez * ns;
+    if (rho == 0.0) { py = in.y; px = in.x; }       // h == n: phi_h = atan2(0,0) = 0
+    double pd = atan2(py, px);
+    if (pd < 0.0) pd += kPi;                          // reciprocity fold
+    Coords c;
+    c.xh = th <= 0.0 ? 0.0 : sqrt((th / kHalfPi) * n_th * n_th);
+    c.xd = td / kHalfPi * n_td;
+    c.xp = pd / kPi * n_pd;
+    return c;
+}
+
+// ---- a4: table fetch -------------------------------------------------------------------------
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct Rgbd { double r, g, b; };
+
+__device__ __forceinline__ Rgbd lookup_nearest(const MaterialDev &m, const Coords &c)
+{
+    int ih = clampi((int)c.xh, 0, m.n_th - 1);
+    int id = clampi((int)c.xd, 0, m.n_td - 1);
+    int ip = clampi((int)c.xp, 0, m.n_pd - 1);
+    float4 t = m.texels[(size_t)ih * m.row_th + (size_t)id * m.row_td + ip];
+    return { (double)t.x, (double)t.y, (double)t.z };
+}
+
+// clamped axis: i0 in [0,n-1], f in [0,1]; i0+1 is always a valid (padded) index
+__device__ __forceinline__ void split_clamped(double x, int n, int &i0, double &f)
+{
+    int i = clampi((int)floor(x), 0, n - 1);
+    double fr = x - (double)i;
+    f = fr < 0.0 ? 0.0 : (fr > 1.0 ? 1.0 : fr);
+    i0 = i;
+}
+// periodic axis: i0 in [0,n-1]; i0+1 <= n hits the appended wrap texel
+__device__ __forceinline__ void split_periodic(double x, int n, int &i0, double &f)
+{
+    double fl = floor(x);
+    int i = (int)fl;
+    f = x - fl;
+    i = i % n;
+    i0 = i < 0 ? i + n : i;
+}
+
+__device__ __forceinline__ Rgbd lookup_trilinear(const MaterialDev &m, const Coords &c, int node)
+{
+    const double shift = node ? 0.5 : 0.0;
+    int h0, d0, p0; double fh, fd, fp;
+    split_clamped(c.xh - shift, m.n_th, h0, fh);
+    split_clamped(c.xd - shift, m.n_td, d0, fd);
+    split_periodic(c.xp - shift, m.n_pd, p0, fp);
+    const float4 *b = m.texels + ((size_t)h0 * m.row_th + (size_t)d0 * m.row_td + p0);
+    // issue all eight 16-B gathers before any use
+    const float4 t000 = b[0],                 t001 = b[1];
+    const float4 t010 = b[m.row_td],          t011 = b[m.row_td + 1];
+    const float4 t100 = b[m.row_th],          t101 = b[m.row_th + 1];
+    const float4 t110 = b[m.row_th + m.row_td], t111 = b[m.row_th + m.row_td + 1];
+    const double gh = 1.0 - fh, gd = 1.0 - fd, gp = 1.0 - fp;
+    const double w000 = gh * gd * gp, w001 = gh * gd * fp, w010 = gh * fd * gp, w011 = gh * fd * fp;
+    const double w100 = fh * gd * gp, w101 = fh * gd * fp, w110 = fh * fd * gp, w111 = fh * fd * fp;
+    Rgbd o;
+    o.r = w000 * t000.x + w001 * t001.x + w010 * t010.x + w011 * t011.x + w100 * t100.x + w101 * t101.x + w110 * t110.x + w111 * t111.x;
+    o.g = w000 * t000.y + w001 * t001.y + w010 * t010.y + w011 * t011.y + w100 * t100.y + w101 * t101.y + w110 * t110.y + w111 * t111.y;
+    o.b = w000 * t000.z + w001 * t001.z + w010 * t010.z + w011 * t011.z + w100 * t100.z + w101 * t101.z + w110 * t110.z + w111 * t111.z;
+    return o;
+}
+
+// BRDF value (no cosine) of a table material for unit in/out
+__device__ __forceinline__ Rgbd table_brdf(const MaterialDev &m, const Options &o, const Vec3d &in, const Vec3d &out)
+{
+    Coords c = half_diff_coords(in, out, m.n_th, m.n_td, m.n_pd);
+    return o.lookup ? lookup_trilinear(m, c, o.node) : lookup_nearest(m, c);
+}
+
+// ---- a6: cosine-hemisphere sampling, pinned f32 sequence (bit-identical to oracle/merl_oracle.c) --
+__device__ __forceinline__ void sincos_quarter_f32(float t, float &s, float &c)
+{
+#pragma clang fp contract(off)
+    const float S0 = -0x1.555552p-3f, S1 = 0x1.110c28p-7f, S2 = -0x1.9ac98ep-13f;
+    const float C0 = 0x1.555552p-5f, C1 = -0x1.6c10dp-10f, C2 = 0x1.9b31dep-16f;
+    float z = t * t;
+    float p = __builtin_fmaf(S2, z, S1); p = __builtin_fmaf(p, z, S0);
+    float pz = p * z;
+    s = __builtin_fmaf(pz, t, t);
+    float q = __builtin_fmaf(C2, z, C1); q = __builtin_fmaf(q, z, C0);
+    float qz = q * z;
+    c = __builtin_fmaf(qz, z, __builtin_fmaf(-0.5f, z, 1.0f));
+}
+
+__device__ __forceinline__ void square_to_cosine_hemisphere(int disk_map, float u0, float u1, float &x, float &y, float &z)
+{
+#pragma clang fp contract(off)
+    const float QUARTER_PI = 0.78539816339744830962f;
+    float a = 2.0f * u0 - 1.0f, b = 2.0f * u1 - 1.0f;
+    if (a == 0.0f && b == 0.0f) {
+        x = 0.0f; y = 0.0f;
+    } else {
+        float aa = a * a, bb = b * b;
+        bool first = disk_map ? !(fabsf(a) < fabsf(b)) : (aa > bb);
+        float r = first ? a : b;
+        float ratio = first ? __fdiv_rn(b, a) : __fdiv_rn(a, b);
+        float s, c;
+        sincos_quarter_f32(QUARTER_PI * ratio, s, c);
+        x = r * (first ? c : s);
+        y = r * (first ? s : c);
+    }
+    float xx = x * x;
+    float zz = 1.0f - __builtin_fmaf(y, y, xx);
+    z = zz > 0.0f ? __fsqrt_rn(zz) : 0.0f;
+    if (disk_map == 0 && z == 0.0f) z = 1e-10f;
+}
+
+// ---- a9: GGX rough conductor, f64, formula-for-formula the oracle's ---------
+__device__ __forceinline__ double ggx_D(double alpha, const Vec3d &m)
+{
+    if (m.z <= 0.0) return 0.0;
+    double c2 = m.z * m.z;
+    double e = (m.x * m.x + m.y * m.y) / (alpha * alpha) / c2;
+    double root = (1.0 + e) * c2;
+    double r = 1.0 / (kPi * alpha * alpha * root * root);
+    return r * m.z < 1e-20 ? 0.0 : r;
+}
+__device__ __forceinline__ double ggx_G1(double alpha, const Vec3d &v, const Vec3d &m)
+{
+    double vm = v.x * m.x + v.y * m.y + v.z * m.z;
+    if (vm * v.z <= 0.0) return 0.0;
+    double s2 = 1.0 - v.z * v.z;
+    if (s2 <= 0.0) return 1.0;
+    double tan2 = s2 / (v.z * v.z);
+    return 2.0 / (1.0 + sqrt(1.0 + alpha * alpha * tan2));
+}
+__device__ __forceinline__ double safe_sqrt(double x) { return x > 0.0 ? sqrt(x) : 0.0; }
+__device__ __forceinline__ double fresnel_conductor(double c, double eta, double k)
+{
+    double c2 = c * c, s2 = 1.0 - c2, s4 = s2 * s2;
+    double t1 = eta * eta - k * k - s2;
+    double a2pb2 = safe_sqrt(t1 * t1 + 4.0 * k * k * eta * eta);
+    double a = safe_sqrt(0.5 * (a2pb2 + t1));
+    double term1 = a2pb2 + c2, term2 = 2.0 * a * c;
+    double rs2 = (term1 - term2) / (term1 + term2);
+    double term3 = a2pb2 * c2 + s4, term4 = term2 * s2;
+    double rp2 = rs2 * (term3 - term4) / (term3 + term4);
+    return 0.5 * (rp2 + rs2);
+}
+__device__ __forceinline__ Vec3d unit_sum(const Vec3d &a, const Vec3d &b)
+{
+    double x = a.x + b.x, y = a.y + b.y, z = a.z + b.z;
+    double len = sqrt(x * x + y * y + z * z);
+    if (len > 0.0) { x /= len; y /= len; z /= len; }
+    return { x, y, z };
+}
+// eval with the cosine folded in: F D G / (4 cos ti)
+__device__ __forceinline__ Rgbd ggx_eval(const MaterialDev &g, const Vec3d &in, const Vec3d &out)
+{
+    Vec3d m = unit_sum(in, out);
+    Rgbd o = { 0.0, 0.0, 0.0 };
+    double D = ggx_D(g.alpha, m);
+    if (D == 0.0) return o;
+    double G = ggx_G1(g.alpha, in, m) * ggx_G1(g.alpha, out, m);
+    double model = D * G / (4.0 * in.z);
+    double c = in.x * m.x + in.y * m.y + in.z * m.z;
+    o.r = fresnel_conductor(c, g.eta[0], g.k[0]) * model;
+    o.g = fresnel_conductor(c, g.eta[1], g.k[1]) * model;
+    o.b = fresnel_conductor(c, g.eta[2], g.k[2]) * model;
+    return o;
+}
+__device__ __forceinline__ double ggx_pdf(const MaterialDev &g, const Vec3d &in, const Vec3d &out)
+{
+    Vec3d m = unit_sum(in, out);
+    return ggx_D(g.alpha, m) * ggx_G1(g.alpha, in, m) / (4.0 * in.z);
+}
+__device__ __forceinline__ void ggx_sample_visible_11(double theta_i, double u1, double u2, double &slx, double &sly)
+{
+    if (theta_i < 1e-4) {
+        double r = safe_sqrt(u1 / (1.0 - u1));
+        double phi = 2.0 * kPi * u2;
+        slx = r * cos(phi); sly = r * sin(phi);
+        return;
+    }
+    double tan_i = tan(theta_i);
+    double a = 1.0 / tan_i;
+    double G1 = 2.0 / (1.0 + safe_sqrt(1.0 + 1.0 / (a * a)));
+    double A = 2.0 * u1 / G1 - 1.0;
+    if (fabs(A) == 1.0) A -= (A > 0 ? 1.0 : -1.0) * 1e-12;
+    double tmp = 1.0 / (A * A - 1.0);
+    double B = tan_i;
+    double D = safe_sqrt(B * B * tmp * tmp - (A * A - B * B) * tmp);
+    double s1 = B * tmp - D, s2 = B * tmp + D;
+    slx = (A < 0.0 || s2 > 1.0 / tan_i) ? s1 : s2;
+    double S;
+    if (u2 > 0.5) { S = 1.0; u2 = 2.0 * (u2 - 0.5); }
+    else { S = -1.0; u2 = 2.0 * (0.5 - u2); }
+    double z = (u2 * (u2 * (u2 * (-0.365728915865723) + 0.790235037209296) - 0.424965825137544) + 0.000152998850436920)
+             / (u2 * (u2 * (u2 * (u2 * 0.169507819808272 - 0.397203533833404) - 0.232500544458471) + 1.0) - 0.539825872510702);
+    sly = S * z * sqrt(1.0 + slx * slx);
+}
+// returns false when the sample is rejected (all outputs zero)
+__device__ __forceinline__ bool ggx_sample(const MaterialDev &g, const Vec3d &in, float u0, float u1,
+                                           float wo[3], float &pdf, float weight[3])
+{
+    const double al = g.alpha;
+    double sx = al * in.x, sy = al * in.y, sz = in.z;
+    double sl = sqrt(sx * sx + sy * sy + sz * sz);
+    if (sl > 0.0) { sx /= sl; sy /= sl; sz /= sl; }
+    double theta = 0.0, phi = 0.0;
+    if (sz < 0.99999) { theta = acos(sz); phi = atan2(sy, sx); }
+    double slx, sly;
+    ggx_sample_visible_11(theta, (double)u0, (double)u1, slx, sly);
+    double cp = cos(phi), sp = sin(phi);
+    double mx = (cp * slx - sp * sly) * al, my = (sp * slx + cp * sly) * al;
+    double nrm = 1.0 / sqrt(mx * mx + my * my + 1.0);
+    Vec3d m = { -mx * nrm, -my * nrm, nrm };
+    double c = in.x * m.x + in.y * m.y + in.z * m.z;
+    Vec3d out = { 2.0 * c * m.x - in.x, 2.0 * c * m.y - in.y, 2.0 * c * m.z - in.z };
+    if (!(out.z > 0.0) || !(c > 0.0)) return false;
+    double D = ggx_D(al, m);
+    double p = D * ggx_G1(al, in, m) / (4.0 * in.z);
+    if (!(p > 0.0)) return false;
+    float wx = (float)out.x, wy = (float)out.y, wz = (float)out.z;
+    if (!(wz > 0.0f)) return false;
+    wo[0] = wx; wo[1] = wy; wo[2] = wz;
+    pdf = (float)p;
+    double G1o = ggx_G1(al, out, m);
+    weight[0] = (float)(fresnel_conductor(c, g.eta[0], g.k[0]) * G1o);
+    weight[1] = (float)(fresnel_conductor(c, g.eta[1], g.k[1]) * G1o);
+    weight[2] = (float)(fresnel_conductor(c, g.eta[2], g.k[2]) * G1o);
+    return true;
+}
+
+// ---- a5 / a6 / a7 for one unit, any material kind ------------------------------------------
+// eval(): rgb = f * cos(theta_o), zero unless cos(theta_i) > 0 and cos(theta_o) > 0
+__device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o,
+                                          float wix, float wiy, float wiz, float wox, float woy, float woz,
+                                          float rgb[3])
+{
+    rgb[0] = rgb[1] = rgb[2] = 0.0f;
+    if (!(wiz > 0.0f) || !(woz > 0.0f)) return;
+    Vec3d in = normalized(wix, wiy, wiz), out = normalized(wox, woy, woz);
+    Rgbd v;
+    if (m.kind == KIND_GGX) {
+        v = ggx_eval(m, in, out);
+    } else {
+        v = table_brdf(m, o, in, out);
+        double c = (double)woz;
+        v.r *= c; v.g *= c; v.b *= c;
+    }
+    rgb[0] = (float)v.r; rgb[1] = (float)v.g; rgb[2] = (float)v.b;
+}
+
+__device__ __forceinline__ float unit_pdf(const MaterialDev &m, float wix, float wiy, float wiz, float wox, float woy, float woz)
+{
+    if (!(wiz > 0.0f) || !(woz > 0.0f)) return 0.0f;
+    if (m.kind == KIND_GGX) {
+        Vec3d in = normalized(wix, wiy, wiz), out = normalized(wox, woy, woz);
+        return (float)ggx_pdf(m, in, out);
+    }
+    return woz * kInvPiF;
+}
+
+__device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options &o,
+                                            float wix, float wiy, float wiz, float u0, float u1,
+                                            float wo[3], float &pdf, float weight[3])
+{
+    wo[0] = wo[1] = wo[2] = 0.0f; pdf = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
+    if (!(wiz > 0.0f)) return;
+    if (m.kind == KIND_GGX) {
+        Vec3d in = normalized(wix, wiy, wiz);
+        ggx_sample(m, in, u0, u1, wo, pdf, weight);
+        return;
+    }
+    float x, y, z;
+    square_to_cosine_hemisphere(o.disk_map, u0, u1, x, y, z);
+    wo[0] = x; wo[1] = y; wo[2] = z;
+    float p = z > 0.0f ? z * kInvPiF : 0.0f;
+    pdf = p;
+    if (!(p > 0.0f)) return;
+    float f[3];
+    unit_eval(m, o, wix, wiy, wiz, x, y, z, f);
+    weight[0] = __fdiv_rn(f[0], p); weight[1] = __fdiv_rn(f[1], p); weight[2] = __fdiv_rn(f[2], p);
+}
+
+// ---- synthetic inputs, bit-identical to the oracle's generator ---------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ void hemisphere_dir(uint64_t r, float &dx, float &dy, float &dz)
+{
+#pragma clang fp contract(off)
+    const float TWO_NEG24 = 0x1p-24f, STEP = 0x1.921fb6p-22f;
+    float z = (float)(uint32_t)(((r >> 41) << 1) | 1u) * TWO_NEG24;
+    int32_t k = (int32_t)((r >> 8) & 0xFFFFFFu);
+    int32_t q = (k + (1 << 21)) >> 22;
+    int32_t j = k - (q << 22);
+    float s, c;
+    sincos_quarter_f32((float)j * STEP, s, c);
+    float cs, sn;
+    switch (q & 3) {
+        case 0:  cs = c;  sn = s;  break;
+        case 1:  cs = -s; sn = c;  break;
+        case 2:  cs = -c; sn = -s; break;
+        default: cs = s;  sn = -c; break;
+    }
+    float rr = __fsqrt_rn(__builtin_fmaf(-z, z, 1.0f));
+    dx = rr * cs; dy = rr * sn; dz = z;
+}
+
+} // namespace mrl

@@ -1,0 +1,144 @@
+// merl_kernels.hip — gfx950 kernels of the batched BSDF hot path and their launchers.
+//
+// One lane = one unit (pair) per grid-stride step.  Streams (wi, wo, u in; rgb, pdf, wo', pdf',
+// weight out) are contiguous per wave: 768 B (xyz) / 512 B (uv) / 256 B (scalar) per
+// wave-instruction.  The table gather is 8 x 16 B per lookup from the padded RGBA f32 table
+// (phi_d fastest, so the two phi neighbours of a corner share a 32-B piece).
+#include "merl_kernels.hpp"
+
+namespace mrl {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+enum Mode : int { MODE_EVAL = 0, MODE_PDF = 1, MODE_SAMPLE = 2, MODE_EVAL_SAMPLE = 3 };
+
+__device__ __forceinline__ void load3(const float *p, size_t i, float &x, float &y, float &z)
+{
+    const float *q = p + 3 * i;
+    x = q[0]; y = q[1]; z = q[2];
+}
+__device__ __forceinline__ void store3(float *p, size_t i, const float v[3])
+{
+    float *q = p + 3 * i;
+    q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+}
+
+template <int MODE, bool MULTI>
+__global__ __launch_bounds__(kBlock) void k_batch(BatchArgs a)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+        MaterialDev m;
+        bool valid = true;
+        if constexpr (MULTI) {
+            int id = a.mat[i];
+            valid = id >= 0 && id < a.n_materials;
+            m = a.materials[valid ? id : 0];
+        } else {
+            m = a.single;
+        }
+        float wix, wiy, wiz;
+        load3(a.wi, i, wix, wiy, wiz);
+        if (!valid) wiz = 0.0f;                     // unknown material id: every output zero
+
+        if constexpr (MODE == MODE_EVAL || MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE) {
+            float wox, woy, woz;
+            load3(a.wo, i, wox, woy, woz);
+            if constexpr (MODE != MODE_PDF) {
+                float rgb[3];
+                unit_eval(m, a.opts, wix, wiy, wiz, wox, woy, woz, rgb);
+                store3(a.out_rgb, i, rgb);
+            }
+            if constexpr (MODE != MODE_EVAL) {
+                a.out_pdf[i] = unit_pdf(m, wix, wiy, wiz, wox, woy, woz);
+            }
+        }
+        if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) {
+            float u0 = a.u[2 * i], u1 = a.u[2 * i + 1];
+            float wo2[3], pdf2, w[3];
+            unit_sample(m, a.opts, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
+            store3(a.out_wo, i, wo2);
+            a.out_pdf2[i] = pdf2;
+            store3(a.out_weight, i, w);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_generate_pairs(uint64_t seed, uint64_t first, size_t n,
+                                                          float *wi, float *wo, float *u)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += stride) {
+        uint64_t i = first + t;
+        uint64_t r0 = mix64(seed ^ (3 * i)), r1 = mix64(seed ^ (3 * i + 1)), r2 = mix64(seed ^ (3 * i + 2));
+        float v[3];
+        hemisphere_dir(r0, v[0], v[1], v[2]);
+        store3(wi, t, v);
+        hemisphere_dir(r1, v[0], v[1], v[2]);
+        store3(wo, t, v);
+        u[2 * t + 0] = (float)(uint32_t)(r2 >> 40) * 0x1p-24f;
+        u[2 * t + 1] = (float)(uint32_t)((r2 >> 16) & 0xFFFFFFu) * 0x1p-24f;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_generate_materials(uint64_t seed, uint64_t first, size_t n,
+                                                              int n_materials, int32_t *mat)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += stride) {
+        uint64_t r = mix64((seed ^ 0x4D41544552494131ULL) + (first + t));
+        mat[t] = (int32_t)(((r >> 32) * (uint64_t)n_materials) >> 32);
+    }
+}
+
+inline unsigned grid_for(size_t n, int compute_units)
+{
+    size_t blocks = (n + kBlock - 1) / kBlock;
+    size_t cap = (size_t)compute_units * 8;         // 8 x 256-thread blocks per CU, grid-stride the rest
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+template <int MODE>
+hipError_t launch_mode(const BatchArgs &a, bool multi, int compute_units, hipStream_t stream)
+{
+    dim3 grid(grid_for(a.n, compute_units)), block(kBlock);
+    if (multi) hipLaunchKernelGGL((k_batch<MODE, true>), grid, block, 0, stream, a);
+    else       hipLaunchKernelGGL((k_batch<MODE, false>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int compute_units, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    switch (mode) {
+        case MODE_EVAL:        return launch_mode<MODE_EVAL>(a, multi, compute_units, stream);
+        case MODE_PDF:         return launch_mode<MODE_PDF>(a, multi, compute_units, stream);
+        case MODE_SAMPLE:      return launch_mode<MODE_SAMPLE>(a, multi, compute_units, stream);
+        case MODE_EVAL_SAMPLE: return launch_mode<MODE_EVAL_SAMPLE>(a, multi, compute_units, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_generate_pairs(uint64_t seed, uint64_t first, size_t n, float *wi, float *wo, float *u,
+                                 int compute_units, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_generate_pairs, dim3(grid_for(n, compute_units)), dim3(kBlock), 0, stream, seed, first, n, wi, wo, u);
+    return hipGetLastError();
+}
+
+hipError_t launch_generate_materials(uint64_t seed, uint64_t first, size_t n, int n_materials, int32_t *mat,
+                                     int compute_units, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_generate_materials, dim3(grid_for(n, compute_units)), dim3(kBlock), 0, stream, seed, first, n, n_materials, mat);
+    return hipGetLastError();
+}
+
+} // namespace mrl

@@ -1,0 +1,59 @@
+"""Regenerates tests/golden/*.npz from the CPU oracle (oracle/merl_oracle.c).
+
+    python tests/golden/make_golden.py
+
+PARITY UNPINNED: the reference (/root/reference) ships no source, tests or vectors for this
+path, so these fixtures are outputs of THIS repo's oracle on seeded synthetic tables, not of
+the reference.  They pin the oracle against regressions and give the GPU tests a frozen target;
+the analytic known-answer tests in tests/test_oracle_kat.py are what pins the oracle itself.
+Each file stores inputs, expected outputs and the (kind, seed) that rebuilds its table with
+mitsuba_customization_amd.synth.make_table — the table itself is not stored.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from mitsuba_customization_amd import synth  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+
+N = 2048
+CASES = [
+    # name, table kind, seed, lookup, node, disk_map, first pair index
+    ("merl_ggxtab_trilinear", "ggx_tab", 0, 1, 0, 0, 0),
+    ("merl_ggxtab_center_m3disk", "ggx_tab", 3, 1, 1, 1, 10_000),
+    ("merl_noise_trilinear", "noise", 5, 1, 0, 0, 20_000),
+    ("merl_noise_nearest", "noise", 5, 0, 0, 0, 30_000),
+    ("merl_affine_trilinear", "affine", 0, 1, 0, 0, 40_000),
+]
+
+
+def main():
+    for name, kind, seed, lookup, node, disk, first in CASES:
+        tab = synth.make_table(kind, seed)
+        T = ob.OracleTable(tab)
+        wi, wo, u = ob.generate_pairs(0x5EED, first, N)
+        # a few hand-picked pairs: normal incidence, mirror, retro-reflection, grazing, below horizon
+        s = np.float32(np.sqrt(0.5))
+        wi[:6] = [[0, 0, 1], [s, 0, s], [0.6, 0, 0.8], [0.9999, 0, 0.014142], [0.6, 0, -0.8], [0, 0.6, 0.8]]
+        wo[:6] = [[0, 0, 1], [-s, 0, s], [0.6, 0, 0.8], [0, 0.9999, 0.014142], [0.6, 0, 0.8], [0, 0.6, 0.8]]
+        o = ob.make_opts(lookup, node, disk)
+        rgb, pdf, wo2, pdf2, w = ob.eval_sample_multi([T], wi, wo, u, None, o)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), table_kind=kind, table_seed=seed, lookup=lookup,
+                            node=node, disk_map=disk, wi=wi, wo=wo, u=u, rgb=rgb, pdf=pdf, wo2=wo2, pdf2=pdf2, weight=w)
+    # GGX rough conductor (BASELINE config 3): alpha 0.1, gold-like eta/k
+    alpha = float(np.float32(0.1)); eta = [float(np.float32(x)) for x in (0.143, 0.375, 1.442)]
+    k = [float(np.float32(x)) for x in (3.983, 2.386, 1.603)]
+    G = ob.OracleGgx(alpha, eta, k)
+    wi, wo, u = ob.generate_pairs(0x5EED, 50_000, N)
+    wo2, pdf2, w = G.sample(wi, u)
+    np.savez_compressed(os.path.join(HERE, "ggx_alpha0p1.npz"), table_kind="ggx", table_seed=0, lookup=1, node=0, disk_map=0,
+                        alpha=alpha, eta=np.array(eta), k=np.array(k), wi=wi, wo=wo, u=u,
+                        rgb=G.eval(wi, wo), pdf=G.pdf(wi, wo), wo2=wo2, pdf2=pdf2, weight=w)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every
+symbol include/merl_hip.h declares; without a GPU it refuses to start (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from mitsuba_customization_amd import build, host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_lib()
+    return host.load_library()
+
+
+def test_header_and_binding_list_agree():
+    text = open(os.path.join(ROOT, "include", "merl_hip.h")).read()
+    declared = set(re.findall(r"\b(mrl_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(host.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in host.ABI_SYMBOLS:
+        assert hasattr(lib, name), name
+
+
+def test_strerror(lib):
+    assert lib.mrl_strerror(0) == b"ok"
+    assert b"no CPU fallback" in lib.mrl_strerror(-8)
+    assert lib.mrl_strerror(-1234) == b"unknown status"
+
+
+def test_no_gpu_means_no_context(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    ctx = C.c_void_p()
+    rc = lib.mrl_init(0, C.byref(ctx))
+    assert rc == -8 and not ctx                     # MRL_ERR_NO_DEVICE: fails loudly, no fallback
+    with pytest.raises(host.MerlHipError):
+        host.MerlHip(0)
+
+
+def test_null_context_is_rejected(lib):
+    assert lib.mrl_set_option(None, 0, 1) == -1
+    assert lib.mrl_eval_batch(None, None, None, None, 0, 4, None) == -1
+    assert lib.mrl_material_count(None) == -1
+    assert lib.mrl_destroy(None) == 0

@@ -1,0 +1,25 @@
+"""The oracle still reproduces the committed golden fixtures (regression pin; see
+tests/golden/make_golden.py — parity with the reference itself is unpinned)."""
+import glob
+import os
+
+import numpy as np
+
+
+def test_oracle_reproduces_golden(oracle, tables):
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    assert len(files) >= 6
+    for f in files:
+        z = np.load(f)
+        kind = str(z["table_kind"])
+        if kind == "ggx":
+            G = oracle.OracleGgx(float(z["alpha"]), z["eta"].tolist(), z["k"].tolist())
+            assert np.array_equal(G.eval(z["wi"], z["wo"]), z["rgb"]) and np.array_equal(G.pdf(z["wi"], z["wo"]), z["pdf"])
+            wo2, pdf2, w = G.sample(z["wi"], z["u"])
+            assert np.array_equal(wo2, z["wo2"]) and np.array_equal(pdf2, z["pdf2"]) and np.array_equal(w, z["weight"])
+            continue
+        T = oracle.OracleTable(tables(kind, int(z["table_seed"])))
+        o = oracle.make_opts(int(z["lookup"]), int(z["node"]), int(z["disk_map"]))
+        got = oracle.eval_sample_multi([T], z["wi"], z["wo"], z["u"], None, o)
+        for g, name in zip(got, ("rgb", "pdf", "wo2", "pdf2", "weight")):
+            assert np.array_equal(g, z[name]), (f, name)

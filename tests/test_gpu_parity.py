@@ -1,0 +1,327 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Every compute call goes through
+the C ABI (libmerl_hip.so) and is checked against the CPU oracle on identical input bits.
+
+Tolerances (BASELINE.json north_star): eval RGB, sample direction, pdf, weight <= 1e-6 relative.
+  * sampled directions and cosine pdfs are expected BIT-IDENTICAL (pinned f32 sequence);
+  * rgb / weight: |gpu - oracle| <= 1e-6 * |oracle| + 1e-30 (trilinear);
+  * nearest lookup: a bin can flip on an exact boundary, so the bound must hold for >= 99.99 %.
+Parity is vs this repo's oracle; the reference ships no vectors (parity unpinned).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6
+
+
+def rel_err(got, want):
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    return np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
+
+
+def assert_close(got, want, rel=REL, what=""):
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    bad = np.abs(got - want) > rel * np.abs(want) + 1e-30
+    assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} off, max rel {rel_err(got, want)[bad].max():.3e}"
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    from mitsuba_customization_amd import host
+    h = host.MerlHip(0)
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="module")
+def mats(gpu, tables):
+    """Materials uploaded once: ids by name + the oracle's view of each."""
+    from oracle import binding as ob
+    out = {}
+    for name, kind, seed in [("ggx_tab", "ggx_tab", 0), ("noise", "noise", 5), ("constant", "constant", 0),
+                             ("affine", "affine", 0), ("onehot", "onehot", 0), ("ggx_tab2", "ggx_tab", 9)]:
+        tab = tables(kind, seed)
+        out[name] = (gpu.upload_merl(tab), ob.OracleTable(tab), tab)
+    return out
+
+
+def to_dev(*arrs):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
+
+
+def set_opts(gpu, lookup=1, node=0, disk=0):
+    from mitsuba_customization_amd import host
+    gpu.set_option(host.OPT_LOOKUP, lookup); gpu.set_option(host.OPT_NODE, node); gpu.set_option(host.OPT_DISK_MAP, disk)
+
+
+# ------------------------------------------------------------------ generator
+def test_device_generator_is_bit_identical_to_oracle(gpu, oracle):
+    for first, n in [(0, 5000), (123456789, 3000), ((1 << 40) + 17, 1000)]:
+        wi, wo, u = gpu.generate_pairs(0x5EED, first, n)
+        cwi, cwo, cu = oracle.generate_pairs(0x5EED, first, n)
+        assert np.array_equal(wi.cpu().numpy(), cwi) and np.array_equal(wo.cpu().numpy(), cwo) and np.array_equal(u.cpu().numpy(), cu)
+    m = gpu.generate_materials(0x5EED, 77, 4000, 16).cpu().numpy()
+    assert np.array_equal(m, oracle.generate_materials(0x5EED, 77, 4000, 16))
+
+
+# ------------------------------------------------------------------ eval
+@pytest.mark.parametrize("name", ["ggx_tab", "noise", "constant", "affine", "onehot"])
+@pytest.mark.parametrize("node", [0, 1])
+def test_eval_trilinear_matches_oracle(gpu, oracle, mats, name, node):
+    mid, T, _ = mats[name]
+    set_opts(gpu, 1, node)
+    wi, wo, _ = oracle.generate_pairs(0x5EED, 1000, 20000)
+    dwi, dwo = to_dev(wi, wo)
+    got = gpu.eval(dwi, dwo, material=mid).cpu().numpy()
+    want = T.eval(wi, wo, oracle.make_opts(lookup=1, node=node))
+    assert_close(got, want, what=f"eval {name} node={node}")
+    set_opts(gpu)
+
+
+def test_eval_nearest_matches_oracle(gpu, oracle, mats):
+    mid, T, _ = mats["noise"]
+    set_opts(gpu, 0)
+    wi, wo, _ = oracle.generate_pairs(0x5EED, 7000, 50000)
+    dwi, dwo = to_dev(wi, wo)
+    got = gpu.eval(dwi, dwo, material=mid).cpu().numpy()
+    want = T.eval(wi, wo, oracle.make_opts(lookup=0))
+    ok = np.abs(got.astype(np.float64) - want) <= REL * np.abs(want) + 1e-30
+    assert ok.mean() >= 0.9999, f"nearest: {(~ok).sum()} mismatching values"
+    set_opts(gpu)
+
+
+def test_eval_guards_and_special_directions(gpu, oracle, mats):
+    mid, T, _ = mats["ggx_tab"]
+    s = np.float32(np.sqrt(0.5))
+    wi = np.array([[0, 0, 1], [0, 0, 1], [0.6, 0, 0.8], [0.6, 0, 0.8], [0.6, 0, -0.8], [0.6, 0, 0.8], [1, 0, 0],
+                   [s, 0, s], [0.6, 0, 0.8], [1e-4, 0, 1], [0.3, 0.4, 0.5], [3e-5, 4e-5, 1e-6]], np.float32)
+    wo = np.array([[0, 0, 1], [0.6, 0, 0.8], [0.6, 0, 0.8], [-0.6, 0, 0.8], [0.6, 0, 0.8], [0.6, 0, -0.8], [0, 0, 1],
+                   [-s, 0, s], [0, 0.6, 0.8], [-1e-4, 0, 1], [0.9, 1.2, 1.5], [0, 1, 1e-3]], np.float32)
+    dwi, dwo = to_dev(wi, wo)
+    got = gpu.eval(dwi, dwo, material=mid).cpu().numpy()
+    want = T.eval(wi, wo)
+    # rows 3, 7, 9: exact mirror pairs (h == n): phi_d is arbitrary up to the table's own variation
+    # in phi at theta_h = 0; the synthetic GGX table is phi-independent there, so they must agree too
+    assert_close(got, want, rel=2e-6, what="special directions")
+    assert (got[4] == 0).all() and (got[5] == 0).all() and (got[6] == 0).all()
+    pdf = gpu.pdf(dwi, dwo, material=mid).cpu().numpy()
+    assert np.array_equal(pdf, oracle.pdf(wi, wo))
+
+
+def test_unnormalised_and_nonfinite_inputs(gpu, oracle, mats):
+    mid, T, _ = mats["ggx_tab"]
+    wi = np.array([[0.3, 0.4, 0.5], [3, 4, 5], [np.nan, 0, 1], [0, 0, np.inf]], np.float32)
+    wo = np.array([[0.9, 1.2, 1.5], [0.09, 0.12, 0.15], [0, 0, 1], [0, 0, 1]], np.float32)
+    dwi, dwo = to_dev(wi, wo)
+    got = gpu.eval(dwi, dwo, material=mid).cpu().numpy()
+    want = T.eval(wi, wo)
+    assert_close(got[:2], want[:2], what="unnormalised")       # directions are normalised inside
+    assert np.allclose(got[0] / 1.5, got[1] / 0.15, rtol=1e-6)   # f depends on direction only
+    # NaN / inf propagate or zero exactly as in the oracle (no trap, no hang)
+    assert np.array_equal(np.isnan(got[2:]), np.isnan(want[2:]))
+
+
+# ------------------------------------------------------------------ pdf / sample
+def test_pdf_bit_exact(gpu, oracle, mats):
+    mid, _, _ = mats["constant"]
+    wi, wo, _ = oracle.generate_pairs(1, 0, 30000)
+    wi[::7, 2] *= -1; wo[::11, 2] *= -1
+    dwi, dwo = to_dev(wi, wo)
+    assert np.array_equal(gpu.pdf(dwi, dwo, material=mid).cpu().numpy(), oracle.pdf(wi, wo))
+
+
+@pytest.mark.parametrize("disk", [0, 1])
+@pytest.mark.parametrize("name", ["ggx_tab", "noise"])
+def test_sample_matches_oracle(gpu, oracle, mats, name, disk):
+    mid, T, _ = mats[name]
+    set_opts(gpu, 1, 0, disk)
+    wi, _, u = oracle.generate_pairs(0x5EED, 40000, 30000)
+    u[:6] = [[0.5, 0.5], [1.0, 0.5], [0.5, 0.0], [0.75, 0.75], [0.25, 0.75], [0.0, 0.0]]
+    wi[10, 2] = -wi[10, 2]
+    dwi, du = to_dev(wi, u)
+    wo, pdf, w = [t.cpu().numpy() for t in gpu.sample(dwi, du, material=mid)]
+    cwo, cpdf, cw = T.sample(wi, u, oracle.make_opts(disk_map=disk))
+    assert np.array_equal(wo, cwo), "sampled direction must be bit-identical"
+    assert np.array_equal(pdf, cpdf), "sampled pdf must be bit-identical"
+    assert_close(w, cw, what=f"sample weight {name}")
+    set_opts(gpu)
+
+
+# ------------------------------------------------------------------ fused unit, host pointers, chunks
+def test_eval_sample_fused_equals_parts_and_oracle(gpu, oracle, mats):
+    mid, T, _ = mats["ggx_tab"]
+    wi, wo, u = oracle.generate_pairs(0x5EED, 0, 65536 + 77)       # ragged: not a multiple of the block
+    dwi, dwo, du = to_dev(wi, wo, u)
+    rgb, pdf, wo2, pdf2, w = [t.cpu().numpy() for t in gpu.eval_sample(dwi, dwo, du, material=mid)]
+    assert np.array_equal(rgb, gpu.eval(dwi, dwo, material=mid).cpu().numpy())
+    assert np.array_equal(pdf, gpu.pdf(dwi, dwo, material=mid).cpu().numpy())
+    s_wo, s_pdf, s_w = [t.cpu().numpy() for t in gpu.sample(dwi, du, material=mid)]
+    assert np.array_equal(wo2, s_wo) and np.array_equal(pdf2, s_pdf) and np.array_equal(w, s_w)
+    c_rgb, c_pdf, c_wo2, c_pdf2, c_w = oracle.eval_sample_multi([T], wi, wo, u, None)
+    assert_close(rgb, c_rgb, what="fused rgb"); assert np.array_equal(pdf, c_pdf)
+    assert np.array_equal(wo2, c_wo2) and np.array_equal(pdf2, c_pdf2); assert_close(w, c_w, what="fused weight")
+
+
+def test_host_pointer_path_equals_device_path(gpu, oracle, mats):
+    from mitsuba_customization_amd import host
+    mid, _, _ = mats["noise"]
+    wi, wo, u = oracle.generate_pairs(3, 0, 10000)
+    dwi, dwo, du = to_dev(wi, wo, u)
+    dev = [t.cpu().numpy() for t in gpu.eval_sample(dwi, dwo, du, material=mid)]
+    gpu.set_option(host.OPT_HOST_CHUNK, 3000)                         # force several ragged chunks
+    hst = gpu.eval_sample(wi, wo, u, material=mid)
+    gpu.set_option(host.OPT_HOST_CHUNK, 1 << 22)
+    for a, b in zip(dev, hst):
+        assert np.array_equal(a, b)
+    one = gpu.eval(wi[:1].copy(), wo[:1].copy(), material=mid)        # n = 1 (scalar-call plumbing)
+    assert np.array_equal(one, dev[0][:1])
+
+
+def test_empty_and_error_paths(gpu, oracle, mats):
+    from mitsuba_customization_amd import host
+    mid, _, _ = mats["constant"]
+    z3 = np.zeros((0, 3), np.float32)
+    assert gpu.eval(z3, z3, material=mid).shape == (0, 3)
+    wi, wo, _ = oracle.generate_pairs(3, 0, 16)
+    with pytest.raises(host.MerlHipError) as e:
+        gpu.eval(wi, wo, material=9999)
+    assert e.value.status == -6
+    (dwi,) = to_dev(wi)
+    with pytest.raises(host.MerlHipError) as e:                       # device wi + host wo
+        gpu._check(gpu._lib.mrl_eval_batch(gpu._ctx, dwi.data_ptr(), wo.ctypes.data, None, mid, 16,
+                                           np.empty((16, 3), np.float32).ctypes.data), "mix")
+    assert e.value.status == -7
+    with pytest.raises(host.MerlHipError) as e:
+        gpu.load_merl("/nonexistent/file.binary")
+    assert e.value.status == -3
+
+
+def test_load_merl_file_roundtrip(gpu, oracle, mats, tmp_path):
+    from mitsuba_customization_amd import synth
+    _, T, tab = mats["noise"]
+    p = str(tmp_path / "noise.binary")
+    synth.write_merl_binary(p, tab)
+    mid = gpu.load_merl(p)
+    wi, wo, _ = oracle.generate_pairs(11, 0, 4096)
+    dwi, dwo = to_dev(wi, wo)
+    a = gpu.eval(dwi, dwo, material=mid).cpu().numpy()
+    b = gpu.eval(dwi, dwo, material=mats["noise"][0]).cpu().numpy()
+    assert np.array_equal(a, b)
+    small = str(tmp_path / "small.binary")
+    synth.write_merl_binary(small, synth.make_table("affine", dims=(4, 5, 6)))
+    from mitsuba_customization_amd import host
+    with pytest.raises(host.MerlHipError) as e:
+        gpu.load_merl(small)
+    assert e.value.status == -4
+
+
+# ------------------------------------------------------------------ mixed materials (config 4 shape)
+def test_mixed_materials_match_oracle(gpu, oracle, tables):
+    from oracle import binding as ob
+    tabs = [tables("ggx_tab", 100 + i) if i % 2 == 0 else tables("noise", 100 + i) for i in range(6)]
+    ids = [gpu.upload_merl(t) for t in tabs]
+    base = ids[0]
+    assert ids == list(range(base, base + 6))
+    n = 40000
+    wi, wo, u = oracle.generate_pairs(0x5EED, 9999, n)
+    mat_local = oracle.generate_materials(0x5EED, 9999, n, 6)
+    mat = (mat_local + base).astype(np.int32)
+    mat[5] = -1; mat[6] = 10_000                                      # unknown ids -> all outputs zero
+    dwi, dwo, du = to_dev(wi, wo, u)
+    (dmat,) = to_dev(mat)
+    got = [t.cpu().numpy() for t in gpu.eval_sample(dwi, dwo, du, mat=dmat)]
+    cm = mat_local.copy(); cm[5] = -1; cm[6] = 10_000
+    want = oracle.eval_sample_multi([ob.OracleTable(t) for t in tabs], wi, wo, u, cm)
+    assert_close(got[0], want[0], what="mixed rgb"); assert np.array_equal(got[1], want[1])
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]); assert_close(got[4], want[4], what="mixed weight")
+    for g in got:
+        assert (g[5] == 0).all() and (g[6] == 0).all()
+    # a mixed batch equals per-material single launches, bit for bit
+    for k in range(6):
+        sel = np.nonzero(mat == base + k)[0]
+        swi, swo = to_dev(wi[sel], wo[sel])
+        assert np.array_equal(gpu.eval(swi, swo, material=base + k).cpu().numpy(), got[0][sel])
+
+
+# ------------------------------------------------------------------ customized_measurement (free dims)
+@pytest.mark.parametrize("dims", [(32, 16, 48), (90, 90, 180), (7, 5, 3), (1, 1, 1)])
+def test_custom_table_dims(gpu, oracle, tables, dims):
+    from oracle import binding as ob
+    tab = tables("noise", 42, dims)
+    scale = (0.5, 2.0, 1.25)
+    mid = gpu.upload_table(tab, scale)
+    kind, d = gpu.material_info(mid)
+    assert kind == 1 and d == dims
+    T = ob.OracleTable(tab, scale)
+    wi, wo, u = oracle.generate_pairs(0x5EED, 31, 20000)
+    dwi, dwo, du = to_dev(wi, wo, u)
+    for node in (0, 1):
+        set_opts(gpu, 1, node)
+        got = gpu.eval(dwi, dwo, material=mid).cpu().numpy()
+        assert_close(got, T.eval(wi, wo, oracle.make_opts(node=node)), what=f"custom dims {dims} node {node}")
+    set_opts(gpu)
+    wo2, pdf2, w = [t.cpu().numpy() for t in gpu.sample(dwi, du, material=mid)]
+    cwo, cpdf, cw = T.sample(wi, u)
+    assert np.array_equal(wo2, cwo) and np.array_equal(pdf2, cpdf); assert_close(w, cw, what="custom weight")
+
+
+def test_custom_table_file(gpu, oracle, tables, tmp_path):
+    from mitsuba_customization_amd import synth
+    from oracle import binding as ob
+    tab = tables("noise", 4, (20, 30, 40))
+    p = str(tmp_path / "custom.binary")
+    synth.write_merl_binary(p, tab)
+    mid = gpu.load_table(p, (1.0, 1.0, 1.0))
+    wi, wo, _ = oracle.generate_pairs(5, 0, 5000)
+    dwi, dwo = to_dev(wi, wo)
+    assert_close(gpu.eval(dwi, dwo, material=mid).cpu().numpy(), ob.OracleTable(tab, (1, 1, 1)).eval(wi, wo), what="custom file")
+
+
+# ------------------------------------------------------------------ GGX (config 3)
+def test_ggx_matches_oracle(gpu, oracle):
+    eta, k = (0.143, 0.375, 1.442), (3.983, 2.386, 1.603)
+    for alpha in (0.1, 0.5):
+        mid = gpu.ggx(alpha, eta, k)
+        G = oracle.OracleGgx(np.float32(alpha).item(), [np.float32(x).item() for x in eta], [np.float32(x).item() for x in k])
+        wi, wo, u = oracle.generate_pairs(0x5EED, 555, 30000)
+        wi[0] = (0, 0, 1); wo[0] = (0, 0, 1); wi[1] = (0, 0, 1); u[1] = (0.3, 0.9)     # normal incidence branch
+        dwi, dwo, du = to_dev(wi, wo, u)
+        assert_close(gpu.eval(dwi, dwo, material=mid).cpu().numpy(), G.eval(wi, wo), what=f"ggx eval a={alpha}")
+        assert_close(gpu.pdf(dwi, dwo, material=mid).cpu().numpy(), G.pdf(wi, wo), what="ggx pdf")
+        wo2, pdf2, w = [t.cpu().numpy() for t in gpu.sample(dwi, du, material=mid)]
+        cwo, cpdf, cw = G.sample(wi, u)
+        assert np.abs(wo2.astype(np.float64) - cwo).max() <= 1.2e-7       # f64 -> f32 rounding may flip one ulp
+        assert_close(pdf2, cpdf, rel=2e-6, what="ggx sample pdf"); assert_close(w, cw, what="ggx weight")
+        assert np.array_equal(pdf2 > 0, cpdf > 0)
+
+
+# ------------------------------------------------------------------ golden fixtures
+def test_golden_fixtures(gpu, tables):
+    import glob, os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    assert files, "golden fixtures missing"
+    from mitsuba_customization_amd import host
+    for f in files:
+        z = np.load(f)
+        kind, seed = str(z["table_kind"]), int(z["table_seed"])
+        set_opts(gpu, int(z["lookup"]), int(z["node"]), int(z["disk_map"]))
+        if kind == "ggx":
+            mid = gpu.ggx(float(z["alpha"]), z["eta"].tolist(), z["k"].tolist())
+        else:
+            mid = gpu.upload_merl(tables(kind, seed))
+        dwi, dwo, du = to_dev(z["wi"], z["wo"], z["u"])
+        rgb, pdf, wo2, pdf2, w = [t.cpu().numpy() for t in gpu.eval_sample(dwi, dwo, du, material=mid)]
+        if int(z["lookup"]) == 1:
+            assert_close(rgb, z["rgb"], what=f"{os.path.basename(f)} rgb"); assert_close(w, z["weight"], what="weight")
+        else:
+            ok = np.abs(rgb - z["rgb"]) <= REL * np.abs(z["rgb"]) + 1e-30
+            assert ok.mean() > 0.999
+        assert_close(pdf, z["pdf"], rel=2e-6 if kind == "ggx" else 0.0, what="pdf")
+        assert np.abs(wo2 - z["wo2"]).max() <= (1.2e-7 if kind == "ggx" else 0.0)
+        assert_close(pdf2, z["pdf2"], rel=2e-6 if kind == "ggx" else 0.0, what="pdf2")
+    set_opts(gpu)
