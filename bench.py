@@ -167,7 +167,7 @@ def main():
         from oracle import binding as ob                       # checker / cpu_baseline leg only
         k = min(args.parity_sample, n)
         if k > 0:
-            idx = torch.linspace(0, n - 1, k, device=dev).long()
+            idx = (torch.arange(k, device=dev, dtype=torch.int64) * (n - 1)) // max(k - 1, 1)   # exact integers (f32 linspace rounds n-1 up to n)
             hin = [x[idx].cpu().numpy() for x in (wi, wo, u)]
             hout = [x[idx].cpu().numpy() for x in out]
             lookup = 1 if args.lookup == "trilinear" else 0

@@ -68,8 +68,11 @@ const char *mrl_strerror(int status);
 const char *mrl_last_error(const mrl_ctx *ctx);
 int mrl_set_option(mrl_ctx *ctx, int option, int value);
 int mrl_get_option(const mrl_ctx *ctx, int option, int *value);
-/* launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own */
+/* launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL is HIP's default
+ * (null) stream, which is what torch uses unless a stream context is active */
 int mrl_set_stream(mrl_ctx *ctx, void *hip_stream);
+/* back to the context's own non-blocking stream (the state after mrl_init) */
+int mrl_reset_stream(mrl_ctx *ctx);
 int mrl_synchronize(mrl_ctx *ctx);
 int mrl_device_info(const mrl_ctx *ctx, char *name, size_t name_len, int *compute_units, size_t *total_mem);
 

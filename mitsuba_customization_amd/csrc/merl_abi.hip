@@ -363,7 +363,14 @@ int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
 int mrl_set_stream(mrl_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return MRL_ERR_INVALID;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;     // NULL = HIP's default stream
+    return MRL_OK;
+}
+
+int mrl_reset_stream(mrl_ctx *ctx)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    ctx->stream = ctx->own_stream;
     return MRL_OK;
 }
 

@@ -163,7 +163,7 @@ __device__ __forceinline__ void square_to_cosine_hemisphere(int disk_map, float 
         float aa = a * a, bb = b * b;
         bool first = disk_map ? !(fabsf(a) < fabsf(b)) : (aa > bb);
         float r = first ? a : b;
-        float ratio = first ? __fdiv_rn(b, a) : __fdiv_rn(a, b);
+        float ratio = first ? (b / a) : (a / b);
         float s, c;
         sincos_quarter_f32(QUARTER_PI * ratio, s, c);
         x = r * (first ? c : s);
@@ -171,7 +171,7 @@ __device__ __forceinline__ void square_to_cosine_hemisphere(int disk_map, float 
     }
     float xx = x * x;
     float zz = 1.0f - __builtin_fmaf(y, y, xx);
-    z = zz > 0.0f ? __fsqrt_rn(zz) : 0.0f;
+    z = zz > 0.0f ? __builtin_sqrtf(zz) : 0.0f;
     if (disk_map == 0 && z == 0.0f) z = 1e-10f;
 }
 
@@ -341,7 +341,7 @@ __device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options 
     if (!(p > 0.0f)) return;
     float f[3];
     unit_eval(m, o, wix, wiy, wiz, x, y, z, f);
-    weight[0] = __fdiv_rn(f[0], p); weight[1] = __fdiv_rn(f[1], p); weight[2] = __fdiv_rn(f[2], p);
+    weight[0] = (f[0] / p); weight[1] = (f[1] / p); weight[2] = (f[2] / p);
 }
 
 // ---- synthetic inputs, bit-identical to the oracle's generator ---------------
@@ -369,7 +369,7 @@ __device__ __forceinline__ void hemisphere_dir(uint64_t r, float &dx, float &dy,
         case 2:  cs = -c; sn = -s; break;
         default: cs = s;  sn = -c; break;
     }
-    float rr = __fsqrt_rn(__builtin_fmaf(-z, z, 1.0f));
+    float rr = __builtin_sqrtf(__builtin_fmaf(-z, z, 1.0f));
     dx = rr * cs; dy = rr * sn; dz = z;
 }
 

@@ -22,7 +22,7 @@ KIND_MERL, KIND_TABLE, KIND_GGX = 0, 1, 2
 # every symbol include/merl_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "mrl_init", "mrl_destroy", "mrl_strerror", "mrl_last_error", "mrl_set_option", "mrl_get_option",
-    "mrl_set_stream", "mrl_synchronize", "mrl_device_info",
+    "mrl_set_stream", "mrl_reset_stream", "mrl_synchronize", "mrl_device_info",
     "mrl_material_load_merl", "mrl_material_upload_f64", "mrl_material_upload_table", "mrl_material_load_table",
     "mrl_material_ggx", "mrl_material_count", "mrl_material_info",
     "mrl_eval_batch", "mrl_pdf_batch", "mrl_sample_batch", "mrl_eval_sample_batch",
@@ -64,6 +64,7 @@ def load_library(path: Optional[str] = None):
     L.mrl_set_option.argtypes = [vp, C.c_int, C.c_int]
     L.mrl_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.mrl_set_stream.argtypes = [vp, vp]
+    L.mrl_reset_stream.argtypes = [vp]
     L.mrl_synchronize.argtypes = [vp]
     L.mrl_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
     L.mrl_material_load_merl.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
@@ -168,7 +169,7 @@ class MerlHip:
         self._check(self._lib.mrl_set_stream(self._ctx, C.c_void_p(s)), "mrl_set_stream")
 
     def use_own_stream(self):
-        self._check(self._lib.mrl_set_stream(self._ctx, None), "mrl_set_stream")
+        self._check(self._lib.mrl_reset_stream(self._ctx), "mrl_reset_stream")
 
     def synchronize(self):
         self._check(self._lib.mrl_synchronize(self._ctx), "mrl_synchronize")

@@ -37,9 +37,13 @@ def main():
         T = ob.OracleTable(tab)
         wi, wo, u = ob.generate_pairs(0x5EED, first, N)
         # a few hand-picked pairs: normal incidence, mirror, retro-reflection, grazing, below horizon
+        # (only on the GGX-shaped table: at theta_d = 0 or theta_h = 0 the angle phi_d is undefined, so
+        #  the exact retro-reflection / normal-incidence pairs are meaningful only where the table does
+        #  not vary with phi_d there — true of a physical BRDF, not of the noise / affine tables)
         s = np.float32(np.sqrt(0.5))
-        wi[:6] = [[0, 0, 1], [s, 0, s], [0.6, 0, 0.8], [0.9999, 0, 0.014142], [0.6, 0, -0.8], [0, 0.6, 0.8]]
-        wo[:6] = [[0, 0, 1], [-s, 0, s], [0.6, 0, 0.8], [0, 0.9999, 0.014142], [0.6, 0, 0.8], [0, 0.6, 0.8]]
+        if kind == "ggx_tab":
+            wi[:6] = [[0, 0, 1], [s, 0, s], [0.6, 0, 0.8], [0.9999, 0, 0.014142], [0.6, 0, -0.8], [0, 0.6, 0.8]]
+            wo[:6] = [[0, 0, 1], [-s, 0, s], [0.6, 0, 0.8], [0, 0.9999, 0.014142], [0.6, 0, 0.8], [0, 0.6, 0.8]]
         o = ob.make_opts(lookup, node, disk)
         rgb, pdf, wo2, pdf2, w = ob.eval_sample_multi([T], wi, wo, u, None, o)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), table_kind=kind, table_seed=seed, lookup=lookup,
