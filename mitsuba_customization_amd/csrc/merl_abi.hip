@@ -38,7 +38,7 @@ struct mrl_ctx {
     mrl::MaterialDev *d_materials = nullptr;
     size_t d_materials_cap = 0;
     mrl::Options opts{ 1, 0, 0 };
-    int kernel_variant = 0;
+    int kernel_variant = 1;
     size_t host_chunk = (size_t)1 << 22;
     void *d_stage = nullptr;
     size_t d_stage_units = 0;
@@ -210,7 +210,7 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
     a.opts = ctx->opts;
     bool multi = c.mat != nullptr;
     if (!multi) a.single = ctx->materials[(size_t)c.single_id].dev;
-    MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->compute_units, ctx->stream));
+    MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->kernel_variant, ctx->compute_units, ctx->stream));
     return MRL_OK;
 }
 

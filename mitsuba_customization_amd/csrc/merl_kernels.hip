@@ -5,6 +5,7 @@
 // wave-instruction.  The table gather is 8 x 16 B per lookup from the padded RGBA f32 table
 // (phi_d fastest, so the two phi neighbours of a corner share a 32-B piece).
 #include "merl_kernels.hpp"
+#include "merl_table_fast.hpp"
 
 namespace mrl {
 
@@ -66,6 +67,53 @@ __global__ __launch_bounds__(kBlock) void k_batch(BatchArgs a)
     }
 }
 
+// ---- variant 1: tuned table path (merl_table_fast.hpp); GGX lanes of a mixed batch take the generic functions ----
+template <int MODE, bool MULTI>
+__global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+        MaterialDev m;
+        bool known = true;
+        if constexpr (MULTI) {
+            int id = a.mat[i];
+            known = id >= 0 && id < a.n_materials;
+            m = a.materials[known ? id : 0];
+        } else {
+            m = a.single;
+        }
+        float wix, wiy, wiz;
+        load3(a.wi, i, wix, wiy, wiz);
+        if (!known) wiz = 0.0f;
+        float wox = 0.0f, woy = 0.0f, woz = 1.0f, u0 = 0.0f, u1 = 0.0f;
+        if constexpr (MODE != MODE_SAMPLE) load3(a.wo, i, wox, woy, woz);
+        if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) { u0 = a.u[2 * i]; u1 = a.u[2 * i + 1]; }
+
+        float rgb[3], pdf = 0.0f, wo2[3], pdf2, w[3];
+        if (MULTI && m.kind == KIND_GGX) {
+            if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) unit_eval(m, a.opts, wix, wiy, wiz, wox, woy, woz, rgb);
+            if constexpr (MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE) pdf = unit_pdf(m, wix, wiy, wiz, wox, woy, woz);
+            if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) unit_sample(m, a.opts, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
+        } else {
+            if constexpr (MODE == MODE_PDF) {
+                pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
+            } else {
+                const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
+                if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) fast::unit_eval(m, a.opts, in, wiz, wox, woy, woz, rgb);
+                if constexpr (MODE == MODE_EVAL_SAMPLE) pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
+                if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) fast::unit_sample(m, a.opts, in, wiz, u0, u1, wo2, pdf2, w);
+            }
+        }
+        if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) store3(a.out_rgb, i, rgb);
+        if constexpr (MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE) a.out_pdf[i] = pdf;
+        if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) {
+            store3(a.out_wo, i, wo2);
+            a.out_pdf2[i] = pdf2;
+            store3(a.out_weight, i, w);
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_generate_pairs(uint64_t seed, uint64_t first, size_t n,
                                                           float *wi, float *wo, float *u)
 {
@@ -103,24 +151,32 @@ inline unsigned grid_for(size_t n, int compute_units)
 }
 
 template <int MODE>
-hipError_t launch_mode(const BatchArgs &a, bool multi, int compute_units, hipStream_t stream)
+hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int compute_units, hipStream_t stream)
 {
     dim3 grid(grid_for(a.n, compute_units)), block(kBlock);
-    if (multi) hipLaunchKernelGGL((k_batch<MODE, true>), grid, block, 0, stream, a);
-    else       hipLaunchKernelGGL((k_batch<MODE, false>), grid, block, 0, stream, a);
+    // variant 0: generic kernel (every kind, ocml math) — the A/B baseline;
+    // variant 1: tuned table kernel; a single-material GGX launch has no table path and stays generic
+    const bool tuned = variant >= 1 && (multi || a.single.kind != KIND_GGX);
+    if (tuned) {
+        if (multi) hipLaunchKernelGGL((k_table<MODE, true>), grid, block, 0, stream, a);
+        else       hipLaunchKernelGGL((k_table<MODE, false>), grid, block, 0, stream, a);
+    } else {
+        if (multi) hipLaunchKernelGGL((k_batch<MODE, true>), grid, block, 0, stream, a);
+        else       hipLaunchKernelGGL((k_batch<MODE, false>), grid, block, 0, stream, a);
+    }
     return hipGetLastError();
 }
 
 } // namespace
 
-hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int compute_units, hipStream_t stream)
+hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int compute_units, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     switch (mode) {
-        case MODE_EVAL:        return launch_mode<MODE_EVAL>(a, multi, compute_units, stream);
-        case MODE_PDF:         return launch_mode<MODE_PDF>(a, multi, compute_units, stream);
-        case MODE_SAMPLE:      return launch_mode<MODE_SAMPLE>(a, multi, compute_units, stream);
-        case MODE_EVAL_SAMPLE: return launch_mode<MODE_EVAL_SAMPLE>(a, multi, compute_units, stream);
+        case MODE_EVAL:        return launch_mode<MODE_EVAL>(a, multi, variant, compute_units, stream);
+        case MODE_PDF:         return launch_mode<MODE_PDF>(a, multi, variant, compute_units, stream);
+        case MODE_SAMPLE:      return launch_mode<MODE_SAMPLE>(a, multi, variant, compute_units, stream);
+        case MODE_EVAL_SAMPLE: return launch_mode<MODE_EVAL_SAMPLE>(a, multi, variant, compute_units, stream);
     }
     return hipErrorInvalidValue;
 }

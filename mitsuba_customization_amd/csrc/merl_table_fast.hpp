@@ -1,0 +1,163 @@
+// merl_table_fast.hpp — the tuned per-lane path for table materials (MERL / customized_measurement).
+//
+// Same real-valued functions as merl_device.hpp (rows a2–a6 of SURVEY.md §8a), re-expressed for
+// the CDNA4 VALU:
+//   * f64 division / sqrt / atan2 from ocml (IEEE-exact, ~100+ instructions each with their
+//     scaling and special-case paths) are replaced by v_rcp_f64 / v_rsq_f64 seeds + one Newton
+//     step + a residual correction (<= 1 ulp-ish, no denormal scaling: operands here are O(1)),
+//     and a reduced-range odd polynomial for atan (|r| <= tan(pi/8), degree 8 in r^2, abs error
+//     9.4e-15).  The table coordinate stays good to ~1e-13 texel — far inside the 1e-8 budget.
+//   * branch-free: guards become selects at the very end, so the eval lookup and the sample
+//     lookup of one unit sit in one basic block and their 16 gathers overlap with the ALU work.
+#pragma once
+#include "merl_device.hpp"
+
+namespace mrl {
+namespace fast {
+
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
+// n / d for finite d != 0: reciprocal + Newton + one residual correction
+__device__ __forceinline__ double div_fast(double n, double d)
+{
+    double y = rcp_nr(d);
+    double q = n * y;
+    double r = __builtin_fma(-d, q, n);
+    return __builtin_fma(r, y, q);
+}
+
+// sqrt(x) and 1/sqrt(x) for x > 0 (x == 0 gives sqrt 0, rsqrt unspecified-but-finite-free)
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);       // residual of the square root
+    g = __builtin_fma(d, h, g);
+    s = x > 0.0 ? g : 0.0;
+    rs = h + h;
+}
+__device__ __forceinline__ double sqrt_fast(double x)
+{
+    double s, rs;
+    sqrt_rsqrt(x, s, rs);
+    return s;
+}
+
+// atan2(a, b) for a >= 0, b >= 0 -> [0, pi/2]; atan2(0, 0) = 0
+__device__ __forceinline__ double atan2_q1(double a, double b)
+{
+    constexpr double T = 0.41421356237309503;           // tan(pi/8)
+    constexpr double QUARTER_PI = 0.78539816339744830962;
+    const bool swap = a > b;
+    const double mn = swap ? b : a, mx = swap ? a : b;
+    const bool big = mn > T * mx;
+    const double num = big ? mn - mx : mn;
+    double den = big ? mn + mx : mx;
+    den = den == 0.0 ? 1.0 : den;
+    const double r = div_fast(num, den);                  // |r| <= tan(pi/8)
+    const double z = r * r;
+    double p = 0x1.f5ef263ad0056p-6;
+    p = __builtin_fma(p, z, -0x1.e116a805760c8p-5);
+    p = __builtin_fma(p, z, 0x1.35c9c1f5f80ecp-4);
+    p = __builtin_fma(p, z, -0x1.73d90b0295f34p-4);
+    p = __builtin_fma(p, z, 0x1.c714c3f46eb8ep-4);
+    p = __builtin_fma(p, z, -0x1.249228bbcc3c1p-3);
+    p = __builtin_fma(p, z, 0x1.9999990f93ea4p-3);
+    p = __builtin_fma(p, z, -0x1.55555554e3467p-2);
+    p = __builtin_fma(p, z, 0x1.fffffffffff02p-1);
+    const double t = __builtin_fma(r, p, big ? QUARTER_PI : 0.0);
+    return swap ? kHalfPi - t : t;
+}
+
+struct Vec3 { double x, y, z; };
+
+__device__ __forceinline__ Vec3 normalize_f32(float x, float y, float z)
+{
+    double dx = x, dy = y, dz = z;
+    double s, rs;
+    sqrt_rsqrt(__builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz)), s, rs);
+    return { dx * rs, dy * rs, dz * rs };
+}
+
+// a2 + a3 for unit in/out (see merl_device.hpp::half_diff_coords for the derivation)
+__device__ __forceinline__ Coords coords(const Vec3 &in, const Vec3 &out, double k_th, double k_td, double k_pd)
+{
+    const double sx = in.x + out.x, sy = in.y + out.y, sz = in.z + out.z;
+    const double ex = in.x - out.x, ey = in.y - out.y, ez = in.z - out.z;
+    const double rho2 = __builtin_fma(sx, sx, sy * sy);
+    const double s2 = __builtin_fma(sz, sz, rho2);
+    const double e2 = __builtin_fma(ex, ex, __builtin_fma(ey, ey, ez * ez));
+    const double rho = sqrt_fast(rho2), ns = sqrt_fast(s2), ne = sqrt_fast(e2);
+    const double th = atan2_q1(rho, sz);
+    const double td = atan2_q1(ne, ns);
+    double py = __builtin_fma(ey, sx, -(ex * sy));
+    double px = -ez * ns;
+    const bool degenerate = rho2 == 0.0;                  // h == n: phi_h = atan2(0,0) = 0
+    py = degenerate ? in.y : py;
+    px = degenerate ? in.x : px;
+    const double t = atan2_q1(__builtin_fabs(py), __builtin_fabs(px));
+    const double pd = ((px < 0.0) != (py < 0.0)) ? kPi - t : t;   // atan2(py,px) folded into [0,pi]
+    Coords c;
+    c.xh = sqrt_fast(th * k_th);                          // k_th = n_th^2 / (pi/2)
+    c.xd = td * k_td;                                     // k_td = n_td / (pi/2)
+    c.xp = pd * k_pd;                                     // k_pd = n_pd / pi
+    return c;
+}
+
+// per-material constants of the coordinate maps
+struct TableMaps {
+    double k_th, k_td, k_pd;
+    __device__ __forceinline__ explicit TableMaps(const MaterialDev &m)
+        : k_th((double)m.n_th * (double)m.n_th / kHalfPi), k_td((double)m.n_td / kHalfPi), k_pd((double)m.n_pd / kPi) {}
+};
+
+// BRDF value (no cosine) — gathers issued as early as the addresses exist
+__device__ __forceinline__ Rgbd table_brdf(const MaterialDev &m, const Options &o, const Vec3 &in, const Vec3 &out)
+{
+    const TableMaps k(m);
+    const Coords c = coords(in, out, k.k_th, k.k_td, k.k_pd);
+    return o.lookup ? lookup_trilinear(m, c, o.node) : lookup_nearest(m, c);
+}
+
+// a5: eval (cosine included); valid == false gives zeros
+__device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o, const Vec3 &in,
+                                          float wiz, float wox, float woy, float woz, float rgb[3])
+{
+    const Vec3 out = normalize_f32(wox, woy, woz);
+    Rgbd v = table_brdf(m, o, in, out);
+    const double c = (double)woz;
+    const bool valid = (wiz > 0.0f) && (woz > 0.0f);
+    rgb[0] = valid ? (float)(v.r * c) : 0.0f;
+    rgb[1] = valid ? (float)(v.g * c) : 0.0f;
+    rgb[2] = valid ? (float)(v.b * c) : 0.0f;
+}
+
+// a6: sample
+__device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options &o, const Vec3 &in, float wiz,
+                                            float u0, float u1, float wo[3], float &pdf, float weight[3])
+{
+    float x, y, z;
+    square_to_cosine_hemisphere(o.disk_map, u0, u1, x, y, z);
+    const bool valid = wiz > 0.0f;
+    const float p = z > 0.0f ? z * kInvPiF : 0.0f;
+    float f[3];
+    unit_eval(m, o, in, wiz, x, y, z, f);
+    const bool has = valid && (p > 0.0f);
+    const float ps = has ? p : 1.0f;
+    wo[0] = valid ? x : 0.0f; wo[1] = valid ? y : 0.0f; wo[2] = valid ? z : 0.0f;
+    pdf = valid ? p : 0.0f;
+    weight[0] = has ? f[0] / ps : 0.0f;
+    weight[1] = has ? f[1] / ps : 0.0f;
+    weight[2] = has ? f[2] / ps : 0.0f;
+}
+
+} // namespace fast
+} // namespace mrl
