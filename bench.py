@@ -36,6 +36,7 @@ def parse():
     p.add_argument("--table", default="ggx_tab", help="synthetic table kind, or a path to a real MERL .binary")
     p.add_argument("--lookup", choices=["trilinear", "nearest"], default="trilinear")
     p.add_argument("--kernel", type=int, default=-1, help="kernel variant (MRL_OPT_KERNEL); -1 = library default")
+    p.add_argument("--layout", type=int, default=-1, help="table layout (MRL_OPT_TABLE_LAYOUT); -1 = library default")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-units", type=int, default=0, help="units for the CPU baseline sample (0 = auto, ~1-3 s wall)")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the separately reported RCCL gather leg")
@@ -70,6 +71,8 @@ def main():
     if args.kernel >= 0:
         gpu.set_option(host.OPT_KERNEL, args.kernel)
     gpu.set_option(host.OPT_LOOKUP, 1 if args.lookup == "trilinear" else 0)
+    if args.layout >= 0:
+        gpu.set_option(host.OPT_TABLE_LAYOUT, args.layout)
 
     if os.path.exists(args.table):
         table = synth.read_merl_binary(args.table)
@@ -133,6 +136,7 @@ def main():
             "table": table_name,
             "lookup": args.lookup,
             "kernel_variant": gpu.get_option(host.OPT_KERNEL),
+            "table_layout": gpu.get_option(host.OPT_TABLE_LAYOUT),
             "sharding": f"index tiles x{world}, tables replicated, no data-path collective",
         },
         "roofline": {

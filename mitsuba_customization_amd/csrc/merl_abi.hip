@@ -39,6 +39,7 @@ struct mrl_ctx {
     size_t d_materials_cap = 0;
     mrl::Options opts{ 1, 0, 0 };
     int kernel_variant = 1;
+    int table_layout = 0;            // layout of tables uploaded from now on (mrl::Layout)
     size_t host_chunk = (size_t)1 << 22;
     void *d_stage = nullptr;
     size_t d_stage_units = 0;
@@ -126,8 +127,27 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1;
     const size_t plane = (size_t)n_th * n_td * n_pd;
+    const int layout = ctx->table_layout;
     std::vector<float4> host;
-    try { host.resize(H * D * P); } catch (const std::bad_alloc &) { return fail(ctx, MRL_ERR_OOM, "host staging for table"); }
+    try { host.resize(layout == mrl::LAYOUT_BRICK ? plane * 8 : H * D * P); } catch (const std::bad_alloc &) { return fail(ctx, MRL_ERR_OOM, "host staging for table"); }
+    auto texel = [&](size_t sh, size_t sd, size_t sp, int ch) -> float {
+        double v = planar[(sh * n_td + sd) * n_pd + sp + (size_t)ch * plane] * scale[ch];
+        return v > 0.0 ? (float)v : 0.0f;
+    };
+    if (layout == mrl::LAYOUT_BRICK) {
+        // brick (ih,id,ip): the 8 corners (ih+a clamped, id+b clamped, ip+c wrapped), RGB packed, in one 128-B line
+        for (size_t ih = 0; ih < (size_t)n_th; ++ih)
+            for (size_t id = 0; id < (size_t)n_td; ++id)
+                for (size_t ip = 0; ip < (size_t)n_pd; ++ip) {
+                    float *dst = reinterpret_cast<float *>(host.data() + ((ih * n_td + id) * n_pd + ip) * 8);
+                    for (int k = 0; k < 8; ++k) {
+                        size_t sh = std::min<size_t>(ih + (k >> 2), n_th - 1), sd = std::min<size_t>(id + ((k >> 1) & 1), n_td - 1);
+                        size_t sp = (ip + (k & 1)) % (size_t)n_pd;
+                        for (int ch = 0; ch < 3; ++ch) dst[3 * k + ch] = texel(sh, sd, sp, ch);
+                    }
+                    for (int pad = 24; pad < 32; ++pad) dst[pad] = 0.0f;
+                }
+    } else
     for (size_t ih = 0; ih < H; ++ih) {
         size_t sh = std::min<size_t>(ih, n_th - 1);
         for (size_t id = 0; id < D; ++id) {
@@ -153,6 +173,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     m.dev.row_td = (int)P;
     m.dev.row_th = (int)(D * P);
     m.dev.texels = m.d_texels;
+    m.dev.layout = layout;
     ctx->materials.push_back(m);
     int rc = sync_material_array(ctx);
     if (rc != MRL_OK) { ctx->materials.pop_back(); (void)hipFree(m.d_texels); return rc; }
@@ -210,7 +231,7 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
     a.opts = ctx->opts;
     bool multi = c.mat != nullptr;
     if (!multi) a.single = ctx->materials[(size_t)c.single_id].dev;
-    MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->kernel_variant, ctx->compute_units, ctx->stream));
+    MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->kernel_variant, ctx->table_layout, ctx->compute_units, ctx->stream));
     return MRL_OK;
 }
 
@@ -343,6 +364,14 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
         case MRL_OPT_DISK_MAP: if (value < 0 || value > 1) break; ctx->opts.disk_map = value; return MRL_OK;
         case MRL_OPT_KERNEL:   if (value < 0) break; ctx->kernel_variant = value; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: if (value < 1) break; ctx->host_chunk = (size_t)value; return MRL_OK;
+        case MRL_OPT_TABLE_LAYOUT: {
+            if (value < 0 || value > 1) break;
+            if (value != ctx->table_layout)
+                for (const auto &m : ctx->materials)
+                    if (m.dev.kind != mrl::KIND_GGX) return fail(ctx, MRL_ERR_INVALID, "table layout is context-wide: set it before the first table is uploaded");
+            ctx->table_layout = value;
+            return MRL_OK;
+        }
     }
     return fail(ctx, MRL_ERR_INVALID, "bad option or value");
 }
@@ -356,6 +385,7 @@ int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
         case MRL_OPT_DISK_MAP: *value = ctx->opts.disk_map; return MRL_OK;
         case MRL_OPT_KERNEL: *value = ctx->kernel_variant; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: *value = (int)ctx->host_chunk; return MRL_OK;
+        case MRL_OPT_TABLE_LAYOUT: *value = ctx->table_layout; return MRL_OK;
     }
     return MRL_ERR_INVALID;
 }

@@ -22,6 +22,7 @@ constexpr double kHalfPi = 1.57079632679489661923;
 constexpr float kInvPiF = 0.31830988618379067154f;
 
 enum Kind : int { KIND_MERL = 0, KIND_TABLE = 1, KIND_GGX = 2 };
+enum Layout : int { LAYOUT_ROWS = 0, LAYOUT_BRICK = 1 };
 
 // One material as the kernels see it (array in device memory; single-material launches get it
 // by value, i.e. in SGPRs).
@@ -30,7 +31,9 @@ struct MaterialDev {
     int n_th, n_td, n_pd;        // logical dims
     int row_td;                  // texels per theta_d row      = n_pd + 1 (phi wrap texel appended)
     int row_th;                  // texels per theta_h slab     = (n_td + 1) * (n_pd + 1)
-    const float4 *texels;        // [(n_th+1)][(n_td+1)][(n_pd+1)] RGBA f32, scaled, negatives clamped
+    const float4 *texels;        // layout 0: [(n_th+1)][(n_td+1)][(n_pd+1)] RGBA f32, scaled, negatives clamped
+                                 // layout 1: [n_th][n_td][n_pd] bricks of 128 B = the cell's 8 corners, RGB f32 packed
+    int layout;                  // LAYOUT_ROWS / LAYOUT_BRICK
     double alpha;                // GGX
     double eta[3], k[3];
 };
@@ -80,11 +83,16 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 struct Rgbd { double r, g, b; };
 
-__device__ __forceinline__ Rgbd lookup_nearest(const MaterialDev &m, const Coords &c)
+template <int LAYOUT>
+__device__ __forceinline__ Rgbd lookup_nearest_t(const MaterialDev &m, const Coords &c)
 {
     int ih = clampi((int)c.xh, 0, m.n_th - 1);
     int id = clampi((int)c.xd, 0, m.n_td - 1);
     int ip = clampi((int)c.xp, 0, m.n_pd - 1);
+    if constexpr (LAYOUT == LAYOUT_BRICK) {
+        const float4 t = m.texels[(((size_t)ih * m.n_td + id) * m.n_pd + ip) * 8];     // corner 0 = the texel itself
+        return { (double)t.x, (double)t.y, (double)t.z };
+    }
     float4 t = m.texels[(size_t)ih * m.row_th + (size_t)id * m.row_td + ip];
     return { (double)t.x, (double)t.y, (double)t.z };
 }
@@ -107,27 +115,49 @@ __device__ __forceinline__ void split_periodic(double x, int n, int &i0, double 
     i0 = i < 0 ? i + n : i;
 }
 
-__device__ __forceinline__ Rgbd lookup_trilinear(const MaterialDev &m, const Coords &c, int node)
+template <int LAYOUT>
+__device__ __forceinline__ Rgbd lookup_trilinear_t(const MaterialDev &m, const Coords &c, int node)
 {
     const double shift = node ? 0.5 : 0.0;
     int h0, d0, p0; double fh, fd, fp;
     split_clamped(c.xh - shift, m.n_th, h0, fh);
     split_clamped(c.xd - shift, m.n_td, d0, fd);
     split_periodic(c.xp - shift, m.n_pd, p0, fp);
+    const double gh = 1.0 - fh, gd = 1.0 - fd, gp = 1.0 - fp;
+    const double w000 = gh * gd * gp, w001 = gh * gd * fp, w010 = gh * fd * gp, w011 = gh * fd * fp;
+    const double w100 = fh * gd * gp, w101 = fh * gd * fp, w110 = fh * fd * gp, w111 = fh * fd * fp;
+    if constexpr (LAYOUT == LAYOUT_BRICK) {
+        // one 128-B line holds the whole neighbourhood: 8 corners x RGB f32 = 96 B, six 16-B loads
+        const float4 *q = m.texels + (((size_t)h0 * m.n_td + d0) * m.n_pd + p0) * 8;
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+        // corner k (k = 4a + 2b + c) channel ch = float[3k + ch]
+        Rgbd o;
+        o.r = w000 * q0.x + w001 * q0.w + w010 * q1.z + w011 * q2.y + w100 * q3.x + w101 * q3.w + w110 * q4.z + w111 * q5.y;
+        o.g = w000 * q0.y + w001 * q1.x + w010 * q1.w + w011 * q2.z + w100 * q3.y + w101 * q4.x + w110 * q4.w + w111 * q5.z;
+        o.b = w000 * q0.z + w001 * q1.y + w010 * q2.x + w011 * q2.w + w100 * q3.z + w101 * q4.y + w110 * q5.x + w111 * q5.w;
+        return o;
+    }
     const float4 *b = m.texels + ((size_t)h0 * m.row_th + (size_t)d0 * m.row_td + p0);
     // issue all eight 16-B gathers before any use
     const float4 t000 = b[0],                 t001 = b[1];
     const float4 t010 = b[m.row_td],          t011 = b[m.row_td + 1];
     const float4 t100 = b[m.row_th],          t101 = b[m.row_th + 1];
     const float4 t110 = b[m.row_th + m.row_td], t111 = b[m.row_th + m.row_td + 1];
-    const double gh = 1.0 - fh, gd = 1.0 - fd, gp = 1.0 - fp;
-    const double w000 = gh * gd * gp, w001 = gh * gd * fp, w010 = gh * fd * gp, w011 = gh * fd * fp;
-    const double w100 = fh * gd * gp, w101 = fh * gd * fp, w110 = fh * fd * gp, w111 = fh * fd * fp;
     Rgbd o;
     o.r = w000 * t000.x + w001 * t001.x + w010 * t010.x + w011 * t011.x + w100 * t100.x + w101 * t101.x + w110 * t110.x + w111 * t111.x;
     o.g = w000 * t000.y + w001 * t001.y + w010 * t010.y + w011 * t011.y + w100 * t100.y + w101 * t101.y + w110 * t110.y + w111 * t111.y;
     o.b = w000 * t000.z + w001 * t001.z + w010 * t010.z + w011 * t011.z + w100 * t100.z + w101 * t101.z + w110 * t110.z + w111 * t111.z;
     return o;
+}
+
+// runtime-layout wrappers (generic kernel)
+__device__ __forceinline__ Rgbd lookup_nearest(const MaterialDev &m, const Coords &c)
+{
+    return m.layout == LAYOUT_BRICK ? lookup_nearest_t<LAYOUT_BRICK>(m, c) : lookup_nearest_t<LAYOUT_ROWS>(m, c);
+}
+__device__ __forceinline__ Rgbd lookup_trilinear(const MaterialDev &m, const Coords &c, int node)
+{
+    return m.layout == LAYOUT_BRICK ? lookup_trilinear_t<LAYOUT_BRICK>(m, c, node) : lookup_trilinear_t<LAYOUT_ROWS>(m, c, node);
 }
 
 // BRDF value (no cosine) of a table material for unit in/out

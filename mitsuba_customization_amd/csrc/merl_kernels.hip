@@ -25,6 +25,20 @@ __device__ __forceinline__ void store3(float *p, size_t i, const float v[3])
     float *q = p + 3 * i;
     q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
 }
+// streaming (read-once / write-once) accesses: the nt hint keeps them from displacing table
+// lines in the XCD's L2
+template <bool NT> __device__ __forceinline__ float ldf(const float *p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
+template <bool NT> __device__ __forceinline__ void stf(float *p, float v) { if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template <bool NT> __device__ __forceinline__ void load3s(const float *p, size_t i, float &x, float &y, float &z)
+{
+    const float *q = p + 3 * i;
+    x = ldf<NT>(q); y = ldf<NT>(q + 1); z = ldf<NT>(q + 2);
+}
+template <bool NT> __device__ __forceinline__ void store3s(float *p, size_t i, const float v[3])
+{
+    float *q = p + 3 * i;
+    stf<NT>(q, v[0]); stf<NT>(q + 1, v[1]); stf<NT>(q + 2, v[2]);
+}
 
 template <int MODE, bool MULTI>
 __global__ __launch_bounds__(kBlock) void k_batch(BatchArgs a)
@@ -68,7 +82,7 @@ __global__ __launch_bounds__(kBlock) void k_batch(BatchArgs a)
 }
 
 // ---- variant 1: tuned table path (merl_table_fast.hpp); GGX lanes of a mixed batch take the generic functions ----
-template <int MODE, bool MULTI>
+template <int MODE, bool MULTI, bool NT, int LOOKUP, int LAYOUT>
 __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
 {
     const size_t stride = (size_t)gridDim.x * kBlock;
@@ -83,11 +97,11 @@ __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
             m = a.single;
         }
         float wix, wiy, wiz;
-        load3(a.wi, i, wix, wiy, wiz);
+        load3s<NT>(a.wi, i, wix, wiy, wiz);
         if (!known) wiz = 0.0f;
         float wox = 0.0f, woy = 0.0f, woz = 1.0f, u0 = 0.0f, u1 = 0.0f;
-        if constexpr (MODE != MODE_SAMPLE) load3(a.wo, i, wox, woy, woz);
-        if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) { u0 = a.u[2 * i]; u1 = a.u[2 * i + 1]; }
+        if constexpr (MODE != MODE_SAMPLE) load3s<NT>(a.wo, i, wox, woy, woz);
+        if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) { u0 = ldf<NT>(a.u + 2 * i); u1 = ldf<NT>(a.u + 2 * i + 1); }
 
         float rgb[3], pdf = 0.0f, wo2[3], pdf2, w[3];
         if (MULTI && m.kind == KIND_GGX) {
@@ -99,17 +113,184 @@ __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
                 pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
             } else {
                 const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
-                if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) fast::unit_eval(m, a.opts, in, wiz, wox, woy, woz, rgb);
+                if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) fast::unit_eval<LOOKUP, LAYOUT>(m, a.opts, in, wiz, wox, woy, woz, rgb);
                 if constexpr (MODE == MODE_EVAL_SAMPLE) pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
-                if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) fast::unit_sample(m, a.opts, in, wiz, u0, u1, wo2, pdf2, w);
+                if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) fast::unit_sample<LOOKUP, LAYOUT>(m, a.opts, in, wiz, u0, u1, wo2, pdf2, w);
             }
         }
-        if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) store3(a.out_rgb, i, rgb);
-        if constexpr (MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE) a.out_pdf[i] = pdf;
+        if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) store3s<NT>(a.out_rgb, i, rgb);
+        if constexpr (MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE) stf<NT>(a.out_pdf + i, pdf);
         if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) {
-            store3(a.out_wo, i, wo2);
-            a.out_pdf2[i] = pdf2;
-            store3(a.out_weight, i, w);
+            store3s<NT>(a.out_wo, i, wo2);
+            stf<NT>(a.out_pdf2 + i, pdf2);
+            store3s<NT>(a.out_weight, i, w);
+        }
+    }
+}
+
+// ---- variant 3: brick layout + cooperative LDS-DMA fetch of the interpolation neighbourhood ----------
+// With one lane per unit, every lane's six 16-B loads of its brick hit a different 128-B line: the CU's
+// texture addresser (TCP tag lookup, one lane-address per clock) becomes the limit (TA_BUSY 84 %,
+// profiles/r01_v2_brick_pmc_summary.json).  Here the wave fetches its 64 bricks cooperatively instead:
+// in step k lanes 8g..8g+7 copy the 128-B brick of unit 8k+g with ONE global_load_lds_dwordx4 (16 B per
+// lane, the eight lanes cover the whole line: 2 tag lookups instead of 6-8), straight into LDS with no
+// VGPR staging.  Brick addresses travel between lanes by ds_bpermute.  The LDS image of a DMA is
+// lane-linear, so the 16-B piece a lane copies is XOR-swizzled on the SOURCE side
+// (piece = (lane&7) ^ ((unit>>1)&7)); unit j then reads its piece p at slot 8j + (p ^ ((j>>1)&7)),
+// which is bank-conflict-free for ds_read_b128's 16-lane groups.
+constexpr int kDmaBlock = 256;
+
+__device__ __forceinline__ unsigned brick_swz(unsigned unit) { return (unit >> 1) & 7u; }
+
+template <bool MULTI>
+__device__ __forceinline__ void brick_dma(const float4 *single_base, uint32_t idx, const float4 *lane_base,
+                                          float4 *lds_slots, unsigned lane)
+{
+    const unsigned g = lane >> 3, piece_lane = lane & 7u;
+    uint32_t lo = 0, hi = 0;
+    if constexpr (MULTI) {
+        const uint64_t addr = (uint64_t)(lane_base + (size_t)idx * 8);
+        lo = (uint32_t)addr; hi = (uint32_t)(addr >> 32);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned unit = 8u * k + g;
+        const unsigned piece = piece_lane ^ brick_swz(unit);
+        const float4 *src;
+        if constexpr (MULTI) {
+            const uint32_t slo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(unit << 2), (int)lo);
+            const uint32_t shi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(unit << 2), (int)hi);
+            src = (const float4 *)(((uint64_t)shi << 32) | slo) + piece;
+        } else {
+            const uint32_t sidx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(unit << 2), (int)idx);
+            src = single_base + (size_t)sidx * 8 + piece;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds_slots + k * 64), 16, 0, 0);
+    }
+}
+
+struct BrickWeights { double fh, fd, fp; };
+
+// a3 tail for the brick layout: cell index + interpolation fractions
+__device__ __forceinline__ uint32_t brick_cell(const MaterialDev &m, const Coords &c, int node, BrickWeights &w)
+{
+    const double shift = node ? 0.5 : 0.0;
+    int h0, d0, p0;
+    split_clamped(c.xh - shift, m.n_th, h0, w.fh);
+    split_clamped(c.xd - shift, m.n_td, d0, w.fd);
+    split_periodic(c.xp - shift, m.n_pd, p0, w.fp);
+    return (uint32_t)((h0 * m.n_td + d0) * m.n_pd + p0);
+}
+
+__device__ __forceinline__ Rgbd brick_interp(const float4 *lds_slots, unsigned lane, const BrickWeights &w)
+{
+    const unsigned f = brick_swz(lane);
+    const float4 *q = lds_slots + 8u * lane;
+    const float4 q0 = q[0u ^ f], q1 = q[1u ^ f], q2 = q[2u ^ f], q3 = q[3u ^ f], q4 = q[4u ^ f], q5 = q[5u ^ f];
+    const double gh = 1.0 - w.fh, gd = 1.0 - w.fd, gp = 1.0 - w.fp;
+    const double w000 = gh * gd * gp, w001 = gh * gd * w.fp, w010 = gh * w.fd * gp, w011 = gh * w.fd * w.fp;
+    const double w100 = w.fh * gd * gp, w101 = w.fh * gd * w.fp, w110 = w.fh * w.fd * gp, w111 = w.fh * w.fd * w.fp;
+    Rgbd o;
+    o.r = w000 * q0.x + w001 * q0.w + w010 * q1.z + w011 * q2.y + w100 * q3.x + w101 * q3.w + w110 * q4.z + w111 * q5.y;
+    o.g = w000 * q0.y + w001 * q1.x + w010 * q1.w + w011 * q2.z + w100 * q3.y + w101 * q4.x + w110 * q4.w + w111 * q5.z;
+    o.b = w000 * q0.z + w001 * q1.y + w010 * q2.x + w011 * q2.w + w100 * q3.z + w101 * q4.y + w110 * q5.x + w111 * q5.w;
+    return o;
+}
+
+template <int MODE, bool MULTI, bool NT>
+__global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
+{
+    static_assert(MODE != MODE_PDF, "pdf needs no table");
+    constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
+    constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
+    constexpr int LOOKUPS = (HAS_EVAL ? 1 : 0) + (HAS_SAMPLE ? 1 : 0);
+    __shared__ float4 lds[kDmaBlock / 64][LOOKUPS][512];      // 8 KB per wave and lookup
+
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float4 *ldsA = lds[wave][0];
+    float4 *ldsB = lds[wave][LOOKUPS - 1];
+    const size_t stride = (size_t)gridDim.x * kDmaBlock;
+    for (size_t base = (size_t)blockIdx.x * kDmaBlock + wave * 64u; base < a.n; base += stride) {
+        const size_t i_raw = base + lane;
+        const bool active = i_raw < a.n;
+        const size_t i = active ? i_raw : a.n - 1;            // tail lanes recompute the last unit, store nothing
+
+        MaterialDev m;
+        bool known = true;
+        if constexpr (MULTI) {
+            int id = a.mat[i];
+            known = id >= 0 && id < a.n_materials;
+            m = a.materials[known ? id : 0];
+        } else {
+            m = a.single;
+        }
+        const bool is_table = m.kind != KIND_GGX;
+        // lanes without a table (GGX / unknown id) still take part in the cooperative copy: give them a
+        // harmless, valid 128-B source (the material array itself) and cell 0
+        const float4 *lane_base = (MULTI && !is_table) ? (const float4 *)a.materials : m.texels;
+
+        float wix, wiy, wiz;
+        load3s<NT>(a.wi, i, wix, wiy, wiz);
+        if (!known) wiz = 0.0f;
+        float wox = 0.0f, woy = 0.0f, woz = 1.0f, u0 = 0.0f, u1 = 0.0f;
+        if constexpr (HAS_EVAL) load3s<NT>(a.wo, i, wox, woy, woz);
+        if constexpr (HAS_SAMPLE) { u0 = ldf<NT>(a.u + 2 * i); u1 = ldf<NT>(a.u + 2 * i + 1); }
+
+        const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
+        const fast::TableMaps maps(m);
+        BrickWeights wA, wB;
+        uint32_t cellA = 0, cellB = 0;
+        float sx = 0.0f, sy = 0.0f, sz = 1.0f;
+        if constexpr (HAS_EVAL) {
+            const fast::Vec3 out = fast::normalize_f32(wox, woy, woz);
+            cellA = brick_cell(m, fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wA);
+            if (MULTI && !is_table) cellA = 0;
+        }
+        if constexpr (HAS_SAMPLE) {
+            square_to_cosine_hemisphere(a.opts.disk_map, u0, u1, sx, sy, sz);
+            const fast::Vec3 out = fast::normalize_f32(sx, sy, sz);
+            cellB = brick_cell(m, fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wB);
+            if (MULTI && !is_table) cellB = 0;
+        }
+        if constexpr (HAS_EVAL) brick_dma<MULTI>(m.texels, cellA, lane_base, ldsA, lane);
+        if constexpr (HAS_SAMPLE) brick_dma<MULTI>(m.texels, cellB, lane_base, ldsB, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed (own wave only: no barrier)
+
+        float rgb[3] = { 0.0f, 0.0f, 0.0f }, pdf = 0.0f, wo2[3] = { 0.0f, 0.0f, 0.0f }, pdf2 = 0.0f, w[3] = { 0.0f, 0.0f, 0.0f };
+        if constexpr (HAS_EVAL) {
+            const Rgbd v = brick_interp(ldsA, lane, wA);
+            const bool valid = (wiz > 0.0f) && (woz > 0.0f);
+            const double c = (double)woz;
+            rgb[0] = valid ? (float)(v.r * c) : 0.0f; rgb[1] = valid ? (float)(v.g * c) : 0.0f; rgb[2] = valid ? (float)(v.b * c) : 0.0f;
+            if constexpr (MODE == MODE_EVAL_SAMPLE) pdf = valid ? woz * kInvPiF : 0.0f;
+        }
+        if constexpr (HAS_SAMPLE) {
+            const Rgbd v = brick_interp(ldsB, lane, wB);
+            const bool valid = wiz > 0.0f;
+            const float p = sz > 0.0f ? sz * kInvPiF : 0.0f;
+            const bool has = valid && (p > 0.0f);
+            const double c = (double)sz;
+            const float f0 = has ? (float)(v.r * c) : 0.0f, f1 = has ? (float)(v.g * c) : 0.0f, f2 = has ? (float)(v.b * c) : 0.0f;
+            const float ps = has ? p : 1.0f;
+            wo2[0] = valid ? sx : 0.0f; wo2[1] = valid ? sy : 0.0f; wo2[2] = valid ? sz : 0.0f;
+            pdf2 = valid ? p : 0.0f;
+            w[0] = f0 / ps; w[1] = f1 / ps; w[2] = f2 / ps;
+        }
+        asm volatile("" ::: "memory");                        // LDS reads above stay ahead of the next step's DMA
+        if (MULTI && !is_table) {                             // GGX lanes of a mixed batch: generic functions
+            if constexpr (HAS_EVAL) unit_eval(m, a.opts, wix, wiy, wiz, wox, woy, woz, rgb);
+            if constexpr (MODE == MODE_EVAL_SAMPLE) pdf = unit_pdf(m, wix, wiy, wiz, wox, woy, woz);
+            if constexpr (HAS_SAMPLE) unit_sample(m, a.opts, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
+        }
+        if (active) {
+            if constexpr (HAS_EVAL) store3s<NT>(a.out_rgb, i, rgb);
+            if constexpr (MODE == MODE_EVAL_SAMPLE) stf<NT>(a.out_pdf + i, pdf);
+            if constexpr (HAS_SAMPLE) {
+                store3s<NT>(a.out_wo, i, wo2);
+                stf<NT>(a.out_pdf2 + i, pdf2);
+                store3s<NT>(a.out_weight, i, w);
+            }
         }
     }
 }
@@ -150,16 +331,47 @@ inline unsigned grid_for(size_t n, int compute_units)
     return (unsigned)blocks;
 }
 
+// runtime (multi, nt, lookup, layout) -> compile-time kernel
+template <int MODE, bool MULTI, bool NT, int LOOKUP>
+void launch_table3(const BatchArgs &a, int layout, dim3 grid, dim3 block, hipStream_t stream)
+{
+    if (layout == LAYOUT_BRICK) hipLaunchKernelGGL((k_table<MODE, MULTI, NT, LOOKUP, LAYOUT_BRICK>), grid, block, 0, stream, a);
+    else                        hipLaunchKernelGGL((k_table<MODE, MULTI, NT, LOOKUP, LAYOUT_ROWS>), grid, block, 0, stream, a);
+}
+template <int MODE, bool MULTI, bool NT>
+void launch_table2(const BatchArgs &a, int lookup, int layout, dim3 grid, dim3 block, hipStream_t stream)
+{
+    if (lookup) launch_table3<MODE, MULTI, NT, 1>(a, layout, grid, block, stream);
+    else        launch_table3<MODE, MULTI, NT, 0>(a, layout, grid, block, stream);
+}
 template <int MODE>
-hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int compute_units, hipStream_t stream)
+void launch_table(const BatchArgs &a, bool multi, bool nt, int lookup, int layout, dim3 grid, dim3 block, hipStream_t stream)
+{
+    if (multi) { if (nt) launch_table2<MODE, true, true>(a, lookup, layout, grid, block, stream); else launch_table2<MODE, true, false>(a, lookup, layout, grid, block, stream); }
+    else       { if (nt) launch_table2<MODE, false, true>(a, lookup, layout, grid, block, stream); else launch_table2<MODE, false, false>(a, lookup, layout, grid, block, stream); }
+}
+
+template <int MODE>
+hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, int compute_units, hipStream_t stream)
 {
     dim3 grid(grid_for(a.n, compute_units)), block(kBlock);
     // variant 0: generic kernel (every kind, ocml math) — the A/B baseline;
     // variant 1: tuned table kernel; a single-material GGX launch has no table path and stays generic
     const bool tuned = variant >= 1 && (multi || a.single.kind != KIND_GGX);
+    if constexpr (MODE != MODE_PDF) {
+        // variant 3: cooperative LDS-DMA brick fetch (brick layout + trilinear only; otherwise variant 2)
+        if (tuned && variant >= 3 && layout == LAYOUT_BRICK && a.opts.lookup == 1) {
+            // 64 KB (two lookups) or 32 KB (one) of LDS per 256-thread block: 2 or 4 blocks per CU
+            constexpr int per_cu = (MODE == MODE_EVAL_SAMPLE) ? 2 : 4;
+            size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;
+            if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
+            if (multi) hipLaunchKernelGGL((k_table_dma<MODE, true, true>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);
+            else       hipLaunchKernelGGL((k_table_dma<MODE, false, true>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);
+            return hipGetLastError();
+        }
+    }
     if (tuned) {
-        if (multi) hipLaunchKernelGGL((k_table<MODE, true>), grid, block, 0, stream, a);
-        else       hipLaunchKernelGGL((k_table<MODE, false>), grid, block, 0, stream, a);
+        launch_table<MODE>(a, multi, variant >= 2, a.opts.lookup, layout, grid, block, stream);
     } else {
         if (multi) hipLaunchKernelGGL((k_batch<MODE, true>), grid, block, 0, stream, a);
         else       hipLaunchKernelGGL((k_batch<MODE, false>), grid, block, 0, stream, a);
@@ -169,14 +381,14 @@ hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int compute_
 
 } // namespace
 
-hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int compute_units, hipStream_t stream)
+hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int layout, int compute_units, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     switch (mode) {
-        case MODE_EVAL:        return launch_mode<MODE_EVAL>(a, multi, variant, compute_units, stream);
-        case MODE_PDF:         return launch_mode<MODE_PDF>(a, multi, variant, compute_units, stream);
-        case MODE_SAMPLE:      return launch_mode<MODE_SAMPLE>(a, multi, variant, compute_units, stream);
-        case MODE_EVAL_SAMPLE: return launch_mode<MODE_EVAL_SAMPLE>(a, multi, variant, compute_units, stream);
+        case MODE_EVAL:        return launch_mode<MODE_EVAL>(a, multi, variant, layout, compute_units, stream);
+        case MODE_PDF:         return launch_mode<MODE_PDF>(a, multi, variant, layout, compute_units, stream);
+        case MODE_SAMPLE:      return launch_mode<MODE_SAMPLE>(a, multi, variant, layout, compute_units, stream);
+        case MODE_EVAL_SAMPLE: return launch_mode<MODE_EVAL_SAMPLE>(a, multi, variant, layout, compute_units, stream);
     }
     return hipErrorInvalidValue;
 }

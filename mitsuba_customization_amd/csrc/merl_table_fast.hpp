@@ -119,20 +119,25 @@ struct TableMaps {
         : k_th((double)m.n_th * (double)m.n_th / kHalfPi), k_td((double)m.n_td / kHalfPi), k_pd((double)m.n_pd / kPi) {}
 };
 
-// BRDF value (no cosine) — gathers issued as early as the addresses exist
+// BRDF value (no cosine).  LOOKUP and LAYOUT are compile-time so that the eval lookup and the
+// sample lookup of a unit stay in ONE basic block: their gathers are then all in flight together
+// (a wave-uniform runtime branch here halves the memory-level parallelism and doubles the time).
+template <int LOOKUP, int LAYOUT>
 __device__ __forceinline__ Rgbd table_brdf(const MaterialDev &m, const Options &o, const Vec3 &in, const Vec3 &out)
 {
     const TableMaps k(m);
     const Coords c = coords(in, out, k.k_th, k.k_td, k.k_pd);
-    return o.lookup ? lookup_trilinear(m, c, o.node) : lookup_nearest(m, c);
+    if constexpr (LOOKUP) return lookup_trilinear_t<LAYOUT>(m, c, o.node);
+    else return lookup_nearest_t<LAYOUT>(m, c);
 }
 
 // a5: eval (cosine included); valid == false gives zeros
+template <int LOOKUP, int LAYOUT>
 __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o, const Vec3 &in,
                                           float wiz, float wox, float woy, float woz, float rgb[3])
 {
     const Vec3 out = normalize_f32(wox, woy, woz);
-    Rgbd v = table_brdf(m, o, in, out);
+    Rgbd v = table_brdf<LOOKUP, LAYOUT>(m, o, in, out);
     const double c = (double)woz;
     const bool valid = (wiz > 0.0f) && (woz > 0.0f);
     rgb[0] = valid ? (float)(v.r * c) : 0.0f;
@@ -141,6 +146,7 @@ __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o
 }
 
 // a6: sample
+template <int LOOKUP, int LAYOUT>
 __device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options &o, const Vec3 &in, float wiz,
                                             float u0, float u1, float wo[3], float &pdf, float weight[3])
 {
@@ -149,7 +155,7 @@ __device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options 
     const bool valid = wiz > 0.0f;
     const float p = z > 0.0f ? z * kInvPiF : 0.0f;
     float f[3];
-    unit_eval(m, o, in, wiz, x, y, z, f);
+    unit_eval<LOOKUP, LAYOUT>(m, o, in, wiz, x, y, z, f);
     const bool has = valid && (p > 0.0f);
     const float ps = has ? p : 1.0f;
     wo[0] = valid ? x : 0.0f; wo[1] = valid ? y : 0.0f; wo[2] = valid ? z : 0.0f;

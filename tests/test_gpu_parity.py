@@ -327,26 +327,39 @@ def test_golden_fixtures(gpu, tables):
     set_opts(gpu)
 
 
-# ------------------------------------------------------------------ kernel variants (MRL_OPT_KERNEL)
-@pytest.mark.parametrize("name", ["ggx_tab", "noise", "affine"])
-def test_kernel_variants_match_oracle_and_each_other(gpu, oracle, mats, name):
-    """Every implementation variant of the table kernels must pass the same parity bar; they
-    may differ from each other only in the last f32 ulp of rgb / weight."""
+# ------------------------------------------------------------------ kernel variants / table layouts
+@pytest.mark.parametrize("kind,seed", [("ggx_tab", 0), ("noise", 5), ("affine", 0)])
+def test_kernel_variants_and_layouts_match_oracle(gpu, oracle, tables, kind, seed):
+    """Every implementation variant (MRL_OPT_KERNEL) and table layout (MRL_OPT_TABLE_LAYOUT) must
+    pass the same parity bar; between themselves they may differ only in the last f32 ulp."""
     from mitsuba_customization_amd import host
-    mid, T, _ = mats[name]
+    from oracle import binding as ob
+    tab = tables(kind, seed)
+    T = ob.OracleTable(tab)
     wi, wo, u = oracle.generate_pairs(0x5EED, 2_000_000, 50000)
     dwi, dwo, du = to_dev(wi, wo, u)
-    want = oracle.eval_sample_multi([T], wi, wo, u, None)
-    default = gpu.get_option(host.OPT_KERNEL)
     results = {}
-    try:
-        for variant in (0, 1):
-            gpu.set_option(host.OPT_KERNEL, variant)
-            got = [t.cpu().numpy() for t in gpu.eval_sample(dwi, dwo, du, material=mid)]
-            assert_close(got[0], want[0], what=f"variant {variant} rgb"); assert np.array_equal(got[1], want[1])
-            assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
-            assert_close(got[4], want[4], what=f"variant {variant} weight")
-            results[variant] = got
-    finally:
-        gpu.set_option(host.OPT_KERNEL, default)
-    assert_close(results[1][0], results[0][0], rel=2.5e-7, what="variant 1 vs 0 rgb")
+    for layout in (host.LAYOUT_ROWS, host.LAYOUT_BRICK):
+        with host.MerlHip(0) as g:                       # the layout is context-wide: one context per layout
+            g.set_option(host.OPT_TABLE_LAYOUT, layout)
+            mid = g.upload_merl(tab)
+            with pytest.raises(host.MerlHipError):       # ... and frozen once a table exists
+                g.set_option(host.OPT_TABLE_LAYOUT, 1 - layout)
+            for lookup, node in ((1, 0), (1, 1), (0, 0)):
+                set_opts(g, lookup, node)
+                want = oracle.eval_sample_multi([T], wi, wo, u, None, oracle.make_opts(lookup=lookup, node=node))
+                for variant in (0, 1, 2, 3):
+                    g.set_option(host.OPT_KERNEL, variant)
+                    got = [t.cpu().numpy() for t in g.eval_sample(dwi, dwo, du, material=mid)]
+                    tag = f"layout {layout} lookup {lookup} node {node} variant {variant}"
+                    if lookup == 1:
+                        assert_close(got[0], want[0], what=tag + " rgb"); assert_close(got[4], want[4], what=tag + " weight")
+                    else:
+                        ok = np.abs(got[0].astype(np.float64) - want[0]) <= REL * np.abs(want[0]) + 1e-30
+                        assert ok.mean() >= 0.9999, tag
+                    assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+                    results[(layout, lookup, node, variant)] = got[0]
+    base = results[(0, 1, 0, 1)]
+    for key, r in results.items():
+        if key[1:3] == (1, 0):
+            assert_close(r, base, rel=2.5e-7, what=f"{key} vs rows/variant 1")
