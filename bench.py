@@ -22,9 +22,39 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 B_STREAM = 76           # algorithmic HBM bytes per eval+sample unit: 32 in + 44 out
+B_GATHER = 192          # algorithmic table bytes per unit: 2 lookups x 8 texels x 12 B (reported beside)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW")
 HBM_COPY_GBS = 6290.0   # measured float4 copy on the same chip (same guide)
 SEED = 0x5EED
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) // int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def measured_traffic(variant: int, layout: int, units: int):
+    """HBM/fabric bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json),
+    if one exists for this kernel variant, table layout and batch size; else None."""
+    try:
+        rows = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["rows"]
+        for r in rows:
+            if r["kernel_variant"] == variant and r["table_layout"] == layout and r["units"] == units:
+                return r
+    except Exception:
+        pass
+    return None
 
 
 def parse():
@@ -116,6 +146,12 @@ def main():
     total_units = float(n) * world * args.steps
     value = total_units / elapsed / 1e6                     # M eval+sample units / s, whole job
     achieved = B_STREAM * n / (kernel_ms * 1e-3) / 1e9      # GB/s of algorithmic stream bytes, one launch on one GPU
+    achieved_g = (B_STREAM + B_GATHER) * n / (kernel_ms * 1e-3) / 1e9
+    variant, layout = gpu.get_option(host.OPT_KERNEL), gpu.get_option(host.OPT_TABLE_LAYOUT)
+    kname = {0: "k_batch<eval_sample>", 1: "k_table<eval_sample>", 2: "k_table<eval_sample,nt>"}.get(variant, "k_table_dma<eval_sample>")
+    if variant >= 3 and (layout != 1 or args.lookup != "trilinear"):
+        kname = "k_table<eval_sample,nt>"
+    traffic = measured_traffic(variant, layout, n)
 
     result = {
         "metric": "bsdf_eval_sample_throughput",
@@ -135,8 +171,8 @@ def main():
             "units_per_gpu_per_step": n,
             "table": table_name,
             "lookup": args.lookup,
-            "kernel_variant": gpu.get_option(host.OPT_KERNEL),
-            "table_layout": gpu.get_option(host.OPT_TABLE_LAYOUT),
+            "kernel_variant": variant,
+            "table_layout": layout,
             "sharding": f"index tiles x{world}, tables replicated, no data-path collective",
         },
         "roofline": {
@@ -145,13 +181,18 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
-            "kernel": "k_batch<eval_sample>",
+            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+            "traffic_source": traffic["source"] if traffic else None,
+            "kernel": kname,
             "kernel_ms": round(kernel_ms, 4),
             "bytes_per_unit": B_STREAM,
             "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 5),
-            "note": "algorithmic stream bytes only (32 B in + 44 B out per unit); the 2x8-texel table gather "
-                    "(192 B/unit) is served by L2/Infinity Cache and is not counted (SURVEY.md §8d)",
+            "with_gather": {"bytes_per_unit": B_STREAM + B_GATHER, "achieved": round(achieved_g, 2),
+                            "frac": round(achieved_g / HBM_PEAK_GBS, 5)},
+            "note": "achieved/frac count the algorithmic STREAM bytes only (32 B in + 44 B out per unit, SURVEY.md §8d). "
+                    "With the brick layout the table no longer fits any cache level (187 MB per table, L2 hit 0 %), so the "
+                    "2 x 8-texel gather (192 B/unit algorithmic, 256 B/unit fetched as two 128-B lines) is fabric/HBM "
+                    "traffic too: with_gather prices stream + gather bytes against the same peak",
         },
     }
 
@@ -184,15 +225,11 @@ def main():
                 worst = max(worst, float(np.quantile(err, 0.999) if lookup == 0 else err.max()))
             result["parity"] = {"sample": k, "max_rel_err_vs_oracle": worst, "tolerance": 1e-6, "pinned": False}
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            try:
-                cores = len(os.sched_getaffinity(0))
-            except Exception:
-                pass
+            cores = host_cores()
             lookup = 1 if args.lookup == "trilinear" else 0
             s1, _ = ob.bench_merl(table, 1 << 18, 1, SEED, True, ob.make_opts(lookup=lookup))     # calibration, 1 thread
             rate1 = (1 << 18) / s1
-            cpu_n = args.cpu_units or int(min(16 * (1 << 20), max(1 << 20, rate1 * cores * 2.0)))
+            cpu_n = args.cpu_units or int(min(64 * (1 << 20), max(1 << 20, rate1 * cores * 1.0)))   # ~1 s wall, ~cores s of CPU work
             sN, _ = ob.bench_merl(table, cpu_n, cores, SEED, True, ob.make_opts(lookup=lookup))
             result["cpu_baseline"] = {
                 "value": round(cpu_n / sN / 1e6, 4),

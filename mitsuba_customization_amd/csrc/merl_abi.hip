@@ -38,8 +38,8 @@ struct mrl_ctx {
     mrl::MaterialDev *d_materials = nullptr;
     size_t d_materials_cap = 0;
     mrl::Options opts{ 1, 0, 0 };
-    int kernel_variant = 1;
-    int table_layout = 0;            // layout of tables uploaded from now on (mrl::Layout)
+    int kernel_variant = 3;          // MRL_OPT_KERNEL default: cooperative LDS-DMA brick fetch
+    int table_layout = 1;            // layout of tables uploaded from now on (mrl::Layout)
     size_t host_chunk = (size_t)1 << 22;
     void *d_stage = nullptr;
     size_t d_stage_units = 0;

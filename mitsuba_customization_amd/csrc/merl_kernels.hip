@@ -113,9 +113,9 @@ __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
                 pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
             } else {
                 const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
-                if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) fast::unit_eval<LOOKUP, LAYOUT>(m, a.opts, in, wiz, wox, woy, woz, rgb);
+                if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) fast::unit_eval<LOOKUP, LAYOUT>(m, a.opts, in, wix, wiy, wiz, wox, woy, woz, rgb);
                 if constexpr (MODE == MODE_EVAL_SAMPLE) pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
-                if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) fast::unit_sample<LOOKUP, LAYOUT>(m, a.opts, in, wiz, u0, u1, wo2, pdf2, w);
+                if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) fast::unit_sample<LOOKUP, LAYOUT>(m, a.opts, in, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
             }
         }
         if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) store3s<NT>(a.out_rgb, i, rgb);
@@ -138,7 +138,10 @@ __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
 // lane-linear, so the 16-B piece a lane copies is XOR-swizzled on the SOURCE side
 // (piece = (lane&7) ^ ((unit>>1)&7)); unit j then reads its piece p at slot 8j + (p ^ ((j>>1)&7)),
 // which is bank-conflict-free for ds_read_b128's 16-lane groups.
-constexpr int kDmaBlock = 256;
+#ifndef MRL_DMA_BLOCK
+#define MRL_DMA_BLOCK 256
+#endif
+constexpr int kDmaBlock = MRL_DMA_BLOCK;
 
 __device__ __forceinline__ unsigned brick_swz(unsigned unit) { return (unit >> 1) & 7u; }
 
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
         if constexpr (HAS_EVAL) {
             const Rgbd v = brick_interp(ldsA, lane, wA);
             const bool valid = (wiz > 0.0f) && (woz > 0.0f);
-            const double c = (double)woz;
+            const double c = fast::cos_or_nan(wix, wiy, wiz, wox, woy, woz);
             rgb[0] = valid ? (float)(v.r * c) : 0.0f; rgb[1] = valid ? (float)(v.g * c) : 0.0f; rgb[2] = valid ? (float)(v.b * c) : 0.0f;
             if constexpr (MODE == MODE_EVAL_SAMPLE) pdf = valid ? woz * kInvPiF : 0.0f;
         }
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
             const bool valid = wiz > 0.0f;
             const float p = sz > 0.0f ? sz * kInvPiF : 0.0f;
             const bool has = valid && (p > 0.0f);
-            const double c = (double)sz;
+            const double c = fast::cos_or_nan(wix, wiy, wiz, sx, sy, sz);
             const float f0 = has ? (float)(v.r * c) : 0.0f, f1 = has ? (float)(v.g * c) : 0.0f, f2 = has ? (float)(v.b * c) : 0.0f;
             const float ps = has ? p : 1.0f;
             wo2[0] = valid ? sx : 0.0f; wo2[1] = valid ? sy : 0.0f; wo2[2] = valid ? sz : 0.0f;
@@ -362,7 +365,7 @@ hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, 
         // variant 3: cooperative LDS-DMA brick fetch (brick layout + trilinear only; otherwise variant 2)
         if (tuned && variant >= 3 && layout == LAYOUT_BRICK && a.opts.lookup == 1) {
             // 64 KB (two lookups) or 32 KB (one) of LDS per 256-thread block: 2 or 4 blocks per CU
-            constexpr int per_cu = (MODE == MODE_EVAL_SAMPLE) ? 2 : 4;
+            constexpr int per_cu = ((MODE == MODE_EVAL_SAMPLE) ? 2 : 4) * (256 / kDmaBlock);
             size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;
             if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
             if (multi) hipLaunchKernelGGL((k_table_dma<MODE, true, true>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);

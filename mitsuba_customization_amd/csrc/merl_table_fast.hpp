@@ -4,9 +4,9 @@
 // the CDNA4 VALU:
 //   * f64 division / sqrt / atan2 from ocml (IEEE-exact, ~100+ instructions each with their
 //     scaling and special-case paths) are replaced by v_rcp_f64 / v_rsq_f64 seeds + one Newton
-//     step + a residual correction (<= 1 ulp-ish, no denormal scaling: operands here are O(1)),
-//     and a reduced-range odd polynomial for atan (|r| <= tan(pi/8), degree 8 in r^2, abs error
-//     9.4e-15).  The table coordinate stays good to ~1e-13 texel — far inside the 1e-8 budget.
+//     step (relative error ~1e-15, no denormal scaling: operands here are O(1)), and a
+//     reduced-range odd polynomial for atan (|r| <= tan(pi/8), degree 8 in r^2, abs error
+//     9.4e-15).  The table coordinate stays good to ~1e-12 texel — far inside the 1e-8 budget.
 //   * branch-free: guards become selects at the very end, so the eval lookup and the sample
 //     lookup of one unit sit in one basic block and their 16 gathers overlap with the ALU work.
 #pragma once
@@ -22,47 +22,50 @@ __device__ __forceinline__ double rcp_nr(double x)
     return __builtin_fma(y, e, y);
 }
 
-// n / d for finite d != 0: reciprocal + Newton + one residual correction
+// n / d for finite d != 0: v_rcp_f64 seed + one Newton step (relative error ~1e-15; the
+// coordinate budget is 1e-10, so no residual correction)
 __device__ __forceinline__ double div_fast(double n, double d)
 {
-    double y = rcp_nr(d);
-    double q = n * y;
-    double r = __builtin_fma(-d, q, n);
-    return __builtin_fma(r, y, q);
+    return n * rcp_nr(d);
 }
 
-// sqrt(x) and 1/sqrt(x) for x > 0 (x == 0 gives sqrt 0, rsqrt unspecified-but-finite-free)
+constexpr double kTiny = 1e-280;
+
+// sqrt(x) and 1/sqrt(x) for x >= 0: v_rsq_f64 seed + one coupled Newton step.  x is floored at
+// kTiny so that x == 0 needs no select (sqrt -> 1e-140 ~ 0).
 __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs)
 {
+    x = __builtin_fmax(x, kTiny);
     double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
     double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
+    s = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
-    double d = __builtin_fma(-g, g, x);       // residual of the square root
-    g = __builtin_fma(d, h, g);
-    s = x > 0.0 ? g : 0.0;
     rs = h + h;
 }
 __device__ __forceinline__ double sqrt_fast(double x)
 {
-    double s, rs;
-    sqrt_rsqrt(x, s, rs);
-    return s;
+    x = __builtin_fmax(x, kTiny);
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    return __builtin_fma(g, r, g);
 }
 
-// atan2(a, b) for a >= 0, b >= 0 -> [0, pi/2]; atan2(0, 0) = 0
+// atan2(a, b) for a >= 0, b >= 0 -> [0, pi/2].
+// With mn = min, mx = max:  atan(mn/mx) = pi/8 + atan(r),  r = (mn - c mx) / (mx + c mn),  c = tan(pi/8),
+// and |r| <= c for every mn/mx in [0,1] — a fixed rotation by pi/8, so no range select is needed.
+// atan(r) = r P(r^2), P of degree 8 (abs error 9.4e-15 on |r| <= c).  a > b mirrors about pi/4.
+// (a, b) = (0, 0) returns pi/8: phi_d is undefined there (degenerate h or retro-reflection).
 __device__ __forceinline__ double atan2_q1(double a, double b)
 {
-    constexpr double T = 0.41421356237309503;           // tan(pi/8)
-    constexpr double QUARTER_PI = 0.78539816339744830962;
-    const bool swap = a > b;
-    const double mn = swap ? b : a, mx = swap ? a : b;
-    const bool big = mn > T * mx;
-    const double num = big ? mn - mx : mn;
-    double den = big ? mn + mx : mx;
-    den = den == 0.0 ? 1.0 : den;
-    const double r = div_fast(num, den);                  // |r| <= tan(pi/8)
+    constexpr double C = 0.41421356237309503;            // tan(pi/8)
+    constexpr double PI_8 = 0.39269908169872415481;
+    constexpr double PI_3_8 = 1.17809724509617246442;
+    const double mn = __builtin_fmin(a, b), mx = __builtin_fmax(a, b);
+    const double num = __builtin_fma(-C, mx, mn);
+    const double den = __builtin_fmax(__builtin_fma(C, mn, mx), kTiny);
+    const double r = div_fast(num, den);
     const double z = r * r;
     double p = 0x1.f5ef263ad0056p-6;
     p = __builtin_fma(p, z, -0x1.e116a805760c8p-5);
@@ -73,8 +76,9 @@ __device__ __forceinline__ double atan2_q1(double a, double b)
     p = __builtin_fma(p, z, 0x1.9999990f93ea4p-3);
     p = __builtin_fma(p, z, -0x1.55555554e3467p-2);
     p = __builtin_fma(p, z, 0x1.fffffffffff02p-1);
-    const double t = __builtin_fma(r, p, big ? QUARTER_PI : 0.0);
-    return swap ? kHalfPi - t : t;
+    const bool swap = a > b;
+    // swap ? (3pi/8 - r p) : (pi/8 + r p)
+    return __builtin_fma(swap ? -r : r, p, swap ? PI_3_8 : PI_8);
 }
 
 struct Vec3 { double x, y, z; };
@@ -85,6 +89,14 @@ __device__ __forceinline__ Vec3 normalize_f32(float x, float y, float z)
     double s, rs;
     sqrt_rsqrt(__builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz)), s, rs);
     return { dx * rs, dy * rs, dz * rs };
+}
+
+// NaN / inf directions: the kTiny floors above would turn them into finite garbage; an f64 CPU
+// evaluation propagates NaN instead, so the cosine factor is poisoned when either input is not finite.
+__device__ __forceinline__ double cos_or_nan(float wix, float wiy, float wiz, float wox, float woy, float woz)
+{
+    const float t = (wix + wiy + wiz) + (wox + woy + woz);          // NaN or inf iff some component is
+    return (__builtin_fabsf(t) <= 3.0e38f) ? (double)woz : __builtin_nan("");
 }
 
 // a2 + a3 for unit in/out (see merl_device.hpp::half_diff_coords for the derivation)
@@ -134,11 +146,11 @@ __device__ __forceinline__ Rgbd table_brdf(const MaterialDev &m, const Options &
 // a5: eval (cosine included); valid == false gives zeros
 template <int LOOKUP, int LAYOUT>
 __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o, const Vec3 &in,
-                                          float wiz, float wox, float woy, float woz, float rgb[3])
+                                          float wix, float wiy, float wiz, float wox, float woy, float woz, float rgb[3])
 {
     const Vec3 out = normalize_f32(wox, woy, woz);
     Rgbd v = table_brdf<LOOKUP, LAYOUT>(m, o, in, out);
-    const double c = (double)woz;
+    const double c = cos_or_nan(wix, wiy, wiz, wox, woy, woz);
     const bool valid = (wiz > 0.0f) && (woz > 0.0f);
     rgb[0] = valid ? (float)(v.r * c) : 0.0f;
     rgb[1] = valid ? (float)(v.g * c) : 0.0f;
@@ -147,7 +159,8 @@ __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o
 
 // a6: sample
 template <int LOOKUP, int LAYOUT>
-__device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options &o, const Vec3 &in, float wiz,
+__device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options &o, const Vec3 &in,
+                                            float wix, float wiy, float wiz,
                                             float u0, float u1, float wo[3], float &pdf, float weight[3])
 {
     float x, y, z;
@@ -155,7 +168,7 @@ __device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options 
     const bool valid = wiz > 0.0f;
     const float p = z > 0.0f ? z * kInvPiF : 0.0f;
     float f[3];
-    unit_eval<LOOKUP, LAYOUT>(m, o, in, wiz, x, y, z, f);
+    unit_eval<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, x, y, z, f);
     const bool has = valid && (p > 0.0f);
     const float ps = has ? p : 1.0f;
     wo[0] = valid ? x : 0.0f; wo[1] = valid ? y : 0.0f; wo[2] = valid ? z : 0.0f;
