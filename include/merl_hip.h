@@ -116,6 +116,10 @@ int mrl_device_alloc(mrl_ctx *ctx, size_t bytes, void **out);
 int mrl_device_free(mrl_ctx *ctx, void *ptr);
 int mrl_copy_to_device(mrl_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
 int mrl_copy_to_host(mrl_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+/* pinned host memory the device can dereference: a batch call on such pointers runs zero-copy
+ * (this is what the plugin adapters' scalar eval()/sample()/pdf() calls use for their 1-unit batches) */
+int mrl_host_alloc(mrl_ctx *ctx, size_t bytes, void **out);
+int mrl_host_free(mrl_ctx *ctx, void *ptr);
 /* hipEvent pair recorded on the stream the kernels are launched on */
 int mrl_timer_start(mrl_ctx *ctx);
 int mrl_timer_stop(mrl_ctx *ctx, float *elapsed_ms);   /* records, synchronises, returns ms */

@@ -1,0 +1,57 @@
+"""Builds the plugin adapters and their test drivers with g++ (host C++ only — every compute call
+goes through libmerl_hip.so).  Outputs under mitsuba_customization_amd/lib/:
+
+    plugins06/merl.so, plugins06/customized_measurement.so     Mitsuba 0.6 plugins (CreateInstance / GetDescription)
+    plugins3/merl.so,  plugins3/customized_measurement.so      Mitsuba 3 plugins (plugin_name / plugin_descr / ...)
+    driver06, driver3                                          stand-ins for the hosts' plugin managers (tests)
+
+Against a real Mitsuba tree: add -DMERL_USE_REAL_MITSUBA and the tree's include dirs instead of mirror/.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+LIBDIR = os.path.join(PKG, "lib")
+CXX = shutil.which("g++") or "g++"
+CXXFLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-fvisibility=hidden"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_all(force: bool = False):
+    outs = []
+    common = glob.glob(os.path.join(HERE, "common", "*.hpp")) + [os.path.join(os.path.dirname(PKG), "include", "merl_hip.h")]
+    for host, mirror_hdr in (("mitsuba06", "mitsuba.h"), ("mitsuba3", "mitsuba3.h")):
+        src_dir = os.path.join(HERE, host)
+        out_dir = os.path.join(LIBDIR, "plugins06" if host == "mitsuba06" else "plugins3")
+        os.makedirs(out_dir, exist_ok=True)
+        inc = ["-I", os.path.join(src_dir, "mirror")]
+        deps = common + glob.glob(os.path.join(src_dir, "*.hpp")) + [os.path.join(src_dir, "mirror", "mitsuba", mirror_hdr)]
+        for name in ("merl", "customized_measurement"):
+            src = os.path.join(src_dir, name + ".cpp")
+            out = os.path.join(out_dir, name + ".so")
+            if force or _stale(out, deps + [src]):
+                # $ORIGIN/.. = mitsuba_customization_amd/lib, where libmerl_hip.so lives
+                subprocess.check_call([CXX] + CXXFLAGS + inc + ["-shared", "-o", out, src, "-L", LIBDIR, "-lmerl_hip",
+                                                                  "-Wl,-rpath,$ORIGIN/..", "-lpthread"])
+            outs.append(out)
+        drv_src = os.path.join(HERE, "tests", "driver06.cpp" if host == "mitsuba06" else "driver3.cpp")
+        drv = os.path.join(LIBDIR, "driver06" if host == "mitsuba06" else "driver3")
+        if force or _stale(drv, deps + [drv_src, os.path.join(HERE, "tests", "driver_common.hpp")]):
+            subprocess.check_call([CXX] + [f for f in CXXFLAGS if f != "-fvisibility=hidden"] + inc + ["-o", drv, drv_src, "-ldl"])
+        outs.append(drv)
+    return outs
+
+
+if __name__ == "__main__":
+    print("\n".join(build_all(force=True)))

@@ -1,0 +1,21 @@
+// batched_bsdf.hpp — the wavefront extension a host renderer reaches with
+// dynamic_cast<const BatchedBSDF *>(bsdf).  It is the batched entry into the plugin boundary
+// (SURVEY.md §3.4): arrays are f32, xyzxyz… / uvuv…, host or device pointers (include/merl_hip.h).
+#pragma once
+#include <cstddef>
+
+class BatchedBSDF {
+public:
+    virtual ~BatchedBSDF() {}
+    // BSDF::eval(bRec, ESolidAngle) for n pairs
+    virtual void evalBatch(const float *wi, const float *wo, size_t n, float *rgb) const = 0;
+    // BSDF::pdf(bRec, ESolidAngle) for n pairs
+    virtual void pdfBatch(const float *wi, const float *wo, size_t n, float *pdf) const = 0;
+    // BSDF::sample(bRec, pdf, sample) for n pairs: writes wo, pdf and eval/pdf
+    virtual void sampleBatch(const float *wi, const float *u, size_t n, float *wo, float *pdf, float *weight) const = 0;
+    // the fused unit: eval + pdf of (wi, wo) and sample(wi, u)
+    virtual void evalSampleBatch(const float *wi, const float *wo, const float *u, size_t n,
+                                 float *rgb, float *pdf, float *wo2, float *pdf2, float *weight) const = 0;
+    // device-pointer calls are asynchronous: wait for them
+    virtual void synchronize() const = 0;
+};

@@ -1,0 +1,144 @@
+// measured_bsdf.hpp — Mitsuba 0.6 BSDF plugin classes "merl" and "customized_measurement" over
+// libmerl_hip (reference: /root/reference/README.md:1 names both plugins; their sources are absent,
+// so the class follows the public Mitsuba 0.6 BSDF interface).
+//
+// Scene usage (same as any 0.6 bsdf):
+//   <bsdf type="merl"> <string name="filename" value="gold-metallic-paint.binary"/> </bsdf>
+//   <bsdf type="customized_measurement"> <string name="filename" value="mine.binary"/>
+//        <float name="scaleR" value="1"/> ... </bsdf>
+// Optional: interpolation = "trilinear" (default) | "nearest";  node = "integer" (default) | "center";
+//           device = GPU ordinal (default 0).
+#pragma once
+#ifdef MERL_USE_REAL_MITSUBA
+#include <mitsuba/render/bsdf.h>
+#include <mitsuba/core/properties.h>
+#else
+#include <mitsuba/mitsuba.h>
+#endif
+
+#include "../common/batched_bsdf.hpp"
+#include "../common/merl_gpu_material.hpp"
+
+MTS_NAMESPACE_BEGIN
+
+class MeasuredBSDFBase : public BSDF, public BatchedBSDF {
+public:
+    explicit MeasuredBSDFBase(const Properties &props) : BSDF(props)
+    {
+        m_filename = props.getString("filename");
+        m_key.device = props.getInteger("device", 0);
+        m_key.lookup = merl_gpu::parse_lookup(props.getString("interpolation", "trilinear"));
+        m_key.node = merl_gpu::parse_node(props.getString("node", "integer"));
+        m_key.disk_map = 0;                       // Mitsuba 0.6's squareToUniformDiskConcentric flavour
+    }
+
+    void configure() override
+    {
+        m_components.clear();
+        m_components.push_back(EGlossyReflection | EFrontSide);
+        m_usesRayDifferentials = false;
+        BSDF::configure();
+    }
+
+    // eval: f * cos(theta_o); zero unless both directions are on the front side, the measure is the
+    // solid angle and the query asks for the (only) reflection lobe
+    Spectrum eval(const BSDFSamplingRecord &bRec, EMeasure measure) const override
+    {
+        if (!(bRec.typeMask & EGlossyReflection) || measure != ESolidAngle || (bRec.component != -1 && bRec.component != 0))
+            return Spectrum(0.0f);
+        const float wi[3] = { bRec.wi.x, bRec.wi.y, bRec.wi.z }, wo[3] = { bRec.wo.x, bRec.wo.y, bRec.wo.z };
+        float rgb[3];
+        m_material.eval1(wi, wo, rgb);
+        Spectrum s;
+        s.fromLinearRGB(rgb[0], rgb[1], rgb[2]);
+        return s;
+    }
+
+    Float pdf(const BSDFSamplingRecord &bRec, EMeasure measure) const override
+    {
+        if (!(bRec.typeMask & EGlossyReflection) || measure != ESolidAngle || (bRec.component != -1 && bRec.component != 0))
+            return 0.0f;
+        const float wi[3] = { bRec.wi.x, bRec.wi.y, bRec.wi.z }, wo[3] = { bRec.wo.x, bRec.wo.y, bRec.wo.z };
+        return m_material.pdf1(wi, wo);
+    }
+
+    Spectrum sample(BSDFSamplingRecord &bRec, Float &pdf, const Point2 &sample) const override
+    {
+        pdf = 0.0f;
+        if (!(bRec.typeMask & EGlossyReflection) || (bRec.component != -1 && bRec.component != 0))
+            return Spectrum(0.0f);
+        const float wi[3] = { bRec.wi.x, bRec.wi.y, bRec.wi.z }, u[2] = { sample.x, sample.y };
+        float wo[3], w[3];
+        m_material.sample1(wi, u, wo, pdf, w);
+        if (!(pdf > 0.0f)) return Spectrum(0.0f);
+        bRec.wo = Vector(wo[0], wo[1], wo[2]);
+        bRec.eta = 1.0f;
+        bRec.sampledComponent = 0;
+        bRec.sampledType = EGlossyReflection;
+        Spectrum s;
+        s.fromLinearRGB(w[0], w[1], w[2]);
+        return s;
+    }
+
+    Spectrum sample(BSDFSamplingRecord &bRec, const Point2 &sample_) const override
+    {
+        Float pdf;
+        return sample(bRec, pdf, sample_);
+    }
+
+    // ---- BatchedBSDF ----
+    void evalBatch(const float *wi, const float *wo, size_t n, float *rgb) const override { m_material.eval_batch(wi, wo, n, rgb); }
+    void pdfBatch(const float *wi, const float *wo, size_t n, float *pdf) const override { m_material.pdf_batch(wi, wo, n, pdf); }
+    void sampleBatch(const float *wi, const float *u, size_t n, float *wo, float *pdf, float *weight) const override
+    {
+        m_material.sample_batch(wi, u, n, wo, pdf, weight);
+    }
+    void evalSampleBatch(const float *wi, const float *wo, const float *u, size_t n,
+                         float *rgb, float *pdf, float *wo2, float *pdf2, float *weight) const override
+    {
+        m_material.eval_sample_batch(wi, wo, u, n, rgb, pdf, wo2, pdf2, weight);
+    }
+    void synchronize() const override { m_material.synchronize(); }
+
+    std::string toString() const override
+    {
+        std::ostringstream oss;
+        oss << pluginName() << "[filename=\"" << m_filename << "\", device=" << m_key.device
+            << ", interpolation=" << (m_key.lookup ? "trilinear" : "nearest") << ", material=" << m_material.id() << "]";
+        return oss.str();
+    }
+
+protected:
+    virtual const char *pluginName() const = 0;
+    std::string m_filename;
+    merl_gpu::ContextKey m_key;
+    merl_gpu::Material m_material;
+};
+
+// type="merl": MERL .binary (90 x 90 x 180, fixed channel scales)
+class MerlBSDF : public MeasuredBSDFBase {
+public:
+    explicit MerlBSDF(const Properties &props) : MeasuredBSDFBase(props)
+    {
+        m_material = merl_gpu::Material::load_merl(m_key, m_filename);
+    }
+    MTS_DECLARE_CLASS()
+protected:
+    const char *pluginName() const override { return "MerlBSDF"; }
+};
+
+// type="customized_measurement": same parameterisation, table dims from the file header, channel
+// scales from the scene (the reference's own format is unknown — SURVEY.md Appendix B item 7)
+class CustomizedMeasurement : public MeasuredBSDFBase {
+public:
+    explicit CustomizedMeasurement(const Properties &props) : MeasuredBSDFBase(props)
+    {
+        const double scale[3] = { props.getFloat("scaleR", 1.0f), props.getFloat("scaleG", 1.0f), props.getFloat("scaleB", 1.0f) };
+        m_material = merl_gpu::Material::load_table(m_key, m_filename, scale);
+    }
+    MTS_DECLARE_CLASS()
+protected:
+    const char *pluginName() const override { return "CustomizedMeasurement"; }
+};
+
+MTS_NAMESPACE_END

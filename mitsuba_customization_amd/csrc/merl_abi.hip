@@ -558,6 +558,24 @@ int mrl_copy_to_host(mrl_ctx *ctx, void *dst_host, const void *src_device, size_
     return MRL_OK;
 }
 
+int mrl_host_alloc(mrl_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out) return MRL_ERR_INVALID;
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    MRL_HIP(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable));
+    return MRL_OK;
+}
+
+int mrl_host_free(mrl_ctx *ctx, void *ptr)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    if (!ptr) return MRL_OK;
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MRL_HIP(ctx, hipHostFree(ptr));
+    return MRL_OK;
+}
+
 int mrl_timer_start(mrl_ctx *ctx)
 {
     if (!ctx) return MRL_ERR_INVALID;

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "mrl_material_ggx", "mrl_material_count", "mrl_material_info",
     "mrl_eval_batch", "mrl_pdf_batch", "mrl_sample_batch", "mrl_eval_sample_batch",
     "mrl_generate_pairs", "mrl_generate_materials",
-    "mrl_device_alloc", "mrl_device_free", "mrl_copy_to_device", "mrl_copy_to_host",
+    "mrl_device_alloc", "mrl_device_free", "mrl_copy_to_device", "mrl_copy_to_host", "mrl_host_alloc", "mrl_host_free",
     "mrl_timer_start", "mrl_timer_stop",
 )
 
@@ -85,6 +85,8 @@ def load_library(path: Optional[str] = None):
     L.mrl_device_free.argtypes = [vp, vp]
     L.mrl_copy_to_device.argtypes = [vp, vp, vp, C.c_size_t]
     L.mrl_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t]
+    L.mrl_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.mrl_host_free.argtypes = [vp, vp]
     L.mrl_timer_start.argtypes = [vp]
     L.mrl_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     if path is None:
