@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Side measurements quoted in DESIGN.md (not the bench line): eval-only / sample-only rates, the
+PCIe-inclusive rate of the host-pointer path, scalar plugin-call latency.   python tools/extra_rates.py"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from mitsuba_customization_amd import host, synth
+
+gpu = host.MerlHip(0)
+mid = gpu.upload_merl(synth.make_table("ggx_tab", 0))
+n = 64 << 20
+wi, wo, u = gpu.generate_pairs(0x5EED, 0, n)
+res = {}
+
+
+def timed(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    gpu.timer_start()
+    for _ in range(reps):
+        fn()
+    return gpu.timer_stop() / reps
+
+
+o_rgb = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+ms = timed(lambda: gpu.eval(wi, wo, material=mid, out=o_rgb))
+res["eval_only"] = {"ms": ms, "Meval_per_s": n / ms / 1e3, "stream_GBps": 36 * n / ms / 1e6}
+o_s = (torch.empty((n, 3), dtype=torch.float32, device="cuda"), torch.empty((n,), dtype=torch.float32, device="cuda"),
+       torch.empty((n, 3), dtype=torch.float32, device="cuda"))
+ms = timed(lambda: gpu.sample(wi, u, material=mid, out=o_s))
+res["sample_only"] = {"ms": ms, "Msample_per_s": n / ms / 1e3}
+o_p = torch.empty((n,), dtype=torch.float32, device="cuda")
+ms = timed(lambda: gpu.pdf(wi, wo, material=mid, out=o_p))
+res["pdf_only"] = {"ms": ms, "Mpdf_per_s": n / ms / 1e3, "stream_GBps": 28 * n / ms / 1e6}
+
+# host-pointer path: pageable numpy arrays in, numpy arrays out (H2D + kernel + D2H, chunked)
+m = 16 << 20
+hwi, hwo, hu = wi[:m].cpu().numpy(), wo[:m].cpu().numpy(), u[:m].cpu().numpy()
+gpu.eval_sample(hwi, hwo, hu, material=mid)
+t0 = time.perf_counter()
+gpu.eval_sample(hwi, hwo, hu, material=mid)
+dt = time.perf_counter() - t0
+res["host_pointer_eval_sample"] = {"units": m, "s": dt, "Munits_per_s": m / dt / 1e6, "PCIe_bytes_per_unit": 76,
+                                   "note": "pageable host memory, synchronous 4M-unit chunks (PCIe-inclusive; never the bench value)"}
+print(json.dumps(res, indent=1))
