@@ -73,6 +73,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-units", type=int, default=0, help="units for the CPU baseline sample (0 = auto, ~1-3 s wall)")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the separately reported RCCL gather leg")
+    p.add_argument("--gather-units", type=int, default=16 << 20, help="N>1: units per rank moved by the gather leg")
     p.add_argument("--parity-sample", type=int, default=4096)
     return p.parse_args()
 
@@ -93,9 +94,14 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_pg = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
+    if world > 1 and not use_pg:
+        sys.exit("bench.py: WORLD_SIZE > 1 without a rendezvous (use torch.distributed.run)")
+    if use_pg:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(minutes=10))
 
     from mitsuba_customization_amd import host, synth
 
@@ -146,7 +152,7 @@ def main():
         gpu.eval_sample(wi, wo, u, mat=mat, material=mid, out=out)
 
     def fence():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -160,7 +166,7 @@ def main():
     kernel_ms = gpu.timer_stop() / max(args.steps, 1)       # avg launch duration of the dominant kernel
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
@@ -221,14 +227,29 @@ def main():
 
     # ---- N>1: the RCCL result gather, reported beside (never inside) `value` ----
     if world > 1 and not args.no_gather:
+        # bounded: the first <= 16M units of every rank's outputs (704 MB per rank); every rank first agrees
+        # that its buffers exist, so that a failed allocation on one rank skips the leg everywhere
+        # instead of leaving the others waiting in a send
+        g_units = min(n, args.gather_units)
+        ok, full, err = 1, None, ""
         try:
             from mitsuba_customization_amd import shard
-            g = shard.bench_gather(out, steps=max(2, min(args.steps, 5)))
+            local = [o[:g_units] for o in out]
             if rank == 0:
-                result["gather"] = g
-        except Exception as e:  # the gather leg must never hide the compute number
-            if rank == 0:
-                result["gather"] = {"error": repr(e)}
+                full = [torch.empty((g_units * world,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in local]
+        except Exception as e:
+            ok, err = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            g = shard.bench_gather(local, steps=3, out=full)
+            g["units_per_rank"] = g_units
+            g["extrapolated_ms_for_full_step"] = round(g["ms"] * n / g_units, 3)
+        else:
+            g = {"skipped": err or "another rank could not allocate its buffers"}
+        del full
+        if rank == 0:
+            result["gather"] = g
 
     # ---- rank 0, N=1: parity sample vs the oracle + CPU baseline on the host cores ----
     if rank == 0:
@@ -273,7 +294,7 @@ def main():
         print(json.dumps(result), flush=True)
 
     gpu.close()
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -231,7 +231,9 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
     a.opts = ctx->opts;
     bool multi = c.mat != nullptr;
     if (!multi) a.single = ctx->materials[(size_t)c.single_id].dev;
-    MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->kernel_variant, ctx->table_layout, ctx->compute_units, ctx->stream));
+    bool has_ggx = false;
+    for (const auto &m : ctx->materials) has_ggx = has_ggx || m.dev.kind == mrl::KIND_GGX;
+    MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->kernel_variant, ctx->table_layout, has_ggx, ctx->compute_units, ctx->stream));
     return MRL_OK;
 }
 

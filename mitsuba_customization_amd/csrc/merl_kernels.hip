@@ -201,7 +201,9 @@ __device__ __forceinline__ Rgbd brick_interp(const float4 *lds_slots, unsigned l
     return o;
 }
 
-template <int MODE, bool MULTI, bool NT>
+// GGX: the batch may contain analytic (GGX) materials; false drops that code path from the kernel
+// (mixed batches of table materials only: half the registers, twice the waves)
+template <int MODE, bool MULTI, bool NT, bool GGX>
 __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
 {
     static_assert(MODE != MODE_PDF, "pdf needs no table");
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
         } else {
             m = a.single;
         }
-        const bool is_table = m.kind != KIND_GGX;
+        const bool is_table = !GGX || m.kind != KIND_GGX;
         // lanes without a table (GGX / unknown id) still take part in the cooperative copy: give them a
         // harmless, valid 128-B source (the material array itself) and cell 0
         const float4 *lane_base = (MULTI && !is_table) ? (const float4 *)a.materials : m.texels;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
             w[0] = f0 / ps; w[1] = f1 / ps; w[2] = f2 / ps;
         }
         asm volatile("" ::: "memory");                        // LDS reads above stay ahead of the next step's DMA
-        if (MULTI && !is_table) {                             // GGX lanes of a mixed batch: generic functions
+        if (MULTI && GGX && !is_table) {                      // GGX lanes of a mixed batch: generic functions
             if constexpr (HAS_EVAL) unit_eval(m, a.opts, wix, wiy, wiz, wox, woy, woz, rgb);
             if constexpr (MODE == MODE_EVAL_SAMPLE) pdf = unit_pdf(m, wix, wiy, wiz, wox, woy, woz);
             if constexpr (HAS_SAMPLE) unit_sample(m, a.opts, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
@@ -355,7 +357,7 @@ void launch_table(const BatchArgs &a, bool multi, bool nt, int lookup, int layou
 }
 
 template <int MODE>
-hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, int compute_units, hipStream_t stream)
+hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, bool has_ggx, int compute_units, hipStream_t stream)
 {
     dim3 grid(grid_for(a.n, compute_units)), block(kBlock);
     // variant 0: generic kernel (every kind, ocml math) — the A/B baseline;
@@ -368,8 +370,9 @@ hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, 
             constexpr int per_cu = ((MODE == MODE_EVAL_SAMPLE) ? 2 : 4) * (256 / kDmaBlock);
             size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;
             if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
-            if (multi) hipLaunchKernelGGL((k_table_dma<MODE, true, true>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);
-            else       hipLaunchKernelGGL((k_table_dma<MODE, false, true>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);
+            if (multi && has_ggx) hipLaunchKernelGGL((k_table_dma<MODE, true, true, true>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);
+            else if (multi)       hipLaunchKernelGGL((k_table_dma<MODE, true, true, false>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);
+            else                  hipLaunchKernelGGL((k_table_dma<MODE, false, true, false>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);
             return hipGetLastError();
         }
     }
@@ -384,14 +387,14 @@ hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, 
 
 } // namespace
 
-hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int layout, int compute_units, hipStream_t stream)
+hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int layout, bool has_ggx, int compute_units, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     switch (mode) {
-        case MODE_EVAL:        return launch_mode<MODE_EVAL>(a, multi, variant, layout, compute_units, stream);
-        case MODE_PDF:         return launch_mode<MODE_PDF>(a, multi, variant, layout, compute_units, stream);
-        case MODE_SAMPLE:      return launch_mode<MODE_SAMPLE>(a, multi, variant, layout, compute_units, stream);
-        case MODE_EVAL_SAMPLE: return launch_mode<MODE_EVAL_SAMPLE>(a, multi, variant, layout, compute_units, stream);
+        case MODE_EVAL:        return launch_mode<MODE_EVAL>(a, multi, variant, layout, has_ggx, compute_units, stream);
+        case MODE_PDF:         return launch_mode<MODE_PDF>(a, multi, variant, layout, has_ggx, compute_units, stream);
+        case MODE_SAMPLE:      return launch_mode<MODE_SAMPLE>(a, multi, variant, layout, has_ggx, compute_units, stream);
+        case MODE_EVAL_SAMPLE: return launch_mode<MODE_EVAL_SAMPLE>(a, multi, variant, layout, has_ggx, compute_units, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -23,7 +23,8 @@ struct BatchArgs {
 // mode: 0 eval, 1 pdf, 2 sample, 3 eval+sample
 // variant: MRL_OPT_KERNEL (0 generic, 1 tuned table path, 2 tuned + non-temporal streams)
 // layout: the context-wide table layout (every table of a context has the same one)
-hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int layout, int compute_units, hipStream_t stream);
+// has_ggx: the context holds at least one analytic (GGX) material, so a mixed batch may contain such lanes
+hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int layout, bool has_ggx, int compute_units, hipStream_t stream);
 hipError_t launch_generate_pairs(uint64_t seed, uint64_t first, size_t n, float *wi, float *wo, float *u,
                                  int compute_units, hipStream_t stream);
 hipError_t launch_generate_materials(uint64_t seed, uint64_t first, size_t n, int n_materials, int32_t *mat,

@@ -157,15 +157,16 @@ def run_sharded(compute: Callable[[int, int], Sequence[torch.Tensor]], n_total: 
     return full if is_root else None
 
 
-def bench_gather(local: Sequence[torch.Tensor], steps: int = 3, dst: int = 0, group=None) -> dict:
+def bench_gather(local: Sequence[torch.Tensor], steps: int = 3, dst: int = 0, group=None,
+                 out: Optional[Sequence[torch.Tensor]] = None) -> dict:
     """Times the result gather of one step's outputs (all ranks hold equal tiles) — reported by
     bench.py beside the compute throughput, never inside it."""
     world, rank = _world(group)
     n_local = int(local[0].shape[0])
     n_total = n_local * world
     nbytes = sum(t.element_size() * t.numel() for t in local)
-    full = None
-    if rank == dst:
+    full = list(out) if (out is not None and rank == dst) else None
+    if rank == dst and full is None:
         full = [torch.empty((n_total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in local]
     gather_tiles(local, n_total, dst, group, out=full)          # warm-up: connection set-up
     times = []
