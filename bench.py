@@ -268,10 +268,12 @@ def main():
                 hm = None if mat is None else (mat[idx] - ids[0]).cpu().numpy()
                 ref = ob.eval_sample_multi([ob.OracleTable(t) for t in tables], hin[0], hin[1], hin[2], hm, ob.make_opts(lookup=lookup))
             worst = 0.0
-            for got, want in zip(hout, ref):
+            for k_out, (got, want) in enumerate(zip(hout, ref)):
                 got = got.astype(np.float64); want = want.astype(np.float64)
                 err = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
-                err = np.where(np.abs(got - want) <= 1e-30 + (1.2e-7 if args.config == "ggx64m" else 0.0), 0.0, err)
+                # GGX sampled directions are f64 results rounded to f32: one ulp (1.2e-7 absolute) may flip
+                slack = 1.2e-7 if (args.config == "ggx64m" and k_out == 2) else 0.0
+                err = np.where(np.abs(got - want) <= 1e-30 + slack, 0.0, err)
                 worst = max(worst, float(np.quantile(err, 0.999) if lookup == 0 else err.max()))
             result["parity"] = {"sample": k, "max_rel_err_vs_oracle": worst, "tolerance": 1e-6, "pinned": False}
         if world == 1 and not args.no_cpu_baseline and args.config == "merl64m":

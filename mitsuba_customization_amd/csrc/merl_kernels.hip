@@ -6,6 +6,7 @@
 // (phi_d fastest, so the two phi neighbours of a corner share a 32-B piece).
 #include "merl_kernels.hpp"
 #include "merl_table_fast.hpp"
+#include "merl_ggx_fast.hpp"
 
 namespace mrl {
 
@@ -300,6 +301,46 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
     }
 }
 
+// ---- tuned GGX rough conductor (single-material launches of an analytic material) ----------------
+template <int MODE, bool NT>
+__global__ __launch_bounds__(kBlock) void k_ggx(BatchArgs a)
+{
+    constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
+    constexpr bool HAS_PDF = MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE;
+    constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
+    const fast::GgxConsts g(a.single);
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+        float wix, wiy, wiz;
+        load3s<NT>(a.wi, i, wix, wiy, wiz);
+        const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
+        if constexpr (HAS_EVAL || HAS_PDF) {
+            float wox, woy, woz;
+            load3s<NT>(a.wo, i, wox, woy, woz);
+            const fast::Vec3 out = fast::normalize_f32(wox, woy, woz);
+            double v[3], p;
+            fast::ggx_eval_pdf(g, in, out, v, p);
+            const bool valid = (wiz > 0.0f) && (woz > 0.0f);
+            const double poison = fast::cos_or_nan(wix, wiy, wiz, wox, woy, 1.0f);     // 1.0, or NaN for non-finite input
+            if constexpr (HAS_EVAL) {
+                const float rgb[3] = { valid ? (float)(v[0] * poison) : 0.0f, valid ? (float)(v[1] * poison) : 0.0f,
+                                       valid ? (float)(v[2] * poison) : 0.0f };
+                store3s<NT>(a.out_rgb, i, rgb);
+            }
+            if constexpr (HAS_PDF) stf<NT>(a.out_pdf + i, valid ? (float)(p * poison) : 0.0f);
+        }
+        if constexpr (HAS_SAMPLE) {
+            const float u0 = ldf<NT>(a.u + 2 * i), u1 = ldf<NT>(a.u + 2 * i + 1);
+            float wo2[3], pdf2, w[3];
+            fast::ggx_sample(g, in, u0, u1, wo2, pdf2, w);
+            if (!(wiz > 0.0f)) { wo2[0] = wo2[1] = wo2[2] = 0.0f; pdf2 = 0.0f; w[0] = w[1] = w[2] = 0.0f; }
+            store3s<NT>(a.out_wo, i, wo2);
+            stf<NT>(a.out_pdf2 + i, pdf2);
+            store3s<NT>(a.out_weight, i, w);
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_generate_pairs(uint64_t seed, uint64_t first, size_t n,
                                                           float *wi, float *wo, float *u)
 {
@@ -363,6 +404,10 @@ hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, 
     // variant 0: generic kernel (every kind, ocml math) — the A/B baseline;
     // variant 1: tuned table kernel; a single-material GGX launch has no table path and stays generic
     const bool tuned = variant >= 1 && (multi || a.single.kind != KIND_GGX);
+    if (variant >= 1 && !multi && a.single.kind == KIND_GGX) {     // tuned analytic kernel
+        hipLaunchKernelGGL((k_ggx<MODE, true>), grid, block, 0, stream, a);
+        return hipGetLastError();
+    }
     if constexpr (MODE != MODE_PDF) {
         // variant 3: cooperative LDS-DMA brick fetch (brick layout + trilinear only; otherwise variant 2)
         if (tuned && variant >= 3 && layout == LAYOUT_BRICK && a.opts.lookup == 1) {
