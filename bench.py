@@ -50,7 +50,7 @@ def measured_traffic(variant: int, layout: int, units: int):
     try:
         rows = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["rows"]
         for r in rows:
-            if r["kernel_variant"] == variant and r["table_layout"] == layout and r["units"] == units:
+            if r["kernel_variant"] == min(variant, 3) and r["table_layout"] == layout and r["units"] == units:
                 return r
     except Exception:
         pass
@@ -177,6 +177,8 @@ def main():
     achieved_g = (B_STREAM + B_GATHER) * n / (kernel_ms * 1e-3) / 1e9
     variant, layout = gpu.get_option(host.OPT_KERNEL), gpu.get_option(host.OPT_TABLE_LAYOUT)
     kname = {0: "k_batch<eval_sample>", 1: "k_table<eval_sample>", 2: "k_table<eval_sample,nt>"}.get(variant, "k_table_dma<eval_sample>")
+    if args.config == "ggx64m":
+        kname = "k_ggx<eval_sample>" if variant >= 1 else "k_batch<eval_sample>"
     if variant >= 3 and (layout != 1 or args.lookup != "trilinear"):
         kname = "k_table<eval_sample,nt>"
     traffic = measured_traffic(variant, layout, n)

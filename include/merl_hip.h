@@ -55,8 +55,10 @@ enum mrl_option {
     MRL_OPT_LOOKUP = 0,        /* 0 nearest (BRDFRead), 1 trilinear (default) */
     MRL_OPT_NODE = 1,          /* trilinear node position: 0 integer coordinate (default), 1 texel centre */
     MRL_OPT_DISK_MAP = 2,      /* concentric disk flavour: 0 Mitsuba 0.6 (default), 1 Mitsuba 3 */
-    MRL_OPT_KERNEL = 3,        /* implementation variant of the table kernels: 0 generic, 1 tuned
-                                  math, 2 + non-temporal streams, 3 + cooperative LDS-DMA brick fetch (default).
+    MRL_OPT_KERNEL = 3,        /* implementation variant of the kernels: 0 generic, 1 tuned math,
+                                  2 + non-temporal streams, 3 (default) + cooperative LDS-DMA brick fetch,
+                                  4 = 3 + ballot/prefix partition of a batch that mixes table and analytic
+                                  materials into one dense queue per kind (pays only when most units are analytic).
                                   Every variant passes the same parity tests; they differ in speed only. */
     MRL_OPT_HOST_CHUNK = 4,    /* units per staging chunk for host-pointer calls */
     MRL_OPT_TABLE_LAYOUT = 5   /* HBM layout of the context's tables, settable only while it holds no table:

@@ -34,6 +34,9 @@ struct mrl_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // kind-partitioned mixed batches: [2][queue_cap] unit indices + partition work area behind them
+    uint32_t *d_queues = nullptr;
+    size_t queue_cap = 0;
     std::vector<MaterialHost> materials;
     mrl::MaterialDev *d_materials = nullptr;
     size_t d_materials_cap = 0;
@@ -220,6 +223,21 @@ struct BatchCall {
     float *out_rgb, *out_pdf, *out_wo, *out_pdf2, *out_weight;
 };
 
+constexpr size_t kMaxSegments = 256 * 8 + 64;     // partition_geometry caps segments at 8 per CU
+
+int ensure_queues(mrl_ctx *ctx, size_t units)
+{
+    if (units <= ctx->queue_cap) return MRL_OK;
+    if (ctx->d_queues) {
+        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_queues);
+        ctx->d_queues = nullptr; ctx->queue_cap = 0;
+    }
+    MRL_HIP(ctx, hipMalloc((void **)&ctx->d_queues, (2 * units + 4 * kMaxSegments + 2) * sizeof(uint32_t)));
+    ctx->queue_cap = units;
+    return MRL_OK;
+}
+
 int launch_device(mrl_ctx *ctx, const BatchCall &c)
 {
     mrl::BatchArgs a;
@@ -231,8 +249,28 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
     a.opts = ctx->opts;
     bool multi = c.mat != nullptr;
     if (!multi) a.single = ctx->materials[(size_t)c.single_id].dev;
-    bool has_ggx = false;
-    for (const auto &m : ctx->materials) has_ggx = has_ggx || m.dev.kind == mrl::KIND_GGX;
+    bool has_ggx = false, has_table = false;
+    for (const auto &m : ctx->materials) { has_ggx = has_ggx || m.dev.kind == mrl::KIND_GGX; has_table = has_table || m.dev.kind != mrl::KIND_GGX; }
+    // MRL_OPT_KERNEL >= 4: a batch that may mix table and analytic materials is split into one dense queue
+    // per kind (count / scan / partition, no atomics); each queue then runs through its dedicated kernel
+    if (multi && has_ggx && has_table && ctx->kernel_variant >= 4 && c.mode != 1 && ctx->table_layout == mrl::LAYOUT_BRICK &&
+        ctx->opts.lookup == 1 && c.n < ((size_t)1 << 32)) {
+        uint32_t segments = 0, seg_len = 0;
+        mrl::partition_geometry(c.n, ctx->compute_units, &segments, &seg_len);
+        if (segments > kMaxSegments) return fail(ctx, MRL_ERR_INVALID, "partition geometry");
+        int rc = ensure_queues(ctx, c.n);
+        if (rc != MRL_OK) return rc;
+        uint32_t *q_table = ctx->d_queues, *q_ggx = ctx->d_queues + ctx->queue_cap, *work = ctx->d_queues + 2 * ctx->queue_cap;
+        MRL_HIP(ctx, mrl::launch_partition_kinds(c.mat, c.n, ctx->d_materials, a.n_materials, q_table, q_ggx, work,
+                                                 segments, seg_len, ctx->stream));
+        const uint32_t *totals = work + 4 * (size_t)segments;
+        mrl::BatchArgs qa = a;
+        qa.idx = q_table; qa.idx_count = totals;
+        MRL_HIP(ctx, mrl::launch_batch_queue(c.mode, qa, false, ctx->compute_units, ctx->stream));
+        qa.idx = q_ggx; qa.idx_count = totals + 1;
+        MRL_HIP(ctx, mrl::launch_batch_queue(c.mode, qa, true, ctx->compute_units, ctx->stream));
+        return MRL_OK;
+    }
     MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->kernel_variant, ctx->table_layout, has_ggx, ctx->compute_units, ctx->stream));
     return MRL_OK;
 }
@@ -350,6 +388,7 @@ int mrl_destroy(mrl_ctx *ctx)
     for (auto &m : ctx->materials) if (m.d_texels) (void)hipFree(m.d_texels);
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_queues) (void)hipFree(ctx->d_queues);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

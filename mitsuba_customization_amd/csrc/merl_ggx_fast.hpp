@@ -18,8 +18,8 @@ struct GgxConsts {                 // per material, computed once per launch (SG
     __device__ __forceinline__ explicit GgxConsts(const MaterialDev &m)
     {
         alpha = m.alpha;
-        inv_alpha2 = 1.0 / (m.alpha * m.alpha);
-        inv_pi_alpha2 = 1.0 / (kPi * m.alpha * m.alpha);
+        inv_alpha2 = rcp_nr(m.alpha * m.alpha);
+        inv_pi_alpha2 = inv_alpha2 * 0.31830988618379067154;
         for (int c = 0; c < 3; ++c) {
             eta2_k2[c] = m.eta[c] * m.eta[c] - m.k[c] * m.k[c];
             four_k2_eta2[c] = 4.0 * m.k[c] * m.k[c] * m.eta[c] * m.eta[c];

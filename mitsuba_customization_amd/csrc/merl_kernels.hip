@@ -202,12 +202,117 @@ __device__ __forceinline__ Rgbd brick_interp(const float4 *lds_slots, unsigned l
     return o;
 }
 
-// GGX: the batch may contain analytic (GGX) materials; false drops that code path from the kernel
-// (mixed batches of table materials only: half the registers, twice the waves)
-template <int MODE, bool MULTI, bool NT, bool GGX>
+// One unit's registers while it travels through the DMA kernels.
+struct UnitIO {
+    float wix, wiy, wiz, wox, woy, woz, u0, u1;
+    float rgb[3], pdf, wo2[3], pdf2, w[3];
+};
+
+// Table lanes of one wave: transform, cooperative brick copy, blend.  EVERY lane of the wave must call
+// it (the copy is wave-wide); lanes whose material is not a table pass is_table = false, take part with
+// a harmless source and keep their outputs untouched.
+template <int MODE, bool MULTI, bool GGX>
+__device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDev &m, bool is_table, UnitIO &io,
+                                            const fast::Vec3 &in, float4 *ldsA, float4 *ldsB, unsigned lane)
+{
+    constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
+    constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
+    // a valid 128-B source for lanes without a table: the material array itself, cell 0
+    const float4 *lane_base = (GGX && !is_table) ? (const float4 *)a.materials : m.texels;
+    const fast::TableMaps maps(m);
+    BrickWeights wA, wB;
+    uint32_t cellA = 0, cellB = 0;
+    float sx = 0.0f, sy = 0.0f, sz = 1.0f;
+    if constexpr (HAS_EVAL) {
+        const fast::Vec3 out = fast::normalize_f32(io.wox, io.woy, io.woz);
+        cellA = brick_cell(m, fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wA);
+        if (GGX && !is_table) cellA = 0;
+    }
+    if constexpr (HAS_SAMPLE) {
+        square_to_cosine_hemisphere(a.opts.disk_map, io.u0, io.u1, sx, sy, sz);
+        const fast::Vec3 out = fast::normalize_f32(sx, sy, sz);
+        cellB = brick_cell(m, fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wB);
+        if (GGX && !is_table) cellB = 0;
+    }
+    if constexpr (HAS_EVAL) brick_dma<MULTI>(m.texels, cellA, lane_base, ldsA, lane);
+    if constexpr (HAS_SAMPLE) brick_dma<MULTI>(m.texels, cellB, lane_base, ldsB, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA has landed (own wave only: no barrier)
+
+    if constexpr (HAS_EVAL) {
+        const Rgbd v = brick_interp(ldsA, lane, wA);
+        const bool valid = (io.wiz > 0.0f) && (io.woz > 0.0f);
+        const double c = fast::cos_or_nan(io.wix, io.wiy, io.wiz, io.wox, io.woy, io.woz);
+        if (!GGX || is_table) {
+            io.rgb[0] = valid ? (float)(v.r * c) : 0.0f; io.rgb[1] = valid ? (float)(v.g * c) : 0.0f; io.rgb[2] = valid ? (float)(v.b * c) : 0.0f;
+            if constexpr (MODE == MODE_EVAL_SAMPLE) io.pdf = valid ? io.woz * kInvPiF : 0.0f;
+        }
+    }
+    if constexpr (HAS_SAMPLE) {
+        const Rgbd v = brick_interp(ldsB, lane, wB);
+        const bool valid = io.wiz > 0.0f;
+        const float p = sz > 0.0f ? sz * kInvPiF : 0.0f;
+        const bool has = valid && (p > 0.0f);
+        const double c = fast::cos_or_nan(io.wix, io.wiy, io.wiz, sx, sy, sz);
+        const float f0 = has ? (float)(v.r * c) : 0.0f, f1 = has ? (float)(v.g * c) : 0.0f, f2 = has ? (float)(v.b * c) : 0.0f;
+        const float ps = has ? p : 1.0f;
+        if (!GGX || is_table) {
+            io.wo2[0] = valid ? sx : 0.0f; io.wo2[1] = valid ? sy : 0.0f; io.wo2[2] = valid ? sz : 0.0f;
+            io.pdf2 = valid ? p : 0.0f;
+            io.w[0] = f0 / ps; io.w[1] = f1 / ps; io.w[2] = f2 / ps;
+        }
+    }
+    asm volatile("" ::: "memory");                            // LDS reads above stay ahead of the next step's DMA
+}
+
+// One analytic (GGX) lane: tuned functions of merl_ggx_fast.hpp
+template <int MODE>
+__device__ __forceinline__ void ggx_lane(const MaterialDev &m, UnitIO &io, const fast::Vec3 &in)
+{
+    constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
+    constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
+    const fast::GgxConsts g(m);
+    if constexpr (HAS_EVAL) {
+        const fast::Vec3 out = fast::normalize_f32(io.wox, io.woy, io.woz);
+        double v[3], p;
+        fast::ggx_eval_pdf(g, in, out, v, p);
+        const bool valid = (io.wiz > 0.0f) && (io.woz > 0.0f);
+        const double poison = fast::cos_or_nan(io.wix, io.wiy, io.wiz, io.wox, io.woy, 1.0f);
+        io.rgb[0] = valid ? (float)(v[0] * poison) : 0.0f; io.rgb[1] = valid ? (float)(v[1] * poison) : 0.0f;
+        io.rgb[2] = valid ? (float)(v[2] * poison) : 0.0f;
+        if constexpr (MODE == MODE_EVAL_SAMPLE) io.pdf = valid ? (float)(p * poison) : 0.0f;
+    }
+    if constexpr (HAS_SAMPLE) {
+        fast::ggx_sample(g, in, io.u0, io.u1, io.wo2, io.pdf2, io.w);
+        if (!(io.wiz > 0.0f)) { io.wo2[0] = io.wo2[1] = io.wo2[2] = 0.0f; io.pdf2 = 0.0f; io.w[0] = io.w[1] = io.w[2] = 0.0f; }
+    }
+}
+
+template <int MODE, bool NT>
+__device__ __forceinline__ void store_unit(const BatchArgs &a, size_t i, const UnitIO &io)
+{
+    constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
+    constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
+    if constexpr (HAS_EVAL) store3s<NT>(a.out_rgb, i, io.rgb);
+    if constexpr (MODE == MODE_EVAL_SAMPLE) stf<NT>(a.out_pdf + i, io.pdf);
+    if constexpr (HAS_SAMPLE) {
+        store3s<NT>(a.out_wo, i, io.wo2);
+        stf<NT>(a.out_pdf2 + i, io.pdf2);
+        store3s<NT>(a.out_weight, i, io.w);
+    }
+}
+
+// GGX: the batch may contain analytic (GGX) materials next to table materials; their lanes run the tuned
+// GGX functions after the table lanes, under divergence (a mixed wave pays for both paths; kind-uniform
+// waves skip the other path through wave-uniform branches).  GGX = false drops that code from the kernel.
+// The alternative — partitioning the batch into per-kind queues first, MRL_OPT_KERNEL 4 — is measured in
+// it wins only when most units are analytic, because a sparse queue reads whole 128-B lines
+// of the stream arrays for 12 B of payload.
+// INDEXED: the kernel walks a list of unit indices (one kind's queue built by k_partition_kinds) instead of [0, n).
+template <int MODE, bool MULTI, bool NT, bool GGX, bool INDEXED = false>
 __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
 {
     static_assert(MODE != MODE_PDF, "pdf needs no table");
+    static_assert(MULTI || !GGX, "a single-material GGX launch uses k_ggx");
     constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
     constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
     constexpr int LOOKUPS = (HAS_EVAL ? 1 : 0) + (HAS_SAMPLE ? 1 : 0);
@@ -217,10 +322,12 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
     float4 *ldsA = lds[wave][0];
     float4 *ldsB = lds[wave][LOOKUPS - 1];
     const size_t stride = (size_t)gridDim.x * kDmaBlock;
-    for (size_t base = (size_t)blockIdx.x * kDmaBlock + wave * 64u; base < a.n; base += stride) {
-        const size_t i_raw = base + lane;
-        const bool active = i_raw < a.n;
-        const size_t i = active ? i_raw : a.n - 1;            // tail lanes recompute the last unit, store nothing
+    const size_t n_items = INDEXED ? (size_t)*a.idx_count : a.n;
+    for (size_t base = (size_t)blockIdx.x * kDmaBlock + wave * 64u; base < n_items; base += stride) {
+        const size_t j_raw = base + lane;
+        const bool active = j_raw < n_items;
+        const size_t j = active ? j_raw : n_items - 1;        // tail lanes recompute the last unit, store nothing
+        const size_t i = INDEXED ? (size_t)a.idx[j] : j;
 
         MaterialDev m;
         bool known = true;
@@ -232,85 +339,37 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
             m = a.single;
         }
         const bool is_table = !GGX || m.kind != KIND_GGX;
-        // lanes without a table (GGX / unknown id) still take part in the cooperative copy: give them a
-        // harmless, valid 128-B source (the material array itself) and cell 0
-        const float4 *lane_base = (MULTI && !is_table) ? (const float4 *)a.materials : m.texels;
 
-        float wix, wiy, wiz;
-        load3s<NT>(a.wi, i, wix, wiy, wiz);
-        if (!known) wiz = 0.0f;
-        float wox = 0.0f, woy = 0.0f, woz = 1.0f, u0 = 0.0f, u1 = 0.0f;
-        if constexpr (HAS_EVAL) load3s<NT>(a.wo, i, wox, woy, woz);
-        if constexpr (HAS_SAMPLE) { u0 = ldf<NT>(a.u + 2 * i); u1 = ldf<NT>(a.u + 2 * i + 1); }
+        UnitIO io = {};
+        io.woz = 1.0f;
+        load3s<NT>(a.wi, i, io.wix, io.wiy, io.wiz);
+        if (!known) io.wiz = 0.0f;
+        if constexpr (HAS_EVAL) load3s<NT>(a.wo, i, io.wox, io.woy, io.woz);
+        if constexpr (HAS_SAMPLE) { io.u0 = ldf<NT>(a.u + 2 * i); io.u1 = ldf<NT>(a.u + 2 * i + 1); }
+        const fast::Vec3 in = fast::normalize_f32(io.wix, io.wiy, io.wiz);
 
-        const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
-        const fast::TableMaps maps(m);
-        BrickWeights wA, wB;
-        uint32_t cellA = 0, cellB = 0;
-        float sx = 0.0f, sy = 0.0f, sz = 1.0f;
-        if constexpr (HAS_EVAL) {
-            const fast::Vec3 out = fast::normalize_f32(wox, woy, woz);
-            cellA = brick_cell(m, fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wA);
-            if (MULTI && !is_table) cellA = 0;
+        if (!GGX || __ballot(is_table) != 0ull)               // wave-uniform
+            table_lanes<MODE, MULTI, GGX>(a, m, is_table, io, in, ldsA, ldsB, lane);
+        if constexpr (GGX) {
+            if (!is_table) ggx_lane<MODE>(m, io, in);
         }
-        if constexpr (HAS_SAMPLE) {
-            square_to_cosine_hemisphere(a.opts.disk_map, u0, u1, sx, sy, sz);
-            const fast::Vec3 out = fast::normalize_f32(sx, sy, sz);
-            cellB = brick_cell(m, fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wB);
-            if (MULTI && !is_table) cellB = 0;
-        }
-        if constexpr (HAS_EVAL) brick_dma<MULTI>(m.texels, cellA, lane_base, ldsA, lane);
-        if constexpr (HAS_SAMPLE) brick_dma<MULTI>(m.texels, cellB, lane_base, ldsB, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed (own wave only: no barrier)
-
-        float rgb[3] = { 0.0f, 0.0f, 0.0f }, pdf = 0.0f, wo2[3] = { 0.0f, 0.0f, 0.0f }, pdf2 = 0.0f, w[3] = { 0.0f, 0.0f, 0.0f };
-        if constexpr (HAS_EVAL) {
-            const Rgbd v = brick_interp(ldsA, lane, wA);
-            const bool valid = (wiz > 0.0f) && (woz > 0.0f);
-            const double c = fast::cos_or_nan(wix, wiy, wiz, wox, woy, woz);
-            rgb[0] = valid ? (float)(v.r * c) : 0.0f; rgb[1] = valid ? (float)(v.g * c) : 0.0f; rgb[2] = valid ? (float)(v.b * c) : 0.0f;
-            if constexpr (MODE == MODE_EVAL_SAMPLE) pdf = valid ? woz * kInvPiF : 0.0f;
-        }
-        if constexpr (HAS_SAMPLE) {
-            const Rgbd v = brick_interp(ldsB, lane, wB);
-            const bool valid = wiz > 0.0f;
-            const float p = sz > 0.0f ? sz * kInvPiF : 0.0f;
-            const bool has = valid && (p > 0.0f);
-            const double c = fast::cos_or_nan(wix, wiy, wiz, sx, sy, sz);
-            const float f0 = has ? (float)(v.r * c) : 0.0f, f1 = has ? (float)(v.g * c) : 0.0f, f2 = has ? (float)(v.b * c) : 0.0f;
-            const float ps = has ? p : 1.0f;
-            wo2[0] = valid ? sx : 0.0f; wo2[1] = valid ? sy : 0.0f; wo2[2] = valid ? sz : 0.0f;
-            pdf2 = valid ? p : 0.0f;
-            w[0] = f0 / ps; w[1] = f1 / ps; w[2] = f2 / ps;
-        }
-        asm volatile("" ::: "memory");                        // LDS reads above stay ahead of the next step's DMA
-        if (MULTI && GGX && !is_table) {                      // GGX lanes of a mixed batch: generic functions
-            if constexpr (HAS_EVAL) unit_eval(m, a.opts, wix, wiy, wiz, wox, woy, woz, rgb);
-            if constexpr (MODE == MODE_EVAL_SAMPLE) pdf = unit_pdf(m, wix, wiy, wiz, wox, woy, woz);
-            if constexpr (HAS_SAMPLE) unit_sample(m, a.opts, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
-        }
-        if (active) {
-            if constexpr (HAS_EVAL) store3s<NT>(a.out_rgb, i, rgb);
-            if constexpr (MODE == MODE_EVAL_SAMPLE) stf<NT>(a.out_pdf + i, pdf);
-            if constexpr (HAS_SAMPLE) {
-                store3s<NT>(a.out_wo, i, wo2);
-                stf<NT>(a.out_pdf2 + i, pdf2);
-                store3s<NT>(a.out_weight, i, w);
-            }
-        }
+        if (active) store_unit<MODE, NT>(a, i, io);
     }
 }
 
 // ---- tuned GGX rough conductor (single-material launches of an analytic material) ----------------
-template <int MODE, bool NT>
+// INDEXED: walks the GGX queue of a kind-partitioned mixed batch; the material is then per lane.
+template <int MODE, bool NT, bool INDEXED = false>
 __global__ __launch_bounds__(kBlock) void k_ggx(BatchArgs a)
 {
     constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
     constexpr bool HAS_PDF = MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE;
     constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
-    const fast::GgxConsts g(a.single);
     const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+    const size_t n_items = INDEXED ? (size_t)*a.idx_count : a.n;
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_items; j += stride) {
+        const size_t i = INDEXED ? (size_t)a.idx[j] : j;
+        const fast::GgxConsts g(INDEXED ? a.materials[a.mat[i]] : a.single);   // queue entries are known GGX ids
         float wix, wiy, wiz;
         load3s<NT>(a.wi, i, wix, wiy, wiz);
         const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
@@ -338,6 +397,100 @@ __global__ __launch_bounds__(kBlock) void k_ggx(BatchArgs a)
             stf<NT>(a.out_pdf2 + i, pdf2);
             store3s<NT>(a.out_weight, i, w);
         }
+    }
+}
+
+// ---- variant 4: per-kind queues for batches that mix table and analytic materials -----------------
+// A random mix makes every wave of a fused kernel pay for both code paths, at the register budget of
+// their union.  Instead the batch is partitioned once into two DENSE queues of unit indices and each
+// queue runs through its own dedicated kernel at that kernel's best occupancy (the fabric-bound table
+// kernel, the VALU-bound GGX kernel).  The partition uses no atomics (one queue counter would serialise
+// ~1M wave atomics into 15+ ms) and is deterministic:
+//   k_count_kinds      block b counts the kinds of segment b = units [b*seg_len, (b+1)*seg_len)
+//   k_scan_segments    one block: exclusive prefix of the per-segment counts -> queue offsets, totals
+//   k_partition_kinds  block b again walks its segment in 256-unit tiles: per wave a ballot of each
+//                      kind, popcount for the wave's count, mbcnt for the lane's rank (the wavefront
+//                      ballot/prefix), a prefix over the block's 4 waves in LDS, running offsets in
+//                      registers; lane writes its unit index to offset[b][kind] + rank
+// Queue entries ascend, so the consumers' indexed loads/stores stay line-friendly, and consumers see a
+// dense [0, total) range: no idle lanes, no load imbalance between blocks.
+struct KindFlags { bool tab, ggx; };
+__device__ __forceinline__ KindFlags kind_of(const int32_t *mat, size_t i, bool in_range, const MaterialDev *materials, int n_materials)
+{
+    const int id = in_range ? mat[i] : -1;
+    const bool known = id >= 0 && id < n_materials;
+    const bool ggx = known && materials[id].kind == KIND_GGX;
+    return { in_range && !ggx, ggx };                         // unknown ids ride the table queue and come out as zeros
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_kinds(const int32_t *mat, size_t n, const MaterialDev *materials, int n_materials,
+                                                       uint32_t *counts, uint32_t seg_len)
+{
+    __shared__ unsigned s_sum[2];
+    if (threadIdx.x < 2) s_sum[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t first = (size_t)blockIdx.x * seg_len;
+    const size_t last = first + seg_len < n ? first + seg_len : n;
+    unsigned t = 0, g = 0;
+    for (size_t i = first + threadIdx.x; i < last; i += kBlock) {
+        const KindFlags k = kind_of(mat, i, true, materials, n_materials);
+        t += k.tab; g += k.ggx;
+    }
+    // wave reduce by ballot-free shuffle, then one LDS atomic per wave
+    for (int off = 32; off > 0; off >>= 1) { t += __shfl_down(t, off); g += __shfl_down(g, off); }
+    if ((threadIdx.x & 63u) == 0) { atomicAdd(&s_sum[0], t); atomicAdd(&s_sum[1], g); }
+    __syncthreads();
+    if (threadIdx.x < 2) counts[2 * blockIdx.x + threadIdx.x] = s_sum[threadIdx.x];
+}
+
+// counts[S][2] -> offsets[S][2] (exclusive prefix per kind), totals[2]; S <= a few thousand: one block
+__global__ __launch_bounds__(kBlock) void k_scan_segments(const uint32_t *counts, uint32_t segments, uint32_t *offsets, uint32_t *totals)
+{
+    __shared__ unsigned s_part[kBlock][2];
+    const unsigned tid = threadIdx.x;
+    const unsigned per = (segments + kBlock - 1) / kBlock;
+    const unsigned lo = tid * per, hi = lo + per < segments ? lo + per : segments;
+    unsigned t = 0, g = 0;
+    for (unsigned s = lo; s < hi; ++s) { t += counts[2 * s]; g += counts[2 * s + 1]; }
+    s_part[tid][0] = t; s_part[tid][1] = g;
+    __syncthreads();
+    unsigned bt = 0, bg = 0;
+    for (unsigned k = 0; k < tid; ++k) { bt += s_part[k][0]; bg += s_part[k][1]; }
+    for (unsigned s = lo; s < hi; ++s) {
+        offsets[2 * s] = bt; offsets[2 * s + 1] = bg;
+        bt += counts[2 * s]; bg += counts[2 * s + 1];
+    }
+    if (tid == kBlock - 1) { totals[0] = bt; totals[1] = bg; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_partition_kinds(const int32_t *mat, size_t n, const MaterialDev *materials,
+                                                           int n_materials, uint32_t *queue_table, uint32_t *queue_ggx,
+                                                           const uint32_t *offsets, uint32_t seg_len)
+{
+    constexpr int WAVES = kBlock / 64;
+    __shared__ unsigned s_cnt[2][WAVES][2];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const size_t first = (size_t)blockIdx.x * seg_len;
+    const size_t last = first + seg_len < n ? first + seg_len : n;
+    unsigned t_run = offsets[2 * blockIdx.x], g_run = offsets[2 * blockIdx.x + 1], parity = 0;
+    for (size_t tile = first; tile < last; tile += kBlock) {          // block-uniform trip count
+        const size_t i = tile + tid;
+        const KindFlags k = kind_of(mat, i, i < last, materials, n_materials);
+        const unsigned long long mg = __ballot(k.ggx), mt = __ballot(k.tab);
+        if (lane == 0) { s_cnt[parity][wave][0] = (unsigned)__popcll(mt); s_cnt[parity][wave][1] = (unsigned)__popcll(mg); }
+        __syncthreads();
+        unsigned t_before = 0, g_before = 0, t_tile = 0, g_tile = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const unsigned ct = s_cnt[parity][w][0], cg = s_cnt[parity][w][1];
+            t_tile += ct; g_tile += cg;
+            t_before += (unsigned)w < wave ? ct : 0u;
+            g_before += (unsigned)w < wave ? cg : 0u;
+        }
+        if (k.tab) queue_table[t_run + t_before + __builtin_amdgcn_mbcnt_hi((unsigned)(mt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mt, 0u))] = (uint32_t)i;
+        if (k.ggx) queue_ggx[g_run + g_before + __builtin_amdgcn_mbcnt_hi((unsigned)(mg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mg, 0u))] = (uint32_t)i;
+        t_run += t_tile; g_run += g_tile;
+        parity ^= 1u;                                         // double-buffered counts: one barrier per tile
     }
 }
 
@@ -415,9 +568,10 @@ hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, 
             constexpr int per_cu = ((MODE == MODE_EVAL_SAMPLE) ? 2 : 4) * (256 / kDmaBlock);
             size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;
             if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
-            if (multi && has_ggx) hipLaunchKernelGGL((k_table_dma<MODE, true, true, true>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);
-            else if (multi)       hipLaunchKernelGGL((k_table_dma<MODE, true, true, false>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);
-            else                  hipLaunchKernelGGL((k_table_dma<MODE, false, true, false>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);
+            const dim3 g((unsigned)blocks), b(kDmaBlock);
+            if (multi && has_ggx)      hipLaunchKernelGGL((k_table_dma<MODE, true, true, true>), g, b, 0, stream, a);
+            else if (multi)            hipLaunchKernelGGL((k_table_dma<MODE, true, true, false>), g, b, 0, stream, a);
+            else                       hipLaunchKernelGGL((k_table_dma<MODE, false, true, false>), g, b, 0, stream, a);
             return hipGetLastError();
         }
     }
@@ -440,6 +594,64 @@ hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, i
         case MODE_PDF:         return launch_mode<MODE_PDF>(a, multi, variant, layout, has_ggx, compute_units, stream);
         case MODE_SAMPLE:      return launch_mode<MODE_SAMPLE>(a, multi, variant, layout, has_ggx, compute_units, stream);
         case MODE_EVAL_SAMPLE: return launch_mode<MODE_EVAL_SAMPLE>(a, multi, variant, layout, has_ggx, compute_units, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+void partition_geometry(size_t n, int compute_units, uint32_t *segments, uint32_t *seg_len)
+{
+    size_t s = (n + kBlock - 1) / kBlock;
+    const size_t cap = (size_t)compute_units * 8;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    size_t len = (n + s - 1) / s;
+    len = (len + kBlock - 1) / kBlock * kBlock;
+    *segments = (uint32_t)((n + len - 1) / len);
+    *seg_len = (uint32_t)len;
+}
+
+// work: uint32 [2*segments counts][2*segments offsets][2 totals]; queues: dense, n entries each at most
+hipError_t launch_partition_kinds(const int32_t *mat, size_t n, const MaterialDev *materials, int n_materials,
+                                  uint32_t *queue_table, uint32_t *queue_ggx, uint32_t *work,
+                                  uint32_t segments, uint32_t seg_len, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    uint32_t *counts = work, *offsets = work + 2 * (size_t)segments, *totals = work + 4 * (size_t)segments;
+    hipLaunchKernelGGL(k_count_kinds, dim3(segments), dim3(kBlock), 0, stream, mat, n, materials, n_materials, counts, seg_len);
+    hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(kBlock), 0, stream, counts, segments, offsets, totals);
+    hipLaunchKernelGGL(k_partition_kinds, dim3(segments), dim3(kBlock), 0, stream, mat, n, materials, n_materials,
+                       queue_table, queue_ggx, offsets, seg_len);
+    return hipGetLastError();
+}
+
+namespace {
+template <int MODE>
+hipError_t launch_queue_mode(const BatchArgs &a, bool ggx_queue, int compute_units, hipStream_t stream)
+{
+    if constexpr (MODE == MODE_PDF) {
+        return hipErrorInvalidValue;
+    } else {
+        if (ggx_queue) {
+            hipLaunchKernelGGL((k_ggx<MODE, true, true>), dim3(grid_for(a.n, compute_units)), dim3(kBlock), 0, stream, a);
+        } else {
+            constexpr int per_cu = ((MODE == MODE_EVAL_SAMPLE) ? 2 : 4) * (256 / kDmaBlock);
+            size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;
+            if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
+            hipLaunchKernelGGL((k_table_dma<MODE, true, true, false, true>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);
+        }
+        return hipGetLastError();
+    }
+}
+} // namespace
+
+// one kind's dense queue (a.idx, a.idx_count) of a partitioned mixed batch; a.n = units of the whole batch (grid sizing)
+hipError_t launch_batch_queue(int mode, const BatchArgs &a, bool ggx_queue, int compute_units, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    switch (mode) {
+        case MODE_EVAL:        return launch_queue_mode<MODE_EVAL>(a, ggx_queue, compute_units, stream);
+        case MODE_SAMPLE:      return launch_queue_mode<MODE_SAMPLE>(a, ggx_queue, compute_units, stream);
+        case MODE_EVAL_SAMPLE: return launch_queue_mode<MODE_EVAL_SAMPLE>(a, ggx_queue, compute_units, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -18,6 +18,9 @@ struct BatchArgs {
     const MaterialDev *materials;    // device array (mixed-material launches)
     int n_materials;
     Options opts;
+    // kind-partitioned mixed batches: a dense queue of unit indices (k_partition_kinds), else unused
+    const uint32_t *idx;
+    const uint32_t *idx_count;               // its length, in device memory
 };
 
 // mode: 0 eval, 1 pdf, 2 sample, 3 eval+sample
@@ -25,6 +28,13 @@ struct BatchArgs {
 // layout: the context-wide table layout (every table of a context has the same one)
 // has_ggx: the context holds at least one analytic (GGX) material, so a mixed batch may contain such lanes
 hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int layout, bool has_ggx, int compute_units, hipStream_t stream);
+// kind-partitioned mixed batches (MRL_OPT_KERNEL >= 4): build the two queues, then run one of them
+void partition_geometry(size_t n, int compute_units, uint32_t *segments, uint32_t *seg_len);
+// work: 4*segments + 2 uint32 (counts, offsets, totals[2] at work + 4*segments)
+hipError_t launch_partition_kinds(const int32_t *mat, size_t n, const MaterialDev *materials, int n_materials,
+                                  uint32_t *queue_table, uint32_t *queue_ggx, uint32_t *work,
+                                  uint32_t segments, uint32_t seg_len, hipStream_t stream);
+hipError_t launch_batch_queue(int mode, const BatchArgs &a, bool ggx_queue, int compute_units, hipStream_t stream);
 hipError_t launch_generate_pairs(uint64_t seed, uint64_t first, size_t n, float *wi, float *wo, float *u,
                                  int compute_units, hipStream_t stream);
 hipError_t launch_generate_materials(uint64_t seed, uint64_t first, size_t n, int n_materials, int32_t *mat,

@@ -375,3 +375,53 @@ def test_kernel_variants_and_layouts_match_oracle(gpu, oracle, tables, kind, see
     for key, r in results.items():
         if key[1:3] == (1, 0):
             assert_close(r, base, rel=2.5e-7, what=f"{key} vs rows/variant 1")
+
+
+# ------------------------------------------------------------------ batches that mix material KINDS
+@pytest.mark.parametrize("variant", [0, 3, 4])
+@pytest.mark.parametrize("ggx_share", [0.5, 0.03, 0.97])
+def test_mixed_kinds_table_and_ggx(oracle, tables, variant, ggx_share):
+    """Table and analytic (GGX) materials in one batch.  Variant 4 compacts each 256-unit tile by kind
+    (ballot / mbcnt prefix) before processing; 3 leaves the lanes where they fall; 0 is the generic kernel.
+    All must agree with the oracle unit by unit, including ragged tails and unknown ids."""
+    import torch
+    from mitsuba_customization_amd import host
+    from oracle import binding as ob
+    tabs = [tables("ggx_tab", 300), tables("noise", 301)]
+    eta, k = (0.2, 0.9, 1.1), (3.9, 2.4, 2.2)
+    n = 50_000 + 37
+    wi, wo, u = oracle.generate_pairs(0x5EED, 777_000, n)
+    rng = np.random.default_rng(int(ggx_share * 100) + variant)
+    is_ggx = rng.random(n) < ggx_share
+    with host.MerlHip(0) as g:
+        g.set_option(host.OPT_KERNEL, variant)
+        t_ids = [g.upload_merl(t) for t in tabs]
+        g_ids = [g.ggx(0.1, eta, k), g.ggx(0.4, eta, k)]
+        pick = rng.integers(0, 2, n)
+        mat = np.where(is_ggx, np.asarray(g_ids)[pick], np.asarray(t_ids)[pick]).astype(np.int32)
+        mat[11] = -5; mat[n - 1] = 99
+        dwi, dwo, du = to_dev(wi, wo, u); (dmat,) = to_dev(mat)
+        got = [t.cpu().numpy() for t in g.eval_sample(dwi, dwo, du, mat=dmat)]
+        ev = g.eval(dwi, dwo, mat=dmat).cpu().numpy()
+        sm = [t.cpu().numpy() for t in g.sample(dwi, du, mat=dmat)]
+    assert np.array_equal(ev, got[0]) and all(np.array_equal(a, b) for a, b in zip(sm, got[2:]))
+    # oracle, kind by kind
+    want = [np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)]
+    for j, tid in enumerate(t_ids):
+        sel = np.nonzero(mat == tid)[0]
+        r = ob.eval_sample_multi([ob.OracleTable(tabs[j])], wi[sel], wo[sel], u[sel], None)
+        for a, b in zip(want, r):
+            a[sel] = b
+    for j, gid in enumerate(g_ids):
+        sel = np.nonzero(mat == gid)[0]
+        G = ob.OracleGgx(float(np.float32((0.1, 0.4)[j])), [float(np.float32(x)) for x in eta], [float(np.float32(x)) for x in k])
+        s_wo, s_pdf, s_w = G.sample(wi[sel], u[sel])
+        for a, b in zip(want, (G.eval(wi[sel], wo[sel]), G.pdf(wi[sel], wo[sel]), s_wo, s_pdf, s_w)):
+            a[sel] = b
+    tsel = ~np.isin(mat, g_ids)
+    assert_close(got[0], want[0], what="mixed kinds rgb"); assert_close(got[4], want[4], what="mixed kinds weight")
+    assert_close(got[1], want[1], rel=2e-6, what="pdf"); assert_close(got[3], want[3], rel=2e-6, what="pdf2")
+    assert np.array_equal(got[1][tsel], want[1][tsel]) and np.array_equal(got[2][tsel], want[2][tsel])
+    assert np.abs(got[2].astype(np.float64) - want[2]).max() <= 1.2e-7
+    for arr in got:
+        assert (arr[11] == 0).all() and (arr[n - 1] == 0).all()
