@@ -53,7 +53,7 @@ int main(int argc, char **argv)
     size_t lds = (size_t)wpb * lookups * 8192;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     auto launch = [&]() {
-        if (lookups == 2) { if (aux) hipLaunchKernelGGL((k<2, 2>), grid, block, lds, 0, t, n_lines, iters, sink); else hipLaunchKernelGGL((k<2, 0>), grid, block, lds, 0, t, n_lines, iters, sink); }
+        if (aux == 1) hipLaunchKernelGGL((k<2, 1>), grid, block, lds, 0, t, n_lines, iters, sink); else if (aux == 3) hipLaunchKernelGGL((k<2, 3>), grid, block, lds, 0, t, n_lines, iters, sink); else if (aux == 16) hipLaunchKernelGGL((k<2, 16>), grid, block, lds, 0, t, n_lines, iters, sink); else if (aux == 17) hipLaunchKernelGGL((k<2, 17>), grid, block, lds, 0, t, n_lines, iters, sink); else if (aux == 18) hipLaunchKernelGGL((k<2, 18>), grid, block, lds, 0, t, n_lines, iters, sink); else if (lookups == 2) { if (aux) hipLaunchKernelGGL((k<2, 2>), grid, block, lds, 0, t, n_lines, iters, sink); else hipLaunchKernelGGL((k<2, 0>), grid, block, lds, 0, t, n_lines, iters, sink); }
         else { if (aux) hipLaunchKernelGGL((k<1, 2>), grid, block, lds, 0, t, n_lines, iters, sink); else hipLaunchKernelGGL((k<1, 0>), grid, block, lds, 0, t, n_lines, iters, sink); }
     };
     launch(); CK(hipDeviceSynchronize());
