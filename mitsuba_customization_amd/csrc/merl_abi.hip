@@ -131,45 +131,21 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1;
     const size_t plane = (size_t)n_th * n_td * n_pd;
     const int layout = ctx->table_layout;
-    std::vector<float4> host;
-    try { host.resize(layout == mrl::LAYOUT_BRICK ? plane * 8 : H * D * P); } catch (const std::bad_alloc &) { return fail(ctx, MRL_ERR_OOM, "host staging for table"); }
-    auto texel = [&](size_t sh, size_t sd, size_t sp, int ch) -> float {
-        double v = planar[(sh * n_td + sd) * n_pd + sp + (size_t)ch * plane] * scale[ch];
-        return v > 0.0 ? (float)v : 0.0f;
-    };
-    if (layout == mrl::LAYOUT_BRICK) {
-        // brick (ih,id,ip): the 8 corners (ih+a clamped, id+b clamped, ip+c wrapped), RGB packed, in one 128-B line
-        for (size_t ih = 0; ih < (size_t)n_th; ++ih)
-            for (size_t id = 0; id < (size_t)n_td; ++id)
-                for (size_t ip = 0; ip < (size_t)n_pd; ++ip) {
-                    float *dst = reinterpret_cast<float *>(host.data() + ((ih * n_td + id) * n_pd + ip) * 8);
-                    for (int k = 0; k < 8; ++k) {
-                        size_t sh = std::min<size_t>(ih + (k >> 2), n_th - 1), sd = std::min<size_t>(id + ((k >> 1) & 1), n_td - 1);
-                        size_t sp = (ip + (k & 1)) % (size_t)n_pd;
-                        for (int ch = 0; ch < 3; ++ch) dst[3 * k + ch] = texel(sh, sd, sp, ch);
-                    }
-                    for (int pad = 24; pad < 32; ++pad) dst[pad] = 0.0f;
-                }
-    } else
-    for (size_t ih = 0; ih < H; ++ih) {
-        size_t sh = std::min<size_t>(ih, n_th - 1);
-        for (size_t id = 0; id < D; ++id) {
-            size_t sd = std::min<size_t>(id, n_td - 1);
-            const size_t src_row = (sh * n_td + sd) * n_pd;
-            float4 *dst = host.data() + (ih * D + id) * P;
-            for (size_t ip = 0; ip < P; ++ip) {
-                size_t sp = ip == (size_t)n_pd ? 0 : ip;
-                double r = planar[src_row + sp] * scale[0];
-                double g = planar[src_row + sp + plane] * scale[1];
-                double b = planar[src_row + sp + 2 * plane] * scale[2];
-                dst[ip] = make_float4(r > 0.0 ? (float)r : 0.0f, g > 0.0 ? (float)g : 0.0f, b > 0.0 ? (float)b : 0.0f, 0.0f);
-            }
-        }
-    }
+    const size_t out_texels = layout == mrl::LAYOUT_BRICK ? plane * 8 : H * D * P;
+    // the file payload goes to the device as it is; a kernel scales, clamps and re-lays it out
+    double *d_planar = nullptr;
     MaterialHost m;
-    MRL_HIP(ctx, hipMalloc((void **)&m.d_texels, host.size() * sizeof(float4)));
-    hipError_t e = hipMemcpy(m.d_texels, host.data(), host.size() * sizeof(float4), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(m.d_texels); return fail(ctx, MRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e)); }
+    MRL_HIP(ctx, hipMalloc((void **)&d_planar, 3 * plane * sizeof(double)));
+    hipError_t e = hipMalloc((void **)&m.d_texels, out_texels * sizeof(float4));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_planar, planar, 3 * plane * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = mrl::launch_build_table(d_planar, dims, scale, layout, m.d_texels, ctx->compute_units, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_planar);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (m.d_texels) (void)hipFree(m.d_texels);
+        return fail(ctx, e == hipErrorOutOfMemory ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
+    }
     std::memset(&m.dev, 0, sizeof m.dev);
     m.dev.kind = kind;
     m.dev.n_th = n_th; m.dev.n_td = n_td; m.dev.n_pd = n_pd;

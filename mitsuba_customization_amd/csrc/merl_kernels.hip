@@ -494,6 +494,51 @@ __global__ __launch_bounds__(kBlock) void k_partition_kinds(const int32_t *mat, 
     }
 }
 
+// ---- a1: table re-layout on the device (planar f64 file order -> HBM layout), one thread per output texel/brick ----
+__device__ __forceinline__ float scaled_texel(const double *planar, size_t plane, size_t index, int ch, double scale)
+{
+    const double v = planar[index + (size_t)ch * plane] * scale;
+    return v > 0.0 ? (float)v : 0.0f;                         // MERL's negative "below horizon" markers clamp to 0
+}
+
+__global__ __launch_bounds__(kBlock) void k_build_bricks(const double *planar, int n_th, int n_td, int n_pd,
+                                                        double s0, double s1, double s2, float4 *bricks)
+{
+    const size_t cells = (size_t)n_th * n_td * n_pd, plane = cells;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const double scale[3] = { s0, s1, s2 };
+    for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < cells; c += stride) {
+        const int ip = (int)(c % (size_t)n_pd), id = (int)((c / (size_t)n_pd) % (size_t)n_td), ih = (int)(c / ((size_t)n_pd * n_td));
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int sh = min(ih + (k >> 2), n_th - 1), sd = min(id + ((k >> 1) & 1), n_td - 1), sp = (ip + (k & 1)) % n_pd;
+            const size_t src = ((size_t)sh * n_td + sd) * n_pd + sp;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) v[3 * k + ch] = scaled_texel(planar, plane, src, ch, scale[ch]);
+        }
+#pragma unroll
+        for (int pad = 24; pad < 32; ++pad) v[pad] = 0.0f;
+        float4 *dst = bricks + c * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_build_rows(const double *planar, int n_th, int n_td, int n_pd,
+                                                      double s0, double s1, double s2, float4 *rows)
+{
+    const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1, total = H * D * P, plane = (size_t)n_th * n_td * n_pd;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+        const size_t ip = t % P, id = (t / P) % D, ih = t / (P * D);
+        const size_t sh = ih < (size_t)n_th ? ih : n_th - 1, sd = id < (size_t)n_td ? id : n_td - 1, sp = ip == (size_t)n_pd ? 0 : ip;
+        const size_t src = (sh * n_td + sd) * n_pd + sp;
+        rows[t] = make_float4(scaled_texel(planar, plane, src, 0, s0), scaled_texel(planar, plane, src, 1, s1),
+                              scaled_texel(planar, plane, src, 2, s2), 0.0f);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_generate_pairs(uint64_t seed, uint64_t first, size_t n,
                                                           float *wi, float *wo, float *u)
 {
@@ -654,6 +699,19 @@ hipError_t launch_batch_queue(int mode, const BatchArgs &a, bool ggx_queue, int 
         case MODE_EVAL_SAMPLE: return launch_queue_mode<MODE_EVAL_SAMPLE>(a, ggx_queue, compute_units, stream);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, float4 *d_out,
+                              int compute_units, hipStream_t stream)
+{
+    const size_t cells = (size_t)dims[0] * dims[1] * dims[2];
+    if (layout == LAYOUT_BRICK)
+        hipLaunchKernelGGL(k_build_bricks, dim3(grid_for(cells, compute_units)), dim3(kBlock), 0, stream, d_planar, dims[0], dims[1], dims[2],
+                           scale[0], scale[1], scale[2], d_out);
+    else
+        hipLaunchKernelGGL(k_build_rows, dim3(grid_for((size_t)(dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1), compute_units)), dim3(kBlock), 0, stream,
+                           d_planar, dims[0], dims[1], dims[2], scale[0], scale[1], scale[2], d_out);
+    return hipGetLastError();
 }
 
 hipError_t launch_generate_pairs(uint64_t seed, uint64_t first, size_t n, float *wi, float *wo, float *u,

@@ -35,6 +35,9 @@ hipError_t launch_partition_kinds(const int32_t *mat, size_t n, const MaterialDe
                                   uint32_t *queue_table, uint32_t *queue_ggx, uint32_t *work,
                                   uint32_t segments, uint32_t seg_len, hipStream_t stream);
 hipError_t launch_batch_queue(int mode, const BatchArgs &a, bool ggx_queue, int compute_units, hipStream_t stream);
+// a1: planar f64 table (device copy of the file payload) -> padded rows or bricks
+hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, float4 *d_out,
+                              int compute_units, hipStream_t stream);
 hipError_t launch_generate_pairs(uint64_t seed, uint64_t first, size_t n, float *wi, float *wo, float *u,
                                  int compute_units, hipStream_t stream);
 hipError_t launch_generate_materials(uint64_t seed, uint64_t first, size_t n, int n_materials, int32_t *mat,
