@@ -75,6 +75,9 @@ def parse():
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the separately reported RCCL gather leg")
     p.add_argument("--gather-units", type=int, default=16 << 20, help="N>1: units per rank moved by the gather leg")
     p.add_argument("--parity-sample", type=int, default=4096)
+    p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                   help="control-plane backend; gloo only rehearses the multi-rank logic (ranks may then share one GPU: --share-gpu)")
+    p.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     return p.parse_args()
 
 
@@ -93,6 +96,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_pg = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
     if world > 1 and not use_pg:
@@ -100,8 +105,12 @@ def main():
     if use_pg:
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
-                                timeout=datetime.timedelta(minutes=10))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(minutes=10))
+        else:
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=10))
+    comm_dev = (lambda d: d) if args.dist_backend == "nccl" else (lambda d: torch.device("cpu"))
 
     from mitsuba_customization_amd import host, synth
 
@@ -167,7 +176,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if use_pg:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=comm_dev(dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
@@ -236,12 +245,12 @@ def main():
         ok, full, err = 1, None, ""
         try:
             from mitsuba_customization_amd import shard
-            local = [o[:g_units] for o in out]
+            local = [o[:g_units].to(comm_dev(dev)) for o in out]       # gloo rehearsal: host copies
             if rank == 0:
-                full = [torch.empty((g_units * world,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in local]
+                full = [torch.empty((g_units * world,) + tuple(t.shape[1:]), dtype=t.dtype, device=comm_dev(dev)) for t in local]
         except Exception as e:
             ok, err = 0, repr(e)
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        flag = torch.tensor([ok], dtype=torch.int32, device=comm_dev(dev))
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag[0]) == 1:
             g = shard.bench_gather(local, steps=3, out=full)

@@ -28,6 +28,10 @@ class Table(C.Structure):
                 ("data", C.POINTER(C.c_double)), ("scale", C.c_double * 3)]
 
 
+class Sampling(C.Structure):
+    _fields_ = [("n", C.c_int), ("s", C.POINTER(C.c_double)), ("cdf", C.POINTER(C.c_double)), ("c", C.POINTER(C.c_double))]
+
+
 class Ggx(C.Structure):
     _fields_ = [("alpha", C.c_double), ("eta", C.c_double * 3), ("k", C.c_double * 3)]
 
@@ -71,6 +75,10 @@ def lib():
         L.orc_eval_sample_batch_multi.argtypes = [C.POINTER(Table), C.c_int, C.POINTER(Opts), fp, fp, fp,
                                                   C.POINTER(C.c_int32), C.c_size_t, fp, fp, fp, fp, fp]
         L.orc_square_to_cosine_hemisphere.argtypes = [C.c_int, fp, fp]
+        L.orc_build_sampling.argtypes = [C.POINTER(Table), C.POINTER(Sampling)]
+        L.orc_free_sampling.argtypes = [C.POINTER(Sampling)]
+        L.orc_pdf_table_batch.argtypes = [C.POINTER(Sampling), fp, fp, C.c_size_t, fp]
+        L.orc_sample_table_batch.argtypes = [C.POINTER(Table), C.POINTER(Opts), C.POINTER(Sampling), fp, fp, C.c_size_t, fp, fp, fp]
         L.orc_ggx_eval_batch.argtypes = [C.POINTER(Ggx), fp, fp, C.c_size_t, fp]
         L.orc_ggx_pdf_batch.argtypes = [C.POINTER(Ggx), fp, fp, C.c_size_t, fp]
         L.orc_ggx_sample_batch.argtypes = [C.POINTER(Ggx), fp, fp, C.c_size_t, fp, fp, fp]
@@ -125,6 +133,35 @@ class OracleTable:
         fp = C.POINTER(C.c_float)
         lib().orc_sample_batch(C.byref(self.c), C.byref(opts), pwi, pu, n,
                                wo.ctypes.data_as(fp), pdf.ctypes.data_as(fp), w.ctypes.data_as(fp))
+        return wo, pdf, w
+
+    # ---- table importance sampling ----
+    def sampling(self):
+        if getattr(self, "_sampling", None) is None:
+            self._sampling = Sampling()
+            assert lib().orc_build_sampling(C.byref(self.c), C.byref(self._sampling)) == 0
+        return self._sampling
+
+    def sampling_arrays(self):
+        sp = self.sampling()
+        n = sp.n
+        return (np.ctypeslib.as_array(sp.s, (n + 1,)).copy(), np.ctypeslib.as_array(sp.cdf, (n + 1,)).copy(),
+                np.ctypeslib.as_array(sp.c, (n,)).copy())
+
+    def pdf_table(self, wi, wo):
+        wi, pwi = _f32(wi); wo, pwo = _f32(wo)
+        out = np.empty(wi.shape[0], np.float32)
+        lib().orc_pdf_table_batch(C.byref(self.sampling()), pwi, pwo, wi.shape[0], out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def sample_table(self, wi, u, opts=None):
+        opts = opts or make_opts()
+        wi, pwi = _f32(wi); u, pu = _f32(u)
+        n = wi.shape[0]
+        fp = C.POINTER(C.c_float)
+        wo = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32); w = np.empty((n, 3), np.float32)
+        lib().orc_sample_table_batch(C.byref(self.c), C.byref(opts), C.byref(self.sampling()), pwi, pu, n,
+                                     wo.ctypes.data_as(fp), pdf.ctypes.data_as(fp), w.ctypes.data_as(fp))
         return wo, pdf, w
 
     def lookup(self, th, td, pd, opts=None):

@@ -298,6 +298,128 @@ void orc_sample(const orc_table *t, const orc_opts *o, const float wi[3], const 
     weight[0] = f[0] / p; weight[1] = f[1] / p; weight[2] = f[2] / p;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * §8f item 2 — table importance sampling (see merl_oracle.h for the definition).
+ * ---------------------------------------------------------------------------------------- */
+int orc_build_sampling(const orc_table *t, orc_sampling *out)
+{
+    const int n = t->n_th;
+    out->n = n;
+    out->s = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+    out->cdf = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+    out->c = (double *)malloc(sizeof(double) * (size_t)n);
+    double *D = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!out->s || !out->cdf || !out->c || !D) { free(D); orc_free_sampling(out); return -4; }
+    double mean = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < t->n_td; ++j)
+            for (int k = 0; k < t->n_pd; ++k) {
+                double v[3];
+                texel(t, i, j, k, v);
+                acc += 0.2126 * v[0] + 0.7152 * v[1] + 0.0722 * v[2];
+            }
+        D[i] = acc / ((double)t->n_td * (double)t->n_pd);
+        mean += D[i];
+    }
+    mean /= (double)n;
+    for (int i = 0; i < n; ++i) D[i] = mean > 0.0 ? D[i] + 0.01 * mean : 1.0;
+    for (int i = 0; i <= n; ++i) {
+        double r = (double)i / (double)n;
+        double sn = sin(r * r * (M_PI / 2.0));
+        out->s[i] = i == n ? 1.0 : sn * sn;
+    }
+    double Z = 0.0;
+    for (int i = 0; i < n; ++i) Z += D[i] * (out->s[i + 1] - out->s[i]);
+    double run = 0.0;
+    for (int i = 0; i < n; ++i) {
+        out->cdf[i] = run / Z;
+        run += D[i] * (out->s[i + 1] - out->s[i]);
+        out->c[i] = D[i] / (M_PI * Z);
+    }
+    out->cdf[n] = 1.0;
+    free(D);
+    return 0;
+}
+
+void orc_free_sampling(orc_sampling *sp)
+{
+    free(sp->s); free(sp->cdf); free(sp->c);
+    sp->s = sp->cdf = sp->c = NULL;
+}
+
+/* largest i in [0, n-1] with a[i] <= x */
+static int bin_of(const double *a, int n, double x)
+{
+    int lo = 0, hi = n;           /* invariant: a[lo] <= x < a[hi] (a[n] treated as +inf) */
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (a[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+static double pdf_table_f64(const orc_sampling *sp, const float wi[3], const float wo[3])
+{
+    if (!(wi[2] > 0.0f) || !(wo[2] > 0.0f)) return 0.0;
+    double in[3] = { wi[0], wi[1], wi[2] }, out[3] = { wo[0], wo[1], wo[2] };
+    unit3(in); unit3(out);
+    double h[3] = { in[0] + out[0], in[1] + out[1], in[2] + out[2] };
+    unit3(h);
+    double sin2 = h[0] * h[0] + h[1] * h[1];
+    int i = bin_of(sp->s, sp->n, sin2);
+    double ih = in[0] * h[0] + in[1] * h[1] + in[2] * h[2];
+    double ph = sp->c[i] * h[2] / (4.0 * ih);
+    return 0.5 * ((double)wo[2] * (1.0 / M_PI)) + 0.5 * ph;
+}
+
+float orc_pdf_table(const orc_sampling *sp, const float wi[3], const float wo[3])
+{
+    return (float)pdf_table_f64(sp, wi, wo);
+}
+
+void orc_sample_table(const orc_table *t, const orc_opts *o, const orc_sampling *sp, const float wi[3], const float u[2],
+                      float wo[3], float *pdf, float weight[3])
+{
+    wo[0] = wo[1] = wo[2] = 0.0f; *pdf = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
+    if (!(wi[2] > 0.0f)) return;
+    float d[3];
+    if (u[0] < 0.5f) {
+        const float uu[2] = { 2.0f * u[0], u[1] };
+        orc_square_to_cosine_hemisphere(o->disk_map, uu, d);
+    } else {
+        double x = (double)(2.0f * u[0] - 1.0f);
+        int i = bin_of(sp->cdf, sp->n, x);
+        double xi = (x - sp->cdf[i]) / (sp->cdf[i + 1] - sp->cdf[i]);
+        double sin2 = sp->s[i] + xi * (sp->s[i + 1] - sp->s[i]);
+        double ct = sqrt(1.0 - sin2 > 0.0 ? 1.0 - sin2 : 0.0), st = sqrt(sin2);
+        double phi = 2.0 * M_PI * (double)u[1];
+        double h[3] = { st * cos(phi), st * sin(phi), ct };
+        double in[3] = { wi[0], wi[1], wi[2] };
+        unit3(in);
+        double c = in[0] * h[0] + in[1] * h[1] + in[2] * h[2];
+        d[0] = (float)(2.0 * c * h[0] - in[0]); d[1] = (float)(2.0 * c * h[1] - in[1]); d[2] = (float)(2.0 * c * h[2] - in[2]);
+    }
+    if (!(d[2] > 0.0f)) return;                 /* below the horizon: rejected sample */
+    float p = orc_pdf_table(sp, wi, d);
+    if (!(p > 0.0f)) return;
+    wo[0] = d[0]; wo[1] = d[1]; wo[2] = d[2];
+    *pdf = p;
+    float f[3];
+    orc_eval(t, o, wi, wo, f);
+    weight[0] = f[0] / p; weight[1] = f[1] / p; weight[2] = f[2] / p;
+}
+
+void orc_pdf_table_batch(const orc_sampling *sp, const float *wi, const float *wo, size_t n, float *pdf)
+{
+    for (size_t i = 0; i < n; ++i) pdf[i] = orc_pdf_table(sp, wi + 3 * i, wo + 3 * i);
+}
+void orc_sample_table_batch(const orc_table *t, const orc_opts *o, const orc_sampling *sp, const float *wi, const float *u,
+                            size_t n, float *wo, float *pdf, float *weight)
+{
+    for (size_t i = 0; i < n; ++i) orc_sample_table(t, o, sp, wi + 3 * i, u + 2 * i, wo + 3 * i, pdf + i, weight + 3 * i);
+}
+
 /* ---- batches ---- */
 void orc_eval_batch(const orc_table *t, const orc_opts *o, const float *wi, const float *wo, size_t n, float *rgb)
 {

@@ -89,6 +89,30 @@ void orc_eval_sample_batch_multi(const orc_table *tables, int n_tables, const or
                                  const float *wi, const float *wo, const float *u, const int32_t *mat,
                                  size_t n, float *rgb, float *pdf, float *wo2, float *pdf2, float *weight);
 
+/* ---- §8f item 2 ("next"): table importance sampling for sample()/pdf() ----------------------------
+ * A one-sample mixture of the cosine lobe and a half-vector lobe read off the table:
+ *   theta_h bins are the table's own rows (bin i = [theta_i, theta_i+1], theta_i = (i/n_th)^2 pi/2);
+ *   D_i = mean luminance of row i (+1 % of the mean over rows, so no bin has zero probability);
+ *   p_h(h) = c_i cos(theta_h) inside bin i,  c_i = D_i / (pi sum_j D_j (s_j+1 - s_j)),  s_i = sin^2 theta_i;
+ *   sample(): u1 < 1/2 -> cosine hemisphere with (2 u1, u2); else theta_h by inverting the bin CDF with
+ *             2 u1 - 1 (exact: sin^2 theta_h is uniform inside a bin), phi_h = 2 pi u2, wo = reflect(wi, h);
+ *   pdf(wi, wo) = 1/2 cos(theta_o)/pi + 1/2 p_h(h) / (4 wi.h), h = normalize(wi + wo);
+ *   sample() reports pdf(wi, wo_rounded_to_Float), so pdf(wi, sample.wo) == sample.pdf exactly. */
+typedef struct orc_sampling {
+    int n;            /* = n_th */
+    double *s;        /* [n+1] sin^2(theta_i) */
+    double *cdf;      /* [n+1] */
+    double *c;        /* [n]   */
+} orc_sampling;
+int   orc_build_sampling(const orc_table *t, orc_sampling *out);
+void  orc_free_sampling(orc_sampling *sp);
+float orc_pdf_table(const orc_sampling *sp, const float wi[3], const float wo[3]);
+void  orc_sample_table(const orc_table *t, const orc_opts *o, const orc_sampling *sp, const float wi[3], const float u[2],
+                       float wo[3], float *pdf, float weight[3]);
+void  orc_pdf_table_batch(const orc_sampling *sp, const float *wi, const float *wo, size_t n, float *pdf);
+void  orc_sample_table_batch(const orc_table *t, const orc_opts *o, const orc_sampling *sp, const float *wi, const float *u,
+                             size_t n, float *wo, float *pdf, float *weight);
+
 /* ---- a9: GGX rough conductor (A.6), isotropic alpha, visible-normal sampling ---- */
 typedef struct orc_ggx {
     double alpha;
