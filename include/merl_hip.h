@@ -61,6 +61,9 @@ enum mrl_option {
                                   materials into one dense queue per kind (pays only when most units are analytic).
                                   Every variant passes the same parity tests; they differ in speed only. */
     MRL_OPT_HOST_CHUNK = 4,    /* units per staging chunk for host-pointer calls */
+    MRL_OPT_SAMPLING = 6,      /* sample()/pdf() strategy of table materials: 0 cosine hemisphere (default, the upstream
+                                  convention), 1 table importance sampling: one-sample mixture of the cosine lobe and a
+                                  half-vector lobe read off the table's theta_h rows */
     MRL_OPT_TABLE_LAYOUT = 5   /* HBM layout of the context's tables, settable only while it holds no table:
                                   0 padded rows (24 MB per MERL table),
                                   1 bricks (default): one 128-B line per cell holds its 8 corners (187 MB per MERL table) */

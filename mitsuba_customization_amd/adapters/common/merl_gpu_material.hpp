@@ -37,12 +37,14 @@ inline void check(mrl_ctx *ctx, int rc, const char *what)
 // options in the C ABI, so plugins that ask for different ones on one device get separate contexts.
 struct ContextKey {
     int device, lookup, node, disk_map;
+    int sampling = 0;              // 0 cosine hemisphere, 1 table importance sampling (MRL_OPT_SAMPLING)
     bool operator<(const ContextKey &o) const
     {
         if (device != o.device) return device < o.device;
         if (lookup != o.lookup) return lookup < o.lookup;
         if (node != o.node) return node < o.node;
-        return disk_map < o.disk_map;
+        if (disk_map != o.disk_map) return disk_map < o.disk_map;
+        return sampling < o.sampling;
     }
 };
 
@@ -56,6 +58,7 @@ public:
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_LOOKUP, key.lookup), "mrl_set_option(lookup)");
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_NODE, key.node), "mrl_set_option(node)");
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_DISK_MAP, key.disk_map), "mrl_set_option(disk_map)");
+        check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_SAMPLING, key.sampling), "mrl_set_option(sampling)");
         // scalar-call staging: wi[3] wo[3] u[2] | rgb[3] pdf wo2[3] pdf2 weight[3]
         void *p = nullptr;
         check(m_ctx, mrl_host_alloc(m_ctx, 32 * sizeof(float), &p), "mrl_host_alloc");
@@ -201,6 +204,12 @@ inline int parse_lookup(const std::string &s)
     if (s == "nearest") return 0;
     if (s == "trilinear") return 1;
     throw Error(MRL_ERR_INVALID, "interpolation must be \"nearest\" or \"trilinear\", got \"" + s + "\"");
+}
+inline int parse_sampling(const std::string &s)
+{
+    if (s == "cosine") return 0;
+    if (s == "table") return 1;
+    throw Error(MRL_ERR_INVALID, "sampling must be \"cosine\" or \"table\", got \"" + s + "\"");
 }
 inline int parse_node(const std::string &s)
 {

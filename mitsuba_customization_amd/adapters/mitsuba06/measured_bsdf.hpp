@@ -7,6 +7,7 @@
 //   <bsdf type="customized_measurement"> <string name="filename" value="mine.binary"/>
 //        <float name="scaleR" value="1"/> ... </bsdf>
 // Optional: interpolation = "trilinear" (default) | "nearest";  node = "integer" (default) | "center";
+//           sampling = "cosine" (default, the upstream convention) | "table" (importance sampling off the table);
 //           device = GPU ordinal (default 0).
 #pragma once
 #ifdef MERL_USE_REAL_MITSUBA
@@ -30,6 +31,7 @@ public:
         m_key.lookup = merl_gpu::parse_lookup(props.getString("interpolation", "trilinear"));
         m_key.node = merl_gpu::parse_node(props.getString("node", "integer"));
         m_key.disk_map = 0;                       // Mitsuba 0.6's squareToUniformDiskConcentric flavour
+        m_key.sampling = merl_gpu::parse_sampling(props.getString("sampling", "cosine"));
     }
 
     void configure() override

@@ -34,6 +34,7 @@ public:
         m_key.lookup = merl_gpu::parse_lookup(props.string("interpolation", "trilinear"));
         m_key.node = merl_gpu::parse_node(props.string("node", "integer"));
         m_key.disk_map = 1;                       // Mitsuba 3's square_to_uniform_disk_concentric flavour
+        m_key.sampling = merl_gpu::parse_sampling(props.string("sampling", "cosine"));
         this->m_flags = BSDFFlags::GlossyReflection | BSDFFlags::FrontSide;
         this->m_components.push_back(this->m_flags);
     }

@@ -45,6 +45,7 @@ int main(int argc, char **argv)
     if (argc > 6) props.setString("interpolation", argv[6]);
     if (argc > 9) { props.setFloat("scaleR", (Float)atof(argv[7])); props.setFloat("scaleG", (Float)atof(argv[8])); props.setFloat("scaleB", (Float)atof(argv[9])); }
 
+    if (argc > 10) props.setString("sampling", argv[10]);
     BSDF *bsdf = nullptr;
     try {
         bsdf = static_cast<BSDF *>(create(props));

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -22,7 +23,45 @@ constexpr double kMerlScale[3] = { 1.0 / 1500.0, 1.15 / 1500.0, 1.66 / 1500.0 };
 struct MaterialHost {
     mrl::MaterialDev dev;
     float4 *d_texels = nullptr;
+    double *d_sampling = nullptr;
 };
+
+// Row marginal for table importance sampling (definition: oracle/merl_oracle.h):
+// s[n+1] = sin^2(theta_i), cdf[n+1], c[n]; computed on the host in f64, in the file's loop order.
+std::vector<double> build_sampling(const double *planar, int n_th, int n_td, int n_pd, const double scale[3])
+{
+    const size_t plane = (size_t)n_th * n_td * n_pd;
+    std::vector<double> D((size_t)n_th), out(3 * (size_t)n_th + 2);
+    double *s = out.data(), *cdf = s + (n_th + 1), *c = cdf + (n_th + 1);
+    double mean = 0.0;
+    for (int i = 0; i < n_th; ++i) {
+        double acc = 0.0;
+        const double *row = planar + (size_t)i * n_td * n_pd;
+        for (size_t k = 0; k < (size_t)n_td * n_pd; ++k) {
+            const double r = std::max(row[k] * scale[0], 0.0), g = std::max(row[k + plane] * scale[1], 0.0), b = std::max(row[k + 2 * plane] * scale[2], 0.0);
+            acc += 0.2126 * r + 0.7152 * g + 0.0722 * b;
+        }
+        D[(size_t)i] = acc / ((double)n_td * (double)n_pd);
+        mean += D[(size_t)i];
+    }
+    mean /= (double)n_th;
+    for (int i = 0; i < n_th; ++i) D[(size_t)i] = mean > 0.0 ? D[(size_t)i] + 0.01 * mean : 1.0;
+    const double kHalfPi = 3.14159265358979323846 / 2.0;
+    for (int i = 0; i <= n_th; ++i) {
+        const double r = (double)i / (double)n_th, sn = std::sin(r * r * kHalfPi);
+        s[i] = i == n_th ? 1.0 : sn * sn;
+    }
+    double Z = 0.0;
+    for (int i = 0; i < n_th; ++i) Z += D[(size_t)i] * (s[i + 1] - s[i]);
+    double run = 0.0;
+    for (int i = 0; i < n_th; ++i) {
+        cdf[i] = run / Z;
+        run += D[(size_t)i] * (s[i + 1] - s[i]);
+        c[i] = D[(size_t)i] / (3.14159265358979323846 * Z);
+    }
+    cdf[n_th] = 1.0;
+    return out;
+}
 
 } // namespace
 
@@ -40,7 +79,7 @@ struct mrl_ctx {
     std::vector<MaterialHost> materials;
     mrl::MaterialDev *d_materials = nullptr;
     size_t d_materials_cap = 0;
-    mrl::Options opts{ 1, 0, 0 };
+    mrl::Options opts{ 1, 0, 0, 0 };
     int kernel_variant = 3;          // MRL_OPT_KERNEL default: cooperative LDS-DMA brick fetch
     int table_layout = 1;            // layout of tables uploaded from now on (mrl::Layout)
     size_t host_chunk = (size_t)1 << 22;
@@ -146,8 +185,20 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
         if (m.d_texels) (void)hipFree(m.d_texels);
         return fail(ctx, e == hipErrorOutOfMemory ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
     }
+    {
+        const std::vector<double> sampling = build_sampling(planar, n_th, n_td, n_pd, scale);
+        e = hipMalloc((void **)&m.d_sampling, sampling.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(m.d_sampling, sampling.data(), sampling.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(m.d_texels);
+            if (m.d_sampling) (void)hipFree(m.d_sampling);
+            return fail(ctx, MRL_ERR_HIP, std::string("sampling table upload: ") + hipGetErrorString(e));
+        }
+    }
     std::memset(&m.dev, 0, sizeof m.dev);
     m.dev.kind = kind;
+    m.dev.sampling = m.d_sampling;
     m.dev.n_th = n_th; m.dev.n_td = n_td; m.dev.n_pd = n_pd;
     m.dev.row_td = (int)P;
     m.dev.row_th = (int)(D * P);
@@ -155,7 +206,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     m.dev.layout = layout;
     ctx->materials.push_back(m);
     int rc = sync_material_array(ctx);
-    if (rc != MRL_OK) { ctx->materials.pop_back(); (void)hipFree(m.d_texels); return rc; }
+    if (rc != MRL_OK) { ctx->materials.pop_back(); (void)hipFree(m.d_texels); (void)hipFree(m.d_sampling); return rc; }
     *out_id = (int)ctx->materials.size() - 1;
     return MRL_OK;
 }
@@ -361,7 +412,7 @@ int mrl_destroy(mrl_ctx *ctx)
     if (!ctx) return MRL_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &m : ctx->materials) if (m.d_texels) (void)hipFree(m.d_texels);
+    for (auto &m : ctx->materials) { if (m.d_texels) (void)hipFree(m.d_texels); if (m.d_sampling) (void)hipFree(m.d_sampling); }
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_queues) (void)hipFree(ctx->d_queues);
@@ -379,6 +430,7 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
         case MRL_OPT_LOOKUP:   if (value < 0 || value > 1) break; ctx->opts.lookup = value; return MRL_OK;
         case MRL_OPT_NODE:     if (value < 0 || value > 1) break; ctx->opts.node = value; return MRL_OK;
         case MRL_OPT_DISK_MAP: if (value < 0 || value > 1) break; ctx->opts.disk_map = value; return MRL_OK;
+        case MRL_OPT_SAMPLING: if (value < 0 || value > 1) break; ctx->opts.sampling = value; return MRL_OK;
         case MRL_OPT_KERNEL:   if (value < 0) break; ctx->kernel_variant = value; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: if (value < 1) break; ctx->host_chunk = (size_t)value; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: {
@@ -400,6 +452,7 @@ int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
         case MRL_OPT_LOOKUP: *value = ctx->opts.lookup; return MRL_OK;
         case MRL_OPT_NODE: *value = ctx->opts.node; return MRL_OK;
         case MRL_OPT_DISK_MAP: *value = ctx->opts.disk_map; return MRL_OK;
+        case MRL_OPT_SAMPLING: *value = ctx->opts.sampling; return MRL_OK;
         case MRL_OPT_KERNEL: *value = ctx->kernel_variant; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: *value = (int)ctx->host_chunk; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: *value = ctx->table_layout; return MRL_OK;

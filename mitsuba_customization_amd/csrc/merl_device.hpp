@@ -34,6 +34,7 @@ struct MaterialDev {
     const float4 *texels;        // layout 0: [(n_th+1)][(n_td+1)][(n_pd+1)] RGBA f32, scaled, negatives clamped
                                  // layout 1: [n_th][n_td][n_pd] bricks of 128 B = the cell's 8 corners, RGB f32 packed
     int layout;                  // LAYOUT_ROWS / LAYOUT_BRICK
+    const double *sampling;      // table importance sampling: s[n_th+1] | cdf[n_th+1] | c[n_th]  (see table_pdf below)
     double alpha;                // GGX
     double eta[3], k[3];
 };
@@ -42,6 +43,7 @@ struct Options {
     int lookup;    // 0 nearest, 1 trilinear
     int node;      // 0 integer node, 1 texel centre
     int disk_map;  // 0 Mitsuba 0.6, 1 Mitsuba 3
+    int sampling;  // 0 cosine hemisphere (upstream convention), 1 table importance sampling
 };
 
 struct Vec3d { double x, y, z; };
@@ -322,6 +324,51 @@ __device__ __forceinline__ bool ggx_sample(const MaterialDev &g, const Vec3d &in
     return true;
 }
 
+// ---- table importance sampling (definition in oracle/merl_oracle.h) --------
+// one-sample mixture: u0 < 1/2 -> cosine hemisphere with (2 u0, u1); else theta_h from the table's row
+// marginal (sin^2 theta_h is uniform inside a row bin), phi_h = 2 pi u1, wo = reflect(wi, h).
+// pdf(wi, wo) = 1/2 cos(theta_o)/pi + 1/2 c_i h.z / (4 wi.h)
+__device__ __forceinline__ int bin_of(const double *a, int n, double x)      // largest i in [0,n-1] with a[i] <= x
+{
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ double table_pdf(const MaterialDev &m, const Vec3d &in, const Vec3d &out, float woz)
+{
+    Vec3d h = { in.x + out.x, in.y + out.y, in.z + out.z };
+    const double inv = rsqrt(h.x * h.x + h.y * h.y + h.z * h.z);
+    h.x *= inv; h.y *= inv; h.z *= inv;
+    const int i = bin_of(m.sampling, m.n_th, h.x * h.x + h.y * h.y);
+    const double ih = in.x * h.x + in.y * h.y + in.z * h.z;
+    const double ph = m.sampling[2 * (m.n_th + 1) + i] * h.z / (4.0 * ih);
+    return 0.5 * ((double)woz * 0.31830988618379067154) + 0.5 * ph;
+}
+
+// direction of the mixture sample (Float); z <= 0 means "rejected"
+__device__ __forceinline__ void table_sample_dir(const MaterialDev &m, int disk_map, const Vec3d &in, float u0, float u1,
+                                                 float &x, float &y, float &z)
+{
+    if (u0 < 0.5f) {
+        square_to_cosine_hemisphere(disk_map, 2.0f * u0, u1, x, y, z);
+        return;
+    }
+    const double *s = m.sampling, *cdf = m.sampling + (m.n_th + 1);
+    const double t = (double)(2.0f * u0 - 1.0f);
+    const int i = bin_of(cdf, m.n_th, t);
+    const double xi = (t - cdf[i]) / (cdf[i + 1] - cdf[i]);
+    const double sin2 = s[i] + xi * (s[i + 1] - s[i]);
+    const double ct = sqrt(1.0 - sin2 > 0.0 ? 1.0 - sin2 : 0.0), st = sqrt(sin2);
+    const double phi = 2.0 * kPi * (double)u1;
+    const Vec3d h = { st * cos(phi), st * sin(phi), ct };
+    const double c = in.x * h.x + in.y * h.y + in.z * h.z;
+    x = (float)(2.0 * c * h.x - in.x); y = (float)(2.0 * c * h.y - in.y); z = (float)(2.0 * c * h.z - in.z);
+}
+
 // ---- a5 / a6 / a7 for one unit, any material kind ------------------------------------------
 // eval(): rgb = f * cos(theta_o), zero unless cos(theta_i) > 0 and cos(theta_o) > 0
 __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o,
@@ -342,13 +389,14 @@ __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o
     rgb[0] = (float)v.r; rgb[1] = (float)v.g; rgb[2] = (float)v.b;
 }
 
-__device__ __forceinline__ float unit_pdf(const MaterialDev &m, float wix, float wiy, float wiz, float wox, float woy, float woz)
+__device__ __forceinline__ float unit_pdf(const MaterialDev &m, const Options &o, float wix, float wiy, float wiz, float wox, float woy, float woz)
 {
     if (!(wiz > 0.0f) || !(woz > 0.0f)) return 0.0f;
     if (m.kind == KIND_GGX) {
         Vec3d in = normalized(wix, wiy, wiz), out = normalized(wox, woy, woz);
         return (float)ggx_pdf(m, in, out);
     }
+    if (o.sampling) return (float)table_pdf(m, normalized(wix, wiy, wiz), normalized(wox, woy, woz), woz);
     return woz * kInvPiF;
 }
 
@@ -363,10 +411,18 @@ __device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options 
         ggx_sample(m, in, u0, u1, wo, pdf, weight);
         return;
     }
-    float x, y, z;
-    square_to_cosine_hemisphere(o.disk_map, u0, u1, x, y, z);
+    float x, y, z, p;
+    if (o.sampling) {
+        const Vec3d in = normalized(wix, wiy, wiz);
+        table_sample_dir(m, o.disk_map, in, u0, u1, x, y, z);
+        if (!(z > 0.0f)) return;                          // reflected below the horizon: rejected
+        p = (float)table_pdf(m, in, normalized(x, y, z), z);
+        if (!(p > 0.0f)) return;
+    } else {
+        square_to_cosine_hemisphere(o.disk_map, u0, u1, x, y, z);
+        p = z > 0.0f ? z * kInvPiF : 0.0f;
+    }
     wo[0] = x; wo[1] = y; wo[2] = z;
-    float p = z > 0.0f ? z * kInvPiF : 0.0f;
     pdf = p;
     if (!(p > 0.0f)) return;
     float f[3];

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void k_batch(BatchArgs a)
                 store3(a.out_rgb, i, rgb);
             }
             if constexpr (MODE != MODE_EVAL) {
-                a.out_pdf[i] = unit_pdf(m, wix, wiy, wiz, wox, woy, woz);
+                a.out_pdf[i] = unit_pdf(m, a.opts, wix, wiy, wiz, wox, woy, woz);
             }
         }
         if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) {
@@ -107,15 +107,20 @@ __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
         float rgb[3], pdf = 0.0f, wo2[3], pdf2, w[3];
         if (MULTI && m.kind == KIND_GGX) {
             if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) unit_eval(m, a.opts, wix, wiy, wiz, wox, woy, woz, rgb);
-            if constexpr (MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE) pdf = unit_pdf(m, wix, wiy, wiz, wox, woy, woz);
+            if constexpr (MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE) pdf = unit_pdf(m, a.opts, wix, wiy, wiz, wox, woy, woz);
             if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) unit_sample(m, a.opts, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
         } else {
             if constexpr (MODE == MODE_PDF) {
                 pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
+                if (a.opts.sampling && pdf > 0.0f)
+                    pdf = (float)fast::table_pdf(m, fast::normalize_f32(wix, wiy, wiz), fast::normalize_f32(wox, woy, woz), woz);
             } else {
                 const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
                 if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) fast::unit_eval<LOOKUP, LAYOUT>(m, a.opts, in, wix, wiy, wiz, wox, woy, woz, rgb);
-                if constexpr (MODE == MODE_EVAL_SAMPLE) pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
+                if constexpr (MODE == MODE_EVAL_SAMPLE) {
+                    pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
+                    if (a.opts.sampling && pdf > 0.0f) pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz);
+                }
                 if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) fast::unit_sample<LOOKUP, LAYOUT>(m, a.opts, in, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
             }
         }
@@ -228,8 +233,17 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
         cellA = brick_cell(m, fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wA);
         if (GGX && !is_table) cellA = 0;
     }
+    float sp = 0.0f;                                          // pdf of the sampled direction
     if constexpr (HAS_SAMPLE) {
-        square_to_cosine_hemisphere(a.opts.disk_map, io.u0, io.u1, sx, sy, sz);
+        if (a.opts.sampling && (!GGX || is_table)) {          // option is wave-uniform
+            fast::table_sample_dir(m, a.opts.disk_map, in, io.u0, io.u1, sx, sy, sz);
+            const bool up = sz > 0.0f;
+            if (!up) { sx = 0.0f; sy = 0.0f; sz = 1.0f; }     // rejected: look up a harmless cell, report zeros
+            sp = up ? (float)fast::table_pdf(m, in, fast::normalize_f32(sx, sy, sz), sz) : 0.0f;
+        } else {
+            square_to_cosine_hemisphere(a.opts.disk_map, io.u0, io.u1, sx, sy, sz);
+            sp = sz > 0.0f ? sz * kInvPiF : 0.0f;
+        }
         const fast::Vec3 out = fast::normalize_f32(sx, sy, sz);
         cellB = brick_cell(m, fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wB);
         if (GGX && !is_table) cellB = 0;
@@ -244,13 +258,16 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
         const double c = fast::cos_or_nan(io.wix, io.wiy, io.wiz, io.wox, io.woy, io.woz);
         if (!GGX || is_table) {
             io.rgb[0] = valid ? (float)(v.r * c) : 0.0f; io.rgb[1] = valid ? (float)(v.g * c) : 0.0f; io.rgb[2] = valid ? (float)(v.b * c) : 0.0f;
-            if constexpr (MODE == MODE_EVAL_SAMPLE) io.pdf = valid ? io.woz * kInvPiF : 0.0f;
+            if constexpr (MODE == MODE_EVAL_SAMPLE) {
+                io.pdf = valid ? io.woz * kInvPiF : 0.0f;
+                if (a.opts.sampling && valid) io.pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(io.wox, io.woy, io.woz), io.woz);
+            }
         }
     }
     if constexpr (HAS_SAMPLE) {
         const Rgbd v = brick_interp(ldsB, lane, wB);
-        const bool valid = io.wiz > 0.0f;
-        const float p = sz > 0.0f ? sz * kInvPiF : 0.0f;
+        const float p = sp;
+        const bool valid = (io.wiz > 0.0f) && (!a.opts.sampling || p > 0.0f);
         const bool has = valid && (p > 0.0f);
         const double c = fast::cos_or_nan(io.wix, io.wiy, io.wiz, sx, sy, sz);
         const float f0 = has ? (float)(v.r * c) : 0.0f, f1 = has ? (float)(v.g * c) : 0.0f, f2 = has ? (float)(v.b * c) : 0.0f;

@@ -157,16 +157,59 @@ __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o
     rgb[2] = valid ? (float)(v.b * c) : 0.0f;
 }
 
+// ---- table importance sampling, tuned forms of merl_device.hpp::table_pdf / table_sample_dir ----
+__device__ __forceinline__ void sincos_2pi(double u, double &s, double &c);      // merl_ggx_fast.hpp
+
+__device__ __forceinline__ double table_pdf(const MaterialDev &m, const Vec3 &in, const Vec3 &out, float woz)
+{
+    double hx = in.x + out.x, hy = in.y + out.y, hz = in.z + out.z;
+    double hs, hrs;
+    sqrt_rsqrt(__builtin_fma(hx, hx, __builtin_fma(hy, hy, hz * hz)), hs, hrs);
+    hx *= hrs; hy *= hrs; hz *= hrs;
+    const int i = bin_of(m.sampling, m.n_th, __builtin_fma(hx, hx, hy * hy));
+    const double ih = __builtin_fma(in.x, hx, __builtin_fma(in.y, hy, in.z * hz));
+    const double ph = m.sampling[2 * (m.n_th + 1) + i] * hz * 0.25 * rcp_nr(__builtin_fmax(ih, kTiny));
+    return 0.5 * ((double)woz * 0.31830988618379067154) + 0.5 * ph;
+}
+
+__device__ __forceinline__ void table_sample_dir(const MaterialDev &m, int disk_map, const Vec3 &in, float u0, float u1,
+                                                 float &x, float &y, float &z)
+{
+    if (u0 < 0.5f) {
+        square_to_cosine_hemisphere(disk_map, 2.0f * u0, u1, x, y, z);
+        return;
+    }
+    const double *s = m.sampling, *cdf = m.sampling + (m.n_th + 1);
+    const double t = (double)(2.0f * u0 - 1.0f);
+    const int i = bin_of(cdf, m.n_th, t);
+    const double c0 = cdf[i], s0 = s[i];
+    const double xi = (t - c0) * rcp_nr(cdf[i + 1] - c0);
+    const double sin2 = __builtin_fma(xi, s[i + 1] - s0, s0);
+    const double ct = sqrt_fast(__builtin_fmax(1.0 - sin2, 0.0)), st = sqrt_fast(sin2);
+    double sp, cp;
+    sincos_2pi((double)u1, sp, cp);
+    const double hx = st * cp, hy = st * sp;
+    const double c2 = 2.0 * __builtin_fma(in.x, hx, __builtin_fma(in.y, hy, in.z * ct));
+    x = (float)__builtin_fma(c2, hx, -in.x); y = (float)__builtin_fma(c2, hy, -in.y); z = (float)__builtin_fma(c2, ct, -in.z);
+}
+
 // a6: sample
 template <int LOOKUP, int LAYOUT>
 __device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options &o, const Vec3 &in,
                                             float wix, float wiy, float wiz,
                                             float u0, float u1, float wo[3], float &pdf, float weight[3])
 {
-    float x, y, z;
-    square_to_cosine_hemisphere(o.disk_map, u0, u1, x, y, z);
-    const bool valid = wiz > 0.0f;
-    const float p = z > 0.0f ? z * kInvPiF : 0.0f;
+    float x, y, z, p;
+    if (o.sampling) {                                       // wave-uniform
+        table_sample_dir(m, o.disk_map, in, u0, u1, x, y, z);
+        const bool up = z > 0.0f;
+        if (!up) { x = 0.0f; y = 0.0f; z = 1.0f; }          // rejected: evaluate a harmless direction, report zeros
+        p = up ? (float)table_pdf(m, in, normalize_f32(x, y, z), z) : 0.0f;
+    } else {
+        square_to_cosine_hemisphere(o.disk_map, u0, u1, x, y, z);
+        p = z > 0.0f ? z * kInvPiF : 0.0f;
+    }
+    const bool valid = (wiz > 0.0f) && (!o.sampling || p > 0.0f);
     float f[3];
     unit_eval<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, x, y, z, f);
     const bool has = valid && (p > 0.0f);

@@ -127,3 +127,25 @@ def test_plugin_reports_missing_file(built, tmp_path):
     r = subprocess.run([os.path.join(built, "driver06"), os.path.join(built, "plugins06", "merl.so"), "/nonexistent.binary",
                         "/dev/null", str(tmp_path / "o"), "1"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 5 and "cannot open" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("host,disk", [("06", 0), ("3", 1)])
+def test_plugin_table_sampling_property(built, merl_file, oracle, tables, tmp_path, host, disk):
+    """<string name="sampling" value="table"/> switches sample()/pdf() to table importance sampling."""
+    n, m = 6000, 100
+    wi, wo, u = oracle.generate_pairs(0x5EED, 2024, n)
+    pairs, out = str(tmp_path / "pairs.bin"), str(tmp_path / "out.bin")
+    _write_pairs(pairs, wi, wo, u)
+    drv = os.path.join(built, "driver06" if host == "06" else "driver3")
+    plug = os.path.join(built, "plugins06" if host == "06" else "plugins3", "merl.so")
+    r = subprocess.run([drv, plug, merl_file, pairs, out, str(m), "trilinear", "1", "1", "1", "table"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    scalar, batch = _read_out(out, m, n)
+    assert np.array_equal(scalar, batch[:m])
+    T = oracle.OracleTable(tables("ggx_tab", 0))
+    c_wo, c_pdf, c_w = T.sample_table(wi, u, oracle.make_opts(disk_map=disk))
+    assert np.abs(batch[:, 4:7].astype(np.float64) - c_wo).max() <= 1.2e-7
+    ok = np.abs(batch[:, 7].astype(np.float64) - c_pdf) <= 2e-6 * np.abs(c_pdf) + 1e-30
+    assert ok.mean() > 0.999
+    assert (np.abs(batch[:, 3].astype(np.float64) - T.pdf_table(wi, wo)) <= 2e-6 * T.pdf_table(wi, wo) + 1e-30).all()

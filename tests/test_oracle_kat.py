@@ -335,3 +335,68 @@ def test_generator_properties(oracle):
     m = oracle.generate_materials(0x5EED, 0, 100000, 16)
     assert m.min() == 0 and m.max() == 15
     assert np.abs(np.bincount(m, minlength=16) / m.size - 1 / 16).max() < 5e-3
+
+
+# ---------------------------------------------------------------- §8f item 2: table importance sampling
+def test_sampling_tables_are_normalised(oracle, tables):
+    for kind, seed in (("ggx_tab", 0), ("noise", 3), ("constant", 0)):
+        T = oracle.OracleTable(tables(kind, seed))
+        s, cdf, c = T.sampling_arrays()
+        assert s[0] == 0.0 and s[-1] == 1.0 and (np.diff(s) > 0).all()
+        assert cdf[0] == 0.0 and cdf[-1] == 1.0 and (np.diff(cdf) > 0).all()        # the 1 % floor keeps every bin alive
+        assert abs((c * PI * np.diff(s)).sum() - 1.0) < 1e-12                        # p_h integrates to 1 over the hemisphere
+    # constant table -> D constant -> p_h = cos(theta_h)/pi
+    assert np.allclose(c, 1.0 / PI, rtol=1e-12)
+
+
+def test_table_sampling_pdf_sample_consistency(oracle, tables):
+    T = oracle.OracleTable(tables("ggx_tab", 0))
+    wi, wo, u = _random_pairs(oracle, 40000, first=90000)
+    wo2, pdf2, w = T.sample_table(wi, u)
+    ok = pdf2 > 0
+    assert 0.85 < ok.mean() < 1.0                                 # the half-vector lobe loses what reflects below the horizon
+    assert (wo2[ok][:, 2] > 0).all() and np.abs(np.linalg.norm(wo2[ok].astype(np.float64), axis=1) - 1).max() < 3e-7
+    assert np.array_equal(T.pdf_table(wi[ok], wo2[ok]), pdf2[ok])             # pdf(wi, sample.wo) == sample.pdf, exactly
+    f = T.eval(wi[ok], wo2[ok])
+    assert np.array_equal(w[ok], (f / pdf2[ok, None]).astype(np.float32))     # weight == eval/pdf in Float
+    assert (w[~ok] == 0).all() and (wo2[~ok] == 0).all()
+    # the cosine half of the mixture is the pinned cosine-hemisphere map with (2 u0, u1)
+    lo = u[:, 0] < 0.5
+    uu = u[lo].copy(); uu[:, 0] *= 2
+    assert np.array_equal(wo2[lo], oracle.square_to_cosine_hemisphere(uu, 0))
+    # much lower variance than cosine sampling on a glossy table
+    wc = T.sample(wi, u)[2]
+    assert w.astype(np.float64).var(0).sum() < 0.1 * wc.astype(np.float64).var(0).sum()
+    # below-horizon wi: nothing
+    down = wi[:4].copy(); down[:, 2] *= -1
+    a, b, c = T.sample_table(down, u[:4])
+    assert (a == 0).all() and (b == 0).all() and (c == 0).all() and (T.pdf_table(down, wo[:4]) == 0).all()
+
+
+def test_table_sampling_pdf_integral_and_chi2(oracle, tables):
+    T = oracle.OracleTable(tables("ggx_tab", 0))
+    wi0 = np.array([0.5, 0.0, 0.8660254], np.float32)
+    # quadrature of pdf(wi0, .) over the hemisphere on a (z, phi) grid; bins for the chi-square test
+    nz, nphi, sub = 10, 8, 24
+    z = (np.arange(nz * sub) + 0.5) / (nz * sub); ph = (np.arange(nphi * sub) + 0.5) / (nphi * sub) * 2 * PI
+    zz, pp = np.meshgrid(z, ph, indexing="ij")
+    r = np.sqrt(1 - zz**2)
+    wo = np.stack([r * np.cos(pp), r * np.sin(pp), zz], -1).reshape(-1, 3).astype(np.float32)
+    wi = np.tile(wi0, (wo.shape[0], 1))
+    p = T.pdf_table(wi, wo).astype(np.float64).reshape(nz * sub, nphi * sub) * (2 * PI / (nz * sub * nphi * sub))
+    mass = p.sum()
+    assert 0.85 < mass <= 1.0 + 1e-3
+    expect = p.reshape(nz, sub, nphi, sub).sum(axis=(1, 3))
+    n = 400000
+    _, _, u = _random_pairs(oracle, n, first=123456)
+    wo2, pdf2, _ = T.sample_table(np.tile(wi0, (n, 1)), u)
+    ok = pdf2 > 0
+    assert abs(ok.mean() - mass) < 5e-3                           # accepted fraction == integral of the pdf
+    zi = np.minimum((wo2[ok, 2].astype(np.float64) * nz).astype(int), nz - 1)
+    pi_ = np.minimum(((np.arctan2(wo2[ok, 1], wo2[ok, 0]).astype(np.float64) % (2 * PI)) / (2 * PI) * nphi).astype(int), nphi - 1)
+    hist = np.zeros((nz, nphi)); np.add.at(hist, (zi, pi_), 1)
+    e = expect * n
+    big = e > 20
+    chi2 = ((hist[big] - e[big]) ** 2 / e[big]).sum()
+    # quadrature of a piecewise-constant-in-theta_h density on a (z,phi) grid is itself ~1 % accurate per bin
+    assert chi2 < 3.0 * big.sum(), chi2
