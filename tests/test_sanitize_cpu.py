@@ -1,0 +1,22 @@
+"""AddressSanitizer + UndefinedBehaviorSanitizer over the oracle (CPU build only: GPU sanitizers are
+not available on the pool).  The driver pushes edge inputs (NaN, inf, zero vectors, below-horizon,
+exact mirror / retro pairs, unknown material ids, tiny tables) through every oracle entry point."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc missing")
+def test_oracle_is_clean_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "orc_sanitize")
+    src = [os.path.join(ROOT, "oracle", "sanitize_driver.c"), os.path.join(ROOT, "oracle", "merl_oracle.c")]
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-ffp-contract=off", "-mfma",
+                           "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                           "-o", exe] + src + ["-lm", "-lpthread"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, str(tmp_path / "t.binary")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "sanitize ok" in r.stdout, r.stdout + r.stderr
