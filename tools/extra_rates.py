@@ -47,4 +47,29 @@ gpu.eval_sample(hwi, hwo, hu, material=mid)
 dt = time.perf_counter() - t0
 res["host_pointer_eval_sample"] = {"units": m, "s": dt, "Munits_per_s": m / dt / 1e6, "PCIe_bytes_per_unit": 76,
                                    "note": "pageable host memory, synchronous 4M-unit chunks (PCIe-inclusive; never the bench value)"}
+# pinned host arrays (mrl_host_alloc): the kernel reads and writes host memory over PCIe itself (zero copy)
+import ctypes as C
+L, ctx = gpu._lib, gpu._ctx
+m = 16 << 20
+bufs = {}
+for name, floats in (("wi", 3), ("wo", 3), ("u", 2), ("rgb", 3), ("pdf", 1), ("wo2", 3), ("pdf2", 1), ("w", 3)):
+    p = C.c_void_p()
+    assert L.mrl_host_alloc(ctx, 4 * floats * m, C.byref(p)) == 0
+    bufs[name] = p.value
+for name, src in (("wi", hwi), ("wo", hwo), ("u", hu)):
+    C.memmove(bufs[name], src.ctypes.data, src.nbytes)
+gpu.use_own_stream()
+def zc():
+    rc = L.mrl_eval_sample_batch(ctx, bufs["wi"], bufs["wo"], bufs["u"], None, mid, m, bufs["rgb"], bufs["pdf"], bufs["wo2"], bufs["pdf2"], bufs["w"])
+    assert rc == 0
+    L.mrl_synchronize(ctx)
+zc()
+t0 = time.perf_counter()
+for _ in range(3):
+    zc()
+dt = (time.perf_counter() - t0) / 3
+got = np.ctypeslib.as_array((C.c_float * (3 * 1000)).from_address(bufs["rgb"])).reshape(-1, 3).copy()
+ref = gpu.eval_sample(hwi[:1000], hwo[:1000], hu[:1000], material=mid)[0]
+res["pinned_zero_copy_eval_sample"] = {"units": m, "s": dt, "Munits_per_s": m / dt / 1e6, "PCIe_GBps": 76 * m / dt / 1e9,
+                                       "matches_staged_path": bool(np.array_equal(got, ref))}
 print(json.dumps(res, indent=1))
