@@ -1,9 +1,14 @@
 // merl_kernels.hip — gfx950 kernels of the batched BSDF hot path and their launchers.
 //
-// One lane = one unit (pair) per grid-stride step.  Streams (wi, wo, u in; rgb, pdf, wo', pdf',
-// weight out) are contiguous per wave: 768 B (xyz) / 512 B (uv) / 256 B (scalar) per
-// wave-instruction.  The table gather is 8 x 16 B per lookup from the padded RGBA f32 table
-// (phi_d fastest, so the two phi neighbours of a corner share a 32-B piece).
+// One lane = one unit (pair) per step.  Streams (wi, wo, u in; rgb, pdf, wo', pdf', weight out) are
+// contiguous per wave: 768 B (xyz) / 512 B (uv) / 256 B (scalar) per wave-instruction.
+//   k_batch        generic: every material kind, ocml f64 math (MRL_OPT_KERNEL 0, the A/B baseline)
+//   k_table        tuned f64 math, one lane gathers its own texels (variants 1/2; nearest lookups, rows layout)
+//   k_table_dma    brick layout + cooperative LDS-DMA fetch of the neighbourhood (variant 3, the default)
+//   k_ggx          tuned analytic GGX rough conductor
+//   k_count_kinds / k_scan_segments / k_partition_kinds   ballot/prefix partition of kind-mixed batches (variant 4)
+//   k_build_bricks / k_build_rows   table re-layout at upload;  k_generate_*   synthetic inputs
+// What bounds each of them, with counter evidence: DESIGN.md §5-6.
 #include "merl_kernels.hpp"
 #include "merl_table_fast.hpp"
 #include "merl_ggx_fast.hpp"

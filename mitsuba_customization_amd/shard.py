@@ -95,8 +95,8 @@ def run_sharded(compute: Callable[[int, int], Sequence[torch.Tensor]], n_total: 
     full: Optional[List[torch.Tensor]] = None
     tile_out: List[List[torch.Tensor]] = []
     pending = []          # (works, keepalive tensors)
-    use_cuda = torch.cuda.is_available() and overlap and world > 1
-    comm_stream = torch.cuda.Stream() if use_cuda else None
+    use_cuda = False      # decided by the first chunk's tensors: overlap on a side stream only for device arrays
+    comm_stream = None
 
     def drain(keep: int):
         while len(pending) > keep:
@@ -107,6 +107,9 @@ def run_sharded(compute: Callable[[int, int], Sequence[torch.Tensor]], n_total: 
     for c in range(steps):
         a, b = min(hi, lo + c * chunk), min(hi, lo + (c + 1) * chunk)
         outs = [t for t in compute(a, b)] if b > a else None
+        if outs is not None and comm_stream is None and overlap and world > 1 and gather and outs[0].is_cuda:
+            use_cuda = True
+            comm_stream = torch.cuda.Stream()
         if not gather or world == 1:
             if outs is not None:
                 tile_out.append(outs)
