@@ -156,33 +156,41 @@ constexpr int kDmaBlock = MRL_DMA_BLOCK;
 
 __device__ __forceinline__ unsigned brick_swz(unsigned unit) { return (unit >> 1) & 7u; }
 
+// Source address of the 16-B piece this lane copies in step k (unit 8k + lane/8), gathered from the
+// owning lane by ds_bpermute.  All exchanges of a lookup are issued back to back, BEFORE the copies:
+// a copy needs its address, and interleaving them one by one exposes sixteen bpermute latencies per unit.
 template <bool MULTI>
-__device__ __forceinline__ void brick_dma(const float4 *single_base, uint32_t idx, const float4 *lane_base,
-                                          float4 *lds_slots, unsigned lane)
-{
-    const unsigned g = lane >> 3, piece_lane = lane & 7u;
-    uint32_t lo = 0, hi = 0;
-    if constexpr (MULTI) {
-        const uint64_t addr = (uint64_t)(lane_base + (size_t)idx * 8);
-        lo = (uint32_t)addr; hi = (uint32_t)(addr >> 32);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const unsigned unit = 8u * k + g;
-        const unsigned piece = piece_lane ^ brick_swz(unit);
-        const float4 *src;
+struct BrickSources {
+    const float4 *src[8];
+    __device__ __forceinline__ BrickSources(const float4 *single_base, uint32_t idx, const float4 *lane_base, unsigned lane)
+    {
+        const unsigned g = lane >> 3, piece_lane = lane & 7u;
+        uint32_t lo = 0, hi = 0, got_lo[8], got_hi[8];
         if constexpr (MULTI) {
-            const uint32_t slo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(unit << 2), (int)lo);
-            const uint32_t shi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(unit << 2), (int)hi);
-            src = (const float4 *)(((uint64_t)shi << 32) | slo) + piece;
-        } else {
-            const uint32_t sidx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(unit << 2), (int)idx);
-            src = single_base + (size_t)sidx * 8 + piece;
+            const uint64_t addr = (uint64_t)(lane_base + (size_t)idx * 8);
+            lo = (uint32_t)addr; hi = (uint32_t)(addr >> 32);
         }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(lds_slots + k * 64), 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int sel = (int)((8u * k + g) << 2);
+            got_lo[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)(MULTI ? lo : idx));
+            if constexpr (MULTI) got_hi[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)hi);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned piece = piece_lane ^ brick_swz(8u * k + g);
+            if constexpr (MULTI) src[k] = (const float4 *)(((uint64_t)got_hi[k] << 32) | got_lo[k]) + piece;
+            else src[k] = single_base + (size_t)got_lo[k] * 8 + piece;
+        }
     }
-}
+    __device__ __forceinline__ void copy_to(float4 *lds_slots) const
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src[k],
+                                             (__attribute__((address_space(3))) void *)(lds_slots + k * 64), 16, 0, 0);
+    }
+};
 
 struct BrickWeights { double fh, fd, fp; };
 
@@ -253,8 +261,13 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
         cellB = brick_cell(m, fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wB);
         if (GGX && !is_table) cellB = 0;
     }
-    if constexpr (HAS_EVAL) brick_dma<MULTI>(m.texels, cellA, lane_base, ldsA, lane);
-    if constexpr (HAS_SAMPLE) brick_dma<MULTI>(m.texels, cellB, lane_base, ldsB, lane);
+    {
+        // every address exchange of the unit first, then every copy
+        const BrickSources<MULTI> srcA(m.texels, cellA, lane_base, lane), srcB(m.texels, cellB, lane_base, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (HAS_EVAL) srcA.copy_to(ldsA);
+        if constexpr (HAS_SAMPLE) srcB.copy_to(ldsB);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA has landed (own wave only: no barrier)
 
     if constexpr (HAS_EVAL) {
