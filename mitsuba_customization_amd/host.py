@@ -50,6 +50,13 @@ def load_library(path: Optional[str] = None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    if not os.path.exists(p) and path is None and not os.environ.get("MRL_LIB_PATH"):
+        # a checkout without build outputs: compile in-tree (hipcc cross-compiles gfx950 anywhere)
+        try:
+            from . import build as _build
+            _build.build_lib()
+        except Exception as e:
+            raise RuntimeError(f"{p} is missing and could not be built ({e}); there is no CPU fallback for the hot path") from e
     if not os.path.exists(p):
         raise RuntimeError(f"{p} is missing: build it with `python -m mitsuba_customization_amd.build` "
                            "(there is no CPU fallback for the hot path)")
