@@ -223,6 +223,9 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
             "traffic_source": traffic["source"] if traffic else None,
+            # bytes actually moved per second (profiled traffic / this run's kernel time): how close the launch is to the HBM peak
+            "traffic_GBps": round(traffic["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None,
+            "traffic_frac_of_peak": round(traffic["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
             "kernel": kname,
             "kernel_ms": round(kernel_ms, 4),
             "bytes_per_unit": B_STREAM,
