@@ -121,6 +121,8 @@ def main():
     gpu.set_option(host.OPT_LOOKUP, 1 if args.lookup == "trilinear" else 0)
     if args.layout >= 0:
         gpu.set_option(host.OPT_TABLE_LAYOUT, args.layout)
+    elif args.lookup == "nearest":
+        gpu.set_option(host.OPT_TABLE_LAYOUT, host.LAYOUT_ROWS)     # one texel per lookup: the compact layout wins
 
     GGX = (0.1, (0.143, 0.375, 1.442), (3.983, 2.386, 1.603))      # BASELINE config 3: alpha 0.1, gold-like eta / k
     n_tables = {"merl64m": 1, "ggx64m": 0, "mixed16_256m": 16, "resident100": 100}[args.config]

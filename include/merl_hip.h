@@ -66,7 +66,8 @@ enum mrl_option {
                                   half-vector lobe read off the table's theta_h rows */
     MRL_OPT_TABLE_LAYOUT = 5   /* HBM layout of the context's tables, settable only while it holds no table:
                                   0 padded rows (24 MB per MERL table),
-                                  1 bricks (default): one 128-B line per cell holds its 8 corners (187 MB per MERL table) */
+                                  1 bricks (default): one 128-B line per cell holds its 8 corners (187 MB per MERL table).
+                                  Bricks are 2.3x faster for trilinear lookups, rows 1.45x faster for nearest lookups. */
 };
 
 enum mrl_material_kind { MRL_KIND_MERL = 0, MRL_KIND_TABLE = 1, MRL_KIND_GGX = 2 };

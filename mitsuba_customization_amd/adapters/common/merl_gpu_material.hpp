@@ -56,6 +56,9 @@ public:
         if (rc != MRL_OK)
             throw Error(rc, std::string("mrl_init: ") + mrl_strerror(rc));   // no GPU: there is no CPU fallback
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_LOOKUP, key.lookup), "mrl_set_option(lookup)");
+        // nearest lookups read one texel: the compact rows layout keeps half of them in L2 (32 vs 22 G units/s);
+        // trilinear lookups want the whole neighbourhood in one line: bricks
+        check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_TABLE_LAYOUT, key.lookup == 0 ? 0 : 1), "mrl_set_option(layout)");
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_NODE, key.node), "mrl_set_option(node)");
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_DISK_MAP, key.disk_map), "mrl_set_option(disk_map)");
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_SAMPLING, key.sampling), "mrl_set_option(sampling)");
