@@ -48,6 +48,21 @@ def main():
         rgb, pdf, wo2, pdf2, w = ob.eval_sample_multi([T], wi, wo, u, None, o)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), table_kind=kind, table_seed=seed, lookup=lookup,
                             node=node, disk_map=disk, wi=wi, wo=wo, u=u, rgb=rgb, pdf=pdf, wo2=wo2, pdf2=pdf2, weight=w)
+    # customized_measurement: free dims + channel scales (row a8)
+    dims, scale = (32, 16, 48), (0.5, 2.0, 1.25)
+    tab = synth.make_table("noise", 42, dims)
+    T = ob.OracleTable(tab, scale)
+    wi, wo, u = ob.generate_pairs(0x5EED, 60_000, N)
+    rgb, pdf, wo2, pdf2, w = ob.eval_sample_multi([T], wi, wo, u, None, ob.make_opts(1, 0, 0))
+    np.savez_compressed(os.path.join(HERE, "custom_dims_noise.npz"), table_kind="noise", table_seed=42, lookup=1, node=0, disk_map=0,
+                        dims=np.array(dims), scale=np.array(scale), wi=wi, wo=wo, u=u, rgb=rgb, pdf=pdf, wo2=wo2, pdf2=pdf2, weight=w)
+    # table importance sampling: sample()/pdf() under MRL_OPT_SAMPLING = 1
+    tab = synth.make_table("ggx_tab", 7)
+    T = ob.OracleTable(tab)
+    wi, wo, u = ob.generate_pairs(0x5EED, 70_000, N)
+    wo2, pdf2, w = T.sample_table(wi, u)
+    np.savez_compressed(os.path.join(HERE, "merl_ggxtab_table_sampling.npz"), table_kind="ggx_tab", table_seed=7, lookup=1, node=0, disk_map=0,
+                        sampling=1, wi=wi, wo=wo, u=u, rgb=T.eval(wi, wo), pdf=T.pdf_table(wi, wo), wo2=wo2, pdf2=pdf2, weight=w)
     # GGX rough conductor (BASELINE config 3): alpha 0.1, gold-like eta/k
     alpha = float(np.float32(0.1)); eta = [float(np.float32(x)) for x in (0.143, 0.375, 1.442)]
     k = [float(np.float32(x)) for x in (3.983, 2.386, 1.603)]

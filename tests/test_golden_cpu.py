@@ -8,7 +8,7 @@ import numpy as np
 
 def test_oracle_reproduces_golden(oracle, tables):
     files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-    assert len(files) >= 6
+    assert len(files) >= 8
     for f in files:
         z = np.load(f)
         kind = str(z["table_kind"])
@@ -18,8 +18,13 @@ def test_oracle_reproduces_golden(oracle, tables):
             wo2, pdf2, w = G.sample(z["wi"], z["u"])
             assert np.array_equal(wo2, z["wo2"]) and np.array_equal(pdf2, z["pdf2"]) and np.array_equal(w, z["weight"])
             continue
-        T = oracle.OracleTable(tables(kind, int(z["table_seed"])))
+        dims = tuple(int(d) for d in z["dims"]) if "dims" in z else (90, 90, 180)
+        T = oracle.OracleTable(tables(kind, int(z["table_seed"]), dims), tuple(z["scale"]) if "scale" in z else None)
         o = oracle.make_opts(int(z["lookup"]), int(z["node"]), int(z["disk_map"]))
-        got = oracle.eval_sample_multi([T], z["wi"], z["wo"], z["u"], None, o)
+        if "sampling" in z and int(z["sampling"]) == 1:
+            wo2, pdf2, w = T.sample_table(z["wi"], z["u"], o)
+            got = (T.eval(z["wi"], z["wo"], o), T.pdf_table(z["wi"], z["wo"]), wo2, pdf2, w)
+        else:
+            got = oracle.eval_sample_multi([T], z["wi"], z["wo"], z["u"], None, o)
         for g, name in zip(got, ("rgb", "pdf", "wo2", "pdf2", "weight")):
             assert np.array_equal(g, z[name]), (f, name)

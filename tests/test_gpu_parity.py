@@ -313,30 +313,41 @@ def test_ggx_matches_oracle(gpu, oracle, variant):
 
 
 # ------------------------------------------------------------------ golden fixtures
-def test_golden_fixtures(gpu, tables):
+def test_golden_fixtures(tables):
+    """The committed oracle outputs (tests/golden/, regenerated by make_golden.py) through the C ABI."""
     import glob, os
-    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-    assert files, "golden fixtures missing"
     from mitsuba_customization_amd import host
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    assert len(files) >= 8, "golden fixtures missing"
     for f in files:
         z = np.load(f)
         kind, seed = str(z["table_kind"]), int(z["table_seed"])
-        set_opts(gpu, int(z["lookup"]), int(z["node"]), int(z["disk_map"]))
-        if kind == "ggx":
-            mid = gpu.ggx(float(z["alpha"]), z["eta"].tolist(), z["k"].tolist())
-        else:
-            mid = gpu.upload_merl(tables(kind, seed))
-        dwi, dwo, du = to_dev(z["wi"], z["wo"], z["u"])
-        rgb, pdf, wo2, pdf2, w = [t.cpu().numpy() for t in gpu.eval_sample(dwi, dwo, du, material=mid)]
+        sampling = int(z["sampling"]) if "sampling" in z else 0
+        with host.MerlHip(0) as g:
+            set_opts(g, int(z["lookup"]), int(z["node"]), int(z["disk_map"]))
+            g.set_option(host.OPT_SAMPLING, sampling)
+            if kind == "ggx":
+                mid = g.ggx(float(z["alpha"]), z["eta"].tolist(), z["k"].tolist())
+            elif "dims" in z:
+                mid = g.upload_table(tables(kind, seed, tuple(int(d) for d in z["dims"])), tuple(z["scale"]))
+            else:
+                mid = g.upload_merl(tables(kind, seed))
+            dwi, dwo, du = to_dev(z["wi"], z["wo"], z["u"])
+            rgb, pdf, wo2, pdf2, w = [t.cpu().numpy() for t in g.eval_sample(dwi, dwo, du, material=mid)]
+        name = os.path.basename(f)
+        loose = kind == "ggx" or sampling == 1          # f64 results rounded to Float: a direction may flip one ulp
         if int(z["lookup"]) == 1:
-            assert_close(rgb, z["rgb"], what=f"{os.path.basename(f)} rgb"); assert_close(w, z["weight"], what="weight")
+            ok_rgb = np.abs(rgb - z["rgb"]) <= REL * np.abs(z["rgb"]) + 1e-30
+            ok_w = np.abs(w - z["weight"]) <= (3e-6 if sampling else REL) * np.abs(z["weight"]) + 1e-30
+            assert ok_rgb.all(), name
+            assert ok_w.mean() > (0.999 if sampling else 0.99999), name
         else:
             ok = np.abs(rgb - z["rgb"]) <= REL * np.abs(z["rgb"]) + 1e-30
-            assert ok.mean() > 0.999
-        assert_close(pdf, z["pdf"], rel=2e-6 if kind == "ggx" else 0.0, what="pdf")
-        assert np.abs(wo2 - z["wo2"]).max() <= (1.2e-7 if kind == "ggx" else 0.0)
-        assert_close(pdf2, z["pdf2"], rel=2e-6 if kind == "ggx" else 0.0, what="pdf2")
-    set_opts(gpu)
+            assert ok.mean() > 0.999, name
+        assert_close(pdf, z["pdf"], rel=2e-6 if loose else 0.0, what=name + " pdf")
+        assert np.abs(wo2 - z["wo2"]).max() <= (1.2e-7 if loose else 0.0), name
+        ok_p2 = np.abs(pdf2 - z["pdf2"]) <= (2e-6 if loose else 0.0) * np.abs(z["pdf2"]) + 1e-30
+        assert ok_p2.mean() > (0.999 if sampling else 0.99999), name
 
 
 # ------------------------------------------------------------------ kernel variants / table layouts
