@@ -298,7 +298,7 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
         MRL_HIP(ctx, mrl::launch_batch_queue(c.mode, qa, true, ctx->compute_units, ctx->stream));
         return MRL_OK;
     }
-    MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->kernel_variant, ctx->table_layout, has_ggx, ctx->compute_units, ctx->stream));
+    MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->kernel_variant, ctx->table_layout, has_ggx, has_table, ctx->compute_units, ctx->stream));
     return MRL_OK;
 }
 

@@ -393,8 +393,9 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
 }
 
 // ---- tuned GGX rough conductor (single-material launches of an analytic material) ----------------
-// INDEXED: walks the GGX queue of a kind-partitioned mixed batch; the material is then per lane.
-template <int MODE, bool NT, bool INDEXED = false>
+// PER_LANE: the material comes from mat[i] (a batch over several analytic materials);
+// INDEXED: walks the GGX queue of a kind-partitioned mixed batch (implies PER_LANE).
+template <int MODE, bool NT, bool PER_LANE = false, bool INDEXED = false>
 __global__ __launch_bounds__(kBlock) void k_ggx(BatchArgs a)
 {
     constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
@@ -404,9 +405,16 @@ __global__ __launch_bounds__(kBlock) void k_ggx(BatchArgs a)
     const size_t n_items = INDEXED ? (size_t)*a.idx_count : a.n;
     for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_items; j += stride) {
         const size_t i = INDEXED ? (size_t)a.idx[j] : j;
-        const fast::GgxConsts g(INDEXED ? a.materials[a.mat[i]] : a.single);   // queue entries are known GGX ids
+        bool known = true;
+        int id = 0;
+        if constexpr (PER_LANE || INDEXED) {
+            id = a.mat[i];
+            known = id >= 0 && id < a.n_materials && a.materials[id].kind == KIND_GGX;
+        }
+        const fast::GgxConsts g((PER_LANE || INDEXED) ? a.materials[known ? id : 0] : a.single);
         float wix, wiy, wiz;
         load3s<NT>(a.wi, i, wix, wiy, wiz);
+        if (!known) wiz = 0.0f;                               // unknown material id: every output zero
         const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
         if constexpr (HAS_EVAL || HAS_PDF) {
             float wox, woy, woz;
@@ -631,7 +639,7 @@ void launch_table(const BatchArgs &a, bool multi, bool nt, int lookup, int layou
 }
 
 template <int MODE>
-hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, bool has_ggx, int compute_units, hipStream_t stream)
+hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, bool has_ggx, bool has_table, int compute_units, hipStream_t stream)
 {
     dim3 grid(grid_for(a.n, compute_units)), block(kBlock);
     // variant 0: generic kernel (every kind, ocml math) — the A/B baseline;
@@ -639,6 +647,10 @@ hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, 
     const bool tuned = variant >= 1 && (multi || a.single.kind != KIND_GGX);
     if (variant >= 1 && !multi && a.single.kind == KIND_GGX) {     // tuned analytic kernel
         hipLaunchKernelGGL((k_ggx<MODE, true>), grid, block, 0, stream, a);
+        return hipGetLastError();
+    }
+    if (variant >= 1 && multi && has_ggx && !has_table) {          // a batch over analytic materials only
+        hipLaunchKernelGGL((k_ggx<MODE, true, true>), grid, block, 0, stream, a);
         return hipGetLastError();
     }
     if constexpr (MODE != MODE_PDF) {
@@ -666,14 +678,14 @@ hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, 
 
 } // namespace
 
-hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int layout, bool has_ggx, int compute_units, hipStream_t stream)
+hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int layout, bool has_ggx, bool has_table, int compute_units, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     switch (mode) {
-        case MODE_EVAL:        return launch_mode<MODE_EVAL>(a, multi, variant, layout, has_ggx, compute_units, stream);
-        case MODE_PDF:         return launch_mode<MODE_PDF>(a, multi, variant, layout, has_ggx, compute_units, stream);
-        case MODE_SAMPLE:      return launch_mode<MODE_SAMPLE>(a, multi, variant, layout, has_ggx, compute_units, stream);
-        case MODE_EVAL_SAMPLE: return launch_mode<MODE_EVAL_SAMPLE>(a, multi, variant, layout, has_ggx, compute_units, stream);
+        case MODE_EVAL:        return launch_mode<MODE_EVAL>(a, multi, variant, layout, has_ggx, has_table, compute_units, stream);
+        case MODE_PDF:         return launch_mode<MODE_PDF>(a, multi, variant, layout, has_ggx, has_table, compute_units, stream);
+        case MODE_SAMPLE:      return launch_mode<MODE_SAMPLE>(a, multi, variant, layout, has_ggx, has_table, compute_units, stream);
+        case MODE_EVAL_SAMPLE: return launch_mode<MODE_EVAL_SAMPLE>(a, multi, variant, layout, has_ggx, has_table, compute_units, stream);
     }
     return hipErrorInvalidValue;
 }
@@ -712,7 +724,7 @@ hipError_t launch_queue_mode(const BatchArgs &a, bool ggx_queue, int compute_uni
         return hipErrorInvalidValue;
     } else {
         if (ggx_queue) {
-            hipLaunchKernelGGL((k_ggx<MODE, true, true>), dim3(grid_for(a.n, compute_units)), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL((k_ggx<MODE, true, true, true>), dim3(grid_for(a.n, compute_units)), dim3(kBlock), 0, stream, a);
         } else {
             constexpr int per_cu = ((MODE == MODE_EVAL_SAMPLE) ? 2 : 4) * (256 / kDmaBlock);
             size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;

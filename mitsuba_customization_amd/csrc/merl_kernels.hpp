@@ -26,8 +26,8 @@ struct BatchArgs {
 // mode: 0 eval, 1 pdf, 2 sample, 3 eval+sample
 // variant: MRL_OPT_KERNEL (0 generic, 1 tuned table path, 2 tuned + non-temporal streams)
 // layout: the context-wide table layout (every table of a context has the same one)
-// has_ggx: the context holds at least one analytic (GGX) material, so a mixed batch may contain such lanes
-hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int layout, bool has_ggx, int compute_units, hipStream_t stream);
+// has_ggx / has_table: the context holds at least one analytic (GGX) / one table material, i.e. what a mixed batch may contain
+hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int layout, bool has_ggx, bool has_table, int compute_units, hipStream_t stream);
 // kind-partitioned mixed batches (MRL_OPT_KERNEL >= 4): build the two queues, then run one of them
 void partition_geometry(size_t n, int compute_units, uint32_t *segments, uint32_t *seg_len);
 // work: 4*segments + 2 uint32 (counts, offsets, totals[2] at work + 4*segments)
