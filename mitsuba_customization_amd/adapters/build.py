@@ -50,6 +50,15 @@ def build_all(force: bool = False):
         if force or _stale(drv, deps + [drv_src, os.path.join(HERE, "tests", "driver_common.hpp")]):
             subprocess.check_call([CXX] + [f for f in CXXFLAGS if f != "-fvisibility=hidden"] + inc + ["-o", drv, drv_src, "-ldl"])
         outs.append(drv)
+    # the C ABI from plain C99 (examples/abi_example.c): also proves include/merl_hip.h is a C header
+    ex_src = os.path.join(os.path.dirname(PKG), "examples", "abi_example.c")
+    ex = os.path.join(LIBDIR, "abi_example")
+    if os.path.exists(ex_src) and (force or _stale(ex, [ex_src, os.path.join(os.path.dirname(PKG), "include", "merl_hip.h")])):
+        subprocess.check_call([shutil.which("gcc") or "gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-pedantic",
+                               "-I", os.path.join(os.path.dirname(PKG), "include"), "-o", ex, ex_src,
+                               "-L", LIBDIR, "-lmerl_hip", "-Wl,-rpath,$ORIGIN", "-lm"])
+    if os.path.exists(ex):
+        outs.append(ex)
     return outs
 
 

@@ -149,3 +149,10 @@ def test_plugin_table_sampling_property(built, merl_file, oracle, tables, tmp_pa
     ok = np.abs(batch[:, 7].astype(np.float64) - c_pdf) <= 2e-6 * np.abs(c_pdf) + 1e-30
     assert ok.mean() > 0.999
     assert (np.abs(batch[:, 3].astype(np.float64) - T.pdf_table(wi, wo)) <= 2e-6 * T.pdf_table(wi, wo) + 1e-30).all()
+
+
+@pytest.mark.gpu
+def test_c99_example_runs(built, merl_file):
+    """examples/abi_example.c: the ABI from plain C — pinned zero-copy vs staged host path, error codes."""
+    r = subprocess.run([os.path.join(built, "abi_example"), merl_file], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "example ok" in r.stdout and "agree bit for bit" in r.stdout, r.stdout + r.stderr
