@@ -27,22 +27,22 @@ struct GgxConsts {                 // per material, computed once per launch (SG
     }
 };
 
+// D = 1 / (pi a^2 (cos^2 + sin^2/a^2)^2): the oracle's (1 + tan^2/a^2) cos^2 with the division folded away
 __device__ __forceinline__ double ggx_D(const GgxConsts &g, const Vec3 &m)
 {
-    const double c2 = m.z * m.z;
-    const double e = __builtin_fma(m.x, m.x, m.y * m.y) * g.inv_alpha2 * rcp_nr(__builtin_fmax(c2, kTiny));
-    const double root = (1.0 + e) * c2;
+    const double root = __builtin_fma(__builtin_fma(m.x, m.x, m.y * m.y), g.inv_alpha2, m.z * m.z);
     const double r = g.inv_pi_alpha2 * rcp_nr(__builtin_fmax(root * root, kTiny));
     return (m.z <= 0.0 || r * m.z < 1e-20) ? 0.0 : r;
 }
 
+// G1 = 2 / (1 + sqrt(1 + a^2 tan^2)) = 2 |vz| / (|vz| + sqrt(vz^2 + a^2 (1 - vz^2))): one sqrt, one reciprocal
 __device__ __forceinline__ double ggx_G1(const GgxConsts &g, const Vec3 &v, const Vec3 &m)
 {
     const double vm = __builtin_fma(v.x, m.x, __builtin_fma(v.y, m.y, v.z * m.z));
     const double vz2 = v.z * v.z;
     const double s2 = 1.0 - vz2;
-    const double tan2 = s2 * rcp_nr(__builtin_fmax(vz2, kTiny));
-    const double r = 2.0 * rcp_nr(1.0 + sqrt_fast(__builtin_fma(g.alpha * g.alpha, tan2, 1.0)));
+    const double az = __builtin_fabs(v.z);
+    const double r = 2.0 * az * rcp_nr(__builtin_fmax(az + sqrt_fast(__builtin_fma(g.alpha * g.alpha, s2, vz2)), kTiny));
     const double res = s2 <= 0.0 ? 1.0 : r;
     return vm * v.z <= 0.0 ? 0.0 : res;
 }
@@ -54,9 +54,12 @@ __device__ __forceinline__ double fresnel_conductor(const GgxConsts &g, int ch, 
     const double a2pb2 = sqrt_fast(__builtin_fma(t1, t1, g.four_k2_eta2[ch]));
     const double a = sqrt_fast(0.5 * (a2pb2 + t1));
     const double term1 = a2pb2 + c2, term2 = 2.0 * a * c;
-    const double rs2 = (term1 - term2) * rcp_nr(term1 + term2);
     const double term3 = __builtin_fma(a2pb2, c2, s4), term4 = term2 * s2;
-    const double rp2 = rs2 * (term3 - term4) * rcp_nr(term3 + term4);
+    // Rs = (t1-t2)/(t1+t2), Rp = Rs (t3-t4)/(t3+t4): one reciprocal of the product of both denominators
+    const double d12 = term1 + term2, d34 = term3 + term4;
+    const double inv = rcp_nr(d12 * d34);
+    const double rs2 = (term1 - term2) * d34 * inv;
+    const double rp2 = rs2 * (term3 - term4) * d12 * inv;
     return 0.5 * (rp2 + rs2);
 }
 
