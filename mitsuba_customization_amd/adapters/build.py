@@ -48,7 +48,7 @@ def build_all(force: bool = False):
         drv_src = os.path.join(HERE, "tests", "driver06.cpp" if host == "mitsuba06" else "driver3.cpp")
         drv = os.path.join(LIBDIR, "driver06" if host == "mitsuba06" else "driver3")
         if force or _stale(drv, deps + [drv_src, os.path.join(HERE, "tests", "driver_common.hpp")]):
-            subprocess.check_call([CXX] + [f for f in CXXFLAGS if f != "-fvisibility=hidden"] + inc + ["-o", drv, drv_src, "-ldl"])
+            subprocess.check_call([CXX] + [f for f in CXXFLAGS if f != "-fvisibility=hidden"] + inc + ["-o", drv, drv_src, "-ldl", "-lpthread"])
         outs.append(drv)
     # the C ABI from plain C99 (examples/abi_example.c): also proves include/merl_hip.h is a C header
     ex_src = os.path.join(os.path.dirname(PKG), "examples", "abi_example.c")

@@ -7,6 +7,7 @@
 
 #include <cstring>
 #include <iostream>
+#include <thread>
 
 #include <mitsuba/mitsuba.h>
 
@@ -87,6 +88,34 @@ int main(int argc, char **argv)
         if (!bsdf->eval(q, EDiscrete).isZero() || bsdf->pdf(q, EDiscrete) != 0.f) return 8;
         q.typeMask = BSDF::EDiffuseReflection;
         if (!bsdf->eval(q, ESolidAngle).isZero()) return 8;
+    }
+    // the renderer calls a const BSDF from all of its render threads at once
+    {
+        const unsigned T = 8;
+        std::vector<std::vector<float>> per_thread(T);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < T; ++t)
+            pool.emplace_back([&, t]() {
+                Intersection its_t;
+                for (size_t i = t; i < m; i += T) {
+                    its_t.wi = Vector(p.wi[3 * i], p.wi[3 * i + 1], p.wi[3 * i + 2]);
+                    BSDFSamplingRecord q(its_t, Vector(p.wo[3 * i], p.wo[3 * i + 1], p.wo[3 * i + 2]));
+                    Spectrum f = bsdf->eval(q, ESolidAngle);
+                    BSDFSamplingRecord s(its_t);
+                    Float spdf;
+                    Spectrum w = bsdf->sample(s, spdf, Point2(p.u[2 * i], p.u[2 * i + 1]));
+                    per_thread[t].insert(per_thread[t].end(), { f[0], f[1], f[2], s.wo.x, s.wo.y, s.wo.z, spdf, w[0], w[1], w[2] });
+                }
+            });
+        for (auto &th : pool) th.join();
+        for (unsigned t = 0; t < T; ++t) {
+            size_t k = 0;
+            for (size_t i = t; i < m; i += T, ++k) {
+                const float *o = &scalar[11 * i], *g = &per_thread[t][10 * k];
+                const float want[10] = { o[0], o[1], o[2], o[4], o[5], o[6], o[7], o[8], o[9], o[10] };
+                if (std::memcmp(g, want, sizeof want) != 0) { std::cerr << "threaded scalar call differs at unit " << i << "\n"; return 10; }
+            }
+        }
     }
     const BatchedBSDF *wave = dynamic_cast<const BatchedBSDF *>(bsdf);
     if (!wave) { std::cerr << "plugin is not a BatchedBSDF\n"; return 9; }
