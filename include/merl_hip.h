@@ -15,6 +15,8 @@
  *   mrl_pdf_batch                          BSDF::pdf(bRec, ESolidAngle)    / M3 BSDF::pdf
  *   mrl_sample_batch                       BSDF::sample(bRec, pdf, sample) / M3 BSDF::sample
  *   mrl_eval_sample_batch                  the fused eval + pdf + sample unit (BASELINE metric)
+ *   mrl_*_queue                            the same calls over a wavefront integrator's material queue
+ *                                          (the caller side of the path)
  *
  * Conventions: every function returns 0 on success or a negative mrl_status; no exception
  * crosses the boundary.  All arrays are f32, direction arrays are xyzxyz… (n x 3), sample
@@ -109,6 +111,25 @@ int mrl_sample_batch(mrl_ctx *ctx, const float *wi, const float *u, const int32_
 /* the benchmarked unit: eval(wi,wo) rgb, pdf(wi,wo), sample(wi,u) -> (wo', pdf', weight') */
 int mrl_eval_sample_batch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u,
                           const int32_t *mat, int32_t single_id, size_t n,
+                          float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight);
+
+/* ---- wavefront queues.  A wavefront path tracer keeps its path state in arrays
+ * indexed by path slot and a queue of the slots that hit this BSDF.  These calls process the units
+ * queue[0 .. min(*queue_count, capacity)): inputs are read from, and outputs written to, the slots
+ * the queue names; every other slot is left untouched.  queue_count lives in DEVICE memory (the
+ * kernel that built the queue wrote it), so no host round trip separates queue building from the
+ * BSDF call.  Device(-accessible) pointers only; asynchronous on the context's stream.  The caller
+ * guarantees that every queued index addresses a valid slot of the arrays. ---- */
+int mrl_eval_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                   const uint32_t *queue, const uint32_t *queue_count, size_t capacity, float *out_rgb);
+int mrl_pdf_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                  const uint32_t *queue, const uint32_t *queue_count, size_t capacity, float *out_pdf);
+int mrl_sample_queue(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id,
+                     const uint32_t *queue, const uint32_t *queue_count, size_t capacity,
+                     float *out_wo, float *out_pdf, float *out_weight);
+int mrl_eval_sample_queue(mrl_ctx *ctx, const float *wi, const float *wo, const float *u,
+                          const int32_t *mat, int32_t single_id,
+                          const uint32_t *queue, const uint32_t *queue_count, size_t capacity,
                           float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight);
 
 /* ---- synthetic inputs, generated in place on the device; device pointers only ---- */

@@ -357,6 +357,43 @@ int run_batch(mrl_ctx *ctx, const BatchCall &c)
     return MRL_OK;
 }
 
+// mrl_*_queue: a caller-built queue of unit indices with a device-side length
+int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uint32_t *queue_count)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    if (c.n == 0) return MRL_OK;
+    const bool needs_wo = c.mode != 2, needs_u = c.mode >= 2;
+    const bool has_eval = c.mode == 0 || c.mode == 3, has_pdf = c.mode == 1 || c.mode == 3, has_sample = c.mode >= 2;
+    if (!queue || !queue_count || !c.wi || (needs_wo && !c.wo) || (needs_u && !c.u) || (has_eval && !c.out_rgb) ||
+        (has_pdf && !c.out_pdf) || (has_sample && (!c.out_wo || !c.out_pdf2 || !c.out_weight)))
+        return fail(ctx, MRL_ERR_INVALID, "null array argument");
+    if (c.n > ((size_t)1 << 32)) return fail(ctx, MRL_ERR_INVALID, "queue capacity exceeds 2^32 (indices are uint32)");
+    if (ctx->materials.empty()) return fail(ctx, MRL_ERR_MATERIAL, "no material loaded");
+    if (!c.mat && (c.single_id < 0 || (size_t)c.single_id >= ctx->materials.size()))
+        return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    int kind = common_kind({ c.wi, needs_wo ? c.wo : nullptr, needs_u ? c.u : nullptr, c.mat, queue, queue_count,
+                             has_eval ? c.out_rgb : nullptr, has_pdf ? c.out_pdf : nullptr,
+                             has_sample ? c.out_wo : nullptr, has_sample ? c.out_pdf2 : nullptr,
+                             has_sample ? c.out_weight : nullptr });
+    if (kind != 1) return fail(ctx, MRL_ERR_POINTER_MIX, "queue calls take device pointers only");
+
+    mrl::BatchArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.wi = c.wi; a.wo = c.wo; a.u = c.u; a.mat = c.mat; a.n = c.n;
+    a.out_rgb = c.out_rgb; a.out_pdf = c.out_pdf; a.out_wo = c.out_wo; a.out_pdf2 = c.out_pdf2; a.out_weight = c.out_weight;
+    a.materials = ctx->d_materials;
+    a.n_materials = (int)ctx->materials.size();
+    a.opts = ctx->opts;
+    a.idx = queue; a.idx_count = queue_count;
+    const bool multi = c.mat != nullptr;
+    if (!multi) a.single = ctx->materials[(size_t)c.single_id].dev;
+    bool has_ggx = false, has_table = false;
+    for (const auto &m : ctx->materials) { has_ggx = has_ggx || m.dev.kind == mrl::KIND_GGX; has_table = has_table || m.dev.kind != mrl::KIND_GGX; }
+    MRL_HIP(ctx, mrl::launch_batch_indexed(c.mode, a, multi, ctx->table_layout, has_ggx, has_table, ctx->compute_units, ctx->stream));
+    return MRL_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -572,6 +609,37 @@ int mrl_eval_sample_batch(mrl_ctx *ctx, const float *wi, const float *wo, const 
 {
     BatchCall c{ 3, wi, wo, u, mat, single_id, n, out_rgb, out_pdf, out_wo, out_pdf2, out_weight };
     return run_batch(ctx, c);
+}
+
+int mrl_eval_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                   const uint32_t *queue, const uint32_t *queue_count, size_t capacity, float *out_rgb)
+{
+    BatchCall c = { 0, wi, wo, nullptr, mat, single_id, capacity, out_rgb, nullptr, nullptr, nullptr, nullptr };
+    return run_queue(ctx, c, queue, queue_count);
+}
+
+int mrl_pdf_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                  const uint32_t *queue, const uint32_t *queue_count, size_t capacity, float *out_pdf)
+{
+    BatchCall c = { 1, wi, wo, nullptr, mat, single_id, capacity, nullptr, out_pdf, nullptr, nullptr, nullptr };
+    return run_queue(ctx, c, queue, queue_count);
+}
+
+int mrl_sample_queue(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id,
+                     const uint32_t *queue, const uint32_t *queue_count, size_t capacity,
+                     float *out_wo, float *out_pdf, float *out_weight)
+{
+    BatchCall c = { 2, wi, nullptr, u, mat, single_id, capacity, nullptr, nullptr, out_wo, out_pdf, out_weight };
+    return run_queue(ctx, c, queue, queue_count);
+}
+
+int mrl_eval_sample_queue(mrl_ctx *ctx, const float *wi, const float *wo, const float *u,
+                          const int32_t *mat, int32_t single_id,
+                          const uint32_t *queue, const uint32_t *queue_count, size_t capacity,
+                          float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
+{
+    BatchCall c = { 3, wi, wo, u, mat, single_id, capacity, out_rgb, out_pdf, out_wo, out_pdf2, out_weight };
+    return run_queue(ctx, c, queue, queue_count);
 }
 
 int mrl_generate_pairs(mrl_ctx *ctx, uint64_t seed, uint64_t first_index, size_t n, float *wi, float *wo, float *u)

@@ -46,11 +46,21 @@ template <bool NT> __device__ __forceinline__ void store3s(float *p, size_t i, c
     stf<NT>(q, v[0]); stf<NT>(q + 1, v[1]); stf<NT>(q + 2, v[2]);
 }
 
-template <int MODE, bool MULTI>
+// number of work items of a launch: a.n, or for a queue launch the device-side count clamped to the capacity a.n
+template <bool INDEXED> __device__ __forceinline__ size_t item_count(const BatchArgs &a)
+{
+    if constexpr (INDEXED) { const size_t c = (size_t)*a.idx_count; return c < a.n ? c : a.n; }
+    else return a.n;
+}
+
+// INDEXED: walk the queue a.idx[0 .. *a.idx_count) of unit indices instead of [0, n)
+template <int MODE, bool MULTI, bool INDEXED = false>
 __global__ __launch_bounds__(kBlock) void k_batch(BatchArgs a)
 {
     const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+    const size_t n_items = item_count<INDEXED>(a);
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_items; j += stride) {
+        const size_t i = INDEXED ? (size_t)a.idx[j] : j;
         MaterialDev m;
         bool valid = true;
         if constexpr (MULTI) {
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
     float4 *ldsA = lds[wave][0];
     float4 *ldsB = lds[wave][LOOKUPS - 1];
     const size_t stride = (size_t)gridDim.x * kDmaBlock;
-    const size_t n_items = INDEXED ? (size_t)*a.idx_count : a.n;
+    const size_t n_items = item_count<INDEXED>(a);
     for (size_t base = (size_t)blockIdx.x * kDmaBlock + wave * 64u; base < n_items; base += stride) {
         const size_t j_raw = base + lane;
         const bool active = j_raw < n_items;
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
 
 // ---- tuned GGX rough conductor (single-material launches of an analytic material) ----------------
 // PER_LANE: the material comes from mat[i] (a batch over several analytic materials);
-// INDEXED: walks the GGX queue of a kind-partitioned mixed batch (implies PER_LANE).
+// INDEXED: walks a queue of unit indices (a caller's wavefront queue, or the GGX queue of a kind-partitioned batch).
 template <int MODE, bool NT, bool PER_LANE = false, bool INDEXED = false>
 __global__ __launch_bounds__(kBlock) void k_ggx(BatchArgs a)
 {
@@ -402,16 +412,16 @@ __global__ __launch_bounds__(kBlock) void k_ggx(BatchArgs a)
     constexpr bool HAS_PDF = MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE;
     constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
     const size_t stride = (size_t)gridDim.x * kBlock;
-    const size_t n_items = INDEXED ? (size_t)*a.idx_count : a.n;
+    const size_t n_items = item_count<INDEXED>(a);
     for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_items; j += stride) {
         const size_t i = INDEXED ? (size_t)a.idx[j] : j;
         bool known = true;
         int id = 0;
-        if constexpr (PER_LANE || INDEXED) {
+        if constexpr (PER_LANE) {
             id = a.mat[i];
             known = id >= 0 && id < a.n_materials && a.materials[id].kind == KIND_GGX;
         }
-        const fast::GgxConsts g((PER_LANE || INDEXED) ? a.materials[known ? id : 0] : a.single);
+        const fast::GgxConsts g(PER_LANE ? a.materials[known ? id : 0] : a.single);
         float wix, wiy, wiz;
         load3s<NT>(a.wi, i, wix, wiy, wiz);
         if (!known) wiz = 0.0f;                               // unknown material id: every output zero
@@ -744,6 +754,53 @@ hipError_t launch_batch_queue(int mode, const BatchArgs &a, bool ggx_queue, int 
         case MODE_EVAL:        return launch_queue_mode<MODE_EVAL>(a, ggx_queue, compute_units, stream);
         case MODE_SAMPLE:      return launch_queue_mode<MODE_SAMPLE>(a, ggx_queue, compute_units, stream);
         case MODE_EVAL_SAMPLE: return launch_queue_mode<MODE_EVAL_SAMPLE>(a, ggx_queue, compute_units, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+namespace {
+template <int MODE>
+hipError_t launch_indexed_mode(const BatchArgs &a, bool multi, int layout, bool has_ggx, bool has_table, int compute_units, hipStream_t stream)
+{
+    const dim3 grid(grid_for(a.n, compute_units)), block(kBlock);
+    if (!multi && a.single.kind == KIND_GGX) {
+        hipLaunchKernelGGL((k_ggx<MODE, true, false, true>), grid, block, 0, stream, a);
+        return hipGetLastError();
+    }
+    if (multi && has_ggx && !has_table) {
+        hipLaunchKernelGGL((k_ggx<MODE, true, true, true>), grid, block, 0, stream, a);
+        return hipGetLastError();
+    }
+    if constexpr (MODE != MODE_PDF) {
+        if (layout == LAYOUT_BRICK && a.opts.lookup == 1) {
+            constexpr int per_cu = ((MODE == MODE_EVAL_SAMPLE) ? 2 : 4) * (256 / kDmaBlock);
+            size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;
+            if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
+            const dim3 g((unsigned)blocks), b(kDmaBlock);
+            if (multi && has_ggx)      hipLaunchKernelGGL((k_table_dma<MODE, true, true, true, true>), g, b, 0, stream, a);
+            else if (multi)            hipLaunchKernelGGL((k_table_dma<MODE, true, true, false, true>), g, b, 0, stream, a);
+            else                       hipLaunchKernelGGL((k_table_dma<MODE, false, true, false, true>), g, b, 0, stream, a);
+            return hipGetLastError();
+        }
+    }
+    // rows layout, nearest lookup, pdf: the generic kernel walks the queue
+    if (multi) hipLaunchKernelGGL((k_batch<MODE, true, true>), grid, block, 0, stream, a);
+    else       hipLaunchKernelGGL((k_batch<MODE, false, true>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+} // namespace
+
+// A caller's wavefront queue: units a.idx[0 .. min(*a.idx_count, a.n)) of the arrays in `a`; a.n is the queue's
+// capacity (grid sizing and an upper clamp on the device-side count).
+hipError_t launch_batch_indexed(int mode, const BatchArgs &a, bool multi, int layout, bool has_ggx, bool has_table,
+                                int compute_units, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    switch (mode) {
+        case MODE_EVAL:        return launch_indexed_mode<MODE_EVAL>(a, multi, layout, has_ggx, has_table, compute_units, stream);
+        case MODE_PDF:         return launch_indexed_mode<MODE_PDF>(a, multi, layout, has_ggx, has_table, compute_units, stream);
+        case MODE_SAMPLE:      return launch_indexed_mode<MODE_SAMPLE>(a, multi, layout, has_ggx, has_table, compute_units, stream);
+        case MODE_EVAL_SAMPLE: return launch_indexed_mode<MODE_EVAL_SAMPLE>(a, multi, layout, has_ggx, has_table, compute_units, stream);
     }
     return hipErrorInvalidValue;
 }

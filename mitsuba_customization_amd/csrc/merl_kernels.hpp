@@ -18,7 +18,7 @@ struct BatchArgs {
     const MaterialDev *materials;    // device array (mixed-material launches)
     int n_materials;
     Options opts;
-    // kind-partitioned mixed batches: a dense queue of unit indices (k_partition_kinds), else unused
+    // queue launches: a queue of unit indices (a caller's wavefront queue, or one kind's queue built by k_partition_kinds)
     const uint32_t *idx;
     const uint32_t *idx_count;               // its length, in device memory
 };
@@ -35,6 +35,9 @@ hipError_t launch_partition_kinds(const int32_t *mat, size_t n, const MaterialDe
                                   uint32_t *queue_table, uint32_t *queue_ggx, uint32_t *work,
                                   uint32_t segments, uint32_t seg_len, hipStream_t stream);
 hipError_t launch_batch_queue(int mode, const BatchArgs &a, bool ggx_queue, int compute_units, hipStream_t stream);
+// a caller's wavefront queue (mrl_*_queue): units a.idx[0 .. min(*a.idx_count, a.n)), a.n = the queue's capacity
+hipError_t launch_batch_indexed(int mode, const BatchArgs &a, bool multi, int layout, bool has_ggx, bool has_table,
+                                int compute_units, hipStream_t stream);
 // a1: planar f64 table (device copy of the file payload) -> padded rows or bricks
 hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, float4 *d_out,
                               int compute_units, hipStream_t stream);

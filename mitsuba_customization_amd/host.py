@@ -87,6 +87,10 @@ def load_library(path: Optional[str] = None):
     L.mrl_pdf_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp]
     L.mrl_sample_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp, fp, fp]
     L.mrl_eval_sample_batch.argtypes = [vp, fp, fp, fp, vp, C.c_int32, C.c_size_t, fp, fp, fp, fp, fp]
+    L.mrl_eval_queue.argtypes = [vp, fp, fp, vp, C.c_int32, vp, vp, C.c_size_t, fp]
+    L.mrl_pdf_queue.argtypes = [vp, fp, fp, vp, C.c_int32, vp, vp, C.c_size_t, fp]
+    L.mrl_sample_queue.argtypes = [vp, fp, fp, vp, C.c_int32, vp, vp, C.c_size_t, fp, fp, fp]
+    L.mrl_eval_sample_queue.argtypes = [vp, fp, fp, fp, vp, C.c_int32, vp, vp, C.c_size_t, fp, fp, fp, fp, fp]
     L.mrl_generate_pairs.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, fp, fp, fp]
     L.mrl_generate_materials.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, vp]
     L.mrl_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -283,6 +287,60 @@ class MerlHip:
             _addr(rgb, np.float32, 3, n, "out_rgb"), _addr(pdf, np.float32, None, n, "out_pdf"),
             _addr(wo2, np.float32, 3, n, "out_wo"), _addr(pdf2, np.float32, None, n, "out_pdf2"),
             _addr(w, np.float32, 3, n, "out_weight")), "mrl_eval_sample_batch")
+        return out
+
+    # ---- wavefront queues (device tensors only) ----
+    def _zeros(self, like, shape):
+        import torch
+        return torch.zeros(shape, dtype=torch.float32, device=like.device)
+
+    def _queue(self, wi, queue, count, capacity):
+        """queue: int32 tensor of slot indices (non-negative; read as uint32), count: int32 tensor with one element."""
+        if not (_is_tensor(wi) and _is_tensor(queue) and _is_tensor(count)):
+            raise ValueError("queue calls take GPU tensors")
+        self._prep(wi)
+        cap = int(queue.shape[0]) if capacity is None else int(capacity)
+        if cap > int(queue.shape[0]):
+            raise ValueError("capacity exceeds the queue's length")
+        return _addr(queue, np.int32, None, None, "queue"), _addr(count, np.int32, None, 1, "count"), cap
+
+    def eval_queue(self, wi, wo, queue, count, mat=None, material: int = 0, capacity=None, out=None):
+        """eval() of the slots queue[0 .. min(count, capacity)); other slots of `out` stay as they are."""
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        out = self._zeros(wi, (n, 3)) if out is None else out
+        self._check(self._lib.mrl_eval_queue(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                             _addr(mat, np.int32, None, n, "mat"), material, q, c, cap,
+                                             _addr(out, np.float32, 3, n, "out_rgb")), "mrl_eval_queue")
+        return out
+
+    def pdf_queue(self, wi, wo, queue, count, mat=None, material: int = 0, capacity=None, out=None):
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        out = self._zeros(wi, (n,)) if out is None else out
+        self._check(self._lib.mrl_pdf_queue(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                            _addr(mat, np.int32, None, n, "mat"), material, q, c, cap,
+                                            _addr(out, np.float32, None, n, "out_pdf")), "mrl_pdf_queue")
+        return out
+
+    def sample_queue(self, wi, u, queue, count, mat=None, material: int = 0, capacity=None, out=None):
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        wo, pdf, w = out if out is not None else (self._zeros(wi, (n, 3)), self._zeros(wi, (n,)), self._zeros(wi, (n, 3)))
+        self._check(self._lib.mrl_sample_queue(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(u, np.float32, 2, n, "u"),
+                                               _addr(mat, np.int32, None, n, "mat"), material, q, c, cap,
+                                               _addr(wo, np.float32, 3, n, "out_wo"), _addr(pdf, np.float32, None, n, "out_pdf"),
+                                               _addr(w, np.float32, 3, n, "out_weight")), "mrl_sample_queue")
+        return wo, pdf, w
+
+    def eval_sample_queue(self, wi, wo, u, queue, count, mat=None, material: int = 0, capacity=None, out=None):
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        if out is None:
+            out = (self._zeros(wi, (n, 3)), self._zeros(wi, (n,)), self._zeros(wi, (n, 3)), self._zeros(wi, (n,)), self._zeros(wi, (n, 3)))
+        rgb, pdf, wo2, pdf2, w = out
+        self._check(self._lib.mrl_eval_sample_queue(
+            self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"), _addr(u, np.float32, 2, n, "u"),
+            _addr(mat, np.int32, None, n, "mat"), material, q, c, cap,
+            _addr(rgb, np.float32, 3, n, "out_rgb"), _addr(pdf, np.float32, None, n, "out_pdf"),
+            _addr(wo2, np.float32, 3, n, "out_wo"), _addr(pdf2, np.float32, None, n, "out_pdf2"),
+            _addr(w, np.float32, 3, n, "out_weight")), "mrl_eval_sample_queue")
         return out
 
     # ---- synthetic inputs (device) ----
