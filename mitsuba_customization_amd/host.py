@@ -28,6 +28,7 @@ ABI_SYMBOLS = (
     "mrl_material_load_merl", "mrl_material_upload_f64", "mrl_material_upload_table", "mrl_material_load_table",
     "mrl_material_ggx", "mrl_material_count", "mrl_material_info",
     "mrl_eval_batch", "mrl_pdf_batch", "mrl_sample_batch", "mrl_eval_sample_batch",
+    "mrl_eval_queue", "mrl_pdf_queue", "mrl_sample_queue", "mrl_eval_sample_queue",
     "mrl_generate_pairs", "mrl_generate_materials",
     "mrl_device_alloc", "mrl_device_free", "mrl_copy_to_device", "mrl_copy_to_host", "mrl_host_alloc", "mrl_host_free",
     "mrl_timer_start", "mrl_timer_stop",
