@@ -265,19 +265,62 @@ int ensure_queues(mrl_ctx *ctx, size_t units)
     return MRL_OK;
 }
 
-int launch_device(mrl_ctx *ctx, const BatchCall &c)
+// kernel arguments of a call whose pointers are all device-accessible
+struct DeviceCall {
+    mrl::BatchArgs args;
+    bool multi, has_ggx, has_table;
+};
+
+DeviceCall device_call(const mrl_ctx *ctx, const BatchCall &c)
 {
-    mrl::BatchArgs a;
+    DeviceCall d;
+    mrl::BatchArgs &a = d.args;
     std::memset(&a, 0, sizeof a);
     a.wi = c.wi; a.wo = c.wo; a.u = c.u; a.mat = c.mat; a.n = c.n;
     a.out_rgb = c.out_rgb; a.out_pdf = c.out_pdf; a.out_wo = c.out_wo; a.out_pdf2 = c.out_pdf2; a.out_weight = c.out_weight;
     a.materials = ctx->d_materials;
     a.n_materials = (int)ctx->materials.size();
     a.opts = ctx->opts;
-    bool multi = c.mat != nullptr;
-    if (!multi) a.single = ctx->materials[(size_t)c.single_id].dev;
-    bool has_ggx = false, has_table = false;
-    for (const auto &m : ctx->materials) { has_ggx = has_ggx || m.dev.kind == mrl::KIND_GGX; has_table = has_table || m.dev.kind != mrl::KIND_GGX; }
+    d.multi = c.mat != nullptr;
+    if (!d.multi) a.single = ctx->materials[(size_t)c.single_id].dev;
+    d.has_ggx = d.has_table = false;
+    for (const auto &m : ctx->materials) {
+        d.has_ggx = d.has_ggx || m.dev.kind == mrl::KIND_GGX;
+        d.has_table = d.has_table || m.dev.kind != mrl::KIND_GGX;
+    }
+    return d;
+}
+
+// null-pointer and material checks shared by the whole-array and the queue entry points
+int check_call(mrl_ctx *ctx, const BatchCall &c)
+{
+    const bool needs_wo = c.mode != 2, needs_u = c.mode >= 2;
+    const bool has_eval = c.mode == 0 || c.mode == 3, has_pdf = c.mode == 1 || c.mode == 3, has_sample = c.mode >= 2;
+    if (!c.wi || (needs_wo && !c.wo) || (needs_u && !c.u) || (has_eval && !c.out_rgb) || (has_pdf && !c.out_pdf) ||
+        (has_sample && (!c.out_wo || !c.out_pdf2 || !c.out_weight)))
+        return fail(ctx, MRL_ERR_INVALID, "null array argument");
+    if (ctx->materials.empty()) return fail(ctx, MRL_ERR_MATERIAL, "no material loaded");
+    if (!c.mat && (c.single_id < 0 || (size_t)c.single_id >= ctx->materials.size()))
+        return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
+    return MRL_OK;
+}
+
+// host-or-device kind of the arrays a call of this mode touches (-1: mixed)
+int call_pointer_kind(const BatchCall &c, const void *extra0 = nullptr, const void *extra1 = nullptr)
+{
+    const bool needs_wo = c.mode != 2, needs_u = c.mode >= 2;
+    const bool has_eval = c.mode == 0 || c.mode == 3, has_pdf = c.mode == 1 || c.mode == 3, has_sample = c.mode >= 2;
+    return common_kind({ c.wi, needs_wo ? c.wo : nullptr, needs_u ? c.u : nullptr, c.mat, extra0, extra1,
+                         has_eval ? c.out_rgb : nullptr, has_pdf ? c.out_pdf : nullptr,
+                         has_sample ? c.out_wo : nullptr, has_sample ? c.out_pdf2 : nullptr,
+                         has_sample ? c.out_weight : nullptr });
+}
+
+int launch_device(mrl_ctx *ctx, const BatchCall &c)
+{
+    const DeviceCall d = device_call(ctx, c);
+    const mrl::BatchArgs &a = d.args;
+    const bool multi = d.multi, has_ggx = d.has_ggx, has_table = d.has_table;
     // MRL_OPT_KERNEL >= 4: a batch that may mix table and analytic materials is split into one dense queue
     // per kind (count / scan / partition, no atomics); each queue then runs through its dedicated kernel
     if (multi && has_ggx && has_table && ctx->kernel_variant >= 4 && c.mode != 1 && ctx->table_layout == mrl::LAYOUT_BRICK &&
@@ -308,24 +351,17 @@ int run_batch(mrl_ctx *ctx, const BatchCall &c)
     if (c.n == 0) return MRL_OK;
     const bool needs_wo = c.mode != 2, needs_u = c.mode >= 2;
     const bool has_eval = c.mode == 0 || c.mode == 3, has_pdf = c.mode == 1 || c.mode == 3, has_sample = c.mode >= 2;
-    if (!c.wi || (needs_wo && !c.wo) || (needs_u && !c.u) || (has_eval && !c.out_rgb) || (has_pdf && !c.out_pdf) ||
-        (has_sample && (!c.out_wo || !c.out_pdf2 || !c.out_weight)))
-        return fail(ctx, MRL_ERR_INVALID, "null array argument");
-    if (ctx->materials.empty()) return fail(ctx, MRL_ERR_MATERIAL, "no material loaded");
-    if (!c.mat && (c.single_id < 0 || (size_t)c.single_id >= ctx->materials.size()))
-        return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
+    int rc = check_call(ctx, c);
+    if (rc != MRL_OK) return rc;
     MRL_HIP(ctx, hipSetDevice(ctx->device));
 
-    int kind = common_kind({ c.wi, needs_wo ? c.wo : nullptr, needs_u ? c.u : nullptr, c.mat,
-                             has_eval ? c.out_rgb : nullptr, has_pdf ? c.out_pdf : nullptr,
-                             has_sample ? c.out_wo : nullptr, has_sample ? c.out_pdf2 : nullptr,
-                             has_sample ? c.out_weight : nullptr });
+    const int kind = call_pointer_kind(c);
     if (kind < 0) return fail(ctx, MRL_ERR_POINTER_MIX, "host and device pointers mixed in one call");
     if (kind == 1) return launch_device(ctx, c);
 
     // host pointers: stage through HBM in chunks; returns when the outputs are on the host
     const size_t chunk = std::min(c.n, ctx->host_chunk);
-    int rc = ensure_stage(ctx, chunk);
+    rc = ensure_stage(ctx, chunk);
     if (rc != MRL_OK) return rc;
     char *base = (char *)ctx->d_stage;
     const size_t cu = ctx->d_stage_units;
@@ -362,35 +398,15 @@ int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uin
 {
     if (!ctx) return MRL_ERR_INVALID;
     if (c.n == 0) return MRL_OK;
-    const bool needs_wo = c.mode != 2, needs_u = c.mode >= 2;
-    const bool has_eval = c.mode == 0 || c.mode == 3, has_pdf = c.mode == 1 || c.mode == 3, has_sample = c.mode >= 2;
-    if (!queue || !queue_count || !c.wi || (needs_wo && !c.wo) || (needs_u && !c.u) || (has_eval && !c.out_rgb) ||
-        (has_pdf && !c.out_pdf) || (has_sample && (!c.out_wo || !c.out_pdf2 || !c.out_weight)))
-        return fail(ctx, MRL_ERR_INVALID, "null array argument");
+    if (!queue || !queue_count) return fail(ctx, MRL_ERR_INVALID, "null array argument");
+    int rc = check_call(ctx, c);
+    if (rc != MRL_OK) return rc;
     if (c.n > ((size_t)1 << 32)) return fail(ctx, MRL_ERR_INVALID, "queue capacity exceeds 2^32 (indices are uint32)");
-    if (ctx->materials.empty()) return fail(ctx, MRL_ERR_MATERIAL, "no material loaded");
-    if (!c.mat && (c.single_id < 0 || (size_t)c.single_id >= ctx->materials.size()))
-        return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
     MRL_HIP(ctx, hipSetDevice(ctx->device));
-    int kind = common_kind({ c.wi, needs_wo ? c.wo : nullptr, needs_u ? c.u : nullptr, c.mat, queue, queue_count,
-                             has_eval ? c.out_rgb : nullptr, has_pdf ? c.out_pdf : nullptr,
-                             has_sample ? c.out_wo : nullptr, has_sample ? c.out_pdf2 : nullptr,
-                             has_sample ? c.out_weight : nullptr });
-    if (kind != 1) return fail(ctx, MRL_ERR_POINTER_MIX, "queue calls take device pointers only");
-
-    mrl::BatchArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.wi = c.wi; a.wo = c.wo; a.u = c.u; a.mat = c.mat; a.n = c.n;
-    a.out_rgb = c.out_rgb; a.out_pdf = c.out_pdf; a.out_wo = c.out_wo; a.out_pdf2 = c.out_pdf2; a.out_weight = c.out_weight;
-    a.materials = ctx->d_materials;
-    a.n_materials = (int)ctx->materials.size();
-    a.opts = ctx->opts;
-    a.idx = queue; a.idx_count = queue_count;
-    const bool multi = c.mat != nullptr;
-    if (!multi) a.single = ctx->materials[(size_t)c.single_id].dev;
-    bool has_ggx = false, has_table = false;
-    for (const auto &m : ctx->materials) { has_ggx = has_ggx || m.dev.kind == mrl::KIND_GGX; has_table = has_table || m.dev.kind != mrl::KIND_GGX; }
-    MRL_HIP(ctx, mrl::launch_batch_indexed(c.mode, a, multi, ctx->table_layout, has_ggx, has_table, ctx->compute_units, ctx->stream));
+    if (call_pointer_kind(c, queue, queue_count) != 1) return fail(ctx, MRL_ERR_POINTER_MIX, "queue calls take device pointers only");
+    DeviceCall d = device_call(ctx, c);
+    d.args.idx = queue; d.args.idx_count = queue_count;
+    MRL_HIP(ctx, mrl::launch_batch_indexed(c.mode, d.args, d.multi, ctx->table_layout, d.has_ggx, d.has_table, ctx->compute_units, ctx->stream));
     return MRL_OK;
 }
 
