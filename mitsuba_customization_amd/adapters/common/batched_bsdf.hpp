@@ -3,6 +3,7 @@
 // (SURVEY.md §3.4): arrays are f32, xyzxyz… / uvuv…, host or device pointers (include/merl_hip.h).
 #pragma once
 #include <cstddef>
+#include <cstdint>
 
 class BatchedBSDF {
 public:
@@ -15,6 +16,11 @@ public:
     virtual void sampleBatch(const float *wi, const float *u, size_t n, float *wo, float *pdf, float *weight) const = 0;
     // the fused unit: eval + pdf of (wi, wo) and sample(wi, u)
     virtual void evalSampleBatch(const float *wi, const float *wo, const float *u, size_t n,
+                                 float *rgb, float *pdf, float *wo2, float *pdf2, float *weight) const = 0;
+    // the fused unit over a wavefront queue: slots queue[0 .. min(*count, capacity)) of slot-indexed DEVICE arrays;
+    // count lives in device memory (include/merl_hip.h, mrl_eval_sample_queue)
+    virtual void evalSampleQueue(const float *wi, const float *wo, const float *u,
+                                 const uint32_t *queue, const uint32_t *count, size_t capacity,
                                  float *rgb, float *pdf, float *wo2, float *pdf2, float *weight) const = 0;
     // device-pointer calls are asynchronous: wait for them
     virtual void synchronize() const = 0;

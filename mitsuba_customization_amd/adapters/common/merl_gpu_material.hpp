@@ -191,6 +191,14 @@ public:
         std::lock_guard<std::mutex> lock(m_ctx->mutex());
         check(ctx(), mrl_eval_sample_batch(ctx(), wi, wo, u, nullptr, m_id, n, rgb, pdf, wo2, pdf2, weight), "mrl_eval_sample_batch");
     }
+    void eval_sample_queue(const float *wi, const float *wo, const float *u,
+                           const uint32_t *queue, const uint32_t *count, size_t capacity,
+                           float *rgb, float *pdf, float *wo2, float *pdf2, float *weight) const
+    {
+        std::lock_guard<std::mutex> lock(m_ctx->mutex());
+        check(ctx(), mrl_eval_sample_queue(ctx(), wi, wo, u, nullptr, m_id, queue, count, capacity, rgb, pdf, wo2, pdf2, weight),
+              "mrl_eval_sample_queue");
+    }
     void synchronize() const
     {
         std::lock_guard<std::mutex> lock(m_ctx->mutex());

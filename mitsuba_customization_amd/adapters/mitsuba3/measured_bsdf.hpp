@@ -94,6 +94,12 @@ public:
     {
         m_material.eval_sample_batch(wi, wo, u, n, rgb, pdf, wo2, pdf2, weight);
     }
+    void evalSampleQueue(const float *wi, const float *wo, const float *u,
+                         const uint32_t *queue, const uint32_t *count, size_t capacity,
+                         float *rgb, float *pdf, float *wo2, float *pdf2, float *weight) const override
+    {
+        m_material.eval_sample_queue(wi, wo, u, queue, count, capacity, rgb, pdf, wo2, pdf2, weight);
+    }
     void synchronize() const override { m_material.synchronize(); }
 
     std::string to_string() const override

@@ -85,6 +85,7 @@ int main(int argc, char **argv)
     std::vector<float> rgb(3 * p.n), pdf(p.n), wo2(3 * p.n), pdf2(p.n), wgt(3 * p.n);
     wave->evalSampleBatch(p.wi.data(), p.wo.data(), p.u.data(), p.n, rgb.data(), pdf.data(), wo2.data(), pdf2.data(), wgt.data());
     wave->synchronize();
+    if (!check_queue_call(wave, p, rgb, pdf, wo2, pdf2, wgt)) return 11;
     for (size_t i = 0; i < p.n; ++i) {
         float *o = &batch[11 * i];
         o[0] = rgb[3 * i]; o[1] = rgb[3 * i + 1]; o[2] = rgb[3 * i + 2]; o[3] = pdf[i];

@@ -1,8 +1,11 @@
 // driver_common.hpp — shared bits of the two plugin test drivers (binary I/O with pytest).
 #pragma once
+#include <dlfcn.h>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -28,3 +31,48 @@ inline Pairs read_pairs(const std::string &path)
 
 // file: per unit rgb[3] pdf wo2[3] pdf2 weight[3]  (11 floats), first the scalar-call block (m units), then the batch block (n units)
 inline void write_floats(FILE *f, const std::vector<float> &v) { std::fwrite(v.data(), 4, v.size(), f); }
+
+// The wavefront-queue entry of a BatchedBSDF: every other slot queued, inputs and outputs in pinned device-mapped
+// memory (the driver has no HIP of its own: it borrows mrl_host_alloc from the libmerl_hip.so the plugin loaded).
+// Queued slots must equal the whole-array results bit for bit, other slots must stay untouched.
+template <typename Wave>
+inline bool check_queue_call(const Wave *wave, const Pairs &p, const std::vector<float> &rgb, const std::vector<float> &pdf,
+                             const std::vector<float> &wo2, const std::vector<float> &pdf2, const std::vector<float> &wgt)
+{
+    void *lib = dlopen("libmerl_hip.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!lib) { std::fprintf(stderr, "libmerl_hip.so is not loaded: %s\n", dlerror()); return false; }
+    struct mrl_ctx;
+    auto init = (int (*)(int, mrl_ctx **))dlsym(lib, "mrl_init");
+    auto destroy = (int (*)(mrl_ctx *))dlsym(lib, "mrl_destroy");
+    auto host_alloc = (int (*)(mrl_ctx *, size_t, void **))dlsym(lib, "mrl_host_alloc");
+    auto host_free = (int (*)(mrl_ctx *, void *))dlsym(lib, "mrl_host_free");
+    mrl_ctx *ctx = nullptr;
+    if (!init || !destroy || !host_alloc || !host_free || init(0, &ctx) != 0) return false;
+    const size_t n = p.n;
+    void *raw = nullptr;
+    if (host_alloc(ctx, n * 80 + 64, &raw) != 0) { destroy(ctx); return false; }
+    float *base = static_cast<float *>(raw);
+    float *wi = base, *wo = wi + 3 * n, *u = wo + 3 * n, *o_rgb = u + 2 * n, *o_pdf = o_rgb + 3 * n, *o_wo2 = o_pdf + n,
+          *o_pdf2 = o_wo2 + 3 * n, *o_w = o_pdf2 + n;
+    uint32_t *queue = reinterpret_cast<uint32_t *>(o_w + 3 * n), *count = queue + n;
+    std::memcpy(wi, p.wi.data(), 12 * n); std::memcpy(wo, p.wo.data(), 12 * n); std::memcpy(u, p.u.data(), 8 * n);
+    const float sentinel = -7.0f;
+    for (size_t i = 0; i < 11 * n; ++i) o_rgb[i] = sentinel;
+    uint32_t k = 0;
+    for (size_t i = 0; i < n; i += 2) queue[k++] = (uint32_t)i;
+    *count = k;
+    wave->evalSampleQueue(wi, wo, u, queue, count, k, o_rgb, o_pdf, o_wo2, o_pdf2, o_w);
+    wave->synchronize();
+    bool ok = true;
+    for (size_t i = 0; i < n && ok; ++i) {
+        if (i % 2 == 0)
+            ok = !std::memcmp(o_rgb + 3 * i, &rgb[3 * i], 12) && !std::memcmp(o_pdf + i, &pdf[i], 4) && !std::memcmp(o_wo2 + 3 * i, &wo2[3 * i], 12) &&
+                 !std::memcmp(o_pdf2 + i, &pdf2[i], 4) && !std::memcmp(o_w + 3 * i, &wgt[3 * i], 12);
+        else
+            ok = o_rgb[3 * i] == sentinel && o_pdf[i] == sentinel && o_wo2[3 * i + 2] == sentinel && o_pdf2[i] == sentinel && o_w[3 * i + 1] == sentinel;
+        if (!ok) std::fprintf(stderr, "queue call differs at slot %zu\n", i);
+    }
+    host_free(ctx, raw);
+    destroy(ctx);
+    return ok;
+}
