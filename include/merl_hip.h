@@ -14,6 +14,8 @@
  *   mrl_eval_batch                         BSDF::eval(bRec, ESolidAngle)   / M3 BSDF::eval
  *   mrl_pdf_batch                          BSDF::pdf(bRec, ESolidAngle)    / M3 BSDF::pdf
  *   mrl_sample_batch                       BSDF::sample(bRec, pdf, sample) / M3 BSDF::sample
+ *   mrl_eval_pdf_batch                     M3 BSDF::eval_pdf (one table lookup for both; what a light-sampling
+ *                                          integrator calls for its MIS weight)
  *   mrl_eval_sample_batch                  the fused eval + pdf + sample unit (BASELINE metric)
  *   mrl_*_queue                            the same calls over a wavefront integrator's material queue
  *                                          (the caller side of the path)
@@ -108,6 +110,9 @@ int mrl_pdf_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t 
                   size_t n, float *out_pdf);
 int mrl_sample_batch(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id,
                      size_t n, float *out_wo, float *out_pdf, float *out_weight);
+/* eval and pdf of the same pairs in one launch */
+int mrl_eval_pdf_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                       size_t n, float *out_rgb, float *out_pdf);
 /* the benchmarked unit: eval(wi,wo) rgb, pdf(wi,wo), sample(wi,u) -> (wo', pdf', weight') */
 int mrl_eval_sample_batch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u,
                           const int32_t *mat, int32_t single_id, size_t n,
@@ -124,6 +129,9 @@ int mrl_eval_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t
                    const uint32_t *queue, const uint32_t *queue_count, size_t capacity, float *out_rgb);
 int mrl_pdf_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
                   const uint32_t *queue, const uint32_t *queue_count, size_t capacity, float *out_pdf);
+int mrl_eval_pdf_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                       const uint32_t *queue, const uint32_t *queue_count, size_t capacity,
+                       float *out_rgb, float *out_pdf);
 int mrl_sample_queue(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id,
                      const uint32_t *queue, const uint32_t *queue_count, size_t capacity,
                      float *out_wo, float *out_pdf, float *out_weight);

@@ -12,6 +12,8 @@ public:
     virtual void evalBatch(const float *wi, const float *wo, size_t n, float *rgb) const = 0;
     // BSDF::pdf(bRec, ESolidAngle) for n pairs
     virtual void pdfBatch(const float *wi, const float *wo, size_t n, float *pdf) const = 0;
+    // Mitsuba 3's BSDF::eval_pdf for n pairs (one table lookup serves both)
+    virtual void evalPdfBatch(const float *wi, const float *wo, size_t n, float *rgb, float *pdf) const = 0;
     // BSDF::sample(bRec, pdf, sample) for n pairs: writes wo, pdf and eval/pdf
     virtual void sampleBatch(const float *wi, const float *u, size_t n, float *wo, float *pdf, float *weight) const = 0;
     // the fused unit: eval + pdf of (wi, wo) and sample(wi, u)

@@ -161,9 +161,7 @@ public:
         std::lock_guard<std::mutex> lock(m_ctx->mutex());
         float *p = m_ctx->pinned();
         for (int k = 0; k < 3; ++k) { p[k] = wi[k]; p[3 + k] = wo[k]; }
-        p[6] = 0.5f; p[7] = 0.5f;
-        check(ctx(), mrl_eval_sample_batch(ctx(), p, p + 3, p + 6, nullptr, m_id, 1, p + 8, p + 11, p + 12, p + 15, p + 16),
-              "mrl_eval_sample_batch");
+        check(ctx(), mrl_eval_pdf_batch(ctx(), p, p + 3, nullptr, m_id, 1, p + 8, p + 11), "mrl_eval_pdf_batch");
         check(ctx(), mrl_synchronize(ctx()), "mrl_synchronize");
         for (int k = 0; k < 3; ++k) rgb[k] = p[8 + k];
         pdf = p[11];
@@ -179,6 +177,11 @@ public:
     {
         std::lock_guard<std::mutex> lock(m_ctx->mutex());
         check(ctx(), mrl_pdf_batch(ctx(), wi, wo, nullptr, m_id, n, pdf), "mrl_pdf_batch");
+    }
+    void eval_pdf_batch(const float *wi, const float *wo, size_t n, float *rgb, float *pdf) const
+    {
+        std::lock_guard<std::mutex> lock(m_ctx->mutex());
+        check(ctx(), mrl_eval_pdf_batch(ctx(), wi, wo, nullptr, m_id, n, rgb, pdf), "mrl_eval_pdf_batch");
     }
     void sample_batch(const float *wi, const float *u, size_t n, float *wo, float *pdf, float *weight) const
     {

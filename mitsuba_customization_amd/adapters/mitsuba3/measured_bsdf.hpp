@@ -94,6 +94,10 @@ public:
     {
         m_material.eval_sample_batch(wi, wo, u, n, rgb, pdf, wo2, pdf2, weight);
     }
+    void evalPdfBatch(const float *wi, const float *wo, size_t n, float *rgb, float *pdf) const override
+    {
+        m_material.eval_pdf_batch(wi, wo, n, rgb, pdf);
+    }
     void evalSampleQueue(const float *wi, const float *wo, const float *u,
                          const uint32_t *queue, const uint32_t *count, size_t capacity,
                          float *rgb, float *pdf, float *wo2, float *pdf2, float *weight) const override

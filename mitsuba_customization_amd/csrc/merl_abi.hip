@@ -242,13 +242,17 @@ int ensure_stage(mrl_ctx *ctx, size_t units)
 }
 
 struct BatchCall {
-    int mode;                                    // 0 eval, 1 pdf, 2 sample, 3 eval+sample
+    int mode;                                    // 0 eval, 1 pdf, 2 sample, 3 eval+sample, 4 eval+pdf
     const float *wi, *wo, *u;
     const int32_t *mat;
     int32_t single_id;
     size_t n;
     float *out_rgb, *out_pdf, *out_wo, *out_pdf2, *out_weight;
 };
+
+inline bool call_has_eval(int mode) { return mode == 0 || mode == 3 || mode == 4; }
+inline bool call_has_pdf(int mode) { return mode == 1 || mode == 3 || mode == 4; }
+inline bool call_has_sample(int mode) { return mode == 2 || mode == 3; }
 
 constexpr size_t kMaxSegments = 256 * 8 + 64;     // partition_geometry caps segments at 8 per CU
 
@@ -294,8 +298,8 @@ DeviceCall device_call(const mrl_ctx *ctx, const BatchCall &c)
 // null-pointer and material checks shared by the whole-array and the queue entry points
 int check_call(mrl_ctx *ctx, const BatchCall &c)
 {
-    const bool needs_wo = c.mode != 2, needs_u = c.mode >= 2;
-    const bool has_eval = c.mode == 0 || c.mode == 3, has_pdf = c.mode == 1 || c.mode == 3, has_sample = c.mode >= 2;
+    const bool has_eval = call_has_eval(c.mode), has_pdf = call_has_pdf(c.mode), has_sample = call_has_sample(c.mode);
+    const bool needs_wo = has_eval || has_pdf, needs_u = has_sample;
     if (!c.wi || (needs_wo && !c.wo) || (needs_u && !c.u) || (has_eval && !c.out_rgb) || (has_pdf && !c.out_pdf) ||
         (has_sample && (!c.out_wo || !c.out_pdf2 || !c.out_weight)))
         return fail(ctx, MRL_ERR_INVALID, "null array argument");
@@ -308,8 +312,8 @@ int check_call(mrl_ctx *ctx, const BatchCall &c)
 // host-or-device kind of the arrays a call of this mode touches (-1: mixed)
 int call_pointer_kind(const BatchCall &c, const void *extra0 = nullptr, const void *extra1 = nullptr)
 {
-    const bool needs_wo = c.mode != 2, needs_u = c.mode >= 2;
-    const bool has_eval = c.mode == 0 || c.mode == 3, has_pdf = c.mode == 1 || c.mode == 3, has_sample = c.mode >= 2;
+    const bool has_eval = call_has_eval(c.mode), has_pdf = call_has_pdf(c.mode), has_sample = call_has_sample(c.mode);
+    const bool needs_wo = has_eval || has_pdf, needs_u = has_sample;
     return common_kind({ c.wi, needs_wo ? c.wo : nullptr, needs_u ? c.u : nullptr, c.mat, extra0, extra1,
                          has_eval ? c.out_rgb : nullptr, has_pdf ? c.out_pdf : nullptr,
                          has_sample ? c.out_wo : nullptr, has_sample ? c.out_pdf2 : nullptr,
@@ -349,8 +353,8 @@ int run_batch(mrl_ctx *ctx, const BatchCall &c)
 {
     if (!ctx) return MRL_ERR_INVALID;
     if (c.n == 0) return MRL_OK;
-    const bool needs_wo = c.mode != 2, needs_u = c.mode >= 2;
-    const bool has_eval = c.mode == 0 || c.mode == 3, has_pdf = c.mode == 1 || c.mode == 3, has_sample = c.mode >= 2;
+    const bool has_eval = call_has_eval(c.mode), has_pdf = call_has_pdf(c.mode), has_sample = call_has_sample(c.mode);
+    const bool needs_wo = has_eval || has_pdf, needs_u = has_sample;
     int rc = check_call(ctx, c);
     if (rc != MRL_OK) return rc;
     MRL_HIP(ctx, hipSetDevice(ctx->device));
@@ -625,6 +629,20 @@ int mrl_eval_sample_batch(mrl_ctx *ctx, const float *wi, const float *wo, const 
 {
     BatchCall c{ 3, wi, wo, u, mat, single_id, n, out_rgb, out_pdf, out_wo, out_pdf2, out_weight };
     return run_batch(ctx, c);
+}
+
+int mrl_eval_pdf_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                       size_t n, float *out_rgb, float *out_pdf)
+{
+    BatchCall c{ 4, wi, wo, nullptr, mat, single_id, n, out_rgb, out_pdf, nullptr, nullptr, nullptr };
+    return run_batch(ctx, c);
+}
+
+int mrl_eval_pdf_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                       const uint32_t *queue, const uint32_t *queue_count, size_t capacity, float *out_rgb, float *out_pdf)
+{
+    BatchCall c = { 4, wi, wo, nullptr, mat, single_id, capacity, out_rgb, out_pdf, nullptr, nullptr, nullptr };
+    return run_queue(ctx, c, queue, queue_count);
 }
 
 int mrl_eval_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,

@@ -19,7 +19,11 @@ namespace {
 
 constexpr int kBlock = 256;
 
-enum Mode : int { MODE_EVAL = 0, MODE_PDF = 1, MODE_SAMPLE = 2, MODE_EVAL_SAMPLE = 3 };
+enum Mode : int { MODE_EVAL = 0, MODE_PDF = 1, MODE_SAMPLE = 2, MODE_EVAL_SAMPLE = 3, MODE_EVAL_PDF = 4 };
+// what a mode computes: eval(wi, wo) -> rgb, pdf(wi, wo), sample(wi, u) -> (wo', pdf', weight')
+constexpr bool mode_eval(int m) { return m == MODE_EVAL || m == MODE_EVAL_SAMPLE || m == MODE_EVAL_PDF; }
+constexpr bool mode_pdf(int m) { return m == MODE_PDF || m == MODE_EVAL_SAMPLE || m == MODE_EVAL_PDF; }
+constexpr bool mode_sample(int m) { return m == MODE_SAMPLE || m == MODE_EVAL_SAMPLE; }
 
 __device__ __forceinline__ void load3(const float *p, size_t i, float &x, float &y, float &z)
 {
@@ -74,19 +78,19 @@ __global__ __launch_bounds__(kBlock) void k_batch(BatchArgs a)
         load3(a.wi, i, wix, wiy, wiz);
         if (!valid) wiz = 0.0f;                     // unknown material id: every output zero
 
-        if constexpr (MODE == MODE_EVAL || MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE) {
+        if constexpr (mode_eval(MODE) || mode_pdf(MODE)) {
             float wox, woy, woz;
             load3(a.wo, i, wox, woy, woz);
-            if constexpr (MODE != MODE_PDF) {
+            if constexpr (mode_eval(MODE)) {
                 float rgb[3];
                 unit_eval(m, a.opts, wix, wiy, wiz, wox, woy, woz, rgb);
                 store3(a.out_rgb, i, rgb);
             }
-            if constexpr (MODE != MODE_EVAL) {
+            if constexpr (mode_pdf(MODE)) {
                 a.out_pdf[i] = unit_pdf(m, a.opts, wix, wiy, wiz, wox, woy, woz);
             }
         }
-        if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) {
+        if constexpr (mode_sample(MODE)) {
             float u0 = a.u[2 * i], u1 = a.u[2 * i + 1];
             float wo2[3], pdf2, w[3];
             unit_sample(m, a.opts, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
@@ -116,14 +120,14 @@ __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
         load3s<NT>(a.wi, i, wix, wiy, wiz);
         if (!known) wiz = 0.0f;
         float wox = 0.0f, woy = 0.0f, woz = 1.0f, u0 = 0.0f, u1 = 0.0f;
-        if constexpr (MODE != MODE_SAMPLE) load3s<NT>(a.wo, i, wox, woy, woz);
-        if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) { u0 = ldf<NT>(a.u + 2 * i); u1 = ldf<NT>(a.u + 2 * i + 1); }
+        if constexpr (mode_eval(MODE) || mode_pdf(MODE)) load3s<NT>(a.wo, i, wox, woy, woz);
+        if constexpr (mode_sample(MODE)) { u0 = ldf<NT>(a.u + 2 * i); u1 = ldf<NT>(a.u + 2 * i + 1); }
 
         float rgb[3], pdf = 0.0f, wo2[3], pdf2, w[3];
         if (MULTI && m.kind == KIND_GGX) {
-            if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) unit_eval(m, a.opts, wix, wiy, wiz, wox, woy, woz, rgb);
-            if constexpr (MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE) pdf = unit_pdf(m, a.opts, wix, wiy, wiz, wox, woy, woz);
-            if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) unit_sample(m, a.opts, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
+            if constexpr (mode_eval(MODE)) unit_eval(m, a.opts, wix, wiy, wiz, wox, woy, woz, rgb);
+            if constexpr (mode_pdf(MODE)) pdf = unit_pdf(m, a.opts, wix, wiy, wiz, wox, woy, woz);
+            if constexpr (mode_sample(MODE)) unit_sample(m, a.opts, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
         } else {
             if constexpr (MODE == MODE_PDF) {
                 pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
@@ -131,17 +135,17 @@ __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
                     pdf = (float)fast::table_pdf(m, fast::normalize_f32(wix, wiy, wiz), fast::normalize_f32(wox, woy, woz), woz);
             } else {
                 const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
-                if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) fast::unit_eval<LOOKUP, LAYOUT>(m, a.opts, in, wix, wiy, wiz, wox, woy, woz, rgb);
-                if constexpr (MODE == MODE_EVAL_SAMPLE) {
+                if constexpr (mode_eval(MODE)) fast::unit_eval<LOOKUP, LAYOUT>(m, a.opts, in, wix, wiy, wiz, wox, woy, woz, rgb);
+                if constexpr (mode_pdf(MODE)) {
                     pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
                     if (a.opts.sampling && pdf > 0.0f) pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz);
                 }
-                if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) fast::unit_sample<LOOKUP, LAYOUT>(m, a.opts, in, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
+                if constexpr (mode_sample(MODE)) fast::unit_sample<LOOKUP, LAYOUT>(m, a.opts, in, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
             }
         }
-        if constexpr (MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE) store3s<NT>(a.out_rgb, i, rgb);
-        if constexpr (MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE) stf<NT>(a.out_pdf + i, pdf);
-        if constexpr (MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE) {
+        if constexpr (mode_eval(MODE)) store3s<NT>(a.out_rgb, i, rgb);
+        if constexpr (mode_pdf(MODE)) stf<NT>(a.out_pdf + i, pdf);
+        if constexpr (mode_sample(MODE)) {
             store3s<NT>(a.out_wo, i, wo2);
             stf<NT>(a.out_pdf2 + i, pdf2);
             store3s<NT>(a.out_weight, i, w);
@@ -243,8 +247,8 @@ template <int MODE, bool MULTI, bool GGX>
 __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDev &m, bool is_table, UnitIO &io,
                                             const fast::Vec3 &in, float4 *ldsA, float4 *ldsB, unsigned lane)
 {
-    constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
-    constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
+    constexpr bool HAS_EVAL = mode_eval(MODE);
+    constexpr bool HAS_SAMPLE = mode_sample(MODE);
     // a valid 128-B source for lanes without a table: the material array itself, cell 0
     const float4 *lane_base = (GGX && !is_table) ? (const float4 *)a.materials : m.texels;
     const fast::TableMaps maps(m);
@@ -286,7 +290,7 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
         const double c = fast::cos_or_nan(io.wix, io.wiy, io.wiz, io.wox, io.woy, io.woz);
         if (!GGX || is_table) {
             io.rgb[0] = valid ? (float)(v.r * c) : 0.0f; io.rgb[1] = valid ? (float)(v.g * c) : 0.0f; io.rgb[2] = valid ? (float)(v.b * c) : 0.0f;
-            if constexpr (MODE == MODE_EVAL_SAMPLE) {
+            if constexpr (mode_pdf(MODE)) {
                 io.pdf = valid ? io.woz * kInvPiF : 0.0f;
                 if (a.opts.sampling && valid) io.pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(io.wox, io.woy, io.woz), io.woz);
             }
@@ -313,8 +317,8 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
 template <int MODE>
 __device__ __forceinline__ void ggx_lane(const MaterialDev &m, UnitIO &io, const fast::Vec3 &in)
 {
-    constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
-    constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
+    constexpr bool HAS_EVAL = mode_eval(MODE);
+    constexpr bool HAS_SAMPLE = mode_sample(MODE);
     const fast::GgxConsts g(m);
     if constexpr (HAS_EVAL) {
         const fast::Vec3 out = fast::normalize_f32(io.wox, io.woy, io.woz);
@@ -324,7 +328,7 @@ __device__ __forceinline__ void ggx_lane(const MaterialDev &m, UnitIO &io, const
         const double poison = fast::cos_or_nan(io.wix, io.wiy, io.wiz, io.wox, io.woy, 1.0f);
         io.rgb[0] = valid ? (float)(v[0] * poison) : 0.0f; io.rgb[1] = valid ? (float)(v[1] * poison) : 0.0f;
         io.rgb[2] = valid ? (float)(v[2] * poison) : 0.0f;
-        if constexpr (MODE == MODE_EVAL_SAMPLE) io.pdf = valid ? (float)(p * poison) : 0.0f;
+        if constexpr (mode_pdf(MODE)) io.pdf = valid ? (float)(p * poison) : 0.0f;
     }
     if constexpr (HAS_SAMPLE) {
         fast::ggx_sample(g, in, io.u0, io.u1, io.wo2, io.pdf2, io.w);
@@ -335,10 +339,10 @@ __device__ __forceinline__ void ggx_lane(const MaterialDev &m, UnitIO &io, const
 template <int MODE, bool NT>
 __device__ __forceinline__ void store_unit(const BatchArgs &a, size_t i, const UnitIO &io)
 {
-    constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
-    constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
+    constexpr bool HAS_EVAL = mode_eval(MODE);
+    constexpr bool HAS_SAMPLE = mode_sample(MODE);
     if constexpr (HAS_EVAL) store3s<NT>(a.out_rgb, i, io.rgb);
-    if constexpr (MODE == MODE_EVAL_SAMPLE) stf<NT>(a.out_pdf + i, io.pdf);
+    if constexpr (mode_pdf(MODE)) stf<NT>(a.out_pdf + i, io.pdf);
     if constexpr (HAS_SAMPLE) {
         store3s<NT>(a.out_wo, i, io.wo2);
         stf<NT>(a.out_pdf2 + i, io.pdf2);
@@ -358,8 +362,8 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
 {
     static_assert(MODE != MODE_PDF, "pdf needs no table");
     static_assert(MULTI || !GGX, "a single-material GGX launch uses k_ggx");
-    constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
-    constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
+    constexpr bool HAS_EVAL = mode_eval(MODE);
+    constexpr bool HAS_SAMPLE = mode_sample(MODE);
     constexpr int LOOKUPS = (HAS_EVAL ? 1 : 0) + (HAS_SAMPLE ? 1 : 0);
     __shared__ float4 lds[kDmaBlock / 64][LOOKUPS][512];      // 8 KB per wave and lookup
 
@@ -408,9 +412,9 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
 template <int MODE, bool NT, bool PER_LANE = false, bool INDEXED = false>
 __global__ __launch_bounds__(kBlock) void k_ggx(BatchArgs a)
 {
-    constexpr bool HAS_EVAL = MODE == MODE_EVAL || MODE == MODE_EVAL_SAMPLE;
-    constexpr bool HAS_PDF = MODE == MODE_PDF || MODE == MODE_EVAL_SAMPLE;
-    constexpr bool HAS_SAMPLE = MODE == MODE_SAMPLE || MODE == MODE_EVAL_SAMPLE;
+    constexpr bool HAS_EVAL = mode_eval(MODE);
+    constexpr bool HAS_PDF = mode_pdf(MODE);
+    constexpr bool HAS_SAMPLE = mode_sample(MODE);
     const size_t stride = (size_t)gridDim.x * kBlock;
     const size_t n_items = item_count<INDEXED>(a);
     for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_items; j += stride) {
@@ -696,6 +700,7 @@ hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, i
         case MODE_PDF:         return launch_mode<MODE_PDF>(a, multi, variant, layout, has_ggx, has_table, compute_units, stream);
         case MODE_SAMPLE:      return launch_mode<MODE_SAMPLE>(a, multi, variant, layout, has_ggx, has_table, compute_units, stream);
         case MODE_EVAL_SAMPLE: return launch_mode<MODE_EVAL_SAMPLE>(a, multi, variant, layout, has_ggx, has_table, compute_units, stream);
+        case MODE_EVAL_PDF:    return launch_mode<MODE_EVAL_PDF>(a, multi, variant, layout, has_ggx, has_table, compute_units, stream);
     }
     return hipErrorInvalidValue;
 }
@@ -754,6 +759,7 @@ hipError_t launch_batch_queue(int mode, const BatchArgs &a, bool ggx_queue, int 
         case MODE_EVAL:        return launch_queue_mode<MODE_EVAL>(a, ggx_queue, compute_units, stream);
         case MODE_SAMPLE:      return launch_queue_mode<MODE_SAMPLE>(a, ggx_queue, compute_units, stream);
         case MODE_EVAL_SAMPLE: return launch_queue_mode<MODE_EVAL_SAMPLE>(a, ggx_queue, compute_units, stream);
+        case MODE_EVAL_PDF:    return launch_queue_mode<MODE_EVAL_PDF>(a, ggx_queue, compute_units, stream);
     }
     return hipErrorInvalidValue;
 }
@@ -801,6 +807,7 @@ hipError_t launch_batch_indexed(int mode, const BatchArgs &a, bool multi, int la
         case MODE_PDF:         return launch_indexed_mode<MODE_PDF>(a, multi, layout, has_ggx, has_table, compute_units, stream);
         case MODE_SAMPLE:      return launch_indexed_mode<MODE_SAMPLE>(a, multi, layout, has_ggx, has_table, compute_units, stream);
         case MODE_EVAL_SAMPLE: return launch_indexed_mode<MODE_EVAL_SAMPLE>(a, multi, layout, has_ggx, has_table, compute_units, stream);
+        case MODE_EVAL_PDF:    return launch_indexed_mode<MODE_EVAL_PDF>(a, multi, layout, has_ggx, has_table, compute_units, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -23,7 +23,7 @@ struct BatchArgs {
     const uint32_t *idx_count;               // its length, in device memory
 };
 
-// mode: 0 eval, 1 pdf, 2 sample, 3 eval+sample
+// mode: 0 eval, 1 pdf, 2 sample, 3 eval+sample, 4 eval+pdf
 // variant: MRL_OPT_KERNEL (0 generic, 1 tuned table path, 2 tuned + non-temporal streams)
 // layout: the context-wide table layout (every table of a context has the same one)
 // has_ggx / has_table: the context holds at least one analytic (GGX) / one table material, i.e. what a mixed batch may contain

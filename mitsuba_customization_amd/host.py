@@ -27,8 +27,8 @@ ABI_SYMBOLS = (
     "mrl_set_stream", "mrl_reset_stream", "mrl_synchronize", "mrl_device_info",
     "mrl_material_load_merl", "mrl_material_upload_f64", "mrl_material_upload_table", "mrl_material_load_table",
     "mrl_material_ggx", "mrl_material_count", "mrl_material_info",
-    "mrl_eval_batch", "mrl_pdf_batch", "mrl_sample_batch", "mrl_eval_sample_batch",
-    "mrl_eval_queue", "mrl_pdf_queue", "mrl_sample_queue", "mrl_eval_sample_queue",
+    "mrl_eval_batch", "mrl_pdf_batch", "mrl_sample_batch", "mrl_eval_pdf_batch", "mrl_eval_sample_batch",
+    "mrl_eval_queue", "mrl_pdf_queue", "mrl_eval_pdf_queue", "mrl_sample_queue", "mrl_eval_sample_queue",
     "mrl_generate_pairs", "mrl_generate_materials",
     "mrl_device_alloc", "mrl_device_free", "mrl_copy_to_device", "mrl_copy_to_host", "mrl_host_alloc", "mrl_host_free",
     "mrl_timer_start", "mrl_timer_stop",
@@ -86,6 +86,8 @@ def load_library(path: Optional[str] = None):
     L.mrl_material_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mrl_eval_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp]
     L.mrl_pdf_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp]
+    L.mrl_eval_pdf_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp, fp]
+    L.mrl_eval_pdf_queue.argtypes = [vp, fp, fp, vp, C.c_int32, vp, vp, C.c_size_t, fp, fp]
     L.mrl_sample_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp, fp, fp]
     L.mrl_eval_sample_batch.argtypes = [vp, fp, fp, fp, vp, C.c_int32, C.c_size_t, fp, fp, fp, fp, fp]
     L.mrl_eval_queue.argtypes = [vp, fp, fp, vp, C.c_int32, vp, vp, C.c_size_t, fp]
@@ -267,6 +269,16 @@ class MerlHip:
                                             _addr(out, np.float32, None, n, "out_pdf")), "mrl_pdf_batch")
         return out
 
+    def eval_pdf(self, wi, wo, mat=None, material: int = 0, out=None):
+        """eval and pdf of the same pairs in one launch (Mitsuba 3's eval_pdf).  Returns (rgb, pdf)."""
+        n = int(wi.shape[0]); self._prep(wi)
+        rgb, pdf = out if out is not None else (self._empty(wi, (n, 3)), self._empty(wi, (n,)))
+        self._check(self._lib.mrl_eval_pdf_batch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                 _addr(mat, np.int32, None, n, "mat"), material, n,
+                                                 _addr(rgb, np.float32, 3, n, "out_rgb"), _addr(pdf, np.float32, None, n, "out_pdf")),
+                    "mrl_eval_pdf_batch")
+        return rgb, pdf
+
     def sample(self, wi, u, mat=None, material: int = 0, out=None):
         n = int(wi.shape[0]); self._prep(wi)
         wo, pdf, w = out if out is not None else (self._empty(wi, (n, 3)), self._empty(wi, (n,)), self._empty(wi, (n, 3)))
@@ -321,6 +333,15 @@ class MerlHip:
                                             _addr(mat, np.int32, None, n, "mat"), material, q, c, cap,
                                             _addr(out, np.float32, None, n, "out_pdf")), "mrl_pdf_queue")
         return out
+
+    def eval_pdf_queue(self, wi, wo, queue, count, mat=None, material: int = 0, capacity=None, out=None):
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        rgb, pdf = out if out is not None else (self._zeros(wi, (n, 3)), self._zeros(wi, (n,)))
+        self._check(self._lib.mrl_eval_pdf_queue(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                 _addr(mat, np.int32, None, n, "mat"), material, q, c, cap,
+                                                 _addr(rgb, np.float32, 3, n, "out_rgb"), _addr(pdf, np.float32, None, n, "out_pdf")),
+                    "mrl_eval_pdf_queue")
+        return rgb, pdf
 
     def sample_queue(self, wi, u, queue, count, mat=None, material: int = 0, capacity=None, out=None):
         n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)

@@ -37,6 +37,8 @@ res["sample_only"] = {"ms": ms, "Msample_per_s": n / ms / 1e3}
 o_p = torch.empty((n,), dtype=torch.float32, device="cuda")
 ms = timed(lambda: gpu.pdf(wi, wo, material=mid, out=o_p))
 res["pdf_only"] = {"ms": ms, "Mpdf_per_s": n / ms / 1e3, "stream_GBps": 28 * n / ms / 1e6}
+ms = timed(lambda: gpu.eval_pdf(wi, wo, material=mid, out=(o_rgb, o_p)))
+res["eval_pdf"] = {"ms": ms, "Munits_per_s": n / ms / 1e3, "stream_GBps": 40 * n / ms / 1e6}
 
 # host-pointer path: pageable numpy arrays in, numpy arrays out (H2D + kernel + D2H, chunked)
 m = 16 << 20
