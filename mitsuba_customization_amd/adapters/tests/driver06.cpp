@@ -5,6 +5,7 @@
 //   driver06 --expect-no-device <plugin.so> <table.binary>
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstring>
 #include <iostream>
 #include <thread>
@@ -63,6 +64,7 @@ int main(int argc, char **argv)
     const size_t m = std::min<size_t>(p.n, (size_t)atoll(argv[5]));
     std::vector<float> scalar(11 * m), batch(11 * p.n);
     Intersection its;
+    const auto t_single = std::chrono::steady_clock::now();
     for (size_t i = 0; i < m; ++i) {
         its.wi = Vector(p.wi[3 * i], p.wi[3 * i + 1], p.wi[3 * i + 2]);
         Vector wo(p.wo[3 * i], p.wo[3 * i + 1], p.wo[3 * i + 2]);
@@ -81,6 +83,7 @@ int main(int argc, char **argv)
         Spectrum w2 = bsdf->sample(s2, Point2(p.u[2 * i], p.u[2 * i + 1]));
         if (w2[0] != w[0] || s2.wo.x != s.wo.x) return 7;
     }
+    const double us_single = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_single).count() / (4.0 * m);
     // guards: wrong measure / masked lobe -> zero, without touching the GPU result
     {
         its.wi = Vector(0.f, 0.6f, 0.8f);
@@ -91,7 +94,8 @@ int main(int argc, char **argv)
     }
     // the renderer calls a const BSDF from all of its render threads at once
     {
-        const unsigned T = 8;
+        const unsigned T = 16;
+        const auto t_threads = std::chrono::steady_clock::now();
         std::vector<std::vector<float>> per_thread(T);
         std::vector<std::thread> pool;
         for (unsigned t = 0; t < T; ++t)
@@ -108,6 +112,9 @@ int main(int argc, char **argv)
                 }
             });
         for (auto &th : pool) th.join();
+        const double us_threads = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_threads).count() / (2.0 * m);
+        std::cout << "scalar calls: " << us_single << " us/call from one thread, " << us_threads << " us/call amortised over " << T
+                  << " threads (combined rounds)\n";
         for (unsigned t = 0; t < T; ++t) {
             size_t k = 0;
             for (size_t i = t; i < m; i += T, ++k) {

@@ -156,3 +156,21 @@ def test_c99_example_runs(built, merl_file):
     """examples/abi_example.c: the ABI from plain C — pinned zero-copy vs staged host path, error codes."""
     r = subprocess.run([os.path.join(built, "abi_example"), merl_file], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "example ok" in r.stdout and "agree bit for bit" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_scalar_calls_from_many_threads_are_combined(built, merl_file, oracle, tmp_path):
+    """16 render threads calling the scalar virtual interface share GPU rounds instead of queueing on a mutex."""
+    import re
+    n = m = 16000
+    wi, wo, u = oracle.generate_pairs(7, 0, n)
+    pairs, out = str(tmp_path / "pairs.bin"), str(tmp_path / "out.bin")
+    _write_pairs(pairs, wi, wo, u)
+    r = subprocess.run([os.path.join(built, "driver06"), os.path.join(built, "plugins06", "merl.so"), merl_file, pairs, out, str(m)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr              # includes the bit-for-bit check of every threaded call
+    found = re.search(r"scalar calls: ([0-9.e+-]+) us/call from one thread, ([0-9.e+-]+) us/call amortised over 16 threads", r.stdout)
+    assert found, r.stdout
+    single, combined = float(found.group(1)), float(found.group(2))
+    print(f"scalar plugin call: {single:.1f} us single-threaded, {combined:.2f} us amortised over 16 threads")
+    assert combined < 0.5 * single
