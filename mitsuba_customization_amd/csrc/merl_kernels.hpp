@@ -24,7 +24,7 @@ struct BatchArgs {
 };
 
 // mode: 0 eval, 1 pdf, 2 sample, 3 eval+sample, 4 eval+pdf
-// variant: MRL_OPT_KERNEL (0 generic, 1 tuned table path, 2 tuned + non-temporal streams)
+// variant: MRL_OPT_KERNEL (0 generic, 1 tuned table path, 2 + non-temporal streams, 3 + LDS-DMA brick fetch; 4 is handled by the caller)
 // layout: the context-wide table layout (every table of a context has the same one)
 // has_ggx / has_table: the context holds at least one analytic (GGX) / one table material, i.e. what a mixed batch may contain
 hipError_t launch_batch(int mode, const BatchArgs &a, bool multi, int variant, int layout, bool has_ggx, bool has_table, int compute_units, hipStream_t stream);
