@@ -74,6 +74,7 @@ def parse():
     p.add_argument("--cpu-units", type=int, default=0, help="units for the CPU baseline sample (0 = auto, ~1-3 s wall)")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the separately reported RCCL gather leg")
     p.add_argument("--gather-units", type=int, default=16 << 20, help="N>1: units per rank moved by the gather leg")
+    p.add_argument("--gather-deadline", type=float, default=90.0, help="N>1: seconds after which the gather leg is reported as skipped")
     p.add_argument("--parity-sample", type=int, default=4096)
     p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                    help="control-plane backend; gloo only rehearses the multi-rank logic (ranks may then share one GPU: --share-gpu)")
@@ -241,32 +242,6 @@ def main():
         },
     }
 
-    # ---- N>1: the RCCL result gather, reported beside (never inside) `value` ----
-    if world > 1 and not args.no_gather:
-        # bounded: the first <= 16M units of every rank's outputs (704 MB per rank); every rank first agrees
-        # that its buffers exist, so that a failed allocation on one rank skips the leg everywhere
-        # instead of leaving the others waiting in a send
-        g_units = min(n, args.gather_units)
-        ok, full, err = 1, None, ""
-        try:
-            from mitsuba_customization_amd import shard
-            local = [o[:g_units].to(comm_dev(dev)) for o in out]       # gloo rehearsal: host copies
-            if rank == 0:
-                full = [torch.empty((g_units * world,) + tuple(t.shape[1:]), dtype=t.dtype, device=comm_dev(dev)) for t in local]
-        except Exception as e:
-            ok, err = 0, repr(e)
-        flag = torch.tensor([ok], dtype=torch.int32, device=comm_dev(dev))
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 1:
-            g = shard.bench_gather(local, steps=3, out=full)
-            g["units_per_rank"] = g_units
-            g["extrapolated_ms_for_full_step"] = round(g["ms"] * n / g_units, 3)
-        else:
-            g = {"skipped": err or "another rank could not allocate its buffers"}
-        del full
-        if rank == 0:
-            result["gather"] = g
-
     # ---- rank 0, N=1: parity sample vs the oracle + CPU baseline on the host cores ----
     if rank == 0:
         from oracle import binding as ob                       # checker / cpu_baseline leg only
@@ -309,12 +284,70 @@ def main():
                           f"1-thread rate {rate1 / 1e6:.3f} Meval/s on 2^18 units",
                 "single_thread_value": round(rate1 / 1e6, 4),
             }
+
+    # ---- N>1: the RCCL result gather, reported beside (never inside) `value` ----
+    # The point-to-point leg cannot be rehearsed on a 1-GPU development box, so it runs LAST and under a deadline:
+    # whatever happens in it (an exception on one rank, a peer that never arrives), rank 0 still prints the bench
+    # line — with "gather": {"skipped": reason} — and every rank exits.
+    if world > 1 and not args.no_gather:
+        import threading
+        finished = threading.Event()
+
+        def give_up():
+            if finished.is_set():
+                return
+            if rank == 0:
+                result["gather"] = {"skipped": f"gather leg did not finish within {args.gather_deadline} s"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.gather_deadline, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        # bounded: the first <= 16M units of every rank's outputs (704 MB per rank); every rank first agrees
+        # that its buffers exist, so that a failed allocation on one rank skips the leg everywhere
+        # instead of leaving the others waiting in a send
+        g_units = min(n, args.gather_units)
+        ok, full, err = 1, None, ""
+        try:
+            from mitsuba_customization_amd import shard
+            local = [o[:g_units].to(comm_dev(dev)) for o in out]       # gloo rehearsal: host copies
+            if rank == 0:
+                full = [torch.empty((g_units * world,) + tuple(t.shape[1:]), dtype=t.dtype, device=comm_dev(dev)) for t in local]
+        except Exception as e:
+            ok, err = 0, repr(e)
+        try:
+            flag = torch.tensor([ok], dtype=torch.int32, device=comm_dev(dev))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 1:
+                g = shard.bench_gather(local, steps=3, out=full)
+                g["units_per_rank"] = g_units
+                g["extrapolated_ms_for_full_step"] = round(g["ms"] * n / g_units, 3)
+            else:
+                g = {"skipped": err or "another rank could not allocate its buffers"}
+        except Exception as e:                                          # the other ranks run into the deadline
+            g = {"skipped": repr(e)}
+        del full
+        if rank == 0:
+            result["gather"] = g
+        finished.set()
+        watchdog.cancel()
+
+    if rank == 0:
         print(json.dumps(result), flush=True)
 
-    gpu.close()
     if use_pg:
+        # teardown under a deadline as well: a rank that dropped out of the gather leg must not hold the others here
+        import threading
+        bye = threading.Timer(60.0, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
+        gpu.close()
         dist.barrier()
         dist.destroy_process_group()
+        bye.cancel()
+    else:
+        gpu.close()
 
 
 if __name__ == "__main__":
