@@ -125,6 +125,14 @@ int mrl_eval_sample_batch(mrl_ctx *ctx, const float *wi, const float *wo, const 
  * kernel that built the queue wrote it), so no host round trip separates queue building from the
  * BSDF call.  Device(-accessible) pointers only; asynchronous on the context's stream.  The caller
  * guarantees that every queued index addresses a valid slot of the arrays. ---- */
+/* Per-material compaction (wavefront ballot/prefix, no atomics): a stable partition of the slots [0, n) by
+ * material id.  queue_out[n] receives the slot indices grouped by material, ascending inside each group;
+ * offsets_out[mrl_material_count() + 1]: group m is queue_out[offsets[m] .. offsets[m + 1]);
+ * counts_out[mrl_material_count()]: the group sizes — pass queue_out + offsets[m] (host-known only after a read
+ * back) or simply the whole layout plus &counts_out[m] to the calls below.  Slots whose id names no material are
+ * dropped.  Device pointers only; asynchronous.  n == 0 leaves every count at zero. */
+int mrl_partition_by_material(mrl_ctx *ctx, const int32_t *mat, size_t n,
+                              uint32_t *queue_out, uint32_t *offsets_out, uint32_t *counts_out);
 int mrl_eval_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
                    const uint32_t *queue, const uint32_t *queue_count, size_t capacity, float *out_rgb);
 int mrl_pdf_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,

@@ -76,6 +76,9 @@ struct mrl_ctx {
     // kind-partitioned mixed batches: [2][queue_cap] unit indices + partition work area behind them
     uint32_t *d_queues = nullptr;
     size_t queue_cap = 0;
+    // mrl_partition_by_material: per-chunk count table + totals
+    uint32_t *d_part_work = nullptr;
+    size_t part_work_cap = 0;
     std::vector<MaterialHost> materials;
     mrl::MaterialDev *d_materials = nullptr;
     size_t d_materials_cap = 0;
@@ -473,6 +476,7 @@ int mrl_destroy(mrl_ctx *ctx)
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_queues) (void)hipFree(ctx->d_queues);
+    if (ctx->d_part_work) (void)hipFree(ctx->d_part_work);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -636,6 +640,34 @@ int mrl_eval_pdf_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int
 {
     BatchCall c{ 4, wi, wo, nullptr, mat, single_id, n, out_rgb, out_pdf, nullptr, nullptr, nullptr };
     return run_batch(ctx, c);
+}
+
+int mrl_partition_by_material(mrl_ctx *ctx, const int32_t *mat, size_t n, uint32_t *queue_out, uint32_t *offsets_out, uint32_t *counts_out)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    if (!offsets_out || !counts_out || (n > 0 && (!mat || !queue_out))) return fail(ctx, MRL_ERR_INVALID, "null array argument");
+    if (n > ((size_t)1 << 32)) return fail(ctx, MRL_ERR_INVALID, "more than 2^32 slots (queue entries are uint32)");
+    const int K = (int)ctx->materials.size();
+    if (K == 0) return fail(ctx, MRL_ERR_MATERIAL, "no material loaded");
+    if (K > mrl::kMaxPartitionMaterials) return fail(ctx, MRL_ERR_INVALID, "too many materials for the partition kernel");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    if (common_kind({ mat, queue_out, offsets_out, counts_out }) != 1) return fail(ctx, MRL_ERR_POINTER_MIX, "partition takes device pointers only");
+    if (n == 0) {                                     // nothing to partition: every group is empty
+        MRL_HIP(ctx, hipMemsetAsync(offsets_out, 0, ((size_t)K + 1) * sizeof(uint32_t), ctx->stream));
+        MRL_HIP(ctx, hipMemsetAsync(counts_out, 0, (size_t)K * sizeof(uint32_t), ctx->stream));
+        return MRL_OK;
+    }
+    uint32_t chunks = 0, chunk_len = 0;
+    mrl::material_partition_geometry(n, ctx->compute_units, &chunks, &chunk_len);
+    const size_t need = (size_t)chunks * K + K;
+    if (need > ctx->part_work_cap) {
+        if (ctx->d_part_work) { MRL_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_part_work); ctx->d_part_work = nullptr; ctx->part_work_cap = 0; }
+        MRL_HIP(ctx, hipMalloc((void **)&ctx->d_part_work, need * sizeof(uint32_t)));
+        ctx->part_work_cap = need;
+    }
+    MRL_HIP(ctx, mrl::launch_partition_materials(mat, n, K, queue_out, offsets_out, counts_out, ctx->d_part_work, chunks, chunk_len,
+                                                 ctx->compute_units, ctx->stream));
+    return MRL_OK;
 }
 
 int mrl_eval_pdf_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,

@@ -551,6 +551,98 @@ __global__ __launch_bounds__(kBlock) void k_partition_kinds(const int32_t *mat, 
     }
 }
 
+// ---- per-material compaction for wavefront callers (mrl_partition_by_material) ---------------------
+// A stable partition of the slots [0, n) by material id into one ascending queue per material, built with
+// the wavefront ballot/prefix idiom and no global atomics.  Every WAVE owns a contiguous chunk of the slots
+// and walks it 64 slots at a time; inside a step it peels off one material at a time:
+//     id0  = the id of the first lane not yet served          (readlane of the lowest set bit)
+//     mask = ballot(id == id0)                                 (who else carries it)
+//     rank = mbcnt(mask)                                       (my position among them)
+// so a step costs as many iterations as it holds DISTINCT materials.  Pass 1 leaves counts[chunk][k], pass 2
+// turns them into start offsets (one block per material scans its column; a last block lays the materials
+// end to end), pass 3 repeats the walk and writes slot indices to base[k] + offset[chunk][k] + running + rank.
+constexpr int kPartWaves = kBlock / 64;
+
+__device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// WRITE = false: count; WRITE = true: scatter slot indices.  table: [chunks][K] counts (pass 1 out) or start offsets (pass 3 in)
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_partition_materials(const int32_t *mat, size_t n, int K, uint32_t chunk_len,
+                                                               uint32_t *table, uint32_t *queue)
+{
+    extern __shared__ unsigned s_run[];                       // [kPartWaves][K] running counters, wave-private
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const size_t chunk = (size_t)blockIdx.x * kPartWaves + wave;
+    volatile unsigned *run = s_run + (size_t)wave * K;
+    uint32_t *row = table + chunk * (size_t)K;
+    for (int k = (int)lane; k < K; k += 64) run[k] = WRITE ? row[k] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    const size_t first = chunk * chunk_len;
+    const size_t last = first + chunk_len < n ? first + chunk_len : n;
+    for (size_t base = first; base < last; base += 64) {      // wave-uniform trip count
+        const size_t i = base + lane;
+        const int id = i < last ? mat[i] : -1;
+        const bool valid = id >= 0 && id < K;                 // ids outside the material list are dropped
+        unsigned long long todo = __ballot(valid);
+        while (todo) {                                        // wave-uniform
+            const int leader = __builtin_ctzll(todo);
+            const int id0 = __builtin_amdgcn_readlane(id, leader);
+            const unsigned long long mask = __ballot(valid && id == id0);
+            const unsigned start = run[id0];
+            if constexpr (WRITE) {
+                if (valid && id == id0) queue[start + lane_rank(mask)] = (uint32_t)i;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if ((int)lane == leader) run[id0] = start + (unsigned)__popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+            todo &= ~mask;
+        }
+    }
+    if constexpr (!WRITE) {
+        for (int k = (int)lane; k < K; k += 64) row[k] = run[k];
+    }
+}
+
+// block k: exclusive prefix of column k of counts[chunks][K] in place, column total -> totals[k]
+__global__ __launch_bounds__(kBlock) void k_scan_material_columns(uint32_t *table, uint32_t chunks, int K, uint32_t *totals)
+{
+    __shared__ unsigned s_part[kBlock];
+    const unsigned tid = threadIdx.x, k = blockIdx.x;
+    const unsigned per = (chunks + kBlock - 1) / kBlock;
+    const unsigned lo = tid * per, hi = lo + per < chunks ? lo + per : chunks;
+    unsigned sum = 0;
+    for (unsigned c = lo; c < hi; ++c) sum += table[(size_t)c * K + k];
+    s_part[tid] = sum;
+    __syncthreads();
+    unsigned before = 0;
+    for (unsigned t = 0; t < tid; ++t) before += s_part[t];
+    for (unsigned c = lo; c < hi; ++c) {
+        const unsigned v = table[(size_t)c * K + k];
+        table[(size_t)c * K + k] = before;
+        before += v;
+    }
+    if (tid == kBlock - 1) totals[k] = before;
+}
+
+// one block: materials end to end -> offsets[K + 1], counts[K]; then every column gets its material's base added
+__global__ __launch_bounds__(kBlock) void k_material_bases(const uint32_t *totals, int K, uint32_t *offsets, uint32_t *counts)
+{
+    if (threadIdx.x == 0) {
+        unsigned at = 0;
+        for (int k = 0; k < K; ++k) { offsets[k] = at; counts[k] = totals[k]; at += totals[k]; }
+        offsets[K] = at;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_add_material_bases(uint32_t *table, size_t cells, int K, const uint32_t *offsets)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < cells; j += stride) table[j] += offsets[j % (size_t)K];
+}
+
 // ---- a1: table re-layout on the device (planar f64 file order -> HBM layout), one thread per output texel/brick ----
 __device__ __forceinline__ float scaled_texel(const double *planar, size_t plane, size_t index, int ch, double scale)
 {
@@ -810,6 +902,35 @@ hipError_t launch_batch_indexed(int mode, const BatchArgs &a, bool multi, int la
         case MODE_EVAL_PDF:    return launch_indexed_mode<MODE_EVAL_PDF>(a, multi, layout, has_ggx, has_table, compute_units, stream);
     }
     return hipErrorInvalidValue;
+}
+
+void material_partition_geometry(size_t n, int compute_units, uint32_t *chunks, uint32_t *chunk_len)
+{
+    size_t waves = (n + 63) / 64;
+    const size_t cap = (size_t)compute_units * 8 * kPartWaves;
+    if (waves > cap) waves = cap;
+    if (waves < 1) waves = 1;
+    waves = (waves + kPartWaves - 1) / kPartWaves * kPartWaves;       // whole blocks
+    size_t len = (n + waves - 1) / waves;
+    len = (len + 63) / 64 * 64;
+    if (len < 64) len = 64;
+    *chunks = (uint32_t)waves;
+    *chunk_len = (uint32_t)len;
+}
+
+// work: chunks*K + K uint32 (per-chunk table, totals); K <= kMaxPartitionMaterials (LDS: 4 waves x K counters)
+hipError_t launch_partition_materials(const int32_t *mat, size_t n, int K, uint32_t *queue, uint32_t *offsets, uint32_t *counts,
+                                      uint32_t *work, uint32_t chunks, uint32_t chunk_len, int compute_units, hipStream_t stream)
+{
+    uint32_t *table = work, *totals = work + (size_t)chunks * K;
+    const dim3 grid(chunks / kPartWaves), block(kBlock);
+    const size_t lds = (size_t)kPartWaves * K * sizeof(unsigned);
+    hipLaunchKernelGGL((k_partition_materials<false>), grid, block, lds, stream, mat, n, K, chunk_len, table, queue);
+    hipLaunchKernelGGL(k_scan_material_columns, dim3(K), block, 0, stream, table, chunks, K, totals);
+    hipLaunchKernelGGL(k_material_bases, dim3(1), block, 0, stream, totals, K, offsets, counts);
+    hipLaunchKernelGGL(k_add_material_bases, dim3(grid_for((size_t)chunks * K, compute_units)), block, 0, stream, table, (size_t)chunks * K, K, offsets);
+    hipLaunchKernelGGL((k_partition_materials<true>), grid, block, lds, stream, mat, n, K, chunk_len, table, queue);
+    return hipGetLastError();
 }
 
 hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, float4 *d_out,

@@ -38,6 +38,12 @@ hipError_t launch_batch_queue(int mode, const BatchArgs &a, bool ggx_queue, int 
 // a caller's wavefront queue (mrl_*_queue): units a.idx[0 .. min(*a.idx_count, a.n)), a.n = the queue's capacity
 hipError_t launch_batch_indexed(int mode, const BatchArgs &a, bool multi, int layout, bool has_ggx, bool has_table,
                                 int compute_units, hipStream_t stream);
+// per-material compaction for wavefront callers (mrl_partition_by_material): stable partition of [0, n) by material id
+constexpr int kMaxPartitionMaterials = 2048;
+void material_partition_geometry(size_t n, int compute_units, uint32_t *chunks, uint32_t *chunk_len);
+// work: chunks*K + K uint32; queue: n uint32; offsets: K + 1; counts: K (all device)
+hipError_t launch_partition_materials(const int32_t *mat, size_t n, int K, uint32_t *queue, uint32_t *offsets, uint32_t *counts,
+                                      uint32_t *work, uint32_t chunks, uint32_t chunk_len, int compute_units, hipStream_t stream);
 // a1: planar f64 table (device copy of the file payload) -> padded rows or bricks
 hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, float4 *d_out,
                               int compute_units, hipStream_t stream);

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "mrl_material_load_merl", "mrl_material_upload_f64", "mrl_material_upload_table", "mrl_material_load_table",
     "mrl_material_ggx", "mrl_material_count", "mrl_material_info",
     "mrl_eval_batch", "mrl_pdf_batch", "mrl_sample_batch", "mrl_eval_pdf_batch", "mrl_eval_sample_batch",
-    "mrl_eval_queue", "mrl_pdf_queue", "mrl_eval_pdf_queue", "mrl_sample_queue", "mrl_eval_sample_queue",
+    "mrl_partition_by_material", "mrl_eval_queue", "mrl_pdf_queue", "mrl_eval_pdf_queue", "mrl_sample_queue", "mrl_eval_sample_queue",
     "mrl_generate_pairs", "mrl_generate_materials",
     "mrl_device_alloc", "mrl_device_free", "mrl_copy_to_device", "mrl_copy_to_host", "mrl_host_alloc", "mrl_host_free",
     "mrl_timer_start", "mrl_timer_stop",
@@ -86,6 +86,7 @@ def load_library(path: Optional[str] = None):
     L.mrl_material_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mrl_eval_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp]
     L.mrl_pdf_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp]
+    L.mrl_partition_by_material.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     L.mrl_eval_pdf_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp, fp]
     L.mrl_eval_pdf_queue.argtypes = [vp, fp, fp, vp, C.c_int32, vp, vp, C.c_size_t, fp, fp]
     L.mrl_sample_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp, fp, fp]
@@ -316,6 +317,22 @@ class MerlHip:
         if cap > int(queue.shape[0]):
             raise ValueError("capacity exceeds the queue's length")
         return _addr(queue, np.int32, None, None, "queue"), _addr(count, np.int32, None, 1, "count"), cap
+
+    def partition_by_material(self, mat):
+        """Stable partition of the slots by material id.  Returns (queue, offsets, counts) as int32 GPU tensors:
+        material m owns queue[offsets[m]:offsets[m + 1]] (ascending slot indices), counts[m] of them."""
+        import torch
+        if not (_is_tensor(mat) and mat.is_cuda):
+            raise ValueError("partition_by_material takes a GPU int32 tensor")
+        self._prep(mat)
+        n = int(mat.shape[0]); k = self.material_count()
+        queue = torch.empty((n,), dtype=torch.int32, device=mat.device)
+        offsets = torch.zeros((k + 1,), dtype=torch.int32, device=mat.device)
+        counts = torch.zeros((k,), dtype=torch.int32, device=mat.device)
+        self._check(self._lib.mrl_partition_by_material(self._ctx, _addr(mat, np.int32, None, n, "mat"), n, _addr(queue, np.int32, None, n, "queue"),
+                                                        _addr(offsets, np.int32, None, k + 1, "offsets"), _addr(counts, np.int32, None, k, "counts")),
+                    "mrl_partition_by_material")
+        return queue, offsets, counts
 
     def eval_queue(self, wi, wo, queue, count, mat=None, material: int = 0, capacity=None, out=None):
         """eval() of the slots queue[0 .. min(count, capacity)); other slots of `out` stay as they are."""
