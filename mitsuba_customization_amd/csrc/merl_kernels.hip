@@ -582,9 +582,11 @@ __global__ __launch_bounds__(kBlock) void k_partition_materials(const int32_t *m
     __builtin_amdgcn_wave_barrier();
     const size_t first = chunk * chunk_len;
     const size_t last = first + chunk_len < n ? first + chunk_len : n;
+    int id_next = first + lane < last ? mat[first + lane] : -1;
     for (size_t base = first; base < last; base += 64) {      // wave-uniform trip count
         const size_t i = base + lane;
-        const int id = i < last ? mat[i] : -1;
+        const int id = id_next;
+        id_next = i + 64 < last ? mat[i + 64] : -1;           // next step's ids travel while this step is ranked
         const bool valid = id >= 0 && id < K;                 // ids outside the material list are dropped
         unsigned long long todo = __ballot(valid);
         while (todo) {                                        // wave-uniform
