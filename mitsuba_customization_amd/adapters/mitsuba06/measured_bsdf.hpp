@@ -34,6 +34,30 @@ public:
         m_key.sampling = merl_gpu::parse_sampling(props.getString("sampling", "cosine"));
     }
 
+    // Unserialising constructor (network rendering: the scene object arrives at a worker as a stream).  The
+    // worker reloads the table from the same path onto ITS GPU, so the path must resolve there too.
+    MeasuredBSDFBase(Stream *stream, InstanceManager *manager) : BSDF(stream, manager)
+    {
+        m_filename = stream->readString();
+        m_key.device = stream->readInt();
+        m_key.lookup = stream->readInt();
+        m_key.node = stream->readInt();
+        m_key.disk_map = 0;
+        m_key.sampling = stream->readInt();
+        if (m_key.lookup < 0 || m_key.lookup > 1 || m_key.node < 0 || m_key.node > 1 || m_key.sampling < 0 || m_key.sampling > 1)
+            throw merl_gpu::Error(MRL_ERR_INVALID, "corrupt serialised BSDF");
+    }
+
+    void serialize(Stream *stream, InstanceManager *manager) const override
+    {
+        BSDF::serialize(stream, manager);
+        stream->writeString(m_filename);
+        stream->writeInt(m_key.device);
+        stream->writeInt(m_key.lookup);
+        stream->writeInt(m_key.node);
+        stream->writeInt(m_key.sampling);
+    }
+
     void configure() override
     {
         m_components.clear();
@@ -134,6 +158,11 @@ public:
     {
         m_material = merl_gpu::Material::load_merl(m_key, m_filename);
     }
+    MerlBSDF(Stream *stream, InstanceManager *manager) : MeasuredBSDFBase(stream, manager)
+    {
+        m_material = merl_gpu::Material::load_merl(m_key, m_filename);
+        configure();
+    }
     MTS_DECLARE_CLASS()
 protected:
     const char *pluginName() const override { return "MerlBSDF"; }
@@ -145,12 +174,30 @@ class CustomizedMeasurement : public MeasuredBSDFBase {
 public:
     explicit CustomizedMeasurement(const Properties &props) : MeasuredBSDFBase(props)
     {
-        const double scale[3] = { props.getFloat("scaleR", 1.0f), props.getFloat("scaleG", 1.0f), props.getFloat("scaleB", 1.0f) };
-        m_material = merl_gpu::Material::load_table(m_key, m_filename, scale);
+        m_scale[0] = props.getFloat("scaleR", 1.0f); m_scale[1] = props.getFloat("scaleG", 1.0f); m_scale[2] = props.getFloat("scaleB", 1.0f);
+        load();
+    }
+    CustomizedMeasurement(Stream *stream, InstanceManager *manager) : MeasuredBSDFBase(stream, manager)
+    {
+        for (int c = 0; c < 3; ++c) m_scale[c] = stream->readFloat();
+        load();
+        configure();
+    }
+    void serialize(Stream *stream, InstanceManager *manager) const override
+    {
+        MeasuredBSDFBase::serialize(stream, manager);
+        for (int c = 0; c < 3; ++c) stream->writeFloat(m_scale[c]);
     }
     MTS_DECLARE_CLASS()
 protected:
     const char *pluginName() const override { return "CustomizedMeasurement"; }
+private:
+    void load()
+    {
+        const double scale[3] = { m_scale[0], m_scale[1], m_scale[2] };
+        m_material = merl_gpu::Material::load_table(m_key, m_filename, scale);
+    }
+    Float m_scale[3];
 };
 
 MTS_NAMESPACE_END

@@ -8,6 +8,7 @@
 // empty).  Against a real tree, build the same plugin sources with -DMERL_USE_REAL_MITSUBA and the
 // tree's include path instead of this directory.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <map>
@@ -66,8 +67,37 @@ enum EMeasure { EInvalidMeasure = 0, ESolidAngle = 1, ELength = 2, EArea = 3, ED
 enum ETransportMode { ERadiance = 0, EImportance = 1 };
 
 class Sampler;
-class Stream;
 class InstanceManager;
+
+// ---- Stream: what serialize() writes to and the unserialising constructor reads from (network rendering
+// ships scene objects to worker nodes this way).  The mirror's stream is an in-memory byte queue. ----
+class Stream {
+public:
+    virtual ~Stream() {}
+    void writeString(const std::string &v) { writeUInt((unsigned int)v.size()); m_bytes.insert(m_bytes.end(), v.begin(), v.end()); }
+    std::string readString()
+    {
+        const unsigned int n = readUInt();
+        need(n);
+        std::string v(m_bytes.begin() + (std::ptrdiff_t)m_pos, m_bytes.begin() + (std::ptrdiff_t)(m_pos + n));
+        m_pos += n;
+        return v;
+    }
+    void writeInt(int v) { put(&v, sizeof v); }
+    int readInt() { int v; get(&v, sizeof v); return v; }
+    void writeUInt(unsigned int v) { put(&v, sizeof v); }
+    unsigned int readUInt() { unsigned int v; get(&v, sizeof v); return v; }
+    void writeFloat(Float v) { put(&v, sizeof v); }
+    Float readFloat() { Float v; get(&v, sizeof v); return v; }
+    size_t getSize() const { return m_bytes.size(); }
+    size_t getPos() const { return m_pos; }
+private:
+    void put(const void *p, size_t n) { const char *c = static_cast<const char *>(p); m_bytes.insert(m_bytes.end(), c, c + n); }
+    void need(size_t n) const { if (m_pos + n > m_bytes.size()) throw std::runtime_error("Stream: read past the end"); }
+    void get(void *p, size_t n) { need(n); std::copy(m_bytes.begin() + (std::ptrdiff_t)m_pos, m_bytes.begin() + (std::ptrdiff_t)(m_pos + n), static_cast<char *>(p)); m_pos += n; }
+    std::vector<char> m_bytes;
+    size_t m_pos = 0;
+};
 
 // ---- Properties: the key/value bag the scene XML hands to a plugin constructor ----
 class Properties {
@@ -112,6 +142,7 @@ private:
 class ConfigurableObject : public Object {
 public:
     explicit ConfigurableObject(const Properties &props) : m_properties(props) {}
+    ConfigurableObject(Stream *, InstanceManager *) {}       // unserialising constructor
     virtual void configure() {}
     virtual void serialize(Stream *, InstanceManager *) const {}
     const Properties &getProperties() const { return m_properties; }
@@ -162,6 +193,14 @@ public:
 
     explicit BSDF(const Properties &props)
         : ConfigurableObject(props), m_combinedType(0), m_usesRayDifferentials(false), m_ensureEnergyConservation(true) {}
+    // unserialising constructor + its counterpart, as in Mitsuba 0.6's BSDF: one flag travels
+    BSDF(Stream *stream, InstanceManager *manager)
+        : ConfigurableObject(stream, manager), m_combinedType(0), m_usesRayDifferentials(false), m_ensureEnergyConservation(stream->readInt() != 0) {}
+    void serialize(Stream *stream, InstanceManager *manager) const override
+    {
+        ConfigurableObject::serialize(stream, manager);
+        stream->writeInt(m_ensureEnergyConservation ? 1 : 0);
+    }
 
     virtual Spectrum eval(const BSDFSamplingRecord &bRec, EMeasure measure = ESolidAngle) const = 0;
     virtual Spectrum sample(BSDFSamplingRecord &bRec, const Point2 &sample) const = 0;
@@ -194,4 +233,11 @@ MTS_NAMESPACE_END
     const char MTS_EXPORT *GetDescription() { return descr; }                                       \
     }
 #define MTS_DECLARE_CLASS()
-#define MTS_IMPLEMENT_CLASS_S(name, abstract, super)
+// Mitsuba 0.6 registers an unserialisation function per serialisable class (Class::unserialize ->
+// new name(stream, manager)).  The mirror has no class registry; it exports the same function under a fixed
+// symbol so a test host can rebuild a plugin instance from a stream the way a render worker would.
+#define MTS_IMPLEMENT_CLASS_S(name, abstract, super)                                                \
+    extern "C" MTS_EXPORT void *UnserializeInstance(mitsuba::Stream *stream, mitsuba::InstanceManager *manager) \
+    {                                                                                               \
+        return new mitsuba::name(stream, manager);                                                  \
+    }

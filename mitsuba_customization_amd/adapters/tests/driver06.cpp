@@ -124,6 +124,34 @@ int main(int argc, char **argv)
             }
         }
     }
+    // network rendering: serialize() on the master, the unserialising constructor on a worker -> same answers
+    {
+        typedef void *(*UnserializeFn)(Stream *, InstanceManager *);
+        auto unserialize = (UnserializeFn)dlsym(h, "UnserializeInstance");
+        if (!unserialize) { std::cerr << "plugin lacks UnserializeInstance\n"; return 12; }
+        Stream stream;
+        bsdf->serialize(&stream, nullptr);
+        BSDF *copy = nullptr;
+        try { copy = static_cast<BSDF *>(unserialize(&stream, nullptr)); } catch (const std::exception &e) { std::cerr << "unserialize threw: " << e.what() << "\n"; return 12; }
+        copy->incRef();
+        if (stream.getPos() != stream.getSize() || copy->getType() != bsdf->getType() || copy->getComponentCount() != 1) {
+            std::cerr << "unserialised copy: stream not consumed or type differs: " << copy->toString() << "\n";      // (its material id is a new one)
+            return 12;
+        }
+        for (size_t i = 0; i < std::min<size_t>(m, 50); ++i) {
+            its.wi = Vector(p.wi[3 * i], p.wi[3 * i + 1], p.wi[3 * i + 2]);
+            BSDFSamplingRecord q(its, Vector(p.wo[3 * i], p.wo[3 * i + 1], p.wo[3 * i + 2]));
+            const Spectrum f = copy->eval(q, ESolidAngle);
+            const float got[3] = { f[0], f[1], f[2] };
+            if (std::memcmp(got, &scalar[11 * i], sizeof got) != 0) { std::cerr << "unserialised copy differs at unit " << i << "\n"; return 12; }
+        }
+        copy->decRef();
+        Stream garbage;
+        garbage.writeInt(1); garbage.writeString("x.binary"); garbage.writeInt(0); garbage.writeInt(7);     // truncated + bad option
+        bool threw = false;
+        try { unserialize(&garbage, nullptr); } catch (const std::exception &) { threw = true; }
+        if (!threw) return 12;
+    }
     const BatchedBSDF *wave = dynamic_cast<const BatchedBSDF *>(bsdf);
     if (!wave) { std::cerr << "plugin is not a BatchedBSDF\n"; return 9; }
     std::vector<float> rgb(3 * p.n), pdf(p.n), wo2(3 * p.n), pdf2(p.n), wgt(3 * p.n);
