@@ -98,6 +98,8 @@ int mrl_material_upload_f64(mrl_ctx *ctx, const double *planar_rgb, int *out_id)
 /* customized_measurement: MERL parameterisation with free dims and channel scales */
 int mrl_material_upload_table(mrl_ctx *ctx, const double *planar_rgb, const int dims[3],
                               const double scale[3], int *out_id);
+/* file: int32 dims[3], then planar R,G,B values in MERL order, as f64 (like a MERL file) or f32 (told apart by the
+ * file length) */
 int mrl_material_load_table(mrl_ctx *ctx, const char *path, const double scale[3], int *out_id);
 int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float k[3], int *out_id);
 int mrl_material_count(const mrl_ctx *ctx);

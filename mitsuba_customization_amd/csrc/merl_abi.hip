@@ -214,7 +214,8 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     return MRL_OK;
 }
 
-// a1: MERL .binary reader: int32 dims[3], then 3*n planar doubles
+// a1: MERL .binary reader: int32 dims[3], then 3*n planar doubles.  A customized_measurement
+// table may carry its payload as f32 instead (the file length says which); MERL files are f64 only.
 int read_table_file(mrl_ctx *ctx, const char *path, bool require_merl, std::vector<double> &data, int dims[3])
 {
     if (!path) return fail(ctx, MRL_ERR_INVALID, "null path");
@@ -226,8 +227,22 @@ int read_table_file(mrl_ctx *ctx, const char *path, bool require_merl, std::vect
     long long n = (long long)d[0] * d[1] * d[2];
     if (require_merl && n != 90LL * 90 * 180) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "dims do not match the MERL grid (90*90*360/2)"); }
     if (n > (1LL << 28)) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "table too large"); }
+    bool f32_payload = false;
+    if (!require_merl && std::fseek(f, 0, SEEK_END) == 0) {
+        const long long bytes = (long long)std::ftell(f);
+        f32_payload = bytes == 12 + 3 * n * 4;
+        if (std::fseek(f, 12, SEEK_SET) != 0) { std::fclose(f); return fail(ctx, MRL_ERR_IO, "seek failed"); }
+    }
     try { data.resize(3 * (size_t)n); } catch (const std::bad_alloc &) { std::fclose(f); return fail(ctx, MRL_ERR_OOM, "table buffer"); }
-    size_t got = std::fread(data.data(), sizeof(double), data.size(), f);
+    size_t got;
+    if (f32_payload) {
+        std::vector<float> narrow;
+        try { narrow.resize(data.size()); } catch (const std::bad_alloc &) { std::fclose(f); return fail(ctx, MRL_ERR_OOM, "table buffer"); }
+        got = std::fread(narrow.data(), sizeof(float), narrow.size(), f);
+        for (size_t i = 0; i < got; ++i) data[i] = (double)narrow[i];
+    } else {
+        got = std::fread(data.data(), sizeof(double), data.size(), f);
+    }
     std::fclose(f);
     if (got != data.size()) return fail(ctx, MRL_ERR_FORMAT, "truncated table payload");
     if (require_merl) { dims[0] = kMerlDims[0]; dims[1] = kMerlDims[1]; dims[2] = kMerlDims[2]; }

@@ -41,3 +41,28 @@ def test_device_alloc_copy_roundtrip_and_batch(oracle, tables):
             g.material_info(5)
     want = oracle.OracleTable(tab).eval(wi, wo)
     assert (np.abs(out.astype(np.float64) - want) <= 1e-6 * np.abs(want) + 1e-30).all()
+
+
+def test_customized_table_file_with_f32_payload(tmp_path):
+    """A customized_measurement file may store f32 values: same header, payload width told by the file length."""
+    import struct
+    import torch
+    from mitsuba_customization_amd import host, synth
+    dims = (20, 16, 30)
+    tab32 = synth.make_table("ggx_tab", seed=2, dims=dims).astype(np.float32)
+    path = tmp_path / "custom_f32.binary"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<3i", *dims))
+        f.write(tab32.tobytes())
+    with host.MerlHip(0) as g:
+        a = g.load_table(str(path), scale=(1.0, 0.5, 2.0))
+        b = g.upload_table(tab32.astype(np.float64), scale=(1.0, 0.5, 2.0))
+        assert g.material_info(a) == g.material_info(b) == (host.KIND_TABLE, dims)
+        wi, wo, u = g.generate_pairs(3, 0, 50000)
+        for x, y in zip(g.eval_sample(wi, wo, u, material=a), g.eval_sample(wi, wo, u, material=b)):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+        # a length that is neither payload width is a truncated file
+        with open(path, "ab") as f:
+            f.write(b"\\0" * 8)
+        with pytest.raises(host.MerlHipError):
+            g.load_table(str(path))
