@@ -41,8 +41,19 @@ def build_lib(force: bool = False, asm: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     srcs, deps = lib_sources()
     if force or _newer(LIB, deps):
-        cmd = [HIPCC] + HIP_FLAGS + ["-shared", "-o", LIB] + srcs
-        subprocess.check_call(cmd, cwd=PKG)
+        # several ranks of one job may get here at once in a checkout without build outputs: one of them
+        # compiles (to a private name, renamed into place when complete), the others wait on the lock
+        import fcntl
+        with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or _newer(LIB, deps):
+                tmp = f"{LIB}.{os.getpid()}.tmp"
+                try:
+                    subprocess.check_call([HIPCC] + HIP_FLAGS + ["-shared", "-o", tmp] + srcs, cwd=PKG)
+                    os.replace(tmp, LIB)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
     if asm:
         out = os.path.join(LIBDIR, "asm")
         os.makedirs(out, exist_ok=True)

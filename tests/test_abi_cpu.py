@@ -50,3 +50,15 @@ def test_null_context_is_rejected(lib):
     assert lib.mrl_eval_batch(None, None, None, None, 0, 4, None) == -1
     assert lib.mrl_material_count(None) == -1
     assert lib.mrl_destroy(None) == 0
+
+
+def test_concurrent_builds_do_not_race(tmp_path):
+    """Several ranks importing the package in a checkout without build outputs: every one ends up with a whole library."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from mitsuba_customization_amd import build; "
+            "import ctypes; ctypes.CDLL(build.build_lib()).mrl_strerror; print('ok')" % ROOT)
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(4)]
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0 and "ok" in out, err
