@@ -2,6 +2,7 @@
 """bench.py — BSDF eval+sample throughput on N MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3          # spawns its own 8 ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,6 +11,10 @@ over one batch of synthetic (wi, wo, u) that is already resident in HBM.  The wo
 BASELINE.json configs[1]: single MERL material, 64M pairs per GPU (weak scaling: every rank
 owns the index tile [rank*64M, (rank+1)*64M) and generates it in place, untimed).
 Rank 0 prints ONE JSON line.
+
+Launched without a rendezvous (`WORLD_SIZE` unset) and with --gpus N > 1, this file starts the N ranks itself —
+as a child `python -m torch.distributed.run ... bench.py ...`, BEFORE anything in this process touches torch or
+the GPU — relays rank 0's JSON line and exits with the child's return code.
 """
 import argparse
 import json
@@ -22,10 +27,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 B_STREAM = 76           # algorithmic HBM bytes per eval+sample unit: 32 in + 44 out
+B_MAT = 4               # + the int32 material id of a mixed batch (80 B/unit in configs 4/5)
 B_GATHER = 192          # algorithmic table bytes per unit: 2 lookups x 8 texels x 12 B (reported beside)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW")
 HBM_COPY_GBS = 6290.0   # measured float4 copy on the same chip (same guide)
+GATHER_CEILING_GBS = 7000.0   # random 128-B lines -> LDS, nothing else (tools/microbench/gather128.hip, 187 MB table)
 SEED = 0x5EED
+EXIT_GATHER_FAILED = 3  # the N>1 result-gather leg raised or ran into its deadline (the bench line is still printed)
 
 
 def host_cores() -> int:
@@ -44,20 +52,31 @@ def host_cores() -> int:
     return n
 
 
-def measured_traffic(variant: int, layout: int, units: int):
-    """HBM/fabric bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json),
-    if one exists for this kernel variant, table layout and batch size; else None."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def measured_traffic(variant: int, layout: int, units: int, config: str):
+    """Fabric (L2 <-> memory side) bytes per launch from the committed rocprofv3 PMC passes
+    (profiles/traffic.json), if one exists for this kernel variant, table layout, batch size and config; else None."""
     try:
         rows = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["rows"]
         for r in rows:
-            if r["kernel_variant"] == min(variant, 3) and r["table_layout"] == layout and r["units"] == units:
+            if (r["kernel_variant"] == min(variant, 3) and r["table_layout"] == layout and r["units"] == units
+                    and r.get("config", "merl64m") == config):
                 return r
     except Exception:
         pass
     return None
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
@@ -71,19 +90,108 @@ def parse():
     p.add_argument("--kernel", type=int, default=-1, help="kernel variant (MRL_OPT_KERNEL); -1 = library default")
     p.add_argument("--layout", type=int, default=-1, help="table layout (MRL_OPT_TABLE_LAYOUT); -1 = library default")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-units", type=int, default=0, help="units for the CPU baseline sample (0 = auto, ~1-3 s wall)")
+    p.add_argument("--cpu-reps", type=int, default=5, help="repetitions of each CPU baseline leg (median is reported)")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the separately reported RCCL gather leg")
     p.add_argument("--gather-units", type=int, default=16 << 20, help="N>1: units per rank moved by the gather leg")
-    p.add_argument("--gather-deadline", type=float, default=90.0, help="N>1: seconds after which the gather leg is reported as skipped")
+    p.add_argument("--gather-deadline", type=float, default=90.0, help="N>1: seconds after which the gather leg counts as failed")
     p.add_argument("--parity-sample", type=int, default=4096)
     p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                    help="control-plane backend; gloo only rehearses the multi-rank logic (ranks may then share one GPU: --share-gpu)")
     p.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
-    return p.parse_args()
+    p.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the child ranks are killed")
+    return p.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a rendezvous: start the N ranks as a child torch.distributed.run and
+    relay rank 0's JSON line.  Nothing in THIS process imports torch or touches the GPU (no exec of a process
+    that has initialised HIP; the ranks are ordinary children)."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, start_new_session=True)
+    lines = []
+    deadline = time.monotonic() + args.launch_timeout
+    import threading
+
+    def reader():
+        for line in child.stdout:
+            lines.append(line)
+
+    t = threading.Thread(target=reader, daemon=True)
+    t.start()
+    timed_out = False
+    while child.poll() is None:
+        if time.monotonic() > deadline:
+            timed_out = True
+            try:
+                os.killpg(child.pid, signal.SIGTERM)        # the exact process group this launcher started
+                time.sleep(5.0)
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            break
+        time.sleep(0.2)
+    rc = child.wait()
+    t.join(timeout=5.0)
+    bench_line = None
+    for line in lines:
+        s = line.strip()
+        if s.startswith("{") and '"metric"' in s:
+            bench_line = s
+        else:
+            sys.stderr.write(line)
+    if bench_line is not None:
+        print(bench_line, flush=True)
+    if timed_out:
+        sys.stderr.write(f"bench.py: the {args.gpus} ranks did not finish within {args.launch_timeout} s and were killed\n")
+        return rc or 124
+    if bench_line is None and rc == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 but rank 0 printed no bench line\n")
+        return 1
+    return rc
+
+
+def cpu_baseline(ob, table, lookup: int, reps: int) -> dict:
+    """the scalar f64 oracle behind a Mitsuba-0.6-style virtual call on the GPU box's host cores:
+    N = 2^20 units on one thread (BASELINE configs[0]'s size) and N = 16 * 2^20 units on all threads, median of `reps`."""
+    cores = host_cores()
+    opts = ob.make_opts(lookup=lookup)
+    n1, nN = 1 << 20, 16 << 20
+    t1 = sorted(ob.bench_merl(table, n1, 1, SEED, True, opts)[0] for _ in range(reps))
+    tN = sorted(ob.bench_merl(table, nN, cores, SEED, True, opts)[0] for _ in range(reps))
+    e1 = sorted(ob.bench_merl(table, n1, 1, SEED, False, opts)[0] for _ in range(max(1, reps // 2 + 1)))
+    m1, mN, me = t1[len(t1) // 2], tN[len(tN) // 2], e1[len(e1) // 2]
+    return {
+        "value": round(nN / mN / 1e6, 4),
+        "unit": "Meval/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{nN} eval+sample units of the same workload (pair indices 0..{nN - 1}) on {cores} threads, "
+                  f"and {n1} units (BASELINE configs[0]'s size) on 1 thread; scalar f64 oracle behind a "
+                  f"Mitsuba-0.6-style virtual call, median of {reps} repetitions each",
+        "single_thread_value": round(n1 / m1 / 1e6, 4),
+        "single_thread_eval_only_value": round(n1 / me / 1e6, 4),
+        "single_thread_units": n1,
+        "repetitions": reps,
+        "cpu_model": cpu_model(),
+    }
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))                         # before torch / the GPU are touched in this process
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -92,13 +200,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
     if args.share_gpu:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, the box has {torch.cuda.device_count()} "
+                 "(--share-gpu with --dist-backend gloo rehearses the multi-rank logic on one GPU)")
     torch.cuda.set_device(local_rank)
     use_pg = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
     if world > 1 and not use_pg:
@@ -183,17 +292,52 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
+    b_unit = B_STREAM + (B_MAT if mat is not None else 0)
     total_units = float(n) * world * args.steps
     value = total_units / elapsed / 1e6                     # M eval+sample units / s, whole job
-    achieved = B_STREAM * n / (kernel_ms * 1e-3) / 1e9      # GB/s of algorithmic stream bytes, one launch on one GPU
-    achieved_g = (B_STREAM + B_GATHER) * n / (kernel_ms * 1e-3) / 1e9
+    achieved = b_unit * n / (kernel_ms * 1e-3) / 1e9        # GB/s of algorithmic stream bytes, one launch on one GPU
+    achieved_g = (b_unit + B_GATHER) * n / (kernel_ms * 1e-3) / 1e9
     variant, layout = gpu.get_option(host.OPT_KERNEL), gpu.get_option(host.OPT_TABLE_LAYOUT)
     kname = {0: "k_batch<eval_sample>", 1: "k_table<eval_sample>", 2: "k_table<eval_sample,nt>"}.get(variant, "k_table_dma<eval_sample>")
     if args.config == "ggx64m":
         kname = "k_ggx<eval_sample>" if variant >= 1 else "k_batch<eval_sample>"
     if variant >= 3 and (layout != 1 or args.lookup != "trilinear"):
         kname = "k_table<eval_sample,nt>"
-    traffic = measured_traffic(variant, layout, n)
+    traffic = measured_traffic(variant, layout, n, args.config)
+    mem = gpu.memory_info()
+
+    roofline = {
+        "bound": "hbm",
+        "achieved": round(achieved, 2),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5),
+        # bytes per launch that crossed the L2 <-> memory-side fabric (TCC_EA0 read/write requests); Infinity-Cache
+        # hits are counted in them, so this is an upper bound on HBM bytes (MI355X_MICROARCH.md, HBM section)
+        "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+        "traffic_source": traffic["source"] if traffic else None,
+        "kernel": kname,
+        "kernel_ms": round(kernel_ms, 4),
+        "bytes_per_unit": b_unit,
+        "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 5),
+        "with_gather": {"bytes_per_unit": b_unit + B_GATHER, "achieved": round(achieved_g, 2),
+                        "frac": round(achieved_g / HBM_PEAK_GBS, 5)},
+        "note": "achieved/frac count the algorithmic STREAM bytes only (32 B in + 44 B out per unit, + 4 B material id in "
+                "mixed batches; SURVEY.md §8d).  With the brick layout a table is 187 MB and misses L2, so the 2 x 8-texel "
+                "gather (192 B/unit algorithmic, 256 B/unit fetched as two 128-B lines) crosses the fabric too: with_gather "
+                "prices stream + gather bytes against the same peak",
+    }
+    if traffic:
+        gbps = traffic["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+        roofline["fabric_traffic"] = {
+            "what": "TCC_EA0 read + write request bytes per launch / this run's kernel time: requests served by the "
+                    "Infinity Cache are included, so this is fabric (EA) traffic, not proven HBM traffic",
+            "GBps": round(gbps, 1),
+            "frac_of_random_line_gather_ceiling": round(gbps / GATHER_CEILING_GBS, 4),
+            "frac_of_measured_copy_peak": round(gbps / HBM_COPY_GBS, 4),
+            "frac_of_hbm_spec_peak": round(gbps / HBM_PEAK_GBS, 4),
+            "over_algorithmic_stream_bytes": round(traffic["hbm_bytes_per_launch"] / (b_unit * n), 3),
+        }
 
     result = {
         "metric": "bsdf_eval_sample_throughput",
@@ -211,6 +355,7 @@ def main():
         "config": {
             "workload": workload,
             "materials_resident": len(ids),
+            "resident_table_bytes": mem["table_bytes"],
             "units_per_gpu_per_step": n,
             "table": table_name,
             "lookup": args.lookup,
@@ -218,28 +363,7 @@ def main():
             "table_layout": layout,
             "sharding": f"index tiles x{world}, tables replicated, no data-path collective",
         },
-        "roofline": {
-            "bound": "hbm",
-            "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
-            "traffic_source": traffic["source"] if traffic else None,
-            # bytes actually moved per second (profiled traffic / this run's kernel time): how close the launch is to the HBM peak
-            "traffic_GBps": round(traffic["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None,
-            "traffic_frac_of_peak": round(traffic["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-            "kernel": kname,
-            "kernel_ms": round(kernel_ms, 4),
-            "bytes_per_unit": B_STREAM,
-            "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 5),
-            "with_gather": {"bytes_per_unit": B_STREAM + B_GATHER, "achieved": round(achieved_g, 2),
-                            "frac": round(achieved_g / HBM_PEAK_GBS, 5)},
-            "note": "achieved/frac count the algorithmic STREAM bytes only (32 B in + 44 B out per unit, SURVEY.md §8d). "
-                    "With the brick layout the table no longer fits any cache level (187 MB per table, L2 hit 0 %), so the "
-                    "2 x 8-texel gather (192 B/unit algorithmic, 256 B/unit fetched as two 128-B lines) is fabric/HBM "
-                    "traffic too: with_gather prices stream + gather bytes against the same peak",
-        },
+        "roofline": roofline,
     }
 
     # ---- rank 0, N=1: parity sample vs the oracle + CPU baseline on the host cores ----
@@ -258,48 +382,42 @@ def main():
             else:
                 hm = None if mat is None else (mat[idx] - ids[0]).cpu().numpy()
                 ref = ob.eval_sample_multi([ob.OracleTable(t) for t in tables], hin[0], hin[1], hin[2], hm, ob.make_opts(lookup=lookup))
-            worst = 0.0
+            worst, beyond = 0.0, 0
             for k_out, (got, want) in enumerate(zip(hout, ref)):
                 got = got.astype(np.float64); want = want.astype(np.float64)
                 err = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
                 # GGX sampled directions are f64 results rounded to f32: one ulp (1.2e-7 absolute) may flip
                 slack = 1.2e-7 if (args.config == "ggx64m" and k_out == 2) else 0.0
                 err = np.where(np.abs(got - want) <= 1e-30 + slack, 0.0, err)
-                worst = max(worst, float(np.quantile(err, 0.999) if lookup == 0 else err.max()))
-            result["parity"] = {"sample": k, "max_rel_err_vs_oracle": worst, "tolerance": 1e-6, "pinned": False}
+                worst = max(worst, float(err.max()))
+                beyond += int((err > 1e-6).sum())
+            result["parity"] = {"sample": k, "max_rel_err_vs_oracle": worst, "values_beyond_tolerance": beyond,
+                                "tolerance": 1e-6, "pinned": False}
+            if lookup == 0:
+                result["parity"]["note"] = ("nearest lookup: a coordinate on an exact bin edge may land in the neighbouring texel "
+                                            "(values_beyond_tolerance counts those flips)")
         if world == 1 and not args.no_cpu_baseline and args.config == "merl64m":
-            cores = host_cores()
-            lookup = 1 if args.lookup == "trilinear" else 0
-            s1, _ = ob.bench_merl(table, 1 << 18, 1, SEED, True, ob.make_opts(lookup=lookup))     # calibration, 1 thread
-            rate1 = (1 << 18) / s1
-            cpu_n = args.cpu_units or int(min(64 * (1 << 20), max(1 << 20, rate1 * cores * 1.0)))   # ~1 s wall, ~cores s of CPU work
-            sN, _ = ob.bench_merl(table, cpu_n, cores, SEED, True, ob.make_opts(lookup=lookup))
-            result["cpu_baseline"] = {
-                "value": round(cpu_n / sN / 1e6, 4),
-                "unit": "Meval/s",
-                "cores": cores,
-                "kind": "port",
-                "sample": f"{cpu_n} eval+sample units of the same workload (pair indices 0..{cpu_n - 1}), "
-                          f"scalar f64 oracle behind a Mitsuba-0.6-style virtual call, {cores} threads; "
-                          f"1-thread rate {rate1 / 1e6:.3f} Meval/s on 2^18 units",
-                "single_thread_value": round(rate1 / 1e6, 4),
-            }
+            result["cpu_baseline"] = cpu_baseline(ob, table, 1 if args.lookup == "trilinear" else 0, max(1, args.cpu_reps))
 
     # ---- N>1: the RCCL result gather, reported beside (never inside) `value` ----
-    # The point-to-point leg cannot be rehearsed on a 1-GPU development box, so it runs LAST and under a deadline:
-    # whatever happens in it (an exception on one rank, a peer that never arrives), rank 0 still prints the bench
-    # line — with "gather": {"skipped": reason} — and every rank exits.
+    # It runs LAST and under a deadline.  If it raises on a rank or stalls, rank 0 still prints the bench line with
+    # "gather": {"failed": reason, "phase": ...} and EVERY rank exits with EXIT_GATHER_FAILED (non-zero): a process that
+    # has GPU work in flight behind a dead peer is not retried and not reported as a clean run.
+    exit_code = 0
     if world > 1 and not args.no_gather:
         import threading
         finished = threading.Event()
+        phase = {"name": "alloc"}
 
         def give_up():
             if finished.is_set():
                 return
+            why = f"rank {rank}: gather leg still in phase '{phase['name']}' after {args.gather_deadline} s"
+            sys.stderr.write("bench.py: " + why + "\n")
             if rank == 0:
-                result["gather"] = {"skipped": f"gather leg did not finish within {args.gather_deadline} s"}
+                result["gather"] = {"failed": why, "phase": phase["name"]}
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+            os._exit(EXIT_GATHER_FAILED)
 
         watchdog = threading.Timer(args.gather_deadline, give_up)
         watchdog.daemon = True
@@ -317,16 +435,20 @@ def main():
         except Exception as e:
             ok, err = 0, repr(e)
         try:
+            phase["name"] = "all_reduce(buffers allocated)"
             flag = torch.tensor([ok], dtype=torch.int32, device=comm_dev(dev))
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag[0]) == 1:
+                phase["name"] = "batch_isend_irecv"
                 g = shard.bench_gather(local, steps=3, out=full)
                 g["units_per_rank"] = g_units
                 g["extrapolated_ms_for_full_step"] = round(g["ms"] * n / g_units, 3)
             else:
-                g = {"skipped": err or "another rank could not allocate its buffers"}
-        except Exception as e:                                          # the other ranks run into the deadline
-            g = {"skipped": repr(e)}
+                g = {"skipped": err or "another rank could not allocate its buffers"}     # agreed by every rank: clean
+        except Exception as e:                                          # the peers run into their own deadline
+            g = {"failed": repr(e), "phase": phase["name"]}
+            sys.stderr.write(f"bench.py: rank {rank}: gather leg raised in phase '{phase['name']}': {e!r}\n")
+            exit_code = EXIT_GATHER_FAILED
         del full
         if rank == 0:
             result["gather"] = g
@@ -337,9 +459,16 @@ def main():
         print(json.dumps(result), flush=True)
 
     if use_pg:
-        # teardown under a deadline as well: a rank that dropped out of the gather leg must not hold the others here
+        if exit_code:
+            os._exit(exit_code)                             # peers may be stuck in the leg: no collective teardown
+        # teardown under a deadline as well; a stall here is a failure, not a clean run
         import threading
-        bye = threading.Timer(60.0, lambda: os._exit(0))
+
+        def teardown_stalled():
+            sys.stderr.write(f"bench.py: rank {rank}: teardown (barrier / destroy_process_group) stalled for 60 s\n")
+            os._exit(EXIT_GATHER_FAILED)
+
+        bye = threading.Timer(60.0, teardown_stalled)
         bye.daemon = True
         bye.start()
         gpu.close()

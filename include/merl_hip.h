@@ -63,18 +63,24 @@ enum mrl_option {
                                   2 + non-temporal streams, 3 (default) + cooperative LDS-DMA brick fetch,
                                   4 = 3 + ballot/prefix partition of a batch that mixes table and analytic
                                   materials into one dense queue per kind (pays only when most units are analytic).
-                                  Every variant passes the same parity tests; they differ in speed only. */
+                                  Every variant passes the same parity tests; they differ in speed only.  Values
+                                  outside 0..4 are rejected with MRL_ERR_INVALID. */
     MRL_OPT_HOST_CHUNK = 4,    /* units per staging chunk for host-pointer calls */
     MRL_OPT_SAMPLING = 6,      /* sample()/pdf() strategy of table materials: 0 cosine hemisphere (default, the upstream
                                   convention), 1 table importance sampling: one-sample mixture of the cosine lobe and a
                                   half-vector lobe read off the table's theta_h rows */
-    MRL_OPT_TABLE_LAYOUT = 5   /* HBM layout of the context's tables, settable only while it holds no table:
+    MRL_OPT_TABLE_LAYOUT = 5,  /* HBM layout of the context's tables, settable only while it holds no table:
                                   0 padded rows (24 MB per MERL table),
                                   1 bricks (default): one 128-B line per cell holds its 8 corners (187 MB per MERL table).
                                   Bricks are 2.3x faster for trilinear lookups, rows 1.45x faster for nearest lookups. */
+    MRL_OPT_MEMORY_LIMIT_MB = 7 /* budget for the context's resident material data (tables + sampling marginals), in MiB;
+                                  0 (default) = no budget, the device's free memory is the limit.  An upload that would
+                                  exceed the budget — or the device — fails with MRL_ERR_OOM and leaves the context as it
+                                  was.  Capacity for scale: one MERL table is 186.6 MB as bricks (24.0 MB as rows), so a
+                                  288 GB MI355X holds about 1,500 brick tables (11,000 as rows). */
 };
 
-enum mrl_material_kind { MRL_KIND_MERL = 0, MRL_KIND_TABLE = 1, MRL_KIND_GGX = 2 };
+enum mrl_material_kind { MRL_KIND_MERL = 0, MRL_KIND_TABLE = 1, MRL_KIND_GGX = 2, MRL_KIND_RELEASED = 3 /* tombstone, never reported */ };
 
 /* ---- context ---- */
 int mrl_init(int device_id, mrl_ctx **out);
@@ -102,8 +108,17 @@ int mrl_material_upload_table(mrl_ctx *ctx, const double *planar_rgb, const int 
  * file length) */
 int mrl_material_load_table(mrl_ctx *ctx, const char *path, const double scale[3], int *out_id);
 int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float k[3], int *out_id);
+/* number of material SLOTS (live + released); ids are slot indices */
 int mrl_material_count(const mrl_ctx *ctx);
 int mrl_material_info(const mrl_ctx *ctx, int id, int *kind, int dims[3]);
+/* Frees a material's device memory (plugin destructor).  Waits for the context's stream first.  The slot becomes a
+ * tombstone: batch and queue calls treat its id like an unknown id (every output zero), single_id calls and
+ * mrl_material_info return MRL_ERR_MATERIAL.  A later upload may reuse the slot (lowest free slot first), exactly like
+ * a file descriptor — do not keep ids of released materials in material-id arrays. */
+int mrl_material_release(mrl_ctx *ctx, int id);
+/* Resident bytes of this context: material data (tables + sampling marginals), scratch the context holds (staging,
+ * partition work areas), and the device's free / total memory as the runtime reports them.  Any pointer may be NULL. */
+int mrl_memory_info(const mrl_ctx *ctx, size_t *material_bytes, size_t *workspace_bytes, size_t *device_free, size_t *device_total);
 
 /* ---- batched hot path.  mat == NULL: every unit uses single_id ---- */
 int mrl_eval_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,

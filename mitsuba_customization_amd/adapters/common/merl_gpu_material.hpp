@@ -16,6 +16,8 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -95,6 +97,41 @@ public:
 
     mrl_ctx *raw() const { return m_ctx; }
     std::mutex &mutex() { return m_mutex; }
+
+    // ---- table residency: one upload per (file, channel scales) and context, shared by every plugin instance that
+    // names it (two <bsdf> elements with the same .binary, unserialised copies on a worker, scene reloads); the
+    // table leaves HBM when the last instance dies (mrl_material_release).
+    struct Resident {
+        Context *owner;                                 // kept alive by the Material's shared_ptr<Context>
+        std::string key;
+        int id;
+        ~Resident()
+        {
+            std::lock_guard<std::mutex> call(owner->m_mutex);
+            auto it = owner->m_resident.find(key);      // a newer upload of the same key may already sit there: keep it
+            if (it != owner->m_resident.end() && it->second.expired()) owner->m_resident.erase(it);
+            mrl_material_release(owner->m_ctx, id);     // best effort in a destructor
+        }
+    };
+    // loader(ctx, &id) performs the upload when the key is not resident yet (called with the context mutex held)
+    template <typename Loader>
+    std::shared_ptr<Resident> acquire(const std::string &key, Loader &&loader, const char *what)
+    {
+        std::unique_lock<std::mutex> lock(m_mutex);
+        auto it = m_resident.find(key);
+        if (it != m_resident.end())
+            if (auto sp = it->second.lock()) return sp;
+        int id = -1;
+        check(m_ctx, loader(m_ctx, &id), what);
+        auto sp = std::shared_ptr<Resident>(new Resident{ this, key, id });
+        m_resident[key] = sp;
+        return sp;
+    }
+    size_t resident_tables()
+    {
+        std::lock_guard<std::mutex> lock(m_mutex);
+        return m_resident.size();
+    }
 
     // Post one scalar request and return when its outputs are filled in (throws what the round's call reported).
     // A GPU round lasts ~16 us, so a waiting thread spins for about that long before it sleeps on the condition
@@ -193,6 +230,7 @@ private:
     ContextKey m_key;
     mrl_ctx *m_ctx = nullptr;
     std::mutex m_mutex;                    // serialises calls into the (thread-compatible) C context
+    std::map<std::string, std::weak_ptr<Resident>> m_resident;     // guarded by m_mutex
     float *m_pin = nullptr;
     std::mutex m_post_mutex;               // guards the three members below
     std::condition_variable m_round_done;
@@ -200,27 +238,34 @@ private:
     std::atomic<bool> m_round_in_flight{ false };
 };
 
-// A material living on the GPU + the calls the plugin classes forward to.
+// Canonical name of a table file for the residency map: the resolved absolute path when the file exists.
+inline std::string canonical_path(const std::string &path)
+{
+    char buf[4096];
+    if (::realpath(path.c_str(), buf)) return std::string(buf);
+    return path;
+}
+
+// A material living on the GPU + the calls the plugin classes forward to.  Copies share the resident table.
 class Material {
 public:
     Material() = default;
-    Material(std::shared_ptr<Context> ctx, int id) : m_ctx(std::move(ctx)), m_id(id) {}
 
     static Material load_merl(const ContextKey &key, const std::string &path)
     {
         auto ctx = Context::get(key);
-        std::lock_guard<std::mutex> lock(ctx->mutex());
-        int id = -1;
-        check(ctx->raw(), mrl_material_load_merl(ctx->raw(), path.c_str(), &id), "mrl_material_load_merl");
-        return Material(ctx, id);
+        auto res = ctx->acquire("merl|" + canonical_path(path),
+                                [&](mrl_ctx *c, int *id) { return mrl_material_load_merl(c, path.c_str(), id); }, "mrl_material_load_merl");
+        return Material(ctx, res);
     }
     static Material load_table(const ContextKey &key, const std::string &path, const double scale[3])
     {
         auto ctx = Context::get(key);
-        std::lock_guard<std::mutex> lock(ctx->mutex());
-        int id = -1;
-        check(ctx->raw(), mrl_material_load_table(ctx->raw(), path.c_str(), scale, &id), "mrl_material_load_table");
-        return Material(ctx, id);
+        char sc[128];
+        std::snprintf(sc, sizeof sc, "|%.17g|%.17g|%.17g", scale[0], scale[1], scale[2]);
+        auto res = ctx->acquire("table|" + canonical_path(path) + sc,
+                                [&](mrl_ctx *c, int *id) { return mrl_material_load_table(c, path.c_str(), scale, id); }, "mrl_material_load_table");
+        return Material(ctx, res);
     }
 
     bool valid() const { return m_ctx && m_id >= 0; }
@@ -309,7 +354,12 @@ private:
         if (u) { r.u[0] = u[0]; r.u[1] = u[1]; }
     }
 
+    Material(std::shared_ptr<Context> ctx, std::shared_ptr<Context::Resident> res)
+        : m_ctx(std::move(ctx)), m_res(std::move(res)), m_id(m_res->id) {}
+
+    // declaration order = reverse destruction order: the resident handle (which calls into the context) dies first
     std::shared_ptr<Context> m_ctx;
+    std::shared_ptr<Context::Resident> m_res;
     int m_id = -1;
 };
 

@@ -13,6 +13,7 @@
 #ifdef MERL_USE_REAL_MITSUBA
 #include <mitsuba/render/bsdf.h>
 #include <mitsuba/core/properties.h>
+#include <mitsuba/core/fresolver.h>
 #else
 #include <mitsuba/mitsuba.h>
 #endif
@@ -26,7 +27,8 @@ class MeasuredBSDFBase : public BSDF, public BatchedBSDF {
 public:
     explicit MeasuredBSDFBase(const Properties &props) : BSDF(props)
     {
-        m_filename = props.getString("filename");
+        // scene-relative names resolve through the host's FileResolver, like every 0.6 plugin that reads a file
+        m_filename = Thread::getThread()->getFileResolver()->resolve(props.getString("filename")).string();
         m_key.device = props.getInteger("device", 0);
         m_key.lookup = merl_gpu::parse_lookup(props.getString("interpolation", "trilinear"));
         m_key.node = merl_gpu::parse_node(props.getString("node", "integer"));
@@ -38,7 +40,7 @@ public:
     // worker reloads the table from the same path onto ITS GPU, so the path must resolve there too.
     MeasuredBSDFBase(Stream *stream, InstanceManager *manager) : BSDF(stream, manager)
     {
-        m_filename = stream->readString();
+        m_filename = Thread::getThread()->getFileResolver()->resolve(stream->readString()).string();
         m_key.device = stream->readInt();
         m_key.lookup = stream->readInt();
         m_key.node = stream->readInt();

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <sstream>
 #include <stdexcept>
@@ -68,6 +70,54 @@ enum ETransportMode { ERadiance = 0, EImportance = 1 };
 
 class Sampler;
 class InstanceManager;
+
+// ---- FileResolver / Thread: how a 0.6 plugin turns the scene's "filename" into a path
+// (Thread::getThread()->getFileResolver()->resolve(name): the scene's directory and the data directories are
+// searched; an absolute or unresolvable name comes back unchanged) ----
+struct ResolvedPath {
+    std::string m_path;
+    const std::string &string() const { return m_path; }
+};
+class FileResolver {
+public:
+    // The real resolver is filled by the scene loader (the scene file's directory) and lives in the host's core
+    // library.  The mirror has no such library — every plugin .so carries its own copy — so its search path comes
+    // from the environment: MITSUBA_MIRROR_DATA_PATH = dir[:dir...] (what the test driver sets for "the scene's directory").
+    FileResolver()
+    {
+        if (const char *env = std::getenv("MITSUBA_MIRROR_DATA_PATH")) {
+            std::string all(env);
+            size_t a = 0;
+            while (a <= all.size()) {
+                const size_t b = all.find(':', a);
+                const std::string dir = all.substr(a, b == std::string::npos ? std::string::npos : b - a);
+                if (!dir.empty()) m_dirs.push_back(dir);
+                if (b == std::string::npos) break;
+                a = b + 1;
+            }
+        }
+    }
+    void appendPath(const std::string &dir) { m_dirs.push_back(dir); }
+    void prependPath(const std::string &dir) { m_dirs.insert(m_dirs.begin(), dir); }
+    ResolvedPath resolve(const std::string &name) const
+    {
+        if (!name.empty() && name[0] != '/')
+            for (const std::string &d : m_dirs) {
+                const std::string candidate = d + "/" + name;
+                if (FILE *f = std::fopen(candidate.c_str(), "rb")) { std::fclose(f); return { candidate }; }
+            }
+        return { name };
+    }
+private:
+    std::vector<std::string> m_dirs;
+};
+class Thread {
+public:
+    static Thread *getThread() { static Thread t; return &t; }
+    FileResolver *getFileResolver() { return &m_resolver; }
+private:
+    FileResolver m_resolver;
+};
 
 // ---- Stream: what serialize() writes to and the unserialising constructor reads from (network rendering
 // ships scene objects to worker nodes this way).  The mirror's stream is an in-memory byte queue. ----

@@ -9,9 +9,13 @@
 #ifdef MERL_USE_REAL_MITSUBA
 #include <mitsuba/render/bsdf.h>
 #include <mitsuba/core/properties.h>
+#include <mitsuba/core/fresolver.h>
+#include <mitsuba/core/thread.h>
 #else
 #include <mitsuba/mitsuba3.h>
 #endif
+
+#include <type_traits>
 
 #include "../common/batched_bsdf.hpp"
 #include "../common/merl_gpu_material.hpp"
@@ -27,9 +31,18 @@ public:
     using typename Base::SurfaceInteraction3f;
     using Mask = typename Base::Mask;
 
+    // Scalar variants only: one (wi, wo) per virtual call, Spectrum built from three floats.  Upstream's array
+    // variants (llvm_*, cuda_*) are Dr.Jit traces, which this build replaces by the BatchedBSDF entry points.
+    static_assert(std::is_floating_point<Float>::value,
+                  "merl / customized_measurement: scalar_rgb variants only; array variants go through BatchedBSDF");
+#ifdef MERL_USE_REAL_MITSUBA
+    static_assert(is_rgb_v<Spectrum>, "merl / customized_measurement return RGB coefficients: build an *_rgb variant");
+#endif
+
     explicit MeasuredBSDFBase(const Properties &props) : Base(props)
     {
-        m_filename = props.string("filename");
+        // scene-relative names resolve through the host's FileResolver, like upstream's `measured` plugin
+        m_filename = Thread::thread()->file_resolver()->resolve(props.string("filename")).string();
         m_key.device = props.template get<int>("device", 0);
         m_key.lookup = merl_gpu::parse_lookup(props.string("interpolation", "trilinear"));
         m_key.node = merl_gpu::parse_node(props.string("node", "integer"));

@@ -10,6 +10,8 @@
 // by the explicit wavefront entry points of BatchedBSDF (north_star: no Dr.Jit / LLVM / OptiX).
 #pragma once
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <sstream>
 #include <stdexcept>
@@ -104,6 +106,52 @@ private:
     std::string m_plugin;
     std::map<std::string, std::string> m_str;
     std::map<std::string, double> m_num;
+};
+
+// ---- FileResolver / Thread: Thread::thread()->file_resolver()->resolve(name), as Mitsuba 3 plugins do ----
+struct ResolvedPath {
+    std::string m_path;
+    const std::string &string() const { return m_path; }
+};
+class FileResolver {
+public:
+    // The real resolver is filled by the scene loader (the scene file's directory) and lives in the host's core
+    // library.  The mirror has no such library — every plugin .so carries its own copy — so its search path comes
+    // from the environment: MITSUBA_MIRROR_DATA_PATH = dir[:dir...] (what the test driver sets for "the scene's directory").
+    FileResolver()
+    {
+        if (const char *env = std::getenv("MITSUBA_MIRROR_DATA_PATH")) {
+            std::string all(env);
+            size_t a = 0;
+            while (a <= all.size()) {
+                const size_t b = all.find(':', a);
+                const std::string dir = all.substr(a, b == std::string::npos ? std::string::npos : b - a);
+                if (!dir.empty()) m_dirs.push_back(dir);
+                if (b == std::string::npos) break;
+                a = b + 1;
+            }
+        }
+    }
+    void append(const std::string &dir) { m_dirs.push_back(dir); }
+    void prepend(const std::string &dir) { m_dirs.insert(m_dirs.begin(), dir); }
+    ResolvedPath resolve(const std::string &name) const
+    {
+        if (!name.empty() && name[0] != '/')
+            for (const std::string &d : m_dirs) {
+                const std::string candidate = d + "/" + name;
+                if (FILE *f = std::fopen(candidate.c_str(), "rb")) { std::fclose(f); return { candidate }; }
+            }
+        return { name };
+    }
+private:
+    std::vector<std::string> m_dirs;
+};
+class Thread {
+public:
+    static Thread *thread() { static Thread t; return &t; }
+    FileResolver *file_resolver() { return &m_resolver; }
+private:
+    FileResolver m_resolver;
 };
 
 class Object {

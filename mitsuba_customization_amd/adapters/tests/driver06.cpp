@@ -3,6 +3,7 @@
 // MIPathTracer does (scalar virtual calls) and the way a wavefront host would (BatchedBSDF).
 //   driver06 <plugin.so> <table.binary> <pairs.bin> <out.bin> <n_scalar> [interpolation] [scaleR scaleG scaleB]
 //   driver06 --expect-no-device <plugin.so> <table.binary>
+//   driver06 <plugin.so> <table.binary> --residency <other_table.binary> [cycles]
 #include <dlfcn.h>
 
 #include <chrono>
@@ -42,6 +43,18 @@ int main(int argc, char **argv)
         }
         std::cerr << "constructor succeeded without a GPU?\n";
         return 4;
+    }
+    if (argc >= 4 && std::strcmp(argv[3], "--residency") == 0) {
+        if (argc < 5) { std::cerr << "usage\n"; return 2; }
+        const int cycles = argc > 5 ? atoi(argv[5]) : 50;
+        try {
+            return check_residency([&](int which) {
+                                       Properties q("bsdf");
+                                       q.setString("filename", which ? argv[4] : argv[2]);
+                                       BSDF *b = static_cast<BSDF *>(create(q)); b->incRef(); b->configure(); return b;
+                                   },
+                                   [](BSDF *b) { b->decRef(); }, cycles);
+        } catch (const std::exception &e) { std::cerr << "residency: " << e.what() << "\n"; return 25; }
     }
     if (argc < 6) { std::cerr << "usage\n"; return 2; }
     if (argc > 6) props.setString("interpolation", argv[6]);

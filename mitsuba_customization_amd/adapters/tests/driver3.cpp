@@ -40,6 +40,17 @@ int main(int argc, char **argv)
         }
         return 4;
     }
+    if (argc >= 5 && std::strcmp(argv[3], "--residency") == 0) {
+        const int cycles = argc > 5 ? atoi(argv[5]) : 50;
+        try {
+            return check_residency([&](int which) {
+                                       Properties q("bsdf");
+                                       q.set_string("filename", which ? argv[4] : argv[2]);
+                                       return static_cast<ScalarBSDF *>(create(q));
+                                   },
+                                   [](ScalarBSDF *b) { delete b; }, cycles);
+        } catch (const std::exception &e) { std::cerr << "residency: " << e.what() << "\n"; return 25; }
+    }
     if (argc < 6) { std::cerr << "usage\n"; return 2; }
     if (argc > 6) props.set_string("interpolation", argv[6]);
     if (argc > 9) { props.set_float("scale_r", atof(argv[7])); props.set_float("scale_g", atof(argv[8])); props.set_float("scale_b", atof(argv[9])); }

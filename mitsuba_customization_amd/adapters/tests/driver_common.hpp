@@ -2,6 +2,7 @@
 #pragma once
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -75,4 +76,52 @@ inline bool check_queue_call(const Wave *wave, const Pairs &p, const std::vector
     host_free(ctx, raw);
     destroy(ctx);
     return ok;
+}
+
+// Residency of plugin instances (--residency): two instances that name the same file share ONE resident table, and
+// create/destroy cycles return the device's free memory to where it started (mrl_material_release in the Material's
+// destructor).  make(which) builds a plugin instance over file 0 or file 1, drop() destroys it.  An instance of file 1
+// (the keeper) lives throughout, so the plugin's context stays and what is measured is the release of file 0's table,
+// not the teardown of the context.  Device memory is read through the libmerl_hip.so the plugin loaded (the driver
+// has no HIP of its own).
+template <typename Make, typename Drop>
+inline int check_residency(Make make, Drop drop, int cycles)
+{
+    void *lib = dlopen("libmerl_hip.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!lib) { std::fprintf(stderr, "libmerl_hip.so is not loaded: %s\n", dlerror()); return 20; }
+    struct mrl_ctx;
+    auto init = (int (*)(int, mrl_ctx **))dlsym(lib, "mrl_init");
+    auto destroy = (int (*)(mrl_ctx *))dlsym(lib, "mrl_destroy");
+    auto mem = (int (*)(const mrl_ctx *, size_t *, size_t *, size_t *, size_t *))dlsym(lib, "mrl_memory_info");
+    mrl_ctx *probe = nullptr;
+    if (!init || !destroy || !mem || init(0, &probe) != 0) return 20;
+    auto free_now = [&]() { size_t f = 0; mem(probe, nullptr, nullptr, &f, nullptr); return (long long)f; };
+    const long long slack = 8ll << 20;
+    auto *keeper = make(1);                                 // the plugin's context + the keeper's table
+    const long long with_keeper = free_now();
+    auto *first = make(0);
+    const long long with_one = free_now();
+    const long long table = with_keeper - with_one;         // what one resident table of file 0 costs
+    if (table < (16ll << 20)) { std::fprintf(stderr, "a table upload took only %lld bytes?\n", table); return 21; }
+    auto *second = make(0);                                 // same file: must share the resident table
+    if (with_one - free_now() > slack) { std::fprintf(stderr, "a second instance of the same file took %lld more bytes\n", with_one - free_now()); return 21; }
+    drop(second);
+    for (int c = 0; c < cycles; ++c) {                      // scene reloads while `first` lives: shared, nothing moves
+        auto *x = make(0);
+        drop(x);
+        if (with_one - free_now() > slack) { std::fprintf(stderr, "free memory sank by %lld bytes in shared cycle %d\n", with_one - free_now(), c); return 22; }
+    }
+    drop(first);                                            // last instance of file 0 gone: its table leaves HBM
+    if (with_keeper - free_now() > slack) { std::fprintf(stderr, "%lld bytes stayed resident after the last instance died\n", with_keeper - free_now()); return 23; }
+    for (int c = 0; c < cycles; ++c) {                      // now every cycle uploads and releases the table
+        auto *x = make(0);
+        if (with_keeper - free_now() < table - slack) { std::fprintf(stderr, "cycle %d: the table is not resident while its instance lives\n", c); return 24; }
+        drop(x);
+        if (with_keeper - free_now() > slack) { std::fprintf(stderr, "cycle %d: %lld bytes leaked\n", c, with_keeper - free_now()); return 24; }
+    }
+    drop(keeper);
+    destroy(probe);
+    std::printf("residency ok: %lld MB per table, two instances share it, %d shared + %d upload/release cycles leave free memory flat\n",
+                table >> 20, cycles, cycles);
+    return 0;
 }

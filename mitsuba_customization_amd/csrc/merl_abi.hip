@@ -24,6 +24,8 @@ struct MaterialHost {
     mrl::MaterialDev dev;
     float4 *d_texels = nullptr;
     double *d_sampling = nullptr;
+    size_t bytes = 0;                // device bytes this material holds (table + sampling marginal)
+    bool released = false;           // tombstone left by mrl_material_release; the slot may be reused
 };
 
 // Row marginal for table importance sampling (definition: oracle/merl_oracle.h):
@@ -82,6 +84,10 @@ struct mrl_ctx {
     std::vector<MaterialHost> materials;
     mrl::MaterialDev *d_materials = nullptr;
     size_t d_materials_cap = 0;
+    size_t material_bytes = 0;       // sum of MaterialHost::bytes over live materials
+    size_t memory_limit = 0;         // MRL_OPT_MEMORY_LIMIT_MB in bytes; 0 = none
+    // what a tombstone points at: one all-zero cell (valid in both layouts) + a 1-row sampling marginal
+    void *d_dummy = nullptr;
     mrl::Options opts{ 1, 0, 0, 0 };
     int kernel_variant = 3;          // MRL_OPT_KERNEL default: cooperative LDS-DMA brick fetch
     int table_layout = 1;            // layout of tables uploaded from now on (mrl::Layout)
@@ -105,6 +111,17 @@ int fail(mrl_ctx *ctx, int status, const std::string &msg)
         if (_e != hipSuccess) {                                                              \
             (void)hipGetLastError();                                                         \
             return fail((ctx), MRL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+        }                                                                                    \
+    } while (0)
+
+// an allocation: out-of-memory is its own status (MRL_ERR_OOM), everything else MRL_ERR_HIP
+#define MRL_ALLOC(ctx, expr)                                                                 \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            (void)hipGetLastError();                                                         \
+            return fail((ctx), _e == hipErrorOutOfMemory ? MRL_ERR_OOM : MRL_ERR_HIP,        \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                  \
         }                                                                                    \
     } while (0)
 
@@ -144,7 +161,7 @@ int sync_material_array(mrl_ctx *ctx)
         size_t cap = std::max<size_t>(16, ctx->d_materials_cap * 2);
         while (cap < n) cap *= 2;
         mrl::MaterialDev *fresh = nullptr;
-        MRL_HIP(ctx, hipMalloc((void **)&fresh, cap * sizeof(mrl::MaterialDev)));
+        MRL_ALLOC(ctx, hipMalloc((void **)&fresh, cap * sizeof(mrl::MaterialDev)));
         if (ctx->d_materials) {
             // in-flight launches may still read the old array
             MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -156,6 +173,66 @@ int sync_material_array(mrl_ctx *ctx)
     std::vector<mrl::MaterialDev> host(n);
     for (size_t i = 0; i < n; ++i) host[i] = ctx->materials[i].dev;
     MRL_HIP(ctx, hipMemcpy(ctx->d_materials, host.data(), n * sizeof(mrl::MaterialDev), hipMemcpyHostToDevice));
+    return MRL_OK;
+}
+
+// ---- material slots: budget, tombstones, slot reuse ----------------------------------------------------------------
+// A released slot keeps a valid descriptor — a 1x1x1 table of zeros — so that kernels which meet its id in a
+// material-id array read harmless memory; they treat kind == KIND_RELEASED like an unknown id (every output zero).
+int ensure_dummy(mrl_ctx *ctx)
+{
+    if (ctx->d_dummy) return MRL_OK;
+    const size_t bytes = 256 + 5 * sizeof(double);
+    MRL_ALLOC(ctx, hipMalloc(&ctx->d_dummy, bytes));
+    MRL_HIP(ctx, hipMemset(ctx->d_dummy, 0, bytes));
+    const double marginal[5] = { 0.0, 1.0, 0.0, 1.0, 0.0 };          // s[2] | cdf[2] | c[1]
+    MRL_HIP(ctx, hipMemcpy((char *)ctx->d_dummy + 256, marginal, sizeof marginal, hipMemcpyHostToDevice));
+    return MRL_OK;
+}
+
+mrl::MaterialDev tombstone_dev(const mrl_ctx *ctx)
+{
+    mrl::MaterialDev d;
+    std::memset(&d, 0, sizeof d);
+    d.kind = mrl::KIND_RELEASED;
+    d.n_th = d.n_td = d.n_pd = 1;
+    d.row_td = 2; d.row_th = 4;
+    d.texels = (const float4 *)ctx->d_dummy;
+    d.layout = ctx->table_layout;
+    d.sampling = (const double *)((const char *)ctx->d_dummy + 256);
+    return d;
+}
+
+// MRL_ERR_OOM when `need` more bytes of material data would exceed the context's budget or the device's free memory
+int budget_check(mrl_ctx *ctx, size_t need)
+{
+    if (ctx->memory_limit && ctx->material_bytes + need > ctx->memory_limit)
+        return fail(ctx, MRL_ERR_OOM, "material needs " + std::to_string(need >> 20) + " MiB: over the context's budget (" +
+                                      std::to_string(ctx->material_bytes >> 20) + " of " + std::to_string(ctx->memory_limit >> 20) + " MiB in use)");
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b)
+        return fail(ctx, MRL_ERR_OOM, "material needs " + std::to_string(need >> 20) + " MiB, the device has " + std::to_string(free_b >> 20) + " MiB free");
+    (void)hipGetLastError();
+    return MRL_OK;
+}
+
+// puts a finished material into the lowest released slot (or a new one) and refreshes the device array
+int place_material(mrl_ctx *ctx, const MaterialHost &m, int *out_id)
+{
+    size_t slot = ctx->materials.size();
+    for (size_t i = 0; i < ctx->materials.size(); ++i)
+        if (ctx->materials[i].released) { slot = i; break; }
+    const bool fresh = slot == ctx->materials.size();
+    MaterialHost previous;
+    if (fresh) ctx->materials.push_back(m);
+    else { previous = ctx->materials[slot]; ctx->materials[slot] = m; }
+    int rc = sync_material_array(ctx);
+    if (rc != MRL_OK) {
+        if (fresh) ctx->materials.pop_back(); else ctx->materials[slot] = previous;
+        return rc;
+    }
+    ctx->material_bytes += m.bytes;
+    *out_id = (int)slot;
     return MRL_OK;
 }
 
@@ -174,11 +251,17 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     const size_t plane = (size_t)n_th * n_td * n_pd;
     const int layout = ctx->table_layout;
     const size_t out_texels = layout == mrl::LAYOUT_BRICK ? plane * 8 : H * D * P;
+    const size_t sampling_doubles = 3 * (size_t)n_th + 2;
+    MaterialHost m;
+    m.bytes = out_texels * sizeof(float4) + sampling_doubles * sizeof(double);
+    // budget first: the resident image plus the transient planar copy the re-layout kernel reads
+    int rc = budget_check(ctx, m.bytes + 3 * plane * sizeof(double));
+    if (rc != MRL_OK) return rc;
     // the file payload goes to the device as it is; a kernel scales, clamps and re-lays it out
     double *d_planar = nullptr;
-    MaterialHost m;
-    MRL_HIP(ctx, hipMalloc((void **)&d_planar, 3 * plane * sizeof(double)));
+    MRL_ALLOC(ctx, hipMalloc((void **)&d_planar, 3 * plane * sizeof(double)));
     hipError_t e = hipMalloc((void **)&m.d_texels, out_texels * sizeof(float4));
+    const bool oom = e == hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMemcpyAsync(d_planar, planar, 3 * plane * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = mrl::launch_build_table(d_planar, dims, scale, layout, m.d_texels, ctx->compute_units, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -186,17 +269,18 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (m.d_texels) (void)hipFree(m.d_texels);
-        return fail(ctx, e == hipErrorOutOfMemory ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
+        return fail(ctx, oom ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
     }
     {
         const std::vector<double> sampling = build_sampling(planar, n_th, n_td, n_pd, scale);
         e = hipMalloc((void **)&m.d_sampling, sampling.size() * sizeof(double));
+        const bool oom2 = e == hipErrorOutOfMemory;
         if (e == hipSuccess) e = hipMemcpy(m.d_sampling, sampling.data(), sampling.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(m.d_texels);
             if (m.d_sampling) (void)hipFree(m.d_sampling);
-            return fail(ctx, MRL_ERR_HIP, std::string("sampling table upload: ") + hipGetErrorString(e));
+            return fail(ctx, oom2 ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("sampling table upload: ") + hipGetErrorString(e));
         }
     }
     std::memset(&m.dev, 0, sizeof m.dev);
@@ -207,10 +291,8 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     m.dev.row_th = (int)(D * P);
     m.dev.texels = m.d_texels;
     m.dev.layout = layout;
-    ctx->materials.push_back(m);
-    int rc = sync_material_array(ctx);
-    if (rc != MRL_OK) { ctx->materials.pop_back(); (void)hipFree(m.d_texels); (void)hipFree(m.d_sampling); return rc; }
-    *out_id = (int)ctx->materials.size() - 1;
+    rc = place_material(ctx, m, out_id);
+    if (rc != MRL_OK) { (void)hipFree(m.d_texels); (void)hipFree(m.d_sampling); return rc; }
     return MRL_OK;
 }
 
@@ -254,7 +336,7 @@ int ensure_stage(mrl_ctx *ctx, size_t units)
 {
     if (units <= ctx->d_stage_units) return MRL_OK;
     if (ctx->d_stage) { MRL_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_stage); ctx->d_stage = nullptr; ctx->d_stage_units = 0; }
-    MRL_HIP(ctx, hipMalloc(&ctx->d_stage, units * 80));
+    MRL_ALLOC(ctx, hipMalloc(&ctx->d_stage, units * 80));
     ctx->d_stage_units = units;
     return MRL_OK;
 }
@@ -282,7 +364,7 @@ int ensure_queues(mrl_ctx *ctx, size_t units)
         (void)hipFree(ctx->d_queues);
         ctx->d_queues = nullptr; ctx->queue_cap = 0;
     }
-    MRL_HIP(ctx, hipMalloc((void **)&ctx->d_queues, (2 * units + 4 * kMaxSegments + 2) * sizeof(uint32_t)));
+    MRL_ALLOC(ctx, hipMalloc((void **)&ctx->d_queues, (2 * units + 4 * kMaxSegments + 2) * sizeof(uint32_t)));
     ctx->queue_cap = units;
     return MRL_OK;
 }
@@ -307,9 +389,11 @@ DeviceCall device_call(const mrl_ctx *ctx, const BatchCall &c)
     if (!d.multi) a.single = ctx->materials[(size_t)c.single_id].dev;
     d.has_ggx = d.has_table = false;
     for (const auto &m : ctx->materials) {
+        if (m.released) continue;
         d.has_ggx = d.has_ggx || m.dev.kind == mrl::KIND_GGX;
         d.has_table = d.has_table || m.dev.kind != mrl::KIND_GGX;
     }
+    if (!d.has_ggx && !d.has_table) d.has_table = true;        // only tombstones left: the table path renders them as zeros
     return d;
 }
 
@@ -322,7 +406,7 @@ int check_call(mrl_ctx *ctx, const BatchCall &c)
         (has_sample && (!c.out_wo || !c.out_pdf2 || !c.out_weight)))
         return fail(ctx, MRL_ERR_INVALID, "null array argument");
     if (ctx->materials.empty()) return fail(ctx, MRL_ERR_MATERIAL, "no material loaded");
-    if (!c.mat && (c.single_id < 0 || (size_t)c.single_id >= ctx->materials.size()))
+    if (!c.mat && (c.single_id < 0 || (size_t)c.single_id >= ctx->materials.size() || ctx->materials[(size_t)c.single_id].released))
         return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
     return MRL_OK;
 }
@@ -489,6 +573,7 @@ int mrl_destroy(mrl_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &m : ctx->materials) { if (m.d_texels) (void)hipFree(m.d_texels); if (m.d_sampling) (void)hipFree(m.d_sampling); }
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
+    if (ctx->d_dummy) (void)hipFree(ctx->d_dummy);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_queues) (void)hipFree(ctx->d_queues);
     if (ctx->d_part_work) (void)hipFree(ctx->d_part_work);
@@ -507,15 +592,17 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
         case MRL_OPT_NODE:     if (value < 0 || value > 1) break; ctx->opts.node = value; return MRL_OK;
         case MRL_OPT_DISK_MAP: if (value < 0 || value > 1) break; ctx->opts.disk_map = value; return MRL_OK;
         case MRL_OPT_SAMPLING: if (value < 0 || value > 1) break; ctx->opts.sampling = value; return MRL_OK;
-        case MRL_OPT_KERNEL:   if (value < 0) break; ctx->kernel_variant = value; return MRL_OK;
+        case MRL_OPT_KERNEL:   if (value < 0 || value > 4) break; ctx->kernel_variant = value; return MRL_OK;
+        case MRL_OPT_MEMORY_LIMIT_MB: if (value < 0) break; ctx->memory_limit = (size_t)value << 20; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: if (value < 1) break; ctx->host_chunk = (size_t)value; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: {
             if (value < 0 || value > 1) break;
             if (value != ctx->table_layout)
                 for (const auto &m : ctx->materials)
-                    if (m.dev.kind != mrl::KIND_GGX) return fail(ctx, MRL_ERR_INVALID, "table layout is context-wide: set it before the first table is uploaded");
+                    if (!m.released && m.dev.kind != mrl::KIND_GGX) return fail(ctx, MRL_ERR_INVALID, "table layout is context-wide: set it before the first table is uploaded");
             ctx->table_layout = value;
-            return MRL_OK;
+            for (auto &m : ctx->materials) if (m.released) m.dev.layout = value;    // tombstones follow (valid in both layouts)
+            return ctx->materials.empty() ? MRL_OK : sync_material_array(ctx);
         }
     }
     return fail(ctx, MRL_ERR_INVALID, "bad option or value");
@@ -530,6 +617,7 @@ int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
         case MRL_OPT_DISK_MAP: *value = ctx->opts.disk_map; return MRL_OK;
         case MRL_OPT_SAMPLING: *value = ctx->opts.sampling; return MRL_OK;
         case MRL_OPT_KERNEL: *value = ctx->kernel_variant; return MRL_OK;
+        case MRL_OPT_MEMORY_LIMIT_MB: *value = (int)(ctx->memory_limit >> 20); return MRL_OK;
         case MRL_OPT_HOST_CHUNK: *value = (int)ctx->host_chunk; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: *value = ctx->table_layout; return MRL_OK;
     }
@@ -605,10 +693,46 @@ int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float 
     m.dev.kind = mrl::KIND_GGX;
     m.dev.alpha = (double)alpha;
     for (int c = 0; c < 3; ++c) { m.dev.eta[c] = (double)eta[c]; m.dev.k[c] = (double)k[c]; }
-    ctx->materials.push_back(m);
-    int rc = sync_material_array(ctx);
-    if (rc != MRL_OK) { ctx->materials.pop_back(); return rc; }
-    *out_id = (int)ctx->materials.size() - 1;
+    return place_material(ctx, m, out_id);
+}
+
+int mrl_material_release(mrl_ctx *ctx, int id)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released)
+        return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_dummy(ctx);
+    if (rc != MRL_OK) return rc;
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));             // launches in flight may still read the table
+    MaterialHost &m = ctx->materials[(size_t)id];
+    const MaterialHost before = m;
+    m.dev = tombstone_dev(ctx);
+    m.released = true;
+    rc = sync_material_array(ctx);                               // the device array must stop naming the table first
+    if (rc != MRL_OK) { m = before; return rc; }
+    if (before.d_texels) (void)hipFree(before.d_texels);
+    if (before.d_sampling) (void)hipFree(before.d_sampling);
+    m.d_texels = nullptr; m.d_sampling = nullptr;
+    ctx->material_bytes -= before.bytes;
+    m.bytes = 0;
+    return MRL_OK;
+}
+
+int mrl_memory_info(const mrl_ctx *ctx, size_t *material_bytes, size_t *workspace_bytes, size_t *device_free, size_t *device_total)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    if (material_bytes) *material_bytes = ctx->material_bytes;
+    if (workspace_bytes)
+        *workspace_bytes = ctx->d_stage_units * 80 + (ctx->queue_cap ? (2 * ctx->queue_cap + 4 * kMaxSegments + 2) * sizeof(uint32_t) : 0) +
+                           ctx->part_work_cap * sizeof(uint32_t) + ctx->d_materials_cap * sizeof(mrl::MaterialDev) +
+                           (ctx->d_dummy ? 256 + 5 * sizeof(double) : 0);
+    if (device_free || device_total) {
+        size_t f = 0, t = 0;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); return MRL_ERR_HIP; }
+        if (device_free) *device_free = f;
+        if (device_total) *device_total = t;
+    }
     return MRL_OK;
 }
 
@@ -617,7 +741,7 @@ int mrl_material_count(const mrl_ctx *ctx) { return ctx ? (int)ctx->materials.si
 int mrl_material_info(const mrl_ctx *ctx, int id, int *kind, int dims[3])
 {
     if (!ctx) return MRL_ERR_INVALID;
-    if (id < 0 || (size_t)id >= ctx->materials.size()) return MRL_ERR_MATERIAL;
+    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return MRL_ERR_MATERIAL;
     const mrl::MaterialDev &d = ctx->materials[(size_t)id].dev;
     if (kind) *kind = d.kind;
     if (dims) { dims[0] = d.n_th; dims[1] = d.n_td; dims[2] = d.n_pd; }
@@ -677,7 +801,7 @@ int mrl_partition_by_material(mrl_ctx *ctx, const int32_t *mat, size_t n, uint32
     const size_t need = (size_t)chunks * K + K;
     if (need > ctx->part_work_cap) {
         if (ctx->d_part_work) { MRL_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_part_work); ctx->d_part_work = nullptr; ctx->part_work_cap = 0; }
-        MRL_HIP(ctx, hipMalloc((void **)&ctx->d_part_work, need * sizeof(uint32_t)));
+        MRL_ALLOC(ctx, hipMalloc((void **)&ctx->d_part_work, need * sizeof(uint32_t)));
         ctx->part_work_cap = need;
     }
     MRL_HIP(ctx, mrl::launch_partition_materials(mat, n, K, queue_out, offsets_out, counts_out, ctx->d_part_work, chunks, chunk_len,
@@ -745,7 +869,7 @@ int mrl_device_alloc(mrl_ctx *ctx, size_t bytes, void **out)
 {
     if (!ctx || !out) return MRL_ERR_INVALID;
     MRL_HIP(ctx, hipSetDevice(ctx->device));
-    MRL_HIP(ctx, hipMalloc(out, bytes ? bytes : 1));
+    MRL_ALLOC(ctx, hipMalloc(out, bytes ? bytes : 1));
     return MRL_OK;
 }
 
@@ -781,7 +905,7 @@ int mrl_host_alloc(mrl_ctx *ctx, size_t bytes, void **out)
 {
     if (!ctx || !out) return MRL_ERR_INVALID;
     MRL_HIP(ctx, hipSetDevice(ctx->device));
-    MRL_HIP(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable));
+    MRL_ALLOC(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable));
     return MRL_OK;
 }
 

@@ -21,7 +21,8 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kHalfPi = 1.57079632679489661923;
 constexpr float kInvPiF = 0.31830988618379067154f;
 
-enum Kind : int { KIND_MERL = 0, KIND_TABLE = 1, KIND_GGX = 2 };
+enum Kind : int { KIND_MERL = 0, KIND_TABLE = 1, KIND_GGX = 2,
+                  KIND_RELEASED = 3 };   // tombstone of mrl_material_release: a valid 1x1x1 zero table, treated like an unknown id
 enum Layout : int { LAYOUT_ROWS = 0, LAYOUT_BRICK = 1 };
 
 // One material as the kernels see it (array in device memory; single-material launches get it

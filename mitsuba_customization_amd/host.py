@@ -15,18 +15,19 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRL_LIB_PATH") or os.path.join(_PKG, "lib", "libmerl_hip.so")   # env override: A/B builds
 
-OPT_LOOKUP, OPT_NODE, OPT_DISK_MAP, OPT_KERNEL, OPT_HOST_CHUNK, OPT_TABLE_LAYOUT, OPT_SAMPLING = 0, 1, 2, 3, 4, 5, 6
+OPT_LOOKUP, OPT_NODE, OPT_DISK_MAP, OPT_KERNEL, OPT_HOST_CHUNK, OPT_TABLE_LAYOUT, OPT_SAMPLING, OPT_MEMORY_LIMIT_MB = 0, 1, 2, 3, 4, 5, 6, 7
 SAMPLING_COSINE, SAMPLING_TABLE = 0, 1
 LAYOUT_ROWS, LAYOUT_BRICK = 0, 1
 LOOKUP_NEAREST, LOOKUP_TRILINEAR = 0, 1
 KIND_MERL, KIND_TABLE, KIND_GGX = 0, 1, 2
+ERR_INVALID, ERR_HIP, ERR_IO, ERR_FORMAT, ERR_OOM, ERR_MATERIAL, ERR_POINTER_MIX, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7, -8
 
 # every symbol include/merl_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "mrl_init", "mrl_destroy", "mrl_strerror", "mrl_last_error", "mrl_set_option", "mrl_get_option",
     "mrl_set_stream", "mrl_reset_stream", "mrl_synchronize", "mrl_device_info",
     "mrl_material_load_merl", "mrl_material_upload_f64", "mrl_material_upload_table", "mrl_material_load_table",
-    "mrl_material_ggx", "mrl_material_count", "mrl_material_info",
+    "mrl_material_ggx", "mrl_material_count", "mrl_material_info", "mrl_material_release", "mrl_memory_info",
     "mrl_eval_batch", "mrl_pdf_batch", "mrl_sample_batch", "mrl_eval_pdf_batch", "mrl_eval_sample_batch",
     "mrl_partition_by_material", "mrl_eval_queue", "mrl_pdf_queue", "mrl_eval_pdf_queue", "mrl_sample_queue", "mrl_eval_sample_queue",
     "mrl_generate_pairs", "mrl_generate_materials",
@@ -84,6 +85,8 @@ def load_library(path: Optional[str] = None):
     L.mrl_material_ggx.argtypes = [vp, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.mrl_material_count.argtypes = [vp]
     L.mrl_material_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mrl_material_release.argtypes = [vp, C.c_int]
+    L.mrl_memory_info.argtypes = [vp] + [C.POINTER(C.c_size_t)] * 4
     L.mrl_eval_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp]
     L.mrl_pdf_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp]
     L.mrl_partition_by_material.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
@@ -240,6 +243,15 @@ class MerlHip:
         kind = C.c_int(); dims = (C.c_int * 3)()
         self._check(self._lib.mrl_material_info(self._ctx, mid, C.byref(kind), dims), "mrl_material_info")
         return kind.value, tuple(dims)
+
+    def release_material(self, mid: int):
+        """Frees the material's device memory; its id becomes a tombstone (batch calls render it as zeros)."""
+        self._check(self._lib.mrl_material_release(self._ctx, mid), "mrl_material_release")
+
+    def memory_info(self) -> dict:
+        v = [C.c_size_t() for _ in range(4)]
+        self._check(self._lib.mrl_memory_info(self._ctx, *[C.byref(x) for x in v]), "mrl_memory_info")
+        return {"table_bytes": v[0].value, "workspace_bytes": v[1].value, "device_free": v[2].value, "device_total": v[3].value}
 
     # ---- batches ----
     def _empty(self, like, shape):

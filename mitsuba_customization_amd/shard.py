@@ -42,6 +42,78 @@ def _world(group=None) -> Tuple[int, int]:
     return 1, 0
 
 
+def _peer(group, r: int) -> int:
+    """P2POp addresses peers by GLOBAL rank; tiles are numbered by group rank."""
+    return dist.get_global_rank(group, r) if group is not None else r
+
+
+def _backend_moves_device_tensors(group=None) -> bool:
+    """RCCL ("nccl") moves device tensors itself; gloo's point-to-point only takes host memory."""
+    return dist.get_backend(group) == "nccl"
+
+
+class _Posted:
+    """One chunk's point-to-point messages in flight.  `tensors` keeps the buffers alive until wait()."""
+
+    def __init__(self, works, tensors, after=None):
+        self.works, self.tensors, self.after = works, tensors, after
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        if self.after is not None:
+            self.after()
+        self.tensors = None
+
+
+def _post(specs, group, comm_stream=None, ready=None) -> _Posted:
+    """Posts one group of point-to-point messages.  specs: [("send" | "recv", tensor, group rank of the peer)].
+
+    Host tensors, or device tensors over RCCL: the tensors go to batch_isend_irecv as they are (one grouped
+    ncclSend/ncclRecv set: every peer uses its own xGMI link to the root), issued on `comm_stream` behind the `ready`
+    event when given, so the messages of chunk k overlap the compute of chunk k+1.
+    Device tensors over a host-only backend (gloo rehearsal, ranks sharing one GPU): staged through pinned host
+    buffers on the same side stream — send: D2H copy behind `ready`, then the host message; recv: host message,
+    then an H2D copy into the destination slice when the message is waited for."""
+    if not specs:
+        return _Posted([], [])
+    device = specs[0][1].is_cuda
+    if not device or _backend_moves_device_tensors(group):
+        ops = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, _peer(group, peer), group) for kind, t, peer in specs]
+        if device and comm_stream is not None:
+            with torch.cuda.stream(comm_stream):
+                if ready is not None:
+                    comm_stream.wait_event(ready)
+                return _Posted(dist.batch_isend_irecv(ops), [t for _, t, _ in specs])
+        return _Posted(dist.batch_isend_irecv(ops), [t for _, t, _ in specs])
+    # staged path
+    stream = comm_stream if comm_stream is not None else torch.cuda.current_stream()
+    staged, ops = [], []
+    with torch.cuda.stream(stream):
+        if ready is not None:
+            stream.wait_event(ready)
+        for kind, t, peer in specs:
+            h = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+            if kind == "send":
+                h.copy_(t, non_blocking=True)
+            staged.append((kind, t, h))
+            ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, h, _peer(group, peer), group))
+        copied = torch.cuda.Event()
+        copied.record(stream)
+    copied.synchronize()                                     # the host message reads the pinned buffers
+
+    def land():
+        with torch.cuda.stream(stream):
+            for kind, t, h in staged:
+                if kind == "recv":
+                    t.copy_(h, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(stream)
+        done.synchronize()                                   # pinned buffers may be dropped after this
+
+    return _Posted(dist.batch_isend_irecv(ops), staged, after=land)
+
+
 def gather_tiles(local: Sequence[torch.Tensor], n_total: int, dst: int = 0, group=None,
                  out: Optional[Sequence[torch.Tensor]] = None) -> Optional[List[torch.Tensor]]:
     """Gathers per-rank tile arrays (first dim = units of the rank's tile, in tile_bounds order) to
@@ -56,7 +128,7 @@ def gather_tiles(local: Sequence[torch.Tensor], n_total: int, dst: int = 0, grou
         return [t for t in local]
     if rank == dst:
         full = list(out) if out is not None else [torch.empty((n_total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in local]
-        ops = []
+        specs = []
         for peer in range(world):
             plo, phi = tile_bounds(n_total, world, peer)
             if phi == plo:
@@ -65,16 +137,24 @@ def gather_tiles(local: Sequence[torch.Tensor], n_total: int, dst: int = 0, grou
                 if peer == dst:
                     full[k][plo:phi].copy_(t)
                 else:
-                    ops.append(dist.P2POp(dist.irecv, full[k][plo:phi], peer, group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+                    specs.append(("recv", full[k][plo:phi], peer))
+        _post(specs, group).wait()
         return full
     if hi > lo:
-        ops = [dist.P2POp(dist.isend, t.contiguous(), dst, group) for t in local]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        _post([("send", t.contiguous(), dst) for t in local], group).wait()
     return None
+
+
+def _agree_on_layout(outs, n_total: int, world: int, dst: int, group) -> List[tuple]:
+    """(trailing shape, dtype, device) of every output array, known on the root even when its own tile is empty
+    (n_total < world with dst != 0): group rank 0 always owns a non-empty tile and tells everyone."""
+    dlo, dhi = tile_bounds(n_total, world, dst)
+    if dhi > dlo:
+        return [(tuple(t.shape[1:]), t.dtype, t.device) for t in outs] if outs is not None else []
+    meta = [[(tuple(t.shape[1:]), str(t.dtype).split(".")[-1], t.is_cuda) for t in outs]] if outs is not None else [None]
+    dist.broadcast_object_list(meta, src=_peer(group, 0), group=group)
+    here = torch.device("cuda", torch.cuda.current_device()) if (meta[0] and meta[0][0][2]) else torch.device("cpu")
+    return [(tuple(tail), getattr(torch, dt), here) for tail, dt, _ in meta[0]]
 
 
 def run_sharded(compute: Callable[[int, int], Sequence[torch.Tensor]], n_total: int, chunk: int,
@@ -94,34 +174,32 @@ def run_sharded(compute: Callable[[int, int], Sequence[torch.Tensor]], n_total: 
     is_root = rank == dst
     full: Optional[List[torch.Tensor]] = None
     tile_out: List[List[torch.Tensor]] = []
-    pending = []          # (works, keepalive tensors)
-    use_cuda = False      # decided by the first chunk's tensors: overlap on a side stream only for device arrays
+    pending: List[_Posted] = []
     comm_stream = None
 
     def drain(keep: int):
         while len(pending) > keep:
-            works, _keep = pending.pop(0)
-            for w in works:
-                w.wait()
+            pending.pop(0).wait()
 
     for c in range(steps):
         a, b = min(hi, lo + c * chunk), min(hi, lo + (c + 1) * chunk)
         outs = [t for t in compute(a, b)] if b > a else None
-        if outs is not None and comm_stream is None and overlap and world > 1 and gather and outs[0].is_cuda:
-            use_cuda = True
-            comm_stream = torch.cuda.Stream()
         if not gather or world == 1:
             if outs is not None:
                 tile_out.append(outs)
             continue
+        if c == 0:
+            layout = _agree_on_layout(outs, n_total, world, dst, group)
+            if is_root:
+                full = [torch.empty((n_total,) + tail, dtype=dt, device=dev) for tail, dt, dev in layout]
+            if overlap and layout and layout[0][2].type == "cuda":
+                comm_stream = torch.cuda.Stream()
         ready = None
-        if use_cuda:
+        if comm_stream is not None and outs is not None:
             ready = torch.cuda.Event()
             ready.record()
         if is_root:
-            if full is None and outs is not None:
-                full = [torch.empty((n_total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in outs]
-            ops = []
+            specs = []
             for peer in range(world):
                 plo, phi = tile_bounds(n_total, world, peer)
                 pa, pb = min(phi, plo + c * chunk), min(phi, plo + (c + 1) * chunk)
@@ -132,31 +210,22 @@ def run_sharded(compute: Callable[[int, int], Sequence[torch.Tensor]], n_total: 
                         full[k][pa:pb].copy_(t)
                 else:
                     for k in range(len(full)):
-                        ops.append(dist.P2POp(dist.irecv, full[k][pa:pb], peer, group))
-            if ops:
-                if use_cuda:
-                    with torch.cuda.stream(comm_stream):
-                        comm_stream.wait_event(ready)
-                        pending.append((dist.batch_isend_irecv(ops), outs))
-                else:
-                    pending.append((dist.batch_isend_irecv(ops), outs))
+                        specs.append(("recv", full[k][pa:pb], peer))
+            if specs:
+                pending.append(_post(specs, group, comm_stream, ready))
         elif outs is not None:
-            ops = [dist.P2POp(dist.isend, t.contiguous(), dst, group) for t in outs]
-            if use_cuda:
-                with torch.cuda.stream(comm_stream):
-                    comm_stream.wait_event(ready)
-                    pending.append((dist.batch_isend_irecv(ops), outs))
-            else:
-                pending.append((dist.batch_isend_irecv(ops), outs))
+            pending.append(_post([("send", t.contiguous(), dst) for t in outs], group, comm_stream, ready))
         drain(keep=1)         # at most one chunk of messages in flight behind the compute
     drain(keep=0)
-    if use_cuda:
+    if comm_stream is not None:
         torch.cuda.current_stream().wait_stream(comm_stream)
 
     if not gather or world == 1:
         if not tile_out:
             return []
         return [torch.cat([o[k] for o in tile_out], dim=0) for k in range(len(tile_out[0]))]
+    if is_root and full is None:
+        return []                                            # n_total == 0
     return full if is_root else None
 
 

@@ -25,6 +25,7 @@ int mrl_host_alloc(mrl_ctx *, size_t bytes, void **out) { *out = std::malloc(byt
 int mrl_host_free(mrl_ctx *, void *p) { std::free(p); return MRL_OK; }
 int mrl_material_load_merl(mrl_ctx *c, const char *, int *id) { *id = c->materials++; return MRL_OK; }
 int mrl_material_load_table(mrl_ctx *c, const char *, const double *, int *id) { *id = c->materials++; return MRL_OK; }
+int mrl_material_release(mrl_ctx *, int) { return MRL_OK; }
 int mrl_synchronize(mrl_ctx *) { return MRL_OK; }
 int mrl_eval_sample_batch(mrl_ctx *c, const float *wi, const float *wo, const float *u, const int32_t *mat, int32_t, size_t n,
                           float *rgb, float *pdf, float *wo2, float *pdf2, float *w)

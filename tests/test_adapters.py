@@ -152,6 +152,41 @@ def test_plugin_table_sampling_property(built, merl_file, oracle, tables, tmp_pa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("host", ["06", "3"])
+def test_plugin_instances_share_one_resident_table_and_release_it(built, merl_file, tables, tmp_path, host):
+    """Two <bsdf> elements naming the same .binary hold ONE table in HBM; 50 create/destroy cycles leave free memory flat."""
+    other = str(tmp_path / "other.binary")
+    synth.write_merl_binary(other, tables("ggx_tab", 1))
+    drv = os.path.join(built, "driver06" if host == "06" else "driver3")
+    plug = os.path.join(built, "plugins06" if host == "06" else "plugins3", "merl.so")
+    r = subprocess.run([drv, plug, merl_file, "--residency", other, "50"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "residency ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("host", ["06", "3"])
+def test_plugin_resolves_scene_relative_filename(built, merl_file, oracle, tmp_path, host):
+    """filename="synthetic_ggx_tab.binary" + the scene's directory on the host's FileResolver search path."""
+    n, m = 2000, 20
+    wi, wo, u = oracle.generate_pairs(0x5EED, 1, n)
+    pairs, out_rel, out_abs = str(tmp_path / "pairs.bin"), str(tmp_path / "rel.bin"), str(tmp_path / "abs.bin")
+    _write_pairs(pairs, wi, wo, u)
+    drv = os.path.join(built, "driver06" if host == "06" else "driver3")
+    plug = os.path.join(built, "plugins06" if host == "06" else "plugins3", "merl.so")
+    env = dict(os.environ, MITSUBA_MIRROR_DATA_PATH="/nonexistent-dir:" + os.path.dirname(merl_file))
+    r = subprocess.run([drv, plug, os.path.basename(merl_file), pairs, out_rel, str(m)], capture_output=True, text=True, timeout=300,
+                       env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([drv, plug, merl_file, pairs, out_abs, str(m)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert open(out_rel, "rb").read() == open(out_abs, "rb").read()
+    # without the search path the relative name does not resolve: the constructor reports the I/O error
+    r = subprocess.run([drv, plug, os.path.basename(merl_file), pairs, out_rel, str(m)], capture_output=True, text=True, timeout=120,
+                       cwd=str(tmp_path))
+    assert r.returncode == 5 and "cannot open" in r.stderr
+
+
+@pytest.mark.gpu
 def test_c99_example_runs(built, merl_file):
     """examples/abi_example.c: the ABI from plain C — pinned zero-copy vs staged host path, error codes."""
     r = subprocess.run([os.path.join(built, "abi_example"), merl_file], capture_output=True, text=True, timeout=300)

@@ -97,3 +97,49 @@ def test_gloo_gather_is_bit_identical_to_single_process(tmp_path, world, n_total
     result = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(world, _free_port(), n_total, chunk, result), nprocs=world, join=True)
     assert open(result).read() == "ok"
+
+
+def _edge_worker(rank, world, port, result_path):
+    """ADVICE r1: (a) the root owns an EMPTY tile (n_total < world, dst != 0): it still has to allocate the full arrays;
+    (b) a non-default group: tiles are numbered by group rank, messages addressed by global rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def compute(lo, hi):
+            i = torch.arange(lo, hi, dtype=torch.float32)
+            return [torch.stack([i, 2 * i, 3 * i], 1), (i + 0.5).to(torch.float64)]
+        ok = True
+        # (a) 2 units over 3 ranks, gathered to rank 2 whose tile is empty
+        full = shard.run_sharded(compute, 2, 64, gather=True, dst=2)
+        if rank == 2:
+            ref = compute(0, 2)
+            ok = ok and full is not None and all(torch.equal(a, b) and a.dtype == b.dtype for a, b in zip(full, ref))
+        else:
+            ok = ok and full is None
+        # nothing at all
+        assert shard.run_sharded(compute, 0, 64, gather=True, dst=1) in ([], None)
+        # (b) sub-group {1, 2}: group rank 0 = global rank 1 is the root
+        sub = dist.new_group(ranks=[1, 2])
+        if rank in (1, 2):
+            full = shard.run_sharded(compute, 777, 100, gather=True, dst=0, group=sub)
+            tile = compute(*shard.tile_bounds(777, 2, rank - 1))
+            full2 = shard.gather_tiles(tile, 777, dst=0, group=sub)
+            if rank == 1:
+                ref = compute(0, 777)
+                ok = ok and all(torch.equal(a, b) for a, b in zip(full, ref)) and all(torch.equal(a, b) for a, b in zip(full2, ref))
+            else:
+                ok = ok and full is None and full2 is None
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            open(result_path, "w").write("ok" if int(flag) == 1 else "mismatch")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_empty_root_tile_and_subgroup(tmp_path):
+    result = str(tmp_path / "edge.txt")
+    mp.spawn(_edge_worker, args=(3, _free_port(), result), nprocs=3, join=True)
+    assert open(result).read() == "ok"
