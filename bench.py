@@ -99,6 +99,10 @@ def parse(argv=None):
                    help="control-plane backend; gloo only rehearses the multi-rank logic (ranks may then share one GPU: --share-gpu)")
     p.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     p.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the child ranks are killed")
+    p.add_argument("--no-native-group", action="store_true",
+                   help="N>1: skip the separately reported run of the native C++ host (lib/group_host: one process, mrl_group over the N GPUs, RCCL gather)")
+    p.add_argument("--native-units", type=int, default=8 << 20, help="N>1: units per device of the native C++ host's run")
+    p.add_argument("--native-deadline", type=float, default=240.0, help="N>1: seconds before the native C++ host is killed")
     return p.parse_args(argv)
 
 
@@ -159,6 +163,32 @@ def self_launch(args) -> int:
         sys.stderr.write("bench.py: the ranks exited 0 but rank 0 printed no bench line\n")
         return 1
     return rc
+
+
+def native_group_leg(n_gpus: int, share_gpu: bool, units: int, deadline: float) -> dict:
+    """The native multi-device host path on the same GPUs, reported beside `value`: examples/group_host.cpp (plain C++
+    over mrl_group_*, no Python in it) runs as a CHILD process after this job's ranks have released their GPUs —
+    replicated tables, tiles generated in place, sharded eval+sample with the chunk-pipelined result gather (RCCL
+    point-to-point when the devices are distinct), checked inside the program against a single-device run."""
+    import subprocess
+    exe = os.path.join(ROOT, "mitsuba_customization_amd", "lib", "group_host")
+    if not os.path.exists(exe):
+        return {"skipped": "lib/group_host is not built"}
+    devices = ",".join("0" if share_gpu else str(i) for i in range(n_gpus))
+    cmd = [exe, "--devices", devices, "--units-per-device", str(units), "--chunk", str(max(1, units // 4)),
+           "--steps", "3", "--warmup", "1", "--check"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=deadline)
+    except subprocess.TimeoutExpired:
+        return {"failed": f"lib/group_host did not finish within {deadline} s and was killed", "cmd": " ".join(cmd)}
+    except Exception as e:
+        return {"failed": repr(e), "cmd": " ".join(cmd)}
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"failed": f"exit code {r.returncode}", "stderr": r.stderr[-400:], "cmd": " ".join(cmd)}
+    out = json.loads(line[-1])
+    out["cmd"] = " ".join(cmd)
+    return out
 
 
 def cpu_baseline(ob, table, lookup: int, reps: int) -> dict:
@@ -455,17 +485,24 @@ def main():
         finished.set()
         watchdog.cancel()
 
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    printed = {"done": False}
+
+    def emit():
+        if rank == 0 and not printed["done"]:
+            printed["done"] = True
+            print(json.dumps(result), flush=True)
 
     if use_pg:
         if exit_code:
+            emit()
             os._exit(exit_code)                             # peers may be stuck in the leg: no collective teardown
         # teardown under a deadline as well; a stall here is a failure, not a clean run
         import threading
 
         def teardown_stalled():
             sys.stderr.write(f"bench.py: rank {rank}: teardown (barrier / destroy_process_group) stalled for 60 s\n")
+            result["teardown"] = {"failed": "barrier / destroy_process_group stalled for 60 s"}
+            emit()
             os._exit(EXIT_GATHER_FAILED)
 
         bye = threading.Timer(60.0, teardown_stalled)
@@ -477,6 +514,13 @@ def main():
         bye.cancel()
     else:
         gpu.close()
+
+    # ---- N>1: the native C++ host over the same GPUs, once every rank has let go of them; beside `value`, never in it ----
+    if rank == 0 and world > 1 and not args.no_native_group:
+        del wi, wo, u, out, mat
+        torch.cuda.empty_cache()
+        result["native_group"] = native_group_leg(world, args.share_gpu, args.native_units, args.native_deadline)
+    emit()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,220 @@
+// group_host.cpp — a native C++ host that drives several GPUs through the C ABI's device groups
+// (include/merl_hip.h): no Python, no torch, one process, one mrl_group.  It is what a C++ renderer's
+// multi-GPU outer loop looks like, reduced to the BSDF path: replicate the tables, generate each member's
+// unit tile in place, run the sharded fused eval+sample with the results gathered to a root device
+// (RCCL point-to-point over xGMI, or device copies), time it, and check the gathered arrays bit for bit
+// against a single-device run over the same unit range.
+//
+//   g++ -std=c++17 -O2 -I include examples/group_host.cpp -L mitsuba_customization_amd/lib -lmerl_hip -o group_host
+//   group_host --devices 0,1,2,3 [--transport auto|rccl|copy] [--units-per-device N] [--chunk C] [--tables T]
+//              [--steps K] [--warmup W] [--table file.binary] [--check] [--root R]
+//   (a device may repeat, e.g. --devices 0,0,0: rehearsal on a 1-GPU box, transport = device copies)
+// Prints ONE JSON line; exit code 0 only if every call succeeded and --check (when given) found no difference.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "merl_hip.h"
+
+namespace {
+
+#define GCHECK(call)                                                                                   \
+    do {                                                                                               \
+        int rc_ = (call);                                                                              \
+        if (rc_ != MRL_OK) {                                                                           \
+            std::fprintf(stderr, "%s -> %s (%s)\n", #call, mrl_strerror(rc_), mrl_group_last_error(group)); \
+            return 1;                                                                                  \
+        }                                                                                              \
+    } while (0)
+#define CCHECK(ctx, call)                                                                              \
+    do {                                                                                               \
+        int rc_ = (call);                                                                              \
+        if (rc_ != MRL_OK) {                                                                           \
+            std::fprintf(stderr, "%s -> %s (%s)\n", #call, mrl_strerror(rc_), mrl_last_error(ctx));    \
+            return 1;                                                                                  \
+        }                                                                                              \
+    } while (0)
+
+// A smooth, strictly positive MERL-shaped table (a glossy lobe in theta_h over a diffuse floor), raw file units:
+// stand-in for a measured material when no .binary is given.  Any table exercises the same code; this one
+// spans several decades like measured data does.
+std::vector<double> synthetic_table(int seed)
+{
+    const int H = 90, D = 90, P = 180;
+    const size_t plane = (size_t)H * D * P;
+    std::vector<double> t(3 * plane);
+    const double alpha = 0.05 + 0.03 * (seed % 7), albedo[3] = { 0.3 + 0.05 * (seed % 5), 0.25, 0.2 + 0.04 * (seed % 3) };
+    for (int h = 0; h < H; ++h) {
+        const double th = (double)h * h / (H * (double)H) * 1.5707963267948966;
+        const double c = std::cos(th), tn = std::tan(th);
+        const double lobe = 1.0 / (3.141592653589793 * alpha * alpha * c * c * c * c * std::pow(1.0 + tn * tn / (alpha * alpha), 2.0));
+        for (int d = 0; d < D; ++d) {
+            const double td = (d + 0.5) / D * 1.5707963267948966, fres = 0.04 + 0.96 * std::pow(1.0 - std::cos(td), 5.0);
+            for (int p = 0; p < P; ++p) {
+                const size_t i = ((size_t)h * D + d) * P + p;
+                const double wob = 1.0 + 0.05 * std::sin(0.1 * p + seed);
+                t[i] = 1500.0 * (albedo[0] / 3.141592653589793 + lobe * fres * 0.25) * wob;
+                t[i + plane] = 1500.0 / 1.15 * (albedo[1] / 3.141592653589793 + lobe * fres * 0.25) * wob;
+                t[i + 2 * plane] = 1500.0 / 1.66 * (albedo[2] / 3.141592653589793 + lobe * fres * 0.25) * wob;
+            }
+        }
+    }
+    return t;
+}
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    std::vector<int> devices = { 0 };
+    int transport = MRL_TRANSPORT_AUTO, tables = 1, steps = 5, warmup = 2, root = 0;
+    size_t units_per_device = (size_t)8 << 20, chunk = (size_t)2 << 20;
+    bool check = false;
+    std::string table_file;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "--devices") {
+            devices.clear();
+            std::string s = next();
+            size_t p = 0;
+            while (p <= s.size()) {
+                const size_t q = s.find(',', p);
+                devices.push_back(std::atoi(s.substr(p, q == std::string::npos ? std::string::npos : q - p).c_str()));
+                if (q == std::string::npos) break;
+                p = q + 1;
+            }
+        } else if (a == "--transport") {
+            const std::string t = next();
+            transport = t == "rccl" ? MRL_TRANSPORT_RCCL : t == "copy" ? MRL_TRANSPORT_PEER_COPY : MRL_TRANSPORT_AUTO;
+        } else if (a == "--units-per-device") units_per_device = (size_t)std::atoll(next());
+        else if (a == "--chunk") chunk = (size_t)std::atoll(next());
+        else if (a == "--tables") tables = std::atoi(next());
+        else if (a == "--steps") steps = std::atoi(next());
+        else if (a == "--warmup") warmup = std::atoi(next());
+        else if (a == "--root") root = std::atoi(next());
+        else if (a == "--table") table_file = next();
+        else if (a == "--check") check = true;
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    const int G = (int)devices.size();
+    if (G < 1 || tables < 1 || steps < 1 || root < 0 || root >= G || chunk < 1) { std::fprintf(stderr, "bad arguments\n"); return 2; }
+
+    mrl_group *group = nullptr;
+    {
+        const int rc = mrl_group_init(G, devices.data(), transport, &group);
+        if (rc != MRL_OK) { std::fprintf(stderr, "mrl_group_init -> %s (%s)\n", mrl_strerror(rc), mrl_group_last_error(nullptr)); return 1; }
+    }
+    const int used_transport = mrl_group_transport(group);
+    std::vector<int> ids;
+    for (int t = 0; t < tables; ++t) {
+        int id = -1;
+        if (!table_file.empty()) GCHECK(mrl_group_material_load_merl(group, table_file.c_str(), &id));
+        else { const std::vector<double> tab = synthetic_table(t % 16); GCHECK(mrl_group_material_upload_f64(group, tab.data(), &id)); }
+        ids.push_back(id);
+    }
+    const size_t n_total = units_per_device * (size_t)G;
+    std::vector<mrl_tile_inputs> tiles((size_t)G);
+    GCHECK(mrl_group_generate_tiles(group, 0x5EEDu, 0, n_total, tables > 1 ? tables : 0, tiles.data()));
+
+    mrl_ctx *rctx = nullptr;
+    GCHECK(mrl_group_context(group, root, &rctx));
+    float *out = nullptr;                                        // rgb[3n] pdf[n] wo[3n] pdf2[n] weight[3n] on the root
+    CCHECK(rctx, mrl_device_alloc(rctx, n_total * 11 * sizeof(float), (void **)&out));
+    float *o_rgb = out, *o_pdf = out + 3 * n_total, *o_wo = out + 4 * n_total, *o_pdf2 = out + 7 * n_total, *o_w = out + 8 * n_total;
+
+    // ---- compute only: every member runs its tile into member-local arrays, nothing moves between devices ----
+    std::vector<float *> local((size_t)G, nullptr);
+    std::vector<mrl_ctx *> ctxs((size_t)G, nullptr);
+    for (int r = 0; r < G; ++r) {
+        GCHECK(mrl_group_context(group, r, &ctxs[(size_t)r]));
+        size_t lo, hi;
+        mrl_tile_bounds(n_total, G, r, &lo, &hi);
+        CCHECK(ctxs[(size_t)r], mrl_device_alloc(ctxs[(size_t)r], (hi - lo) * 11 * sizeof(float), (void **)&local[(size_t)r]));
+    }
+    auto compute_only = [&]() -> int {
+        for (int r = 0; r < G; ++r) {
+            size_t lo, hi;
+            mrl_tile_bounds(n_total, G, r, &lo, &hi);
+            const size_t n = hi - lo;
+            float *b = local[(size_t)r];
+            const mrl_tile_inputs &in = tiles[(size_t)r];
+            const int rc = mrl_eval_sample_batch(ctxs[(size_t)r], in.wi, in.wo, in.u, in.mat, ids[0], n, b, b + 3 * n, b + 4 * n, b + 7 * n, b + 8 * n);
+            if (rc != MRL_OK) return rc;
+        }
+        return mrl_group_synchronize(group);
+    };
+    for (int w = 0; w < warmup; ++w) GCHECK(compute_only());
+    double t0 = now_ms();
+    for (int s = 0; s < steps; ++s) GCHECK(compute_only());
+    const double compute_ms = (now_ms() - t0) / steps;
+
+    // ---- end to end: sharded run with the chunk-pipelined gather into the root's arrays ----
+    auto sharded = [&]() -> int {
+        const int rc = mrl_group_eval_sample_sharded(group, tiles.data(), ids[0], n_total, chunk, root, o_rgb, o_pdf, o_wo, o_pdf2, o_w);
+        return rc != MRL_OK ? rc : mrl_group_synchronize(group);
+    };
+    for (int w = 0; w < warmup; ++w) GCHECK(sharded());
+    t0 = now_ms();
+    for (int s = 0; s < steps; ++s) GCHECK(sharded());
+    const double gathered_ms = (now_ms() - t0) / steps;
+    std::vector<float> member_ms((size_t)G, 0.0f);
+    GCHECK(mrl_group_last_timing(group, member_ms.data()));
+
+    // ---- check: the gathered arrays == one device evaluating the whole unit range, bit for bit ----
+    long long mismatches = -1;
+    if (check) {
+        mismatches = 0;
+        const size_t piece = (size_t)4 << 20;                    // compare in pieces: bounded host and device memory
+        float *d_in = nullptr, *d_ref = nullptr;
+        int32_t *d_mat = nullptr;
+        CCHECK(rctx, mrl_device_alloc(rctx, piece * 8 * sizeof(float), (void **)&d_in));
+        CCHECK(rctx, mrl_device_alloc(rctx, piece * 11 * sizeof(float), (void **)&d_ref));
+        CCHECK(rctx, mrl_device_alloc(rctx, piece * sizeof(int32_t), (void **)&d_mat));
+        std::vector<float> h_ref(piece * 11), h_got(piece * 11);
+        for (size_t a = 0; a < n_total; a += piece) {
+            const size_t n = std::min(piece, n_total - a);
+            CCHECK(rctx, mrl_generate_pairs(rctx, 0x5EEDu, a, n, d_in, d_in + 3 * n, d_in + 6 * n));
+            if (tables > 1) CCHECK(rctx, mrl_generate_materials(rctx, 0x5EEDu, a, n, tables, d_mat));
+            CCHECK(rctx, mrl_eval_sample_batch(rctx, d_in, d_in + 3 * n, d_in + 6 * n, tables > 1 ? d_mat : nullptr, ids[0], n,
+                                               d_ref, d_ref + 3 * n, d_ref + 4 * n, d_ref + 7 * n, d_ref + 8 * n));
+            CCHECK(rctx, mrl_copy_to_host(rctx, h_ref.data(), d_ref, n * 11 * sizeof(float)));
+            const float *src[5] = { o_rgb + 3 * a, o_pdf + a, o_wo + 3 * a, o_pdf2 + a, o_w + 3 * a };
+            const size_t width[5] = { 3, 1, 3, 1, 3 }, at[5] = { 0, 3, 4, 7, 8 };
+            for (int k = 0; k < 5; ++k) {
+                CCHECK(rctx, mrl_copy_to_host(rctx, h_got.data(), src[k], n * width[k] * sizeof(float)));
+                const float *want = h_ref.data() + at[k] * n;
+                for (size_t j = 0; j < n * width[k]; ++j)
+                    if (std::memcmp(&h_got[j], &want[j], 4) != 0) ++mismatches;
+            }
+        }
+        CCHECK(rctx, mrl_device_free(rctx, d_in));
+        CCHECK(rctx, mrl_device_free(rctx, d_ref));
+        CCHECK(rctx, mrl_device_free(rctx, d_mat));
+    }
+
+    float slowest = 0.0f;
+    for (float m : member_ms) slowest = std::max(slowest, m);
+    const double bytes_into_root = (double)(n_total - units_per_device) * 44.0;
+    std::printf("{\"what\": \"native C++ host, one process, mrl_group over %d device(s)\", \"devices\": [", G);
+    for (int r = 0; r < G; ++r) std::printf("%s%d", r ? ", " : "", devices[(size_t)r]);
+    std::printf("], \"transport\": \"%s\", \"units_per_device\": %zu, \"chunk_units\": %zu, \"tables_resident\": %d, \"steps\": %d, "
+                "\"compute_only_ms\": %.4f, \"compute_only_Meval_s\": %.1f, \"gathered_ms\": %.4f, \"gathered_Meval_s\": %.1f, "
+                "\"slowest_member_device_ms\": %.4f, \"bytes_into_root\": %.0f, \"root_ingress_GBps\": %.2f, \"check_mismatches\": %lld}\n",
+                used_transport == MRL_TRANSPORT_RCCL ? "rccl" : "peer_copy", units_per_device, chunk, tables, steps,
+                compute_ms, (double)n_total / compute_ms / 1e3, gathered_ms, (double)n_total / gathered_ms / 1e3, slowest,
+                bytes_into_root, gathered_ms > 0 ? bytes_into_root / gathered_ms / 1e6 : 0.0, mismatches);
+    for (int r = 0; r < G; ++r) (void)mrl_device_free(ctxs[(size_t)r], local[(size_t)r]);
+    (void)mrl_device_free(rctx, out);
+    GCHECK(mrl_group_destroy(group));
+    return (check && mismatches != 0) ? 3 : 0;
+}

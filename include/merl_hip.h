@@ -52,7 +52,8 @@ enum mrl_status {
     MRL_ERR_OOM = -5,
     MRL_ERR_MATERIAL = -6,     /* unknown material id */
     MRL_ERR_POINTER_MIX = -7,  /* host and device pointers mixed in one call */
-    MRL_ERR_NO_DEVICE = -8     /* no gfx950 device: there is no CPU fallback */
+    MRL_ERR_NO_DEVICE = -8,    /* no gfx950 device: there is no CPU fallback */
+    MRL_ERR_COMM = -9          /* an RCCL call failed or librccl could not be loaded (see mrl_group_last_error) */
 };
 
 enum mrl_option {
@@ -183,6 +184,72 @@ int mrl_host_free(mrl_ctx *ctx, void *ptr);
 /* hipEvent pair recorded on the stream the kernels are launched on */
 int mrl_timer_start(mrl_ctx *ctx);
 int mrl_timer_stop(mrl_ctx *ctx, float *elapsed_ms);   /* records, synchronises, returns ms */
+
+/* ---- device groups: one host process, several GPUs (SURVEY.md §8b `mrl_init(n_devices, device_ids, ...)`, §8e) ----
+ * The path shards with no data-path collective: member r owns the contiguous unit tile
+ *     [r * ceil(N / G), min(N, (r + 1) * ceil(N / G)))        (mrl_tile_bounds)
+ * keeps every material table replicated, and computes its tile alone on its own stream.  The only communication is
+ * the delivery of per-tile RESULTS to a root device: peers send their chunk straight to the root (grouped
+ * ncclSend / ncclRecv over RCCL: each peer's own xGMI link, not a ring), cut into chunks so that the send of chunk k
+ * overlaps the compute of chunk k + 1.  A group is thread-compatible like a context.  A renderer host stays in
+ * C++ and reaches every GPU of the node through these calls; it replaces nothing in the reference (the reference
+ * has no multi-device path), it is the data-parallel outer loop around mrl_eval_sample_batch. */
+typedef struct mrl_group mrl_group;
+
+enum mrl_group_transport {
+    MRL_TRANSPORT_AUTO = 0,        /* RCCL when the group has >= 2 distinct devices, else device copies */
+    MRL_TRANSPORT_RCCL = 1,        /* grouped ncclSend/ncclRecv on a side stream per device (librccl is loaded on demand) */
+    MRL_TRANSPORT_PEER_COPY = 2    /* hipMemcpyPeerAsync on a side stream per device: no RCCL; also valid when device_ids
+                                      repeats a device (rehearsal of the whole pipeline on a box with fewer GPUs) */
+};
+
+/* per-member device pointers to the tile's inputs, indexed from the tile's first unit; mat may be NULL */
+typedef struct mrl_tile_inputs {
+    const float *wi, *wo, *u;
+    const int32_t *mat;
+} mrl_tile_inputs;
+
+int mrl_group_init(int n_devices, const int *device_ids, int transport, mrl_group **out);
+int mrl_group_destroy(mrl_group *g);
+int mrl_group_size(const mrl_group *g);
+int mrl_group_transport(const mrl_group *g);                       /* the transport in use (never AUTO) */
+const char *mrl_group_last_error(const mrl_group *g);            /* g == NULL: why the last mrl_group_init of this thread failed */
+/* member `rank`'s context (owned by the group): device memory helpers, generators, single-device calls */
+int mrl_group_context(mrl_group *g, int rank, mrl_ctx **out);
+/* replicated state: applied to every member; material ids are the same on every member */
+int mrl_group_set_option(mrl_group *g, int option, int value);
+int mrl_group_material_load_merl(mrl_group *g, const char *path, int *out_id);
+int mrl_group_material_upload_f64(mrl_group *g, const double *planar_rgb, int *out_id);
+int mrl_group_material_upload_table(mrl_group *g, const double *planar_rgb, const int dims[3], const double scale[3], int *out_id);
+int mrl_group_material_ggx(mrl_group *g, float alpha, const float eta[3], const float k[3], int *out_id);
+int mrl_group_material_release(mrl_group *g, int id);
+/* tile / chunk arithmetic (pure functions; usable without a device) */
+void mrl_tile_bounds(size_t n_total, int world, int rank, size_t *lo, size_t *hi);
+/* chunk `step` of member `rank`'s tile: units [*lo, *hi) in global numbering (empty once the tile is exhausted) */
+void mrl_chunk_bounds(size_t n_total, int world, int rank, size_t chunk_units, size_t step, size_t *lo, size_t *hi);
+size_t mrl_chunk_steps(size_t n_total, int world, size_t chunk_units);
+/* Synthetic inputs generated in place on every member for its own tile (a pure function of the unit
+ * index, so the union over members equals mrl_generate_pairs over [first_index, first_index + n_total)).
+ * n_materials > 0 also fills mat with ids in [0, n_materials).  The buffers belong to the group and stay valid until
+ * the next mrl_group_generate_tiles or mrl_group_destroy.  tiles_out: n_devices entries. */
+int mrl_group_generate_tiles(mrl_group *g, uint64_t seed, uint64_t first_index, size_t n_total, int n_materials,
+                             mrl_tile_inputs *tiles_out);
+/* The sharded fused unit: every member computes eval+sample over its tile (inputs: tiles[rank], device pointers on that
+ * member's device) in chunks of chunk_units; results land in the root member's device arrays (n_total units each, global
+ * unit order).  Asynchronous: returns when everything is enqueued; the root member's context stream is ordered after the
+ * last transfer (mrl_group_synchronize waits for every member).  With one member this IS mrl_eval_sample_batch. */
+int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, int32_t single_id, size_t n_total,
+                                  size_t chunk_units, int root,
+                                  float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight);
+/* Host arrays of n units (what a CPU renderer holds): tiles are staged to the members and back concurrently, one
+ * host thread per member; no device-to-device traffic at all.  Returns when the outputs are written. */
+int mrl_group_eval_sample_batch(mrl_group *g, const float *wi, const float *wo, const float *u, const int32_t *mat,
+                                int32_t single_id, size_t n, float *out_rgb, float *out_pdf, float *out_wo,
+                                float *out_pdf2, float *out_weight);
+int mrl_group_synchronize(mrl_group *g);
+/* device time of the last mrl_group_eval_sample_sharded per member (its first launch to its last launch or send),
+ * valid after mrl_group_synchronize: ms_out[n_devices] */
+int mrl_group_last_timing(mrl_group *g, float *ms_out);
 
 #ifdef __cplusplus
 }

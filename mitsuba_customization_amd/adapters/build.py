@@ -59,6 +59,14 @@ def build_all(force: bool = False):
                                "-L", LIBDIR, "-lmerl_hip", "-Wl,-rpath,$ORIGIN", "-lm"])
     if os.path.exists(ex):
         outs.append(ex)
+    # the native multi-GPU host (examples/group_host.cpp): plain C++ over the device-group entry points
+    gh_src = os.path.join(os.path.dirname(PKG), "examples", "group_host.cpp")
+    gh = os.path.join(LIBDIR, "group_host")
+    if os.path.exists(gh_src) and (force or _stale(gh, [gh_src, os.path.join(os.path.dirname(PKG), "include", "merl_hip.h")])):
+        subprocess.check_call([CXX, "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", os.path.join(os.path.dirname(PKG), "include"),
+                               "-o", gh, gh_src, "-L", LIBDIR, "-lmerl_hip", "-Wl,-rpath,$ORIGIN"])
+    if os.path.exists(gh):
+        outs.append(gh)
     return outs
 
 

@@ -96,7 +96,7 @@ inline int check_residency(Make make, Drop drop, int cycles)
     mrl_ctx *probe = nullptr;
     if (!init || !destroy || !mem || init(0, &probe) != 0) return 20;
     auto free_now = [&]() { size_t f = 0; mem(probe, nullptr, nullptr, &f, nullptr); return (long long)f; };
-    const long long slack = 8ll << 20;
+    const long long slack = 64ll << 20;   // the runtime keeps a few freed 2-MiB blocks in its pool; a table is 178 MiB
     auto *keeper = make(1);                                 // the plugin's context + the keeper's table
     const long long with_keeper = free_now();
     auto *first = make(0);

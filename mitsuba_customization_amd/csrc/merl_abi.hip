@@ -532,6 +532,7 @@ const char *mrl_strerror(int status)
         case MRL_ERR_MATERIAL: return "unknown material";
         case MRL_ERR_POINTER_MIX: return "host and device pointers mixed";
         case MRL_ERR_NO_DEVICE: return "no gfx950 device (there is no CPU fallback)";
+        case MRL_ERR_COMM: return "RCCL error";
     }
     return "unknown status";
 }

@@ -33,7 +33,19 @@ ABI_SYMBOLS = (
     "mrl_generate_pairs", "mrl_generate_materials",
     "mrl_device_alloc", "mrl_device_free", "mrl_copy_to_device", "mrl_copy_to_host", "mrl_host_alloc", "mrl_host_free",
     "mrl_timer_start", "mrl_timer_stop",
+    "mrl_group_init", "mrl_group_destroy", "mrl_group_size", "mrl_group_transport", "mrl_group_last_error", "mrl_group_context",
+    "mrl_group_set_option", "mrl_group_material_load_merl", "mrl_group_material_upload_f64", "mrl_group_material_upload_table",
+    "mrl_group_material_ggx", "mrl_group_material_release", "mrl_tile_bounds", "mrl_chunk_bounds", "mrl_chunk_steps",
+    "mrl_group_generate_tiles", "mrl_group_eval_sample_sharded", "mrl_group_eval_sample_batch", "mrl_group_synchronize",
+    "mrl_group_last_timing",
 )
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_PEER_COPY = 0, 1, 2
+ERR_COMM = -9
+
+
+class TileInputs(C.Structure):
+    """mrl_tile_inputs: per-member device pointers to a tile's inputs."""
+    _fields_ = [("wi", C.c_void_p), ("wo", C.c_void_p), ("u", C.c_void_p), ("mat", C.c_void_p)]
 
 
 class MerlHipError(RuntimeError):
@@ -108,6 +120,27 @@ def load_library(path: Optional[str] = None):
     L.mrl_host_free.argtypes = [vp, vp]
     L.mrl_timer_start.argtypes = [vp]
     L.mrl_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    szp = C.POINTER(C.c_size_t)
+    L.mrl_group_init.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.mrl_group_destroy.argtypes = [vp]
+    L.mrl_group_size.argtypes = [vp]
+    L.mrl_group_transport.argtypes = [vp]
+    L.mrl_group_last_error.argtypes = [vp]; L.mrl_group_last_error.restype = C.c_char_p
+    L.mrl_group_context.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.mrl_group_set_option.argtypes = [vp, C.c_int, C.c_int]
+    L.mrl_group_material_load_merl.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
+    L.mrl_group_material_upload_f64.argtypes = [vp, vp, C.POINTER(C.c_int)]
+    L.mrl_group_material_upload_table.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.mrl_group_material_ggx.argtypes = [vp, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.mrl_group_material_release.argtypes = [vp, C.c_int]
+    L.mrl_tile_bounds.argtypes = [C.c_size_t, C.c_int, C.c_int, szp, szp]; L.mrl_tile_bounds.restype = None
+    L.mrl_chunk_bounds.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t, szp, szp]; L.mrl_chunk_bounds.restype = None
+    L.mrl_chunk_steps.argtypes = [C.c_size_t, C.c_int, C.c_size_t]; L.mrl_chunk_steps.restype = C.c_size_t
+    L.mrl_group_generate_tiles.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, C.POINTER(TileInputs)]
+    L.mrl_group_eval_sample_sharded.argtypes = [vp, C.POINTER(TileInputs), C.c_int32, C.c_size_t, C.c_size_t, C.c_int, fp, fp, fp, fp, fp]
+    L.mrl_group_eval_sample_batch.argtypes = [vp, fp, fp, fp, vp, C.c_int32, C.c_size_t, fp, fp, fp, fp, fp]
+    L.mrl_group_synchronize.argtypes = [vp]
+    L.mrl_group_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
     if path is None:
         _lib = L
     return L
@@ -415,3 +448,113 @@ class MerlHip:
         self._check(self._lib.mrl_generate_materials(self._ctx, seed, first, n, n_materials, _addr(out, np.int32, None, n, "mat")),
                     "mrl_generate_materials")
         return out
+
+
+def tile_bounds(n_total: int, world: int, rank: int):
+    """mrl_tile_bounds through the library (pure arithmetic: needs no GPU)."""
+    lo, hi = C.c_size_t(), C.c_size_t()
+    load_library().mrl_tile_bounds(n_total, world, rank, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def chunk_bounds(n_total: int, world: int, rank: int, chunk: int, step: int):
+    lo, hi = C.c_size_t(), C.c_size_t()
+    load_library().mrl_chunk_bounds(n_total, world, rank, chunk, step, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def chunk_steps(n_total: int, world: int, chunk: int) -> int:
+    return int(load_library().mrl_chunk_steps(n_total, world, chunk))
+
+
+class MerlGroup:
+    """mrl_group: one host process, several GPUs (a device id may repeat: rehearsal with device copies)."""
+
+    def __init__(self, devices: Sequence[int], transport: int = TRANSPORT_AUTO):
+        self._lib = load_library()
+        self._g = C.c_void_p()
+        ids = (C.c_int * len(devices))(*devices)
+        rc = self._lib.mrl_group_init(len(devices), ids, transport, C.byref(self._g))
+        if rc != 0:
+            raise MerlHipError(rc, "mrl_group_init", self._lib.mrl_group_last_error(None).decode() or self._lib.mrl_strerror(rc).decode())
+        self.devices = list(devices)
+        self.size = len(devices)
+        self.transport = self._lib.mrl_group_transport(self._g)
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise MerlHipError(rc, what, self._lib.mrl_group_last_error(self._g).decode() or self._lib.mrl_strerror(rc).decode())
+
+    def close(self):
+        if getattr(self, "_g", None) is not None and self._g:
+            self._lib.mrl_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, option: int, value: int):
+        self._check(self._lib.mrl_group_set_option(self._g, option, value), "mrl_group_set_option")
+
+    def upload_merl(self, planar: np.ndarray) -> int:
+        p = np.ascontiguousarray(planar, dtype=np.float64)
+        mid = C.c_int()
+        self._check(self._lib.mrl_group_material_upload_f64(self._g, p.ctypes.data, C.byref(mid)), "mrl_group_material_upload_f64")
+        return mid.value
+
+    def upload_table(self, planar: np.ndarray, scale: Sequence[float] = (1.0, 1.0, 1.0)) -> int:
+        p = np.ascontiguousarray(planar, dtype=np.float64)
+        dims = (C.c_int * 3)(*p.shape[1:]); sc = (C.c_double * 3)(*scale); mid = C.c_int()
+        self._check(self._lib.mrl_group_material_upload_table(self._g, p.ctypes.data, dims, sc, C.byref(mid)), "mrl_group_material_upload_table")
+        return mid.value
+
+    def ggx(self, alpha: float, eta: Sequence[float], k: Sequence[float]) -> int:
+        mid = C.c_int()
+        self._check(self._lib.mrl_group_material_ggx(self._g, alpha, (C.c_float * 3)(*eta), (C.c_float * 3)(*k), C.byref(mid)), "mrl_group_material_ggx")
+        return mid.value
+
+    def release_material(self, mid: int):
+        self._check(self._lib.mrl_group_material_release(self._g, mid), "mrl_group_material_release")
+
+    def generate_tiles(self, seed: int, first: int, n_total: int, n_materials: int = 0):
+        tiles = (TileInputs * self.size)()
+        self._check(self._lib.mrl_group_generate_tiles(self._g, seed, first, n_total, n_materials, tiles), "mrl_group_generate_tiles")
+        return tiles
+
+    def eval_sample_sharded(self, tiles, n_total: int, chunk: int, out, root: int = 0, material: int = 0):
+        """out: five GPU tensors on the root member's device (n_total units).  Asynchronous; synchronize() waits."""
+        rgb, pdf, wo2, pdf2, w = out
+        self._check(self._lib.mrl_group_eval_sample_sharded(
+            self._g, tiles, material, n_total, chunk, root,
+            _addr(rgb, np.float32, 3, n_total, "out_rgb"), _addr(pdf, np.float32, None, n_total, "out_pdf"),
+            _addr(wo2, np.float32, 3, n_total, "out_wo"), _addr(pdf2, np.float32, None, n_total, "out_pdf2"),
+            _addr(w, np.float32, 3, n_total, "out_weight")), "mrl_group_eval_sample_sharded")
+        return out
+
+    def eval_sample_host(self, wi, wo, u, mat=None, material: int = 0):
+        """Host (numpy) arrays split over the members, staged concurrently; returns numpy outputs."""
+        n = int(wi.shape[0])
+        out = (np.empty((n, 3), np.float32), np.empty((n,), np.float32), np.empty((n, 3), np.float32),
+               np.empty((n,), np.float32), np.empty((n, 3), np.float32))
+        self._check(self._lib.mrl_group_eval_sample_batch(
+            self._g, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"), _addr(u, np.float32, 2, n, "u"),
+            _addr(mat, np.int32, None, n, "mat"), material, n,
+            *[_addr(o, np.float32, c, n, "out") for o, c in zip(out, (3, None, 3, None, 3))]), "mrl_group_eval_sample_batch")
+        return out
+
+    def synchronize(self):
+        self._check(self._lib.mrl_group_synchronize(self._g), "mrl_group_synchronize")
+
+    def last_timing(self):
+        ms = (C.c_float * self.size)()
+        self._check(self._lib.mrl_group_last_timing(self._g, ms), "mrl_group_last_timing")
+        return list(ms)

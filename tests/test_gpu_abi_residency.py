@@ -41,12 +41,12 @@ def test_release_gives_memory_back_and_tombstones_render_zero(oracle, tables):
         keep = g.upload_merl(tables("ggx_tab", 1))
         free0 = g.memory_info()["device_free"]
         gone = g.upload_merl(tables("ggx_tab", 0))
-        assert free0 - g.memory_info()["device_free"] >= MERL_BRICK_BYTES - (8 << 20)
+        assert free0 - g.memory_info()["device_free"] >= MERL_BRICK_BYTES - (64 << 20)
         wi, wo, u = g.generate_pairs(0x5EED, 0, n)
         mat = torch.where(torch.arange(n, device=wi.device) % 2 == 0, keep, gone).to(torch.int32)
         before = [t.clone() for t in g.eval_sample(wi, wo, u, mat=mat)]
         g.release_material(gone)
-        assert abs(g.memory_info()["device_free"] - free0) <= (8 << 20)               # the table left HBM
+        assert abs(g.memory_info()["device_free"] - free0) <= (64 << 20)               # the table left HBM
         # the released id: single-material calls reject it, batches render it as an unknown id (zeros)
         with pytest.raises(host.MerlHipError) as e:
             g.eval(wi, wo, material=gone)
@@ -91,7 +91,7 @@ def test_upload_release_cycles_keep_free_memory_flat(tables):
             mid = g.upload_merl(tab)
             assert mid == 1
             g.release_material(mid)
-            assert abs(g.memory_info()["device_free"] - base) <= (8 << 20)
+            assert abs(g.memory_info()["device_free"] - base) <= (64 << 20)
         assert g.memory_info()["table_bytes"] <= MERL_BRICK_BYTES + 4096
 
 
@@ -109,7 +109,7 @@ def test_memory_budget_and_oom(tables):
             g.upload_merl(tab)
         assert e.value.status == host.ERR_OOM and "budget" in str(e.value)
         assert g.memory_info()["table_bytes"] == used and g.material_count() == 2      # the context is as it was
-        assert abs(g.memory_info()["device_free"] - free_before) <= (8 << 20)
+        assert abs(g.memory_info()["device_free"] - free_before) <= (64 << 20)
         g.release_material(a)
         assert g.upload_merl(tab) == a                                                 # room again
         g.set_option(host.OPT_MEMORY_LIMIT_MB, 0)

@@ -1,0 +1,138 @@
+"""Native multi-device host path (mrl_group_*) on the 1-GPU box.  One member: the sharded call IS the single-device
+call.  Several members that name GPU 0 again: the whole pipeline — index tiles, per-member streams, double-buffered
+chunks, transfers behind the computes, ordering of the root's stream — runs with device copies as the transport;
+results must equal a single-device run over the same unit range bit for bit (they are a pure function of the unit
+index).  RCCL itself needs >= 2 GPUs: here only its loading + communicator set-up (one rank) is exercised; the
+point-to-point leg is UNMEASURED on N>1 hardware."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mitsuba_customization_amd", "lib")
+
+
+def _outs(n, dev):
+    import torch
+    return (torch.full((n, 3), -7.0, device=dev), torch.full((n,), -7.0, device=dev), torch.full((n, 3), -7.0, device=dev),
+            torch.full((n,), -7.0, device=dev), torch.full((n, 3), -7.0, device=dev))
+
+
+def _single_device_reference(tabs, n, n_materials, seed=0x5EED, first=0):
+    from mitsuba_customization_amd import host
+    with host.MerlHip(0) as g:
+        ids = [g.upload_merl(t) for t in tabs]
+        wi, wo, u = g.generate_pairs(seed, first, n)
+        mat = g.generate_materials(seed, first, n, n_materials) if n_materials else None
+        return [t.clone() for t in g.eval_sample(wi, wo, u, mat=mat, material=ids[0])]
+
+
+def test_one_member_is_the_single_device_call(tables):
+    import torch
+    from mitsuba_customization_amd import host
+    n = 300_001
+    ref = _single_device_reference([tables("ggx_tab", 0)], n, 0)
+    with host.MerlGroup([0]) as grp:
+        assert grp.size == 1 and grp.transport == host.TRANSPORT_PEER_COPY
+        mid = grp.upload_merl(tables("ggx_tab", 0))
+        tiles = grp.generate_tiles(0x5EED, 0, n)
+        for chunk in (n, 70_000, 1):                        # one launch, several chunks; chunk = 1 only on a small prefix
+            m = n if chunk > 1 else 37
+            out = _outs(m, torch.device("cuda", 0))
+            grp.eval_sample_sharded(tiles, m, chunk, out, root=0, material=mid)
+            grp.synchronize()
+            for a, b in zip(out, ref):
+                assert torch.equal(a.view(torch.int32), b[:m].view(torch.int32))
+        assert grp.last_timing()[0] > 0.0
+
+
+@pytest.mark.parametrize("members,root,n,chunk,n_tables", [(2, 0, 250_003, 60_000, 1), (3, 2, 100_001, 9_000, 3), (4, 1, 5, 2, 1), (3, 0, 2, 64, 1)])
+def test_members_sharing_the_gpu_reproduce_the_single_device_run(tables, members, root, n, chunk, n_tables):
+    import torch
+    from mitsuba_customization_amd import host
+    tabs = [tables("ggx_tab", s) for s in range(n_tables)]
+    ref = _single_device_reference(tabs, n, n_tables if n_tables > 1 else 0)
+    with host.MerlGroup([0] * members) as grp:
+        assert grp.transport == host.TRANSPORT_PEER_COPY
+        ids = [grp.upload_merl(t) for t in tabs]
+        assert ids == list(range(n_tables))
+        tiles = grp.generate_tiles(0x5EED, 0, n, n_tables if n_tables > 1 else 0)
+        out = _outs(n, torch.device("cuda", 0))
+        for _ in range(3):                                  # repeated calls reuse the double buffers
+            grp.eval_sample_sharded(tiles, n, chunk, out, root=root, material=ids[0])
+        grp.synchronize()
+        for a, b in zip(out, ref):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        assert len(grp.last_timing()) == members
+
+
+def test_host_arrays_split_over_members(oracle, tables):
+    from mitsuba_customization_amd import host
+    n = 200_003
+    wi, wo, u = oracle.generate_pairs(0x5EED, 5, n)
+    with host.MerlHip(0) as g:
+        mid = g.upload_merl(tables("ggx_tab", 0))
+        ref = g.eval_sample(wi, wo, u, material=mid)
+    with host.MerlGroup([0, 0, 0]) as grp:
+        mid = grp.upload_merl(tables("ggx_tab", 0))
+        out = grp.eval_sample_host(wi, wo, u, material=mid)
+    for a, b in zip(out, ref):
+        assert np.array_equal(a.view(np.int32), b.view(np.int32))
+    want = oracle.eval_sample_multi([oracle.OracleTable(tables("ggx_tab", 0))], wi, wo, u, None)
+    assert (np.abs(out[0].astype(np.float64) - want[0]) <= 1e-6 * np.abs(want[0]) + 1e-30).all()
+
+
+def test_group_errors_and_replicated_materials(tables):
+    import torch
+    from mitsuba_customization_amd import host
+    with host.MerlGroup([0, 0]) as grp:
+        L = grp._lib
+        a = grp.upload_merl(tables("ggx_tab", 0))
+        b = grp.ggx(0.1, (1, 1, 1), (2, 2, 2))
+        assert (a, b) == (0, 1)
+        grp.release_material(a)
+        assert grp.upload_table(tables("noise", 3, (8, 8, 16))) == a          # the freed slot, on every member
+        grp.set_option(host.OPT_LOOKUP, 1)
+        with pytest.raises(host.MerlHipError):
+            grp.set_option(host.OPT_LOOKUP, 9)
+        tiles = grp.generate_tiles(1, 0, 1000)
+        out = _outs(1000, torch.device("cuda", 0))
+        with pytest.raises(host.MerlHipError):
+            grp.eval_sample_sharded(tiles, 1000, 0, out)                       # chunk of zero units
+        with pytest.raises(host.MerlHipError):
+            grp.eval_sample_sharded(tiles, 1000, 100, out, root=5)
+        with pytest.raises(host.MerlHipError) as e:
+            grp.eval_sample_sharded(tiles, 1000, 100, out, material=99)
+        assert e.value.status == host.ERR_MATERIAL and "member 0" in str(e.value)
+        grp.eval_sample_sharded(tiles, 0, 100, out)                            # nothing to do
+        grp.synchronize()
+
+
+def test_rccl_loads_and_builds_a_communicator():
+    """One rank: librccl is found, ncclCommInitAll succeeds; there is nobody to send to, so no point-to-point call
+    runs — that leg needs >= 2 GPUs (bench.py runs it through lib/group_host when it is given N > 1 GPUs)."""
+    import torch
+    from mitsuba_customization_amd import host, synth
+    with host.MerlGroup([0], transport=host.TRANSPORT_RCCL) as grp:
+        assert grp.transport == host.TRANSPORT_RCCL
+        mid = grp.upload_merl(synth.make_table("ggx_tab", 0))
+        tiles = grp.generate_tiles(0x5EED, 0, 10_000)
+        out = _outs(10_000, torch.device("cuda", 0))
+        grp.eval_sample_sharded(tiles, 10_000, 3_000, out, material=mid)
+        grp.synchronize()
+        assert float(out[0].min()) >= 0.0 and float(out[0].max()) > 0.0
+
+
+def test_native_cpp_host_program():
+    """examples/group_host.cpp: the C++ host over mrl_group_* — three members on GPU 0, 16 mixed tables, gather by
+    device copies, checked inside the program against a single-device run."""
+    r = subprocess.run([os.path.join(LIB, "group_host"), "--devices", "0,0,0", "--units-per-device", str(1 << 20), "--chunk", str(300_000),
+                        "--tables", "16", "--steps", "2", "--warmup", "1", "--check", "--root", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["check_mismatches"] == 0 and out["transport"] == "peer_copy" and out["devices"] == [0, 0, 0]
+    assert out["compute_only_Meval_s"] > 0 and out["gathered_Meval_s"] > 0
