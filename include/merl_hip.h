@@ -81,7 +81,8 @@ enum mrl_option {
                                   288 GB MI355X holds about 1,500 brick tables (11,000 as rows). */
 };
 
-enum mrl_material_kind { MRL_KIND_MERL = 0, MRL_KIND_TABLE = 1, MRL_KIND_GGX = 2, MRL_KIND_RELEASED = 3 /* tombstone, never reported */ };
+enum mrl_material_kind { MRL_KIND_MERL = 0, MRL_KIND_TABLE = 1, MRL_KIND_GGX = 2, MRL_KIND_RELEASED = 3 /* tombstone, never reported */,
+                         MRL_KIND_TABLE_NCH = 4 /* n-channel table: evaluated by the *_nch entry points only */ };
 
 /* ---- context ---- */
 int mrl_init(int device_id, mrl_ctx **out);
@@ -135,6 +136,48 @@ int mrl_eval_pdf_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int
 int mrl_eval_sample_batch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u,
                           const int32_t *mat, int32_t single_id, size_t n,
                           float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight);
+
+/* ---- n-channel tables: customized_measurement beyond RGB (monochrome, RGB + alpha, spectral bins; SURVEY.md §8f
+ * item 3).  Same MERL parameterisation, same transform and trilinear blend; a texel has n_channels values, 1..32.
+ * planar: n_channels planes in MERL order; scale: n_channels factors (NULL = all 1).  Bricks only (the table-layout
+ * option does not apply); HBM per cell: 32 B (1 channel), 64 B (2), 128 B x ceil(n_channels / 4) (4..32).
+ * n_channels == 3 is the RGB path: the material becomes an MRL_KIND_TABLE and every *_nch call with n_channels == 3
+ * forwards to its RGB twin.  In a *_nch batch, ids of materials with another channel count (or analytic, released,
+ * unknown ids) give zeros, like unknown ids do in the RGB calls; a single_id of the wrong width is MRL_ERR_MATERIAL.
+ * out_values / out_weight: n x n_channels floats, channels of a unit adjacent.  pdf is channel-free: mrl_pdf_batch
+ * serves every table kind.  sample()/pdf() follow MRL_OPT_SAMPLING; the row marginal of an n-channel table weighs the
+ * channels equally (the RGB path uses luminance).  Host or device pointers, like the RGB calls. ---- */
+int mrl_material_upload_table_nch(mrl_ctx *ctx, const double *planar, const int dims[3], int n_channels,
+                                  const double *scale, int *out_id);
+/* file: int32 dims[3], then n_channels planes as f64 or f32 (told apart by the file length) */
+int mrl_material_load_table_nch(mrl_ctx *ctx, const char *path, int n_channels, const double *scale, int *out_id);
+int mrl_material_channels(const mrl_ctx *ctx, int id, int *n_channels);
+int mrl_eval_batch_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                       size_t n, int n_channels, float *out_values);
+int mrl_sample_batch_nch(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id,
+                         size_t n, int n_channels, float *out_wo, float *out_pdf, float *out_weight);
+int mrl_eval_pdf_batch_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                           size_t n, int n_channels, float *out_values, float *out_pdf);
+int mrl_eval_sample_batch_nch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u,
+                              const int32_t *mat, int32_t single_id, size_t n, int n_channels,
+                              float *out_values, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight);
+
+/* ---- "tensor_file" container (the RGL material database's *.bsdf files, read by upstream Mitsuba 3's `measured`
+ * plugin).  LOADER ONLY: fields are listed and copied out; the adaptive parameterisation an RGL
+ * *.bsdf describes is not evaluated by this library.  A customized_measurement table may be stored in the container
+ * (float field [channels, n_theta_h, n_theta_d, n_phi_d] + optional "scale" [channels]) and loaded as a material.
+ * dtype codes: 1-8 integers (1-2: 1 byte, 3-4: 2, 5-6: 4, 7-8: 8 bytes), 9 f16, 10 f32, 11 f64.  Host code only. ---- */
+typedef struct mrl_tensor_file mrl_tensor_file;
+int mrl_tensor_file_open(const char *path, mrl_tensor_file **out);
+int mrl_tensor_file_close(mrl_tensor_file *f);
+const char *mrl_tensor_file_last_error(const mrl_tensor_file *f);   /* f == NULL: why the last open / load of this thread failed */
+int mrl_tensor_file_field_count(const mrl_tensor_file *f);
+int mrl_tensor_file_find(const mrl_tensor_file *f, const char *name);             /* index, or < 0 */
+int mrl_tensor_file_field_info(const mrl_tensor_file *f, int index, const char **name, int *dtype, int *ndim, const uint64_t **shape);
+const void *mrl_tensor_file_field_data(const mrl_tensor_file *f, int index, size_t *bytes);   /* raw payload, valid until close */
+int mrl_tensor_file_read_f64(const mrl_tensor_file *f, int index, double *out, size_t capacity);   /* float fields, converted */
+/* field == NULL: "table".  The material is an RGB table for 3 channels, an n-channel table otherwise. */
+int mrl_material_load_tensor_table(mrl_ctx *ctx, const char *path, const char *field, int *out_id, int *out_channels);
 
 /* ---- wavefront queues.  A wavefront path tracer keeps its path state in arrays
  * indexed by path slot and a queue of the slots that hit this BSDF.  These calls process the units

@@ -93,7 +93,7 @@ struct mrl_ctx {
     int table_layout = 1;            // layout of tables uploaded from now on (mrl::Layout)
     size_t host_chunk = (size_t)1 << 22;
     void *d_stage = nullptr;
-    size_t d_stage_units = 0;
+    size_t d_stage_bytes = 0;
     std::string last_error;
 };
 
@@ -291,6 +291,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     m.dev.row_th = (int)(D * P);
     m.dev.texels = m.d_texels;
     m.dev.layout = layout;
+    m.dev.n_ch = 3;
     rc = place_material(ctx, m, out_id);
     if (rc != MRL_OK) { (void)hipFree(m.d_texels); (void)hipFree(m.d_sampling); return rc; }
     return MRL_OK;
@@ -332,12 +333,13 @@ int read_table_file(mrl_ctx *ctx, const char *path, bool require_merl, std::vect
     return MRL_OK;
 }
 
-int ensure_stage(mrl_ctx *ctx, size_t units)
+// staging area of host-pointer calls: `units` units of `unit_bytes` each (80 B for RGB, 56 + 8 C for C channels)
+int ensure_stage(mrl_ctx *ctx, size_t units, size_t unit_bytes)
 {
-    if (units <= ctx->d_stage_units) return MRL_OK;
-    if (ctx->d_stage) { MRL_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_stage); ctx->d_stage = nullptr; ctx->d_stage_units = 0; }
-    MRL_ALLOC(ctx, hipMalloc(&ctx->d_stage, units * 80));
-    ctx->d_stage_units = units;
+    if (units * unit_bytes <= ctx->d_stage_bytes) return MRL_OK;
+    if (ctx->d_stage) { MRL_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_stage); ctx->d_stage = nullptr; ctx->d_stage_bytes = 0; }
+    MRL_ALLOC(ctx, hipMalloc(&ctx->d_stage, units * unit_bytes));
+    ctx->d_stage_bytes = units * unit_bytes;
     return MRL_OK;
 }
 
@@ -348,6 +350,7 @@ struct BatchCall {
     int32_t single_id;
     size_t n;
     float *out_rgb, *out_pdf, *out_wo, *out_pdf2, *out_weight;
+    int n_ch = 0;                                // 0: the RGB entry points; > 0: *_nch calls, out_rgb / out_weight are n x n_ch
 };
 
 inline bool call_has_eval(int mode) { return mode == 0 || mode == 3 || mode == 4; }
@@ -391,7 +394,7 @@ DeviceCall device_call(const mrl_ctx *ctx, const BatchCall &c)
     for (const auto &m : ctx->materials) {
         if (m.released) continue;
         d.has_ggx = d.has_ggx || m.dev.kind == mrl::KIND_GGX;
-        d.has_table = d.has_table || m.dev.kind != mrl::KIND_GGX;
+        d.has_table = d.has_table || m.dev.kind == mrl::KIND_MERL || m.dev.kind == mrl::KIND_TABLE;
     }
     if (!d.has_ggx && !d.has_table) d.has_table = true;        // only tombstones left: the table path renders them as zeros
     return d;
@@ -408,6 +411,13 @@ int check_call(mrl_ctx *ctx, const BatchCall &c)
     if (ctx->materials.empty()) return fail(ctx, MRL_ERR_MATERIAL, "no material loaded");
     if (!c.mat && (c.single_id < 0 || (size_t)c.single_id >= ctx->materials.size() || ctx->materials[(size_t)c.single_id].released))
         return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
+    if (!c.mat) {
+        const mrl::MaterialDev &d = ctx->materials[(size_t)c.single_id].dev;
+        if (c.n_ch == 0 && !mrl::kind_is_rgb_path(d.kind))
+            return fail(ctx, MRL_ERR_MATERIAL, "material has " + std::to_string(d.n_ch) + " channels: use the *_nch entry points");
+        if (c.n_ch > 0 && c.mode != 1 && (d.kind != mrl::KIND_TABLE_NCH || d.n_ch != c.n_ch))
+            return fail(ctx, MRL_ERR_MATERIAL, "material does not have " + std::to_string(c.n_ch) + " channels");
+    }
     return MRL_OK;
 }
 
@@ -426,6 +436,10 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
 {
     const DeviceCall d = device_call(ctx, c);
     const mrl::BatchArgs &a = d.args;
+    if (c.n_ch > 0 && c.mode != 1) {                          // n-channel tables: their own kernels (pdf is channel-free)
+        MRL_HIP(ctx, mrl::launch_batch_nch(c.mode, a, d.multi, c.n_ch, ctx->compute_units, ctx->stream));
+        return MRL_OK;
+    }
     const bool multi = d.multi, has_ggx = d.has_ggx, has_table = d.has_table;
     // MRL_OPT_KERNEL >= 4: a batch that may mix table and analytic materials is split into one dense queue
     // per kind (count / scan / partition, no atomics); each queue then runs through its dedicated kernel
@@ -466,16 +480,18 @@ int run_batch(mrl_ctx *ctx, const BatchCall &c)
     if (kind == 1) return launch_device(ctx, c);
 
     // host pointers: stage through HBM in chunks; returns when the outputs are on the host
+    const size_t C = c.n_ch > 0 ? (size_t)c.n_ch : 3;          // values per unit in out_rgb / out_weight
+    const size_t unit_bytes = 56 + 8 * C;
     const size_t chunk = std::min(c.n, ctx->host_chunk);
-    rc = ensure_stage(ctx, chunk);
+    rc = ensure_stage(ctx, chunk, unit_bytes);
     if (rc != MRL_OK) return rc;
     char *base = (char *)ctx->d_stage;
-    const size_t cu = ctx->d_stage_units;
+    const size_t cu = chunk;
     float *d_wi = (float *)base;               float *d_wo = (float *)(base + 12 * cu);
     float *d_u = (float *)(base + 24 * cu);    int32_t *d_mat = (int32_t *)(base + 32 * cu);
-    float *d_rgb = (float *)(base + 36 * cu);  float *d_pdf = (float *)(base + 48 * cu);
-    float *d_wo2 = (float *)(base + 52 * cu);  float *d_pdf2 = (float *)(base + 64 * cu);
-    float *d_w = (float *)(base + 68 * cu);
+    float *d_pdf = (float *)(base + 36 * cu);  float *d_wo2 = (float *)(base + 40 * cu);
+    float *d_pdf2 = (float *)(base + 52 * cu); float *d_rgb = (float *)(base + 56 * cu);
+    float *d_w = (float *)(base + (56 + 4 * C) * cu);
     for (size_t off = 0; off < c.n; off += chunk) {
         const size_t m = std::min(chunk, c.n - off);
         MRL_HIP(ctx, hipMemcpyAsync(d_wi, c.wi + 3 * off, 12 * m, hipMemcpyHostToDevice, ctx->stream));
@@ -487,12 +503,12 @@ int run_batch(mrl_ctx *ctx, const BatchCall &c)
         d.out_rgb = d_rgb; d.out_pdf = d_pdf; d.out_wo = d_wo2; d.out_pdf2 = d_pdf2; d.out_weight = d_w;
         rc = launch_device(ctx, d);
         if (rc != MRL_OK) return rc;
-        if (has_eval) MRL_HIP(ctx, hipMemcpyAsync(c.out_rgb + 3 * off, d_rgb, 12 * m, hipMemcpyDeviceToHost, ctx->stream));
+        if (has_eval) MRL_HIP(ctx, hipMemcpyAsync(c.out_rgb + C * off, d_rgb, 4 * C * m, hipMemcpyDeviceToHost, ctx->stream));
         if (has_pdf) MRL_HIP(ctx, hipMemcpyAsync(c.out_pdf + off, d_pdf, 4 * m, hipMemcpyDeviceToHost, ctx->stream));
         if (has_sample) {
             MRL_HIP(ctx, hipMemcpyAsync(c.out_wo + 3 * off, d_wo2, 12 * m, hipMemcpyDeviceToHost, ctx->stream));
             MRL_HIP(ctx, hipMemcpyAsync(c.out_pdf2 + off, d_pdf2, 4 * m, hipMemcpyDeviceToHost, ctx->stream));
-            MRL_HIP(ctx, hipMemcpyAsync(c.out_weight + 3 * off, d_w, 12 * m, hipMemcpyDeviceToHost, ctx->stream));
+            MRL_HIP(ctx, hipMemcpyAsync(c.out_weight + C * off, d_w, 4 * C * m, hipMemcpyDeviceToHost, ctx->stream));
         }
         MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -513,6 +529,134 @@ int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uin
     DeviceCall d = device_call(ctx, c);
     d.args.idx = queue; d.args.idx_count = queue_count;
     MRL_HIP(ctx, mrl::launch_batch_indexed(c.mode, d.args, d.multi, ctx->table_layout, d.has_ggx, d.has_table, ctx->compute_units, ctx->stream));
+    return MRL_OK;
+}
+
+
+// n-channel row marginal for table importance sampling: as build_sampling, with the plain mean over the channels in
+// place of the RGB luminance (oracle: orc_build_sampling_nch)
+std::vector<double> build_sampling_nch(const double *planar, int n_th, int n_td, int n_pd, int n_ch, const double *scale)
+{
+    const size_t plane = (size_t)n_th * n_td * n_pd;
+    std::vector<double> D((size_t)n_th), out(3 * (size_t)n_th + 2);
+    double *s = out.data(), *cdf = s + (n_th + 1), *c = cdf + (n_th + 1);
+    double mean = 0.0;
+    for (int i = 0; i < n_th; ++i) {
+        double acc = 0.0;
+        const double *row = planar + (size_t)i * n_td * n_pd;
+        for (size_t k = 0; k < (size_t)n_td * n_pd; ++k) {
+            double sum = 0.0;
+            for (int ch = 0; ch < n_ch; ++ch) sum += std::max(row[k + (size_t)ch * plane] * scale[ch], 0.0);
+            acc += sum / (double)n_ch;
+        }
+        D[(size_t)i] = acc / ((double)n_td * (double)n_pd);
+        mean += D[(size_t)i];
+    }
+    mean /= (double)n_th;
+    for (int i = 0; i < n_th; ++i) D[(size_t)i] = mean > 0.0 ? D[(size_t)i] + 0.01 * mean : 1.0;
+    const double kHalfPi = 3.14159265358979323846 / 2.0;
+    for (int i = 0; i <= n_th; ++i) {
+        const double r = (double)i / (double)n_th, sn = std::sin(r * r * kHalfPi);
+        s[i] = i == n_th ? 1.0 : sn * sn;
+    }
+    double Z = 0.0;
+    for (int i = 0; i < n_th; ++i) Z += D[(size_t)i] * (s[i + 1] - s[i]);
+    double run = 0.0;
+    for (int i = 0; i < n_th; ++i) {
+        cdf[i] = run / Z;
+        run += D[(size_t)i] * (s[i + 1] - s[i]);
+        c[i] = D[(size_t)i] / (3.14159265358979323846 * Z);
+    }
+    cdf[n_th] = 1.0;
+    return out;
+}
+
+// planar f64, n_ch planes -> n-channel bricks in HBM (merl_nch.hip).  n_ch == 3 is the RGB path (packed 96-B bricks).
+int upload_table_nch(mrl_ctx *ctx, const double *planar, const int dims[3], int n_ch, const double *scale, int *out_id)
+{
+    if (!ctx || !planar || !dims || !out_id) return fail(ctx, MRL_ERR_INVALID, "null argument");
+    if (n_ch < 1 || n_ch > mrl::kMaxChannels) return fail(ctx, MRL_ERR_INVALID, "channel count must be 1.." + std::to_string(mrl::kMaxChannels));
+    std::vector<double> ones((size_t)n_ch, 1.0);
+    if (!scale) scale = ones.data();
+    if (n_ch == 3) return upload_table(ctx, planar, dims, scale, mrl::KIND_TABLE, out_id);
+    const int n_th = dims[0], n_td = dims[1], n_pd = dims[2];
+    if (n_th < 1 || n_td < 1 || n_pd < 1 || (long long)n_th * n_td * n_pd > (1LL << 28))
+        return fail(ctx, MRL_ERR_INVALID, "table dims out of range");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t plane = (size_t)n_th * n_td * n_pd;
+    const size_t out_f4 = plane * mrl::nch_brick_float4s(n_ch);
+    const size_t sampling_doubles = 3 * (size_t)n_th + 2;
+    MaterialHost m;
+    m.bytes = out_f4 * sizeof(float4) + sampling_doubles * sizeof(double);
+    const size_t planar_bytes = ((size_t)n_ch * plane + (size_t)n_ch) * sizeof(double);       // payload + the channel scales
+    int rc = budget_check(ctx, m.bytes + planar_bytes);
+    if (rc != MRL_OK) return rc;
+    double *d_planar = nullptr;
+    MRL_ALLOC(ctx, hipMalloc((void **)&d_planar, planar_bytes));
+    double *d_scale = d_planar + (size_t)n_ch * plane;
+    hipError_t e = hipMalloc((void **)&m.d_texels, out_f4 * sizeof(float4));
+    const bool oom = e == hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_planar, planar, (size_t)n_ch * plane * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_scale, scale, (size_t)n_ch * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = mrl::launch_build_table_nch(d_planar, d_scale, dims, n_ch, m.d_texels, ctx->compute_units, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_planar);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (m.d_texels) (void)hipFree(m.d_texels);
+        return fail(ctx, oom ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("n-channel table upload: ") + hipGetErrorString(e));
+    }
+    const std::vector<double> sampling = build_sampling_nch(planar, n_th, n_td, n_pd, n_ch, scale);
+    e = hipMalloc((void **)&m.d_sampling, sampling.size() * sizeof(double));
+    const bool oom2 = e == hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemcpy(m.d_sampling, sampling.data(), sampling.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(m.d_texels);
+        if (m.d_sampling) (void)hipFree(m.d_sampling);
+        return fail(ctx, oom2 ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("sampling table upload: ") + hipGetErrorString(e));
+    }
+    std::memset(&m.dev, 0, sizeof m.dev);
+    m.dev.kind = mrl::KIND_TABLE_NCH;
+    m.dev.sampling = m.d_sampling;
+    m.dev.n_th = n_th; m.dev.n_td = n_td; m.dev.n_pd = n_pd;
+    m.dev.texels = m.d_texels;
+    m.dev.layout = mrl::LAYOUT_BRICK;
+    m.dev.n_ch = n_ch;
+    rc = place_material(ctx, m, out_id);
+    if (rc != MRL_OK) { (void)hipFree(m.d_texels); (void)hipFree(m.d_sampling); return rc; }
+    return MRL_OK;
+}
+
+// customized_measurement file with n_ch planes: int32 dims[3], then planar values as f64 or f32 (told apart by the file length)
+int read_table_file_nch(mrl_ctx *ctx, const char *path, int n_ch, std::vector<double> &data, int dims[3])
+{
+    if (!path) return fail(ctx, MRL_ERR_INVALID, "null path");
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(ctx, MRL_ERR_IO, std::string("cannot open ") + path);
+    int32_t d[3];
+    if (std::fread(d, sizeof(int32_t), 3, f) != 3) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "short header"); }
+    if (d[0] <= 0 || d[1] <= 0 || d[2] <= 0) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "non-positive dims"); }
+    const long long n = (long long)d[0] * d[1] * d[2];
+    if (n > (1LL << 28)) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "table too large"); }
+    if (std::fseek(f, 0, SEEK_END) != 0) { std::fclose(f); return fail(ctx, MRL_ERR_IO, "seek failed"); }
+    const long long bytes = (long long)std::ftell(f);
+    const bool f64_payload = bytes == 12 + (long long)n_ch * n * 8, f32_payload = bytes == 12 + (long long)n_ch * n * 4;
+    if (!f64_payload && !f32_payload) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "file length matches neither an f64 nor an f32 payload of " + std::to_string(n_ch) + " channels"); }
+    if (std::fseek(f, 12, SEEK_SET) != 0) { std::fclose(f); return fail(ctx, MRL_ERR_IO, "seek failed"); }
+    try { data.resize((size_t)n_ch * (size_t)n); } catch (const std::bad_alloc &) { std::fclose(f); return fail(ctx, MRL_ERR_OOM, "table buffer"); }
+    size_t got;
+    if (f32_payload) {
+        std::vector<float> narrow;
+        try { narrow.resize(data.size()); } catch (const std::bad_alloc &) { std::fclose(f); return fail(ctx, MRL_ERR_OOM, "table buffer"); }
+        got = std::fread(narrow.data(), sizeof(float), narrow.size(), f);
+        for (size_t i = 0; i < got; ++i) data[i] = (double)narrow[i];
+    } else {
+        got = std::fread(data.data(), sizeof(double), data.size(), f);
+    }
+    std::fclose(f);
+    if (got != data.size()) return fail(ctx, MRL_ERR_FORMAT, "truncated table payload");
+    dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2];
     return MRL_OK;
 }
 
@@ -600,7 +744,7 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
             if (value < 0 || value > 1) break;
             if (value != ctx->table_layout)
                 for (const auto &m : ctx->materials)
-                    if (!m.released && m.dev.kind != mrl::KIND_GGX) return fail(ctx, MRL_ERR_INVALID, "table layout is context-wide: set it before the first table is uploaded");
+                    if (!m.released && (m.dev.kind == mrl::KIND_MERL || m.dev.kind == mrl::KIND_TABLE)) return fail(ctx, MRL_ERR_INVALID, "table layout is context-wide: set it before the first table is uploaded");
             ctx->table_layout = value;
             for (auto &m : ctx->materials) if (m.released) m.dev.layout = value;    // tombstones follow (valid in both layouts)
             return ctx->materials.empty() ? MRL_OK : sync_material_array(ctx);
@@ -692,6 +836,7 @@ int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float 
     MaterialHost m;
     std::memset(&m.dev, 0, sizeof m.dev);
     m.dev.kind = mrl::KIND_GGX;
+    m.dev.n_ch = 3;
     m.dev.alpha = (double)alpha;
     for (int c = 0; c < 3; ++c) { m.dev.eta[c] = (double)eta[c]; m.dev.k[c] = (double)k[c]; }
     return place_material(ctx, m, out_id);
@@ -725,7 +870,7 @@ int mrl_memory_info(const mrl_ctx *ctx, size_t *material_bytes, size_t *workspac
     if (!ctx) return MRL_ERR_INVALID;
     if (material_bytes) *material_bytes = ctx->material_bytes;
     if (workspace_bytes)
-        *workspace_bytes = ctx->d_stage_units * 80 + (ctx->queue_cap ? (2 * ctx->queue_cap + 4 * kMaxSegments + 2) * sizeof(uint32_t) : 0) +
+        *workspace_bytes = ctx->d_stage_bytes + (ctx->queue_cap ? (2 * ctx->queue_cap + 4 * kMaxSegments + 2) * sizeof(uint32_t) : 0) +
                            ctx->part_work_cap * sizeof(uint32_t) + ctx->d_materials_cap * sizeof(mrl::MaterialDev) +
                            (ctx->d_dummy ? 256 + 5 * sizeof(double) : 0);
     if (device_free || device_total) {
@@ -936,6 +1081,66 @@ int mrl_timer_stop(mrl_ctx *ctx, float *elapsed_ms)
     MRL_HIP(ctx, hipEventSynchronize(ctx->ev1));
     MRL_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
     return MRL_OK;
+}
+
+/* ---- n-channel tables ---- */
+int mrl_material_upload_table_nch(mrl_ctx *ctx, const double *planar, const int dims[3], int n_channels, const double *scale, int *out_id)
+{
+    return upload_table_nch(ctx, planar, dims, n_channels, scale, out_id);
+}
+
+int mrl_material_load_table_nch(mrl_ctx *ctx, const char *path, int n_channels, const double *scale, int *out_id)
+{
+    if (!ctx || !out_id) return MRL_ERR_INVALID;
+    if (n_channels < 1 || n_channels > mrl::kMaxChannels) return fail(ctx, MRL_ERR_INVALID, "channel count must be 1.." + std::to_string(mrl::kMaxChannels));
+    std::vector<double> data; int dims[3];
+    int rc = read_table_file_nch(ctx, path, n_channels, data, dims);
+    if (rc != MRL_OK) return rc;
+    return upload_table_nch(ctx, data.data(), dims, n_channels, scale, out_id);
+}
+
+int mrl_material_channels(const mrl_ctx *ctx, int id, int *n_channels)
+{
+    if (!ctx || !n_channels) return MRL_ERR_INVALID;
+    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return MRL_ERR_MATERIAL;
+    *n_channels = ctx->materials[(size_t)id].dev.n_ch;
+    return MRL_OK;
+}
+
+static int nch_call(mrl_ctx *ctx, BatchCall c, int n_channels)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    if (n_channels < 1 || n_channels > mrl::kMaxChannels) return fail(ctx, MRL_ERR_INVALID, "channel count must be 1.." + std::to_string(mrl::kMaxChannels));
+    c.n_ch = n_channels == 3 ? 0 : n_channels;           // three channels: the RGB path, RGB materials
+    return run_batch(ctx, c);
+}
+
+int mrl_eval_batch_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, int n_channels,
+                       float *out_values)
+{
+    BatchCall c{ 0, wi, wo, nullptr, mat, single_id, n, out_values, nullptr, nullptr, nullptr, nullptr };
+    return nch_call(ctx, c, n_channels);
+}
+
+int mrl_sample_batch_nch(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id, size_t n, int n_channels,
+                         float *out_wo, float *out_pdf, float *out_weight)
+{
+    BatchCall c{ 2, wi, nullptr, u, mat, single_id, n, nullptr, nullptr, out_wo, out_pdf, out_weight };
+    return nch_call(ctx, c, n_channels);
+}
+
+int mrl_eval_pdf_batch_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, int n_channels,
+                           float *out_values, float *out_pdf)
+{
+    BatchCall c{ 4, wi, wo, nullptr, mat, single_id, n, out_values, out_pdf, nullptr, nullptr, nullptr };
+    return nch_call(ctx, c, n_channels);
+}
+
+int mrl_eval_sample_batch_nch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u, const int32_t *mat, int32_t single_id, size_t n,
+                              int n_channels, float *out_values, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
+{
+    BatchCall c{ 3, wi, wo, u, mat, single_id, n, out_values, out_pdf, out_wo, out_pdf2, out_weight };
+    return nch_call(ctx, c, n_channels);
 }
 
 } // extern "C"

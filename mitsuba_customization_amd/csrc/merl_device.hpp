@@ -22,7 +22,10 @@ constexpr double kHalfPi = 1.57079632679489661923;
 constexpr float kInvPiF = 0.31830988618379067154f;
 
 enum Kind : int { KIND_MERL = 0, KIND_TABLE = 1, KIND_GGX = 2,
-                  KIND_RELEASED = 3 };   // tombstone of mrl_material_release: a valid 1x1x1 zero table, treated like an unknown id
+                  KIND_RELEASED = 3,     // tombstone of mrl_material_release: a valid 1x1x1 zero table, treated like an unknown id
+                  KIND_TABLE_NCH = 4 };  // n-channel table (merl_nch.hip): only the *_nch entry points evaluate it
+// the RGB kernels evaluate kinds 0..2; anything above renders as an unknown id (every output zero)
+__host__ __device__ constexpr bool kind_is_rgb_path(int kind) { return kind >= KIND_MERL && kind <= KIND_GGX; }
 enum Layout : int { LAYOUT_ROWS = 0, LAYOUT_BRICK = 1 };
 
 // One material as the kernels see it (array in device memory; single-material launches get it
@@ -35,6 +38,7 @@ struct MaterialDev {
     const float4 *texels;        // layout 0: [(n_th+1)][(n_td+1)][(n_pd+1)] RGBA f32, scaled, negatives clamped
                                  // layout 1: [n_th][n_td][n_pd] bricks of 128 B = the cell's 8 corners, RGB f32 packed
     int layout;                  // LAYOUT_ROWS / LAYOUT_BRICK
+    int n_ch;                    // channels: 3 for the RGB kinds; KIND_TABLE_NCH: 1..32 (bricks of ceil(n_ch/4) x 128 B, or 32 / 64 B for 1 / 2 channels)
     const double *sampling;      // table importance sampling: s[n_th+1] | cdf[n_th+1] | c[n_th]  (see table_pdf below)
     double alpha;                // GGX
     double eta[3], k[3];

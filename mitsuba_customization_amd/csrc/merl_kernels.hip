@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void k_batch(BatchArgs a)
             int id = a.mat[i];
             valid = id >= 0 && id < a.n_materials;
             m = a.materials[valid ? id : 0];
-            valid = valid && m.kind != KIND_RELEASED;
+            valid = valid && kind_is_rgb_path(m.kind);
         } else {
             m = a.single;
         }
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
             int id = a.mat[i];
             known = id >= 0 && id < a.n_materials;
             m = a.materials[known ? id : 0];
-            known = known && m.kind != KIND_RELEASED;
+            known = known && kind_is_rgb_path(m.kind);
         } else {
             m = a.single;
         }
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
             int id = a.mat[i];
             known = id >= 0 && id < a.n_materials;
             m = a.materials[known ? id : 0];
-            known = known && m.kind != KIND_RELEASED;
+            known = known && kind_is_rgb_path(m.kind);
         } else {
             m = a.single;
         }

@@ -20,6 +20,7 @@ SAMPLING_COSINE, SAMPLING_TABLE = 0, 1
 LAYOUT_ROWS, LAYOUT_BRICK = 0, 1
 LOOKUP_NEAREST, LOOKUP_TRILINEAR = 0, 1
 KIND_MERL, KIND_TABLE, KIND_GGX = 0, 1, 2
+KIND_TABLE_NCH = 4
 ERR_INVALID, ERR_HIP, ERR_IO, ERR_FORMAT, ERR_OOM, ERR_MATERIAL, ERR_POINTER_MIX, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7, -8
 
 # every symbol include/merl_hip.h declares (tests check the library exports all of them)
@@ -33,6 +34,10 @@ ABI_SYMBOLS = (
     "mrl_generate_pairs", "mrl_generate_materials",
     "mrl_device_alloc", "mrl_device_free", "mrl_copy_to_device", "mrl_copy_to_host", "mrl_host_alloc", "mrl_host_free",
     "mrl_timer_start", "mrl_timer_stop",
+    "mrl_material_upload_table_nch", "mrl_material_load_table_nch", "mrl_material_channels",
+    "mrl_eval_batch_nch", "mrl_sample_batch_nch", "mrl_eval_pdf_batch_nch", "mrl_eval_sample_batch_nch",
+    "mrl_tensor_file_open", "mrl_tensor_file_close", "mrl_tensor_file_last_error", "mrl_tensor_file_field_count", "mrl_tensor_file_find",
+    "mrl_tensor_file_field_info", "mrl_tensor_file_field_data", "mrl_tensor_file_read_f64", "mrl_material_load_tensor_table",
     "mrl_group_init", "mrl_group_destroy", "mrl_group_size", "mrl_group_transport", "mrl_group_last_error", "mrl_group_context",
     "mrl_group_set_option", "mrl_group_material_load_merl", "mrl_group_material_upload_f64", "mrl_group_material_upload_table",
     "mrl_group_material_ggx", "mrl_group_material_release", "mrl_tile_bounds", "mrl_chunk_bounds", "mrl_chunk_steps",
@@ -120,6 +125,22 @@ def load_library(path: Optional[str] = None):
     L.mrl_host_free.argtypes = [vp, vp]
     L.mrl_timer_start.argtypes = [vp]
     L.mrl_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mrl_material_upload_table_nch.argtypes = [vp, vp, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.mrl_material_load_table_nch.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.mrl_material_channels.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+    L.mrl_eval_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp]
+    L.mrl_sample_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp, fp, fp]
+    L.mrl_eval_pdf_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp, fp]
+    L.mrl_eval_sample_batch_nch.argtypes = [vp, fp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp, fp, fp, fp, fp]
+    L.mrl_tensor_file_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.mrl_tensor_file_close.argtypes = [vp]
+    L.mrl_tensor_file_last_error.argtypes = [vp]; L.mrl_tensor_file_last_error.restype = C.c_char_p
+    L.mrl_tensor_file_field_count.argtypes = [vp]
+    L.mrl_tensor_file_find.argtypes = [vp, C.c_char_p]
+    L.mrl_tensor_file_field_info.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint64))]
+    L.mrl_tensor_file_field_data.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]; L.mrl_tensor_file_field_data.restype = vp
+    L.mrl_tensor_file_read_f64.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.mrl_material_load_tensor_table.argtypes = [vp, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     szp = C.POINTER(C.c_size_t)
     L.mrl_group_init.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.mrl_group_destroy.argtypes = [vp]
@@ -276,6 +297,77 @@ class MerlHip:
         kind = C.c_int(); dims = (C.c_int * 3)()
         self._check(self._lib.mrl_material_info(self._ctx, mid, C.byref(kind), dims), "mrl_material_info")
         return kind.value, tuple(dims)
+
+    # ---- n-channel tables ----
+    def upload_table_nch(self, planar: np.ndarray, scale: Optional[Sequence[float]] = None) -> int:
+        """planar: (n_channels, n_th, n_td, n_pd) f64."""
+        p = np.ascontiguousarray(planar, dtype=np.float64)
+        if p.ndim != 4:
+            raise ValueError("upload_table_nch needs a (n_channels, n_th, n_td, n_pd) array")
+        c = int(p.shape[0])
+        dims = (C.c_int * 3)(*p.shape[1:]); mid = C.c_int()
+        sc = None if scale is None else (C.c_double * c)(*scale)
+        self._check(self._lib.mrl_material_upload_table_nch(self._ctx, p.ctypes.data, dims, c, sc, C.byref(mid)), "mrl_material_upload_table_nch")
+        return mid.value
+
+    def load_table_nch(self, path: str, n_channels: int, scale: Optional[Sequence[float]] = None) -> int:
+        sc = None if scale is None else (C.c_double * n_channels)(*scale); mid = C.c_int()
+        self._check(self._lib.mrl_material_load_table_nch(self._ctx, path.encode(), n_channels, sc, C.byref(mid)), "mrl_material_load_table_nch")
+        return mid.value
+
+    def material_channels(self, mid: int) -> int:
+        c = C.c_int()
+        self._check(self._lib.mrl_material_channels(self._ctx, mid, C.byref(c)), "mrl_material_channels")
+        return c.value
+
+    def eval_nch(self, wi, wo, n_channels: int, mat=None, material: int = 0, out=None):
+        n = int(wi.shape[0]); self._prep(wi)
+        out = self._empty(wi, (n, n_channels)) if out is None else out
+        self._check(self._lib.mrl_eval_batch_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                 _addr(mat, np.int32, None, n, "mat"), material, n, n_channels,
+                                                 _addr(out, np.float32, n_channels, n, "out_values")), "mrl_eval_batch_nch")
+        return out
+
+    def sample_nch(self, wi, u, n_channels: int, mat=None, material: int = 0):
+        n = int(wi.shape[0]); self._prep(wi)
+        wo, pdf, w = self._empty(wi, (n, 3)), self._empty(wi, (n,)), self._empty(wi, (n, n_channels))
+        self._check(self._lib.mrl_sample_batch_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(u, np.float32, 2, n, "u"),
+                                                   _addr(mat, np.int32, None, n, "mat"), material, n, n_channels,
+                                                   _addr(wo, np.float32, 3, n, "out_wo"), _addr(pdf, np.float32, None, n, "out_pdf"),
+                                                   _addr(w, np.float32, n_channels, n, "out_weight")), "mrl_sample_batch_nch")
+        return wo, pdf, w
+
+    def eval_pdf_nch(self, wi, wo, n_channels: int, mat=None, material: int = 0):
+        n = int(wi.shape[0]); self._prep(wi)
+        val, pdf = self._empty(wi, (n, n_channels)), self._empty(wi, (n,))
+        self._check(self._lib.mrl_eval_pdf_batch_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                     _addr(mat, np.int32, None, n, "mat"), material, n, n_channels,
+                                                     _addr(val, np.float32, n_channels, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf")),
+                    "mrl_eval_pdf_batch_nch")
+        return val, pdf
+
+    def eval_sample_nch(self, wi, wo, u, n_channels: int, mat=None, material: int = 0):
+        """Returns (values[n, C], pdf, wo', pdf', weight'[n, C])."""
+        n = int(wi.shape[0]); self._prep(wi)
+        out = (self._empty(wi, (n, n_channels)), self._empty(wi, (n,)), self._empty(wi, (n, 3)), self._empty(wi, (n,)),
+               self._empty(wi, (n, n_channels)))
+        val, pdf, wo2, pdf2, w = out
+        self._check(self._lib.mrl_eval_sample_batch_nch(
+            self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"), _addr(u, np.float32, 2, n, "u"),
+            _addr(mat, np.int32, None, n, "mat"), material, n, n_channels,
+            _addr(val, np.float32, n_channels, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf"),
+            _addr(wo2, np.float32, 3, n, "out_wo"), _addr(pdf2, np.float32, None, n, "out_pdf2"),
+            _addr(w, np.float32, n_channels, n, "out_weight")), "mrl_eval_sample_batch_nch")
+        return out
+
+    def load_tensor_table(self, path: str, field: Optional[str] = None):
+        """A customized_measurement table stored in a tensor_file container.  Returns (material id, channels)."""
+        mid, ch = C.c_int(), C.c_int()
+        rc = self._lib.mrl_material_load_tensor_table(self._ctx, path.encode(), None if field is None else field.encode(), C.byref(mid), C.byref(ch))
+        if rc != 0:
+            detail = self._lib.mrl_tensor_file_last_error(None).decode() or self._lib.mrl_last_error(self._ctx).decode()
+            raise MerlHipError(rc, "mrl_material_load_tensor_table", detail)
+        return mid.value, ch.value
 
     def release_material(self, mid: int):
         """Frees the material's device memory; its id becomes a tombstone (batch calls render it as zeros)."""
@@ -450,6 +542,40 @@ class MerlHip:
         return out
 
 
+TENSOR_DTYPES = {1: "int8/uint8", 2: "int8/uint8", 3: "int16/uint16", 4: "int16/uint16", 5: "int32/uint32", 6: "int32/uint32",
+                 7: "int64/uint64", 8: "int64/uint64", 9: "float16", 10: "float32", 11: "float64"}
+
+
+def read_tensor_file(path: str) -> dict:
+    """Every field of a tensor_file container through the library's reader (host code; needs no GPU):
+    {name: ndarray}; float fields come back as float64, integer fields as raw bytes reshaped to the field's shape."""
+    L = load_library()
+    f = C.c_void_p()
+    rc = L.mrl_tensor_file_open(path.encode(), C.byref(f))
+    if rc != 0:
+        raise MerlHipError(rc, "mrl_tensor_file_open", L.mrl_tensor_file_last_error(None).decode())
+    try:
+        out = {}
+        for i in range(L.mrl_tensor_file_field_count(f)):
+            name, dtype, ndim, shape = C.c_char_p(), C.c_int(), C.c_int(), C.POINTER(C.c_uint64)()
+            assert L.mrl_tensor_file_field_info(f, i, C.byref(name), C.byref(dtype), C.byref(ndim), C.byref(shape)) == 0
+            shp = tuple(int(shape[d]) for d in range(ndim.value))
+            count = int(np.prod(shp)) if shp else 1
+            if dtype.value >= 9:
+                a = np.empty(count, np.float64)
+                assert L.mrl_tensor_file_read_f64(f, i, a.ctypes.data, count) == 0
+                out[name.value.decode()] = a.reshape(shp)
+            else:
+                nbytes = C.c_size_t()
+                ptr = L.mrl_tensor_file_field_data(f, i, C.byref(nbytes))
+                raw = np.frombuffer(C.string_at(ptr, nbytes.value), dtype=np.uint8).copy()
+                width = nbytes.value // max(count, 1)
+                out[name.value.decode()] = raw.view({1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[width]).reshape(shp)
+        return out
+    finally:
+        L.mrl_tensor_file_close(f)
+
+
 def tile_bounds(n_total: int, world: int, rank: int):
     """mrl_tile_bounds through the library (pure arithmetic: needs no GPU)."""
     lo, hi = C.c_size_t(), C.c_size_t()
@@ -521,6 +647,77 @@ class MerlGroup:
         mid = C.c_int()
         self._check(self._lib.mrl_group_material_ggx(self._g, alpha, (C.c_float * 3)(*eta), (C.c_float * 3)(*k), C.byref(mid)), "mrl_group_material_ggx")
         return mid.value
+
+    # ---- n-channel tables ----
+    def upload_table_nch(self, planar: np.ndarray, scale: Optional[Sequence[float]] = None) -> int:
+        """planar: (n_channels, n_th, n_td, n_pd) f64."""
+        p = np.ascontiguousarray(planar, dtype=np.float64)
+        if p.ndim != 4:
+            raise ValueError("upload_table_nch needs a (n_channels, n_th, n_td, n_pd) array")
+        c = int(p.shape[0])
+        dims = (C.c_int * 3)(*p.shape[1:]); mid = C.c_int()
+        sc = None if scale is None else (C.c_double * c)(*scale)
+        self._check(self._lib.mrl_material_upload_table_nch(self._ctx, p.ctypes.data, dims, c, sc, C.byref(mid)), "mrl_material_upload_table_nch")
+        return mid.value
+
+    def load_table_nch(self, path: str, n_channels: int, scale: Optional[Sequence[float]] = None) -> int:
+        sc = None if scale is None else (C.c_double * n_channels)(*scale); mid = C.c_int()
+        self._check(self._lib.mrl_material_load_table_nch(self._ctx, path.encode(), n_channels, sc, C.byref(mid)), "mrl_material_load_table_nch")
+        return mid.value
+
+    def material_channels(self, mid: int) -> int:
+        c = C.c_int()
+        self._check(self._lib.mrl_material_channels(self._ctx, mid, C.byref(c)), "mrl_material_channels")
+        return c.value
+
+    def eval_nch(self, wi, wo, n_channels: int, mat=None, material: int = 0, out=None):
+        n = int(wi.shape[0]); self._prep(wi)
+        out = self._empty(wi, (n, n_channels)) if out is None else out
+        self._check(self._lib.mrl_eval_batch_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                 _addr(mat, np.int32, None, n, "mat"), material, n, n_channels,
+                                                 _addr(out, np.float32, n_channels, n, "out_values")), "mrl_eval_batch_nch")
+        return out
+
+    def sample_nch(self, wi, u, n_channels: int, mat=None, material: int = 0):
+        n = int(wi.shape[0]); self._prep(wi)
+        wo, pdf, w = self._empty(wi, (n, 3)), self._empty(wi, (n,)), self._empty(wi, (n, n_channels))
+        self._check(self._lib.mrl_sample_batch_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(u, np.float32, 2, n, "u"),
+                                                   _addr(mat, np.int32, None, n, "mat"), material, n, n_channels,
+                                                   _addr(wo, np.float32, 3, n, "out_wo"), _addr(pdf, np.float32, None, n, "out_pdf"),
+                                                   _addr(w, np.float32, n_channels, n, "out_weight")), "mrl_sample_batch_nch")
+        return wo, pdf, w
+
+    def eval_pdf_nch(self, wi, wo, n_channels: int, mat=None, material: int = 0):
+        n = int(wi.shape[0]); self._prep(wi)
+        val, pdf = self._empty(wi, (n, n_channels)), self._empty(wi, (n,))
+        self._check(self._lib.mrl_eval_pdf_batch_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                     _addr(mat, np.int32, None, n, "mat"), material, n, n_channels,
+                                                     _addr(val, np.float32, n_channels, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf")),
+                    "mrl_eval_pdf_batch_nch")
+        return val, pdf
+
+    def eval_sample_nch(self, wi, wo, u, n_channels: int, mat=None, material: int = 0):
+        """Returns (values[n, C], pdf, wo', pdf', weight'[n, C])."""
+        n = int(wi.shape[0]); self._prep(wi)
+        out = (self._empty(wi, (n, n_channels)), self._empty(wi, (n,)), self._empty(wi, (n, 3)), self._empty(wi, (n,)),
+               self._empty(wi, (n, n_channels)))
+        val, pdf, wo2, pdf2, w = out
+        self._check(self._lib.mrl_eval_sample_batch_nch(
+            self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"), _addr(u, np.float32, 2, n, "u"),
+            _addr(mat, np.int32, None, n, "mat"), material, n, n_channels,
+            _addr(val, np.float32, n_channels, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf"),
+            _addr(wo2, np.float32, 3, n, "out_wo"), _addr(pdf2, np.float32, None, n, "out_pdf2"),
+            _addr(w, np.float32, n_channels, n, "out_weight")), "mrl_eval_sample_batch_nch")
+        return out
+
+    def load_tensor_table(self, path: str, field: Optional[str] = None):
+        """A customized_measurement table stored in a tensor_file container.  Returns (material id, channels)."""
+        mid, ch = C.c_int(), C.c_int()
+        rc = self._lib.mrl_material_load_tensor_table(self._ctx, path.encode(), None if field is None else field.encode(), C.byref(mid), C.byref(ch))
+        if rc != 0:
+            detail = self._lib.mrl_tensor_file_last_error(None).decode() or self._lib.mrl_last_error(self._ctx).decode()
+            raise MerlHipError(rc, "mrl_material_load_tensor_table", detail)
+        return mid.value, ch.value
 
     def release_material(self, mid: int):
         self._check(self._lib.mrl_group_material_release(self._g, mid), "mrl_group_material_release")

@@ -154,3 +154,64 @@ def read_merl_binary(path: str, require_merl_dims: bool = True) -> np.ndarray:
         if data.size != 3 * n:
             raise ValueError("truncated MERL file")
     return data.reshape((3,) + tuple(int(d) for d in dims))
+
+
+# ---- n-channel tables (customized_measurement beyond RGB) --------------------------------------
+def make_table_nch(kind: str, n_ch: int, seed: int = 0, dims=MERL_DIMS) -> np.ndarray:
+    """(n_ch, n_th, n_td, n_pd) raw values.  "noise": independent hash noise per channel; "spectral": the GGX-shaped
+    lobe of ggx_tab_table with a smooth per-channel (wavelength-like) albedo and Fresnel ramp; "affine": a different
+    affine function of the indices per channel."""
+    if kind == "noise":
+        planes = [noise_table(seed * 131 + 7 * (c // 3) + 1, dims=dims)[c % 3] for c in range(n_ch)]
+        return np.stack(planes, axis=0)
+    if kind == "spectral":
+        base = ggx_tab_table(seed, dims=dims)                     # 3 planes, raw MERL units (divide the scales back out)
+        f = [np.where(base[c] > 0, base[c] * MERL_SCALE[c], -1.0) for c in range(3)]
+        out = np.empty((n_ch,) + tuple(dims), dtype=np.float64)
+        for c in range(n_ch):
+            t = c / max(n_ch - 1, 1)                              # 0 .. 1 across the channels
+            w = np.array([(1 - t) ** 2, 2 * t * (1 - t), t * t])  # smooth blend of the three base planes
+            mix = w[0] * np.maximum(f[0], 0) + w[1] * np.maximum(f[1], 0) + w[2] * np.maximum(f[2], 0)
+            out[c] = np.where(base[0] > 0, mix * (0.8 + 0.4 * np.sin(3.0 * t + seed)), -1.0)
+        return out
+    if kind == "affine":
+        ith, itd, ipd = _grid(dims)
+        return np.stack([10.0 + c + (1.0 + 0.5 * c) * ith + (0.5 + 0.25 * c) * itd + (0.125 * (c + 1)) * ipd for c in range(n_ch)], axis=0)
+    raise ValueError(f"unknown n-channel table kind {kind!r}")
+
+
+def write_table_nch(path: str, planar: np.ndarray, dtype="<f8") -> None:
+    """customized_measurement file with any channel count: int32 dims[3], then the planes (f64 or f32)."""
+    planar = np.ascontiguousarray(planar, dtype=dtype)
+    assert planar.ndim == 4
+    with open(path, "wb") as f:
+        np.asarray(planar.shape[1:], dtype="<i4").tofile(f)
+        planar.tofile(f)
+
+
+# ---- "tensor_file" container (RGL *.bsdf), writer for tests and fixtures -----------------------
+_TENSOR_DTYPE = {np.dtype("uint8"): 1, np.dtype("int8"): 2, np.dtype("uint16"): 3, np.dtype("int16"): 4, np.dtype("uint32"): 5,
+                 np.dtype("int32"): 6, np.dtype("uint64"): 7, np.dtype("int64"): 8, np.dtype("float16"): 9, np.dtype("float32"): 10,
+                 np.dtype("float64"): 11}
+
+
+def write_tensor_file(path: str, fields: dict) -> None:
+    """fields: {name: ndarray}.  Header "tensor_file\\0", version 1.0, field table, payloads (see csrc/merl_tensor_file.hip)."""
+    import struct
+    names = list(fields)
+    arrays = [np.array(fields[k], order="C") for k in names]             # (ascontiguousarray would turn 0-d into 1-d)
+    head = 12 + 2 + 4 + sum(2 + len(k.encode()) + 2 + 1 + 8 + 8 * a.ndim for k, a in zip(names, arrays))
+    offsets, at = [], head
+    for a in arrays:
+        at = (at + 7) // 8 * 8                                   # payloads 8-byte aligned
+        offsets.append(at)
+        at += a.nbytes
+    with open(path, "wb") as f:
+        f.write(b"tensor_file\0" + struct.pack("<BBI", 1, 0, len(names)))
+        for k, a, off in zip(names, arrays, offsets):
+            kb = k.encode()
+            f.write(struct.pack("<H", len(kb)) + kb + struct.pack("<HBQ", a.ndim, _TENSOR_DTYPE[a.dtype], off))
+            f.write(struct.pack(f"<{a.ndim}Q", *a.shape))
+        for a, off in zip(arrays, offsets):
+            f.write(b"\0" * (off - f.tell()))
+            f.write(a.astype(a.dtype.newbyteorder("<")).tobytes())

@@ -32,6 +32,11 @@ class Sampling(C.Structure):
     _fields_ = [("n", C.c_int), ("s", C.POINTER(C.c_double)), ("cdf", C.POINTER(C.c_double)), ("c", C.POINTER(C.c_double))]
 
 
+class TableNch(C.Structure):
+    _fields_ = [("n_th", C.c_int), ("n_td", C.c_int), ("n_pd", C.c_int), ("n_ch", C.c_int),
+                ("data", C.POINTER(C.c_double)), ("scale", C.POINTER(C.c_double))]
+
+
 class Ggx(C.Structure):
     _fields_ = [("alpha", C.c_double), ("eta", C.c_double * 3), ("k", C.c_double * 3)]
 
@@ -79,6 +84,10 @@ def lib():
         L.orc_free_sampling.argtypes = [C.POINTER(Sampling)]
         L.orc_pdf_table_batch.argtypes = [C.POINTER(Sampling), fp, fp, C.c_size_t, fp]
         L.orc_sample_table_batch.argtypes = [C.POINTER(Table), C.POINTER(Opts), C.POINTER(Sampling), fp, fp, C.c_size_t, fp, fp, fp]
+        L.orc_build_sampling_nch.argtypes = [C.POINTER(TableNch), C.POINTER(Sampling)]
+        L.orc_eval_sample_batch_nch.argtypes = [C.POINTER(TableNch), C.c_int, C.c_int, C.POINTER(Opts), C.POINTER(Sampling), fp, fp, fp,
+                                                C.POINTER(C.c_int32), C.c_size_t, fp, fp, fp, fp, fp]
+        L.orc_lookup_nch.argtypes = [C.POINTER(TableNch), C.POINTER(Opts)] + [C.c_double] * 3 + [C.POINTER(C.c_double)]
         L.orc_ggx_eval_batch.argtypes = [C.POINTER(Ggx), fp, fp, C.c_size_t, fp]
         L.orc_ggx_pdf_batch.argtypes = [C.POINTER(Ggx), fp, fp, C.c_size_t, fp]
         L.orc_ggx_sample_batch.argtypes = [C.POINTER(Ggx), fp, fp, C.c_size_t, fp, fp, fp]
@@ -174,6 +183,54 @@ class OracleTable:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         lib().orc_coords(C.byref(self.c), th, td, pd, C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
+
+
+class OracleTableNch:
+    """A planar f64 table (n_ch, n_th, n_td, n_pd) + per-channel scales, as the oracle sees it."""
+
+    def __init__(self, planar: np.ndarray, scale=None):
+        self.planar = np.ascontiguousarray(planar, dtype=np.float64)
+        assert self.planar.ndim == 4
+        self.n_ch = int(self.planar.shape[0])
+        self.scale = np.ascontiguousarray(np.ones(self.n_ch) if scale is None else scale, dtype=np.float64)
+        assert self.scale.shape == (self.n_ch,)
+        self.c = TableNch(self.planar.shape[1], self.planar.shape[2], self.planar.shape[3], self.n_ch, _dp(self.planar), _dp(self.scale))
+        self._sampling = None
+
+    def sampling(self):
+        if self._sampling is None:
+            self._sampling = Sampling()
+            assert lib().orc_build_sampling_nch(C.byref(self.c), C.byref(self._sampling)) == 0
+        return self._sampling
+
+    def lookup(self, th, td, pd, opts=None):
+        opts = opts or make_opts()
+        out = (C.c_double * self.n_ch)()
+        lib().orc_lookup_nch(C.byref(self.c), C.byref(opts), th, td, pd, out)
+        return np.array(out[:])
+
+
+def eval_sample_nch(tables, wi, wo, u, mat=None, opts=None, table_sampling=False, n_ch=None):
+    """tables: list[OracleTableNch]; returns values[n, C], pdf, wo2, pdf2, weight[n, C]."""
+    opts = opts or make_opts()
+    n_ch = n_ch or tables[0].n_ch
+    arr = (TableNch * len(tables))(*[t.c for t in tables])
+    sp = None
+    if table_sampling:
+        sp = (Sampling * len(tables))(*[t.sampling() for t in tables])
+    wi, pwi = _f32(wi); wo, pwo = _f32(wo); u, pu = _f32(u)
+    n = wi.shape[0]
+    pm = None
+    if mat is not None:
+        mat = np.ascontiguousarray(mat, dtype=np.int32)
+        pm = mat.ctypes.data_as(C.POINTER(C.c_int32))
+    fp = C.POINTER(C.c_float)
+    val = np.empty((n, n_ch), np.float32); p = np.empty(n, np.float32)
+    wo2 = np.empty((n, 3), np.float32); p2 = np.empty(n, np.float32); w = np.empty((n, n_ch), np.float32)
+    lib().orc_eval_sample_batch_nch(arr, len(tables), n_ch, C.byref(opts), sp, pwi, pwo, pu, pm, n,
+                                    val.ctypes.data_as(fp), p.ctypes.data_as(fp), wo2.ctypes.data_as(fp),
+                                    p2.ctypes.data_as(fp), w.ctypes.data_as(fp))
+    return val, p, wo2, p2, w
 
 
 def pdf(wi, wo):

@@ -452,6 +452,183 @@ void orc_eval_sample_batch_multi(const orc_table *tables, int n_tables, const or
 }
 
 /* ------------------------------------------------------------------------------------------
+ * §8f item 3 — n-channel tables (see merl_oracle.h).  The index maps only look at the dims, so a
+ * dims-only orc_table view of the n-channel table feeds the functions above.
+ * ---------------------------------------------------------------------------------------- */
+static orc_table dims_view(const orc_table_nch *t)
+{
+    orc_table v;
+    v.n_th = t->n_th; v.n_td = t->n_td; v.n_pd = t->n_pd; v.data = NULL;
+    v.scale[0] = v.scale[1] = v.scale[2] = 1.0;
+    return v;
+}
+
+static void texel_nch(const orc_table_nch *t, int ith, int itd, int ipd, double *out)
+{
+    size_t n = (size_t)t->n_th * t->n_td * t->n_pd;
+    size_t ind = (size_t)ipd + (size_t)t->n_pd * ((size_t)itd + (size_t)t->n_td * (size_t)ith);
+    for (int c = 0; c < t->n_ch; ++c) {
+        double v = t->data[ind + (size_t)c * n] * t->scale[c];
+        out[c] = v > 0.0 ? v : 0.0;
+    }
+}
+
+#define ORC_MAX_CH 64
+
+void orc_lookup_nch(const orc_table_nch *t, const orc_opts *o, double th, double td, double pd, double *out)
+{
+    const orc_table dv = dims_view(t);
+    if (o->lookup == ORC_LOOKUP_NEAREST) {
+        texel_nch(t, orc_theta_half_index(&dv, th), orc_theta_diff_index(&dv, td), orc_phi_diff_index(&dv, pd), out);
+        return;
+    }
+    double shift = o->node == ORC_NODE_CENTER ? 0.5 : 0.0;
+    double xh, xd, xp;
+    orc_coords(&dv, th, td, pd, &xh, &xd, &xp);
+    int h0, h1, d0, d1, p0, p1; double fh, fd, fp;
+    split_clamped(xh - shift, t->n_th, &h0, &h1, &fh);
+    split_clamped(xd - shift, t->n_td, &d0, &d1, &fd);
+    split_periodic(xp - shift, t->n_pd, &p0, &p1, &fp);
+    const int hs[2] = { h0, h1 }, ds[2] = { d0, d1 }, ps[2] = { p0, p1 };
+    const double wh[2] = { 1.0 - fh, fh }, wd[2] = { 1.0 - fd, fd }, wp[2] = { 1.0 - fp, fp };
+    for (int c = 0; c < t->n_ch; ++c) out[c] = 0.0;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+            for (int c = 0; c < 2; ++c) {
+                double v[ORC_MAX_CH];
+                texel_nch(t, hs[a], ds[b], ps[c], v);
+                double w = wh[a] * wd[b] * wp[c];
+                for (int k = 0; k < t->n_ch; ++k) out[k] += w * v[k];
+            }
+}
+
+void orc_eval_nch(const orc_table_nch *t, const orc_opts *o, const float wi[3], const float wo[3], float *out)
+{
+    for (int c = 0; c < t->n_ch; ++c) out[c] = 0.0f;
+    if (!(wi[2] > 0.0f) || !(wo[2] > 0.0f)) return;
+    double in[3] = { wi[0], wi[1], wi[2] }, od[3] = { wo[0], wo[1], wo[2] };
+    unit3(in); unit3(od);
+    double th, ph, td, pd, v[ORC_MAX_CH];
+    orc_half_diff(in, od, &th, &ph, &td, &pd);
+    orc_lookup_nch(t, o, th, td, pd, v);
+    for (int c = 0; c < t->n_ch; ++c) out[c] = (float)(v[c] * (double)wo[2]);
+}
+
+void orc_sample_nch(const orc_table_nch *t, const orc_opts *o, const float wi[3], const float u[2],
+                    float wo[3], float *pdf, float *weight)
+{
+    wo[0] = wo[1] = wo[2] = 0.0f; *pdf = 0.0f;
+    for (int c = 0; c < t->n_ch; ++c) weight[c] = 0.0f;
+    if (!(wi[2] > 0.0f)) return;
+    orc_square_to_cosine_hemisphere(o->disk_map, u, wo);
+    float p = orc_pdf(wi, wo);
+    *pdf = p;
+    if (!(p > 0.0f)) return;
+    float f[ORC_MAX_CH];
+    orc_eval_nch(t, o, wi, wo, f);
+    for (int c = 0; c < t->n_ch; ++c) weight[c] = f[c] / p;
+}
+
+int orc_build_sampling_nch(const orc_table_nch *t, orc_sampling *out)
+{
+    const int n = t->n_th;
+    out->n = n;
+    out->s = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+    out->cdf = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+    out->c = (double *)malloc(sizeof(double) * (size_t)n);
+    double *D = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!out->s || !out->cdf || !out->c || !D) { free(D); orc_free_sampling(out); return -4; }
+    double mean = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < t->n_td; ++j)
+            for (int k = 0; k < t->n_pd; ++k) {
+                double v[ORC_MAX_CH], sum = 0.0;
+                texel_nch(t, i, j, k, v);
+                for (int c = 0; c < t->n_ch; ++c) sum += v[c];
+                acc += sum / (double)t->n_ch;
+            }
+        D[i] = acc / ((double)t->n_td * (double)t->n_pd);
+        mean += D[i];
+    }
+    mean /= (double)n;
+    for (int i = 0; i < n; ++i) D[i] = mean > 0.0 ? D[i] + 0.01 * mean : 1.0;
+    for (int i = 0; i <= n; ++i) {
+        double r = (double)i / (double)n;
+        double sn = sin(r * r * (M_PI / 2.0));
+        out->s[i] = i == n ? 1.0 : sn * sn;
+    }
+    double Z = 0.0;
+    for (int i = 0; i < n; ++i) Z += D[i] * (out->s[i + 1] - out->s[i]);
+    double run = 0.0;
+    for (int i = 0; i < n; ++i) {
+        out->cdf[i] = run / Z;
+        run += D[i] * (out->s[i + 1] - out->s[i]);
+        out->c[i] = D[i] / (M_PI * Z);
+    }
+    out->cdf[n] = 1.0;
+    free(D);
+    return 0;
+}
+
+void orc_sample_table_nch(const orc_table_nch *t, const orc_opts *o, const orc_sampling *sp, const float wi[3], const float u[2],
+                          float wo[3], float *pdf, float *weight)
+{
+    wo[0] = wo[1] = wo[2] = 0.0f; *pdf = 0.0f;
+    for (int c = 0; c < t->n_ch; ++c) weight[c] = 0.0f;
+    if (!(wi[2] > 0.0f)) return;
+    float d[3];
+    if (u[0] < 0.5f) {
+        const float uu[2] = { 2.0f * u[0], u[1] };
+        orc_square_to_cosine_hemisphere(o->disk_map, uu, d);
+    } else {
+        double x = (double)(2.0f * u[0] - 1.0f);
+        int i = bin_of(sp->cdf, sp->n, x);
+        double xi = (x - sp->cdf[i]) / (sp->cdf[i + 1] - sp->cdf[i]);
+        double sin2 = sp->s[i] + xi * (sp->s[i + 1] - sp->s[i]);
+        double ct = sqrt(1.0 - sin2 > 0.0 ? 1.0 - sin2 : 0.0), st = sqrt(sin2);
+        double phi = 2.0 * M_PI * (double)u[1];
+        double h[3] = { st * cos(phi), st * sin(phi), ct };
+        double in[3] = { wi[0], wi[1], wi[2] };
+        unit3(in);
+        double c = in[0] * h[0] + in[1] * h[1] + in[2] * h[2];
+        d[0] = (float)(2.0 * c * h[0] - in[0]); d[1] = (float)(2.0 * c * h[1] - in[1]); d[2] = (float)(2.0 * c * h[2] - in[2]);
+    }
+    if (!(d[2] > 0.0f)) return;
+    float p = orc_pdf_table(sp, wi, d);
+    if (!(p > 0.0f)) return;
+    wo[0] = d[0]; wo[1] = d[1]; wo[2] = d[2];
+    *pdf = p;
+    float f[ORC_MAX_CH];
+    orc_eval_nch(t, o, wi, wo, f);
+    for (int c = 0; c < t->n_ch; ++c) weight[c] = f[c] / p;
+}
+
+void orc_eval_sample_batch_nch(const orc_table_nch *tables, int n_tables, int n_ch, const orc_opts *o, const orc_sampling *sp,
+                               const float *wi, const float *wo, const float *u, const int32_t *mat, size_t n,
+                               float *values, float *pdf, float *wo2, float *pdf2, float *weight)
+{
+    for (size_t i = 0; i < n; ++i) {
+        int m = mat ? mat[i] : 0;
+        float *val = values + (size_t)n_ch * i, *w = weight + (size_t)n_ch * i;
+        if (m < 0 || m >= n_tables || tables[m].n_ch != n_ch) {
+            for (int c = 0; c < n_ch; ++c) { val[c] = 0.0f; w[c] = 0.0f; }
+            pdf[i] = 0; memset(wo2 + 3 * i, 0, 12); pdf2[i] = 0;
+            continue;
+        }
+        const orc_table_nch *t = tables + m;
+        orc_eval_nch(t, o, wi + 3 * i, wo + 3 * i, val);
+        if (sp) {
+            pdf[i] = orc_pdf_table(sp + m, wi + 3 * i, wo + 3 * i);
+            orc_sample_table_nch(t, o, sp + m, wi + 3 * i, u + 2 * i, wo2 + 3 * i, pdf2 + i, w);
+        } else {
+            pdf[i] = orc_pdf(wi + 3 * i, wo + 3 * i);
+            orc_sample_nch(t, o, wi + 3 * i, u + 2 * i, wo2 + 3 * i, pdf2 + i, w);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * a9 — GGX rough conductor (stock upstream plugin, BASELINE config 3).
  * D = 1/(pi a^2 cos^4(tm) (1 + tan^2(tm)/a^2)^2); Smith G1(v) = 2/(1 + sqrt(1 + a^2 tan^2 tv));
  * eval = F(wi.m) D G /(4 cos ti); visible-normal sampling (Heitz & d'Eon 2014);

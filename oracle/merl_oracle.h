@@ -113,6 +113,30 @@ void  orc_pdf_table_batch(const orc_sampling *sp, const float *wi, const float *
 void  orc_sample_table_batch(const orc_table *t, const orc_opts *o, const orc_sampling *sp, const float *wi, const float *u,
                              size_t n, float *wo, float *pdf, float *weight);
 
+/* ---- §8f item 3 ("next"): n-channel tables (customized_measurement beyond RGB) ---------------------------
+ * Same parameterisation, transform, index maps and trilinear blend; a texel has n_ch values (planar: channel c at
+ * data + c*n_th*n_td*n_pd), each with its own scale, negatives clamped to 0.  The sampling marginal weighs the
+ * channels equally (the RGB one uses luminance).  PARITY UNPINNED like everything else here: the reference's
+ * customized_measurement format is unknown. */
+typedef struct orc_table_nch {
+    int n_th, n_td, n_pd, n_ch;
+    const double *data;
+    const double *scale;          /* n_ch factors */
+} orc_table_nch;
+void  orc_lookup_nch(const orc_table_nch *t, const orc_opts *o, double theta_half, double theta_diff, double phi_diff, double *out);
+void  orc_eval_nch(const orc_table_nch *t, const orc_opts *o, const float wi[3], const float wo[3], float *out);
+void  orc_sample_nch(const orc_table_nch *t, const orc_opts *o, const float wi[3], const float u[2],
+                     float wo[3], float *pdf, float *weight);
+int   orc_build_sampling_nch(const orc_table_nch *t, orc_sampling *out);
+void  orc_sample_table_nch(const orc_table_nch *t, const orc_opts *o, const orc_sampling *sp, const float wi[3], const float u[2],
+                           float wo[3], float *pdf, float *weight);
+/* mixed batch of n_ch-channel tables: tables[mat[i]] (mat NULL: tables[0]); ids outside [0, n_tables) or tables of
+ * another width give zeros.  sp: NULL = cosine sampling; else sp[m] is table m's marginal (table sampling for
+ * sample() and pdf()).  values / weight: n x n_ch. */
+void  orc_eval_sample_batch_nch(const orc_table_nch *tables, int n_tables, int n_ch, const orc_opts *o, const orc_sampling *sp,
+                                const float *wi, const float *wo, const float *u, const int32_t *mat, size_t n,
+                                float *values, float *pdf, float *wo2, float *pdf2, float *weight);
+
 /* ---- a9: GGX rough conductor (A.6), isotropic alpha, visible-normal sampling ---- */
 typedef struct orc_ggx {
     double alpha;

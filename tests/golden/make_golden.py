@@ -74,5 +74,25 @@ def main():
                         rgb=G.eval(wi, wo), pdf=G.pdf(wi, wo), wo2=wo2, pdf2=pdf2, weight=w)
 
 
+    # n-channel tables: monochrome noise, 4-channel GGX-shaped, 16-channel "spectral" with table sampling
+    for name, kind, n_ch, seed, dims, first, sampling in (("nch_c1_noise", "noise", 1, 11, (24, 20, 36), 80_000, 0),
+                                                         ("nch_c4_spectral", "spectral", 4, 2, (30, 24, 40), 90_000, 0),
+                                                         ("nch_c16_spectral_table_sampling", "spectral", 16, 3, (20, 16, 24), 100_000, 1)):
+        tab = synth.make_table_nch(kind, n_ch, seed, dims)
+        scale = [0.5 + 0.25 * c for c in range(n_ch)]
+        T = ob.OracleTableNch(tab, scale)
+        wi, wo, u = ob.generate_pairs(0x5EED, first, N)
+        val, pdf, wo2, pdf2, w = ob.eval_sample_nch([T], wi, wo, u, None, ob.make_opts(1, 0, 0), table_sampling=bool(sampling))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), table_kind=kind, table_seed=seed, n_ch=n_ch, dims=np.array(dims),
+                            scale=np.array(scale), lookup=1, node=0, disk_map=0, sampling=sampling, wi=wi, wo=wo, u=u,
+                            rgb=val, pdf=pdf, wo2=wo2, pdf2=pdf2, weight=w)
+    # a customized_measurement table inside a tensor_file container (the RGL *.bsdf container): data fixture for the loader
+    tab = synth.make_table_nch("spectral", 5, 9, (6, 5, 8)).astype(np.float32)
+    synth.write_tensor_file(os.path.join(HERE, "tensor_table_c5.bsdf"),
+                            {"description": np.frombuffer(b"5-channel customized_measurement table, synthetic", dtype=np.uint8),
+                             "table": tab, "scale": np.array([1.0, 0.5, 2.0, 1.5, 0.25]),
+                             "wavelengths": np.linspace(400.0, 700.0, 5).astype(np.float32)})
+
+
 if __name__ == "__main__":
     main()

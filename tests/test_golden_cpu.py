@@ -8,7 +8,7 @@ import numpy as np
 
 def test_oracle_reproduces_golden(oracle, tables):
     files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-    assert len(files) >= 8
+    assert len(files) >= 11
     for f in files:
         z = np.load(f)
         kind = str(z["table_kind"])
@@ -17,6 +17,14 @@ def test_oracle_reproduces_golden(oracle, tables):
             assert np.array_equal(G.eval(z["wi"], z["wo"]), z["rgb"]) and np.array_equal(G.pdf(z["wi"], z["wo"]), z["pdf"])
             wo2, pdf2, w = G.sample(z["wi"], z["u"])
             assert np.array_equal(wo2, z["wo2"]) and np.array_equal(pdf2, z["pdf2"]) and np.array_equal(w, z["weight"])
+            continue
+        if "n_ch" in z:
+            from mitsuba_customization_amd import synth
+            T = oracle.OracleTableNch(synth.make_table_nch(kind, int(z["n_ch"]), int(z["table_seed"]), tuple(int(d) for d in z["dims"])), z["scale"])
+            got = oracle.eval_sample_nch([T], z["wi"], z["wo"], z["u"], None, oracle.make_opts(int(z["lookup"]), int(z["node"]), int(z["disk_map"])),
+                                         table_sampling=bool(int(z["sampling"])))
+            for g, name in zip(got, ("rgb", "pdf", "wo2", "pdf2", "weight")):
+                assert np.array_equal(g, z[name]), (f, name)
             continue
         dims = tuple(int(d) for d in z["dims"]) if "dims" in z else (90, 90, 180)
         T = oracle.OracleTable(tables(kind, int(z["table_seed"]), dims), tuple(z["scale"]) if "scale" in z else None)

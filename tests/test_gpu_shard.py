@@ -80,6 +80,7 @@ def _device_worker(rank, world, port, n_total, chunk, result_path):
 
         full = shard.run_sharded(compute, n_total, chunk, gather=True, dst=1)
         torch.cuda.Stream = real_stream
+        streams_seen.discard(torch.cuda.current_stream().cuda_stream)      # current_stream() also builds Stream objects
         tile = compute(*shard.tile_bounds(n_total, world, rank))
         full2 = shard.gather_tiles(tile, n_total, dst=1)
         if rank == 1:
