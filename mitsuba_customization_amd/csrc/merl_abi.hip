@@ -394,7 +394,8 @@ DeviceCall device_call(const mrl_ctx *ctx, const BatchCall &c)
     for (const auto &m : ctx->materials) {
         if (m.released) continue;
         d.has_ggx = d.has_ggx || m.dev.kind == mrl::KIND_GGX;
-        d.has_table = d.has_table || m.dev.kind == mrl::KIND_MERL || m.dev.kind == mrl::KIND_TABLE;
+        d.has_table = d.has_table || m.dev.kind == mrl::KIND_MERL || m.dev.kind == mrl::KIND_TABLE ||
+                      (c.mode == 1 && m.dev.kind == mrl::KIND_TABLE_NCH);       // pdf serves n-channel tables too
     }
     if (!d.has_ggx && !d.has_table) d.has_table = true;        // only tombstones left: the table path renders them as zeros
     return d;
@@ -413,7 +414,7 @@ int check_call(mrl_ctx *ctx, const BatchCall &c)
         return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
     if (!c.mat) {
         const mrl::MaterialDev &d = ctx->materials[(size_t)c.single_id].dev;
-        if (c.n_ch == 0 && !mrl::kind_is_rgb_path(d.kind))
+        if (c.n_ch == 0 && c.mode != 1 && !mrl::kind_is_rgb_path(d.kind))               // pdf is channel-free
             return fail(ctx, MRL_ERR_MATERIAL, "material has " + std::to_string(d.n_ch) + " channels: use the *_nch entry points");
         if (c.n_ch > 0 && c.mode != 1 && (d.kind != mrl::KIND_TABLE_NCH || d.n_ch != c.n_ch))
             return fail(ctx, MRL_ERR_MATERIAL, "material does not have " + std::to_string(c.n_ch) + " channels");

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void k_batch(BatchArgs a)
             int id = a.mat[i];
             valid = id >= 0 && id < a.n_materials;
             m = a.materials[valid ? id : 0];
-            valid = valid && kind_is_rgb_path(m.kind);
+            valid = valid && (kind_is_rgb_path(m.kind) || (MODE == MODE_PDF && m.kind == KIND_TABLE_NCH));
         } else {
             m = a.single;
         }
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
             int id = a.mat[i];
             known = id >= 0 && id < a.n_materials;
             m = a.materials[known ? id : 0];
-            known = known && kind_is_rgb_path(m.kind);
+            known = known && (kind_is_rgb_path(m.kind) || (MODE == MODE_PDF && m.kind == KIND_TABLE_NCH));
         } else {
             m = a.single;
         }

@@ -321,6 +321,8 @@ def test_golden_fixtures(tables):
     assert len(files) >= 8, "golden fixtures missing"
     for f in files:
         z = np.load(f)
+        if "n_ch" in z:
+            continue                                     # n-channel fixtures: tests/test_gpu_nch.py::test_nch_golden_fixtures
         kind, seed = str(z["table_kind"]), int(z["table_seed"])
         sampling = int(z["sampling"]) if "sampling" in z else 0
         with host.MerlHip(0) as g:
