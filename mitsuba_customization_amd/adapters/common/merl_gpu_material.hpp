@@ -268,6 +268,32 @@ public:
         return Material(ctx, res);
     }
 
+    // a customized_measurement table stored in a tensor_file container (the RGL *.bsdf container): field "table"
+    // [3, n_theta_h, n_theta_d, n_phi_d] (+ optional "scale").  The renderers' RGB builds take three channels; wider
+    // tables are reachable through the C ABI's *_nch calls, not through a Spectrum-returning plugin.
+    static Material load_tensor_table(const ContextKey &key, const std::string &path)
+    {
+        auto ctx = Context::get(key);
+        auto res = ctx->acquire("tensor|" + canonical_path(path),
+                                [&](mrl_ctx *c, int *id) {
+                                    int channels = 0;
+                                    int rc = mrl_material_load_tensor_table(c, path.c_str(), nullptr, id, &channels);
+                                    if (rc == MRL_OK && channels != 3) {
+                                        mrl_material_release(c, *id);
+                                        throw Error(MRL_ERR_FORMAT, path + ": the table has " + std::to_string(channels) +
+                                                                    " channels; this RGB build of the plugin evaluates three (use the *_nch entry points of the C ABI)");
+                                    }
+                                    if (rc != MRL_OK && rc != MRL_ERR_HIP && rc != MRL_ERR_OOM)
+                                        throw Error(rc, std::string("mrl_material_load_tensor_table: ") + mrl_tensor_file_last_error(nullptr));
+                                    return rc;
+                                }, "mrl_material_load_tensor_table");
+        return Material(ctx, res);
+    }
+    static bool is_tensor_file(const std::string &path)
+    {
+        return path.size() > 5 && path.compare(path.size() - 5, 5, ".bsdf") == 0;
+    }
+
     bool valid() const { return m_ctx && m_id >= 0; }
     int id() const { return m_id; }
     mrl_ctx *ctx() const { return m_ctx->raw(); }

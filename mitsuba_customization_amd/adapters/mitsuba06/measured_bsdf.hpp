@@ -197,7 +197,9 @@ private:
     void load()
     {
         const double scale[3] = { m_scale[0], m_scale[1], m_scale[2] };
-        m_material = merl_gpu::Material::load_table(m_key, m_filename, scale);
+        // *.bsdf: the table sits in a tensor_file container and brings its own channel scales
+        m_material = merl_gpu::Material::is_tensor_file(m_filename) ? merl_gpu::Material::load_tensor_table(m_key, m_filename)
+                                                                    : merl_gpu::Material::load_table(m_key, m_filename, scale);
     }
     Float m_scale[3];
 };

@@ -156,7 +156,10 @@ public:
     {
         const double scale[3] = { props.template get<double>("scale_r", 1.0), props.template get<double>("scale_g", 1.0),
                                   props.template get<double>("scale_b", 1.0) };
-        this->m_material = merl_gpu::Material::load_table(this->m_key, this->m_filename, scale);
+        // *.bsdf: the table sits in a tensor_file container and brings its own channel scales
+        this->m_material = merl_gpu::Material::is_tensor_file(this->m_filename)
+                               ? merl_gpu::Material::load_tensor_table(this->m_key, this->m_filename)
+                               : merl_gpu::Material::load_table(this->m_key, this->m_filename, scale);
     }
     MI_DECLARE_CLASS()
 protected:

@@ -26,6 +26,8 @@ int mrl_host_free(mrl_ctx *, void *p) { std::free(p); return MRL_OK; }
 int mrl_material_load_merl(mrl_ctx *c, const char *, int *id) { *id = c->materials++; return MRL_OK; }
 int mrl_material_load_table(mrl_ctx *c, const char *, const double *, int *id) { *id = c->materials++; return MRL_OK; }
 int mrl_material_release(mrl_ctx *, int) { return MRL_OK; }
+int mrl_material_load_tensor_table(mrl_ctx *c, const char *, const char *, int *id, int *ch) { *id = c->materials++; *ch = 3; return MRL_OK; }
+const char *mrl_tensor_file_last_error(const mrl_tensor_file *) { return ""; }
 int mrl_synchronize(mrl_ctx *) { return MRL_OK; }
 int mrl_eval_sample_batch(mrl_ctx *c, const float *wi, const float *wo, const float *u, const int32_t *mat, int32_t, size_t n,
                           float *rgb, float *pdf, float *wo2, float *pdf2, float *w)

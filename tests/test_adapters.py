@@ -123,6 +123,32 @@ def test_customized_measurement_plugin(built, oracle, tables, tmp_path, host, di
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("host", ["06", "3"])
+def test_customized_measurement_reads_a_tensor_file_table(built, oracle, tables, tmp_path, host):
+    """filename="*.bsdf": the table comes out of a tensor_file container (field "table" [3, h, d, p] + "scale")."""
+    dims, scale = (16, 12, 20), (0.5, 2.0, 1.25)
+    tab = tables("ggx_tab", 4, dims).astype(np.float32)
+    tfile = str(tmp_path / "custom.bsdf")
+    synth.write_tensor_file(tfile, {"table": tab, "scale": np.array(scale)})
+    n, m = 4000, 50
+    wi, wo, u = oracle.generate_pairs(0x5EED, 77, n)
+    pairs, out = str(tmp_path / "pairs.bin"), str(tmp_path / "out.bin")
+    _write_pairs(pairs, wi, wo, u)
+    drv = os.path.join(built, "driver06" if host == "06" else "driver3")
+    plug = os.path.join(built, "plugins06" if host == "06" else "plugins3", "customized_measurement.so")
+    r = subprocess.run([drv, plug, tfile, pairs, out, str(m)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    scalar, batch = _read_out(out, m, n)
+    assert np.array_equal(scalar, batch[:m])
+    want = oracle.eval_sample_multi([oracle.OracleTable(tab, scale)], wi, wo, u, None, oracle.make_opts(disk_map=0 if host == "06" else 1))
+    _check(batch, want)
+    # a 5-channel table cannot go through an RGB Spectrum: the constructor says so
+    wide = os.path.join(os.path.dirname(__file__), "golden", "tensor_table_c5.bsdf")
+    r = subprocess.run([drv, plug, wide, pairs, out, str(m)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 5 and "5 channels" in r.stderr
+
+
+@pytest.mark.gpu
 def test_plugin_reports_missing_file(built, tmp_path):
     r = subprocess.run([os.path.join(built, "driver06"), os.path.join(built, "plugins06", "merl.so"), "/nonexistent.binary",
                         "/dev/null", str(tmp_path / "o"), "1"], capture_output=True, text=True, timeout=120)
