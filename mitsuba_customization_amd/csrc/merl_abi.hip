@@ -388,6 +388,7 @@ DeviceCall device_call(const mrl_ctx *ctx, const BatchCall &c)
     a.materials = ctx->d_materials;
     a.n_materials = (int)ctx->materials.size();
     a.opts = ctx->opts;
+    a.safe = tombstone_dev(ctx);
     d.multi = c.mat != nullptr;
     if (!d.multi) a.single = ctx->materials[(size_t)c.single_id].dev;
     d.has_ggx = d.has_table = false;
@@ -708,6 +709,7 @@ int mrl_init(int device_id, mrl_ctx **out)
         return MRL_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (ensure_dummy(ctx) != MRL_OK) { mrl_destroy(ctx); return MRL_ERR_HIP; }      // the safe table of BatchArgs::safe
     *out = ctx;
     return MRL_OK;
 }

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(kBlock) void k_batch(BatchArgs a)
             valid = id >= 0 && id < a.n_materials;
             m = a.materials[valid ? id : 0];
             valid = valid && (kind_is_rgb_path(m.kind) || (MODE == MODE_PDF && m.kind == KIND_TABLE_NCH));
+            if (!valid) m = a.safe;
         } else {
             m = a.single;
         }
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
             known = id >= 0 && id < a.n_materials;
             m = a.materials[known ? id : 0];
             known = known && (kind_is_rgb_path(m.kind) || (MODE == MODE_PDF && m.kind == KIND_TABLE_NCH));
+            if (!known) m = a.safe;
         } else {
             m = a.single;
         }
@@ -387,6 +389,7 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
             known = id >= 0 && id < a.n_materials;
             m = a.materials[known ? id : 0];
             known = known && kind_is_rgb_path(m.kind);
+            if (!known) m = a.safe;
         } else {
             m = a.single;
         }

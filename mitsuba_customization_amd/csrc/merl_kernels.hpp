@@ -17,6 +17,11 @@ struct BatchArgs {
     MaterialDev single;              // by value -> SGPRs (single-material launches)
     const MaterialDev *materials;    // device array (mixed-material launches)
     int n_materials;
+    // what a unit evaluates when its material id names nothing this call can evaluate (out of range, released,
+    // another kind such as an n-channel table): a 1 x 1 x 1 table of zeros in valid device memory.  Its outputs are
+    // forced to zero anyway, but its lookups run (the code is branch-free) and must touch memory that exists — an
+    // n-channel table's cells are narrower than the 128-B bricks these kernels read.
+    MaterialDev safe;
     Options opts;
     // queue launches: a queue of unit indices (a caller's wavefront queue, or one kind's queue built by k_partition_kinds)
     const uint32_t *idx;

@@ -198,3 +198,31 @@ def test_nch_large_batch_tile_invariance():
         part = g.eval_sample_nch(wi[lo:hi].contiguous(), wo[lo:hi].contiguous(), u[lo:hi].contiguous(), C, material=mid)
         assert all(torch.equal(a[lo:hi].view(torch.int32), b.view(torch.int32)) for a, b in zip(full, part))
         assert float(full[0].min()) >= 0.0 and float(full[0].max()) > 0.0 and bool(torch.isfinite(full[4]).all())
+
+
+def test_rgb_batches_never_read_a_narrow_table_as_bricks():
+    """ids of a MERL-sized ONE-channel table (32 B per cell, 47 MB) inside an RGB batch: the RGB kernels read 128-B
+    bricks, so evaluating such an id against its own descriptor would run 140 MB past its allocation; they evaluate
+    the context's safe 1x1x1 table instead and render zeros (all kernel variants, both batch and queue calls)."""
+    import torch
+    from mitsuba_customization_amd import host, synth
+    n = 1 << 20
+    with host.MerlHip(0) as g:
+        rgb = g.upload_merl(synth.make_table("ggx_tab", 0))
+        mono = g.upload_table_nch(np.abs(synth.make_table("ggx_tab", 1)[:1]))
+        wi, wo, u = g.generate_pairs(0x5EED, 0, n)
+        mat = torch.where(torch.arange(n, device=wi.device) % 2 == 0, rgb, mono).to(torch.int32)
+        ref = g.eval_sample(wi, wo, u, material=rgb)
+        for variant in (0, 1, 2, 3):
+            g.set_option(host.OPT_KERNEL, variant)
+            out = g.eval_sample(wi, wo, u, mat=mat)
+            for a, b in zip(out, ref):
+                assert float(a[1::2].abs().max()) == 0.0, variant
+                assert torch.equal(a[0::2], b[0::2]) or variant == 0       # variant 0 is the generic-math kernel: compared below
+            if variant == 0:
+                assert torch.allclose(out[0][0::2], ref[0][0::2], rtol=1e-6, atol=0)
+        g.set_option(host.OPT_KERNEL, 3)
+        q = torch.arange(n, device=wi.device, dtype=torch.int32)
+        cnt = torch.tensor([n], device=wi.device, dtype=torch.int32)
+        outq = g.eval_sample_queue(wi, wo, u, q, cnt, mat=mat)
+        assert float(outq[0][1::2].abs().max()) == 0.0 and torch.equal(outq[0][0::2], ref[0][0::2])
