@@ -50,6 +50,37 @@ int main(int argc, char **argv)
     orc_ggx_pdf_batch(&g, wi, wo, N, pdf);
     orc_ggx_sample_batch(&g, wi, u, N, wo2, pdf2, w);
 
+    /* n-channel tables: 1, 5 and 32 channels, mixed batch with a table of another width and unknown ids, both samplers */
+    {
+        enum { CMAX = 32 };
+        double *wide = (double *)malloc(sizeof(double) * CMAX * n), scale[CMAX];
+        for (size_t i = 0; i < CMAX * n; ++i) wide[i] = (i % 23 == 0) ? -2.0 : 1.0 + (double)(i % 57);
+        for (int c = 0; c < CMAX; ++c) scale[c] = 0.25 + 0.125 * c;
+        const int widths[3] = { 1, 5, 32 };
+        for (int k = 0; k < 3; ++k) {
+            const int C = widths[k];
+            orc_table_nch tabs[2] = { { dims[0], dims[1], dims[2], C, wide, scale }, { dims[0], dims[1], dims[2], C == 1 ? 2 : 1, wide, scale } };
+            orc_sampling sps[2];
+            if (orc_build_sampling_nch(&tabs[0], &sps[0]) != 0 || orc_build_sampling_nch(&tabs[1], &sps[1]) != 0) return 7;
+            float *val = malloc(4 * (size_t)C * N), *wgt = malloc(4 * (size_t)C * N);
+            for (int i = 0; i < N; ++i) mat[i] = (i % 5) - 1;                        /* -1, 0, 1 (other width), 2, 3 (unknown) */
+            for (int lookup = 0; lookup < 2; ++lookup) {
+                orc_opts on = { lookup, lookup, 1 - lookup };
+                orc_eval_sample_batch_nch(tabs, 2, C, &on, NULL, wi, wo, u, mat, N, val, pdf, wo2, pdf2, wgt);
+                orc_eval_sample_batch_nch(tabs, 2, C, &on, sps, wi, wo, u, mat, N, val, pdf, wo2, pdf2, wgt);
+                orc_eval_sample_batch_nch(tabs, 1, C, &on, NULL, wi, wo, u, NULL, N, val, pdf, wo2, pdf2, wgt);
+            }
+            double out[CMAX];
+            orc_opts on = { 1, 0, 0 };
+            orc_lookup_nch(&tabs[0], &on, 0.0, 0.0, 0.0, out);
+            orc_lookup_nch(&tabs[0], &on, 1.5707963, 1.5707963, 3.1415926, out);
+            orc_free_sampling(&sps[0]); orc_free_sampling(&sps[1]);
+            free(val); free(wgt);
+        }
+        free(wide);
+        orc_generate_materials(0x5EED, 0, N, 1, mat);
+    }
+
     orc_bsdf b; orc_opts o = { 1, 0, 0 };
     /* the baseline driver needs MERL dims */
     double *merl = (double *)calloc(3 * (size_t)ORC_MERL_N, sizeof(double));

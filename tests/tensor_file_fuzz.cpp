@@ -1,0 +1,120 @@
+// tensor_file_fuzz.cpp — the tensor_file container reader (csrc/merl_tensor_file.hip, host code) under
+// AddressSanitizer + UBSan: a well-formed file, then thousands of corrupted copies (byte flips, truncations, grown
+// counts, moved offsets).  Every open must either fail with a status or yield fields whose payloads lie inside the
+// file; nothing may read out of bounds.  Built and run by tests/test_sanitize_cpu.py (g++ -x c++ on the .hip source).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/merl_hip.h"
+
+// the only context call the reader makes; records what it was handed
+static int g_uploads = 0;
+extern "C" int mrl_material_upload_table_nch(mrl_ctx *, const double *planar, const int dims[3], int n_channels, const double *scale, int *out_id)
+{
+    double sum = 0.0;
+    const size_t n = (size_t)dims[0] * dims[1] * dims[2] * (size_t)n_channels;
+    for (size_t i = 0; i < n; ++i) sum += planar[i];              // touches every value: ASAN sees an undersized buffer
+    for (int c = 0; c < n_channels; ++c) sum += scale[c];
+    *out_id = sum == 12345.0 ? 1 : 0;
+    ++g_uploads;
+    return MRL_OK;
+}
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+
+static void put(std::vector<unsigned char> &b, const void *p, size_t n) { const unsigned char *c = (const unsigned char *)p; b.insert(b.end(), c, c + n); }
+
+static std::vector<unsigned char> good_file()
+{
+    std::vector<unsigned char> b;
+    put(b, "tensor_file", 12);
+    const uint8_t ver[2] = { 1, 0 }; put(b, ver, 2);
+    const uint32_t nf = 3; put(b, &nf, 4);
+    struct F { const char *name; uint16_t ndim; uint8_t dtype; std::vector<uint64_t> shape; size_t bytes; };
+    const F fs[3] = { { "table", 4, 10, { 2, 3, 2, 4 }, 2 * 3 * 2 * 4 * 4 }, { "scale", 1, 11, { 2 }, 16 }, { "description", 1, 1, { 9 }, 9 } };
+    size_t head = b.size();
+    for (const F &f : fs) head += 2 + std::strlen(f.name) + 2 + 1 + 8 + 8 * f.ndim;
+    uint64_t off = (head + 7) / 8 * 8;
+    std::vector<uint64_t> offs;
+    for (const F &f : fs) { offs.push_back(off); off = (off + f.bytes + 7) / 8 * 8; }
+    for (int i = 0; i < 3; ++i) {
+        const F &f = fs[i];
+        const uint16_t nl = (uint16_t)std::strlen(f.name); put(b, &nl, 2); put(b, f.name, nl);
+        put(b, &f.ndim, 2); put(b, &f.dtype, 1); put(b, &offs[i], 8);
+        for (uint64_t e : f.shape) put(b, &e, 8);
+    }
+    for (int i = 0; i < 3; ++i) {
+        b.resize(offs[i], 0);
+        for (size_t k = 0; k < fs[i].bytes; ++k) b.push_back((unsigned char)(k * 7 + i));
+    }
+    return b;
+}
+
+static int probe(const std::string &path, const std::vector<unsigned char> &bytes)
+{
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return -100;
+    if (!bytes.empty()) std::fwrite(bytes.data(), 1, bytes.size(), f);
+    std::fclose(f);
+    mrl_tensor_file *t = nullptr;
+    int rc = mrl_tensor_file_open(path.c_str(), &t);
+    if (rc != MRL_OK) { (void)mrl_tensor_file_last_error(nullptr); return rc; }
+    const int n = mrl_tensor_file_field_count(t);
+    for (int i = 0; i < n; ++i) {
+        const char *name; int dtype, ndim; const uint64_t *shape;
+        if (mrl_tensor_file_field_info(t, i, &name, &dtype, &ndim, &shape) != MRL_OK) return -101;
+        size_t nbytes = 0;
+        const unsigned char *p = (const unsigned char *)mrl_tensor_file_field_data(t, i, &nbytes);
+        unsigned acc = 0;
+        for (size_t k = 0; k < nbytes; ++k) acc += p[k];               // every payload byte must be readable
+        uint64_t count = 1;
+        for (int d = 0; d < ndim; ++d) count *= shape[d];
+        if (dtype >= 9 && count < (1u << 20)) {
+            std::vector<double> out(count ? count : 1);
+            (void)mrl_tensor_file_read_f64(t, i, out.data(), count);
+            (void)mrl_tensor_file_read_f64(t, i, out.data(), count ? count - 1 : 0);       // too small a buffer: must refuse
+        }
+        (void)mrl_tensor_file_find(t, name);
+        (void)acc;
+    }
+    (void)mrl_tensor_file_field_info(t, n, nullptr, nullptr, nullptr, nullptr);
+    (void)mrl_tensor_file_field_data(t, -1, nullptr);
+    mrl_tensor_file_close(t);
+    int id = -1, ch = 0;
+    (void)mrl_material_load_tensor_table((mrl_ctx *)0x1, path.c_str(), nullptr, &id, &ch);  // the fake context is never dereferenced
+    return rc;
+}
+
+int main(int argc, char **argv)
+{
+    const std::string path = argc > 1 ? argv[1] : "/tmp/tensor_fuzz.bsdf";
+    const std::vector<unsigned char> good = good_file();
+    if (probe(path, good) != MRL_OK || g_uploads != 1) { std::fprintf(stderr, "the well-formed file was rejected\n"); return 1; }
+    int opened = 0, refused = 0;
+    for (int round = 0; round < 6000; ++round) {
+        std::vector<unsigned char> b = good;
+        const int kind = (int)(rnd() % 5);
+        if (kind == 0) {                                               // flip 1..4 bytes of the header / field table
+            for (int k = 0, m = 1 + (int)(rnd() % 4); k < m; ++k) b[rnd() % 120] ^= (unsigned char)(1u << (rnd() % 8));
+        } else if (kind == 1) {                                        // truncate anywhere
+            b.resize(rnd() % b.size());
+        } else if (kind == 2) {                                        // overwrite 8 bytes of the field table with a huge or random value
+            const uint64_t v = (rnd() % 2) ? ~0ull >> (rnd() % 40) : rnd();
+            std::memcpy(&b[18 + rnd() % 100], &v, 8);
+        } else if (kind == 3) {                                        // random byte anywhere
+            b[rnd() % b.size()] = (unsigned char)rnd();
+        } else {                                                       // grow the field count
+            const uint32_t nf = 3 + (uint32_t)(rnd() % 70000); std::memcpy(&b[14], &nf, 4);
+        }
+        const int rc = probe(path, b);
+        if (rc == MRL_OK) ++opened; else ++refused;
+    }
+    std::remove(path.c_str());
+    std::printf("tensor fuzz ok: %d corrupted files opened consistently, %d refused, %d table uploads\n", opened, refused, g_uploads);
+    return refused > 0 ? 0 : 1;
+}

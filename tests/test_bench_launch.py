@@ -70,6 +70,8 @@ def test_self_launch_two_ranks_share_gpu():
     assert out["parity"]["max_rel_err_vs_oracle"] <= 1e-6
     assert "ms" in out["gather"] and out["gather"]["bytes_into_root"] == 44 * (1 << 18)
     assert "cpu_baseline" not in out                                 # N=1 only
+    ng = out["native_group"]                                          # the C++ host over the same "GPUs" (here: GPU 0 twice)
+    assert ng["check_mismatches"] == 0 and ng["devices"] == [0, 0] and ng["transport"] == "peer_copy", ng
 
 
 @pytest.mark.gpu

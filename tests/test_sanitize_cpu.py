@@ -31,3 +31,16 @@ def test_scalar_call_combiner_is_clean_under_tsan(tmp_path):
                            os.path.join(ROOT, "tests", "combiner_tsan.cpp"), "-lpthread"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "combiner ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ missing")
+def test_tensor_file_reader_is_clean_under_asan_ubsan(tmp_path):
+    """The tensor_file container reader parses untrusted files: 6000 corrupted copies of a well-formed file under
+    AddressSanitizer + UBSan (the reader is host C++ inside a .hip source: built here with g++)."""
+    exe = str(tmp_path / "tensor_fuzz")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-fno-omit-frame-pointer", "-o", exe, os.path.join(ROOT, "tests", "tensor_file_fuzz.cpp"),
+                           "-x", "c++", os.path.join(ROOT, "mitsuba_customization_amd", "csrc", "merl_tensor_file.hip")])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, str(tmp_path / "fuzz.bsdf")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "tensor fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
