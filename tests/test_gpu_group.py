@@ -136,3 +136,10 @@ def test_native_cpp_host_program():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["check_mismatches"] == 0 and out["transport"] == "peer_copy" and out["devices"] == [0, 0, 0]
     assert out["compute_only_Meval_s"] > 0 and out["gathered_Meval_s"] > 0
+    # the same program, no Python and no torch in the process: librccl is found by the library's own dlopen and a
+    # one-rank communicator is built (what the N-GPU run of bench.py's "native_group" leg starts with)
+    r = subprocess.run([os.path.join(LIB, "group_host"), "--devices", "0", "--transport", "rccl", "--units-per-device", str(1 << 20),
+                        "--steps", "1", "--warmup", "1", "--check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["transport"] == "rccl" and out["check_mismatches"] == 0
