@@ -66,7 +66,7 @@ enum mrl_option {
                                   materials into one dense queue per kind (pays only when most units are analytic).
                                   Every variant passes the same parity tests; they differ in speed only.  Values
                                   outside 0..4 are rejected with MRL_ERR_INVALID. */
-    MRL_OPT_HOST_CHUNK = 4,    /* units per staging chunk for host-pointer calls */
+    MRL_OPT_HOST_CHUNK = 4,    /* units per staging chunk for host-pointer calls (the pipelined path uses at most 2^20) */
     MRL_OPT_SAMPLING = 6,      /* sample()/pdf() strategy of table materials: 0 cosine hemisphere (default, the upstream
                                   convention), 1 table importance sampling: one-sample mixture of the cosine lobe and a
                                   half-vector lobe read off the table's theta_h rows */
@@ -74,6 +74,10 @@ enum mrl_option {
                                   0 padded rows (24 MB per MERL table),
                                   1 bricks (default): one 128-B line per cell holds its 8 corners (187 MB per MERL table).
                                   Bricks are 2.3x faster for trilinear lookups, rows 1.45x faster for nearest lookups. */
+    MRL_OPT_HOST_THREADS = 8,  /* host-pointer calls on plain (pageable) arrays: threads that copy between the caller's arrays
+                                  and two pinned, device-mapped chunk buffers while the kernel of the previous / next chunk
+                                  reads and writes those buffers over PCIe (default 4, counting the calling thread;
+                                  0 = the staged hipMemcpy path of round 1, ~3x slower) */
     MRL_OPT_MEMORY_LIMIT_MB = 7 /* budget for the context's resident material data (tables + sampling marginals), in MiB;
                                   0 (default) = no budget, the device's free memory is the limit.  An upload that would
                                   exceed the budget — or the device — fails with MRL_ERR_OOM and leaves the context as it

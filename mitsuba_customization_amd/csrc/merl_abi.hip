@@ -6,6 +6,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -67,6 +72,82 @@ std::vector<double> build_sampling(const double *planar, int n_th, int n_td, int
 
 } // namespace
 
+// ---- pipelined host-array path -------------------------------------------------------------------------------------
+// A host that holds plain (pageable) arrays — what a CPU renderer hands over — used to be staged with hipMemcpyAsync,
+// which the runtime serialises through one bounce buffer at ~11 GB/s (140-150 M units/s).  Instead: a few copy threads
+// move chunk c+1 of the caller's arrays into pinned, device-mapped buffers and chunk c-1 of the results out of them,
+// while the kernel of chunk c reads and writes the pinned buffers over PCIe itself (zero copy, no staging in HBM).
+struct CopyPool {
+    struct Seg { void *dst; const void *src; size_t bytes; };
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable wake, done;
+    std::vector<Seg> segs;
+    size_t next = 0, finished = 0;
+    uint64_t generation = 0;
+    bool quit = false;
+
+    void start(int n)
+    {
+        for (int t = 0; t < n; ++t)
+            workers.emplace_back([this]() {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    wake.wait(lk, [&]() { return quit || (generation != seen && next < segs.size()) || (generation != seen && segs.empty()); });
+                    if (quit) return;
+                    if (next >= segs.size()) { seen = generation; continue; }
+                    while (next < segs.size()) {
+                        const Seg sg = segs[next++];
+                        lk.unlock();
+                        std::memcpy(sg.dst, sg.src, sg.bytes);
+                        lk.lock();
+                        if (++finished == segs.size()) done.notify_all();
+                    }
+                    seen = generation;
+                }
+            });
+    }
+    // copies every segment, split into slices so that all workers (and the caller) share the work; returns when done
+    void run(const std::vector<Seg> &whole)
+    {
+        constexpr size_t kSlice = (size_t)2 << 20;
+        std::vector<Seg> sliced;
+        for (const Seg &w : whole)
+            for (size_t off = 0; off < w.bytes; off += kSlice)
+                sliced.push_back({ (char *)w.dst + off, (const char *)w.src + off, std::min(kSlice, w.bytes - off) });
+        if (sliced.empty()) return;
+        if (workers.empty()) { for (const Seg &sg : sliced) std::memcpy(sg.dst, sg.src, sg.bytes); return; }
+        std::unique_lock<std::mutex> lk(mu);
+        segs = std::move(sliced); next = 0; finished = 0; ++generation;
+        wake.notify_all();
+        while (next < segs.size()) {                              // the caller copies too
+            const Seg sg = segs[next++];
+            lk.unlock();
+            std::memcpy(sg.dst, sg.src, sg.bytes);
+            lk.lock();
+            ++finished;
+        }
+        done.wait(lk, [&]() { return finished == segs.size(); });
+        segs.clear();
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        wake.notify_all();
+        for (auto &t : workers) t.join();
+        workers.clear();
+    }
+};
+
+struct HostPipe {
+    char *pin[2] = { nullptr, nullptr };             // per slot: inputs then outputs of one chunk
+    size_t slot_bytes = 0;
+    hipEvent_t done[2] = { nullptr, nullptr };
+    CopyPool pool;
+    int threads = -1;                                // workers the pool was started with
+};
+
 struct mrl_ctx {
     int device = 0;
     int compute_units = 256;
@@ -92,6 +173,8 @@ struct mrl_ctx {
     int kernel_variant = 3;          // MRL_OPT_KERNEL default: cooperative LDS-DMA brick fetch
     int table_layout = 1;            // layout of tables uploaded from now on (mrl::Layout)
     size_t host_chunk = (size_t)1 << 22;
+    int host_threads = 4;            // MRL_OPT_HOST_THREADS: copy threads of the pipelined host-array path; 0 = staged hipMemcpy path
+    HostPipe pipe;
     void *d_stage = nullptr;
     size_t d_stage_bytes = 0;
     std::string last_error;
@@ -467,6 +550,81 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
     return MRL_OK;
 }
 
+// Host arrays, pipelined (see HostPipe): per chunk  copy-in (threads) -> kernel on the pinned slot (zero copy over PCIe)
+// -> copy-out (threads), double buffered so that the copies of chunks c+1 / c-1 overlap the kernel of chunk c.
+int run_host_pipelined(mrl_ctx *ctx, const BatchCall &c)
+{
+    const bool has_eval = call_has_eval(c.mode), has_pdf = call_has_pdf(c.mode), has_sample = call_has_sample(c.mode);
+    const bool needs_wo = has_eval || has_pdf, needs_u = has_sample;
+    const size_t C = c.n_ch > 0 ? (size_t)c.n_ch : 3;
+    const size_t unit_bytes = 56 + 8 * C;
+    const size_t chunk = std::min(std::min(c.n, ctx->host_chunk), (size_t)1 << 20);
+    HostPipe &hp = ctx->pipe;
+    if (chunk * unit_bytes > hp.slot_bytes) {
+        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int s = 0; s < 2; ++s) { if (hp.pin[s]) (void)hipHostFree(hp.pin[s]); hp.pin[s] = nullptr; }
+        hp.slot_bytes = 0;
+        for (int s = 0; s < 2; ++s) {
+            const hipError_t e = hipHostMalloc((void **)&hp.pin[s], chunk * unit_bytes, hipHostMallocMapped | hipHostMallocPortable);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                for (int k = 0; k < 2; ++k) { if (hp.pin[k]) (void)hipHostFree(hp.pin[k]); hp.pin[k] = nullptr; }
+                return fail(ctx, MRL_ERR_OOM, std::string("pinned staging: ") + hipGetErrorString(e));
+            }
+        }
+        hp.slot_bytes = chunk * unit_bytes;
+    }
+    for (int s = 0; s < 2; ++s)
+        if (!hp.done[s]) MRL_HIP(ctx, hipEventCreateWithFlags(&hp.done[s], hipEventDisableTiming));
+    if (hp.threads != ctx->host_threads) {                   // the caller copies as well: n - 1 helpers
+        hp.pool.stop();
+        hp.pool.quit = false;
+        hp.pool.start(std::max(0, ctx->host_threads - 1));
+        hp.threads = ctx->host_threads;
+    }
+    struct Slot { float *wi, *wo, *u; int32_t *mat; float *pdf, *wo2, *pdf2, *rgb, *w; };
+    auto slot = [&](int s) {
+        char *b = hp.pin[s];
+        return Slot{ (float *)b, (float *)(b + 12 * chunk), (float *)(b + 24 * chunk), (int32_t *)(b + 32 * chunk), (float *)(b + 36 * chunk),
+                     (float *)(b + 40 * chunk), (float *)(b + 52 * chunk), (float *)(b + 56 * chunk), (float *)(b + (56 + 4 * C) * chunk) };
+    };
+    const size_t steps = (c.n + chunk - 1) / chunk;
+    for (size_t k = 0; k <= steps; ++k) {
+        if (k < steps) {                                      // copy-in + launch of chunk k
+            const int s = (int)(k & 1);
+            const size_t off = k * chunk, m = std::min(chunk, c.n - off);
+            const Slot sl = slot(s);
+            std::vector<CopyPool::Seg> in = { { sl.wi, c.wi + 3 * off, 12 * m } };
+            if (needs_wo) in.push_back({ sl.wo, c.wo + 3 * off, 12 * m });
+            if (needs_u) in.push_back({ sl.u, c.u + 2 * off, 8 * m });
+            if (c.mat) in.push_back({ sl.mat, c.mat + off, 4 * m });
+            hp.pool.run(in);                                  // slot s was last read by kernel k-2, whose event was waited for below
+            BatchCall d = c;
+            d.wi = sl.wi; d.wo = sl.wo; d.u = sl.u; d.mat = c.mat ? sl.mat : nullptr; d.n = m;
+            d.out_rgb = sl.rgb; d.out_pdf = sl.pdf; d.out_wo = sl.wo2; d.out_pdf2 = sl.pdf2; d.out_weight = sl.w;
+            const int rc = launch_device(ctx, d);
+            if (rc != MRL_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+            MRL_HIP(ctx, hipEventRecord(hp.done[s], ctx->stream));
+        }
+        if (k > 0) {                                          // copy-out of chunk k-1, while the kernel of chunk k runs
+            const int s = (int)((k - 1) & 1);
+            const size_t off = (k - 1) * chunk, m = std::min(chunk, c.n - off);
+            const Slot sl = slot(s);
+            MRL_HIP(ctx, hipEventSynchronize(hp.done[s]));
+            std::vector<CopyPool::Seg> out;
+            if (has_eval) out.push_back({ c.out_rgb + C * off, sl.rgb, 4 * C * m });
+            if (has_pdf) out.push_back({ c.out_pdf + off, sl.pdf, 4 * m });
+            if (has_sample) {
+                out.push_back({ c.out_wo + 3 * off, sl.wo2, 12 * m });
+                out.push_back({ c.out_pdf2 + off, sl.pdf2, 4 * m });
+                out.push_back({ c.out_weight + C * off, sl.w, 4 * C * m });
+            }
+            hp.pool.run(out);
+        }
+    }
+    return MRL_OK;
+}
+
 int run_batch(mrl_ctx *ctx, const BatchCall &c)
 {
     if (!ctx) return MRL_ERR_INVALID;
@@ -481,6 +639,11 @@ int run_batch(mrl_ctx *ctx, const BatchCall &c)
     if (kind < 0) return fail(ctx, MRL_ERR_POINTER_MIX, "host and device pointers mixed in one call");
     if (kind == 1) return launch_device(ctx, c);
 
+    if (ctx->host_threads > 0) {
+        rc = run_host_pipelined(ctx, c);
+        if (rc != MRL_ERR_OOM) return rc;                     // no pinned memory to be had: fall back to the staged path
+        (void)hipGetLastError();
+    }
     // host pointers: stage through HBM in chunks; returns when the outputs are on the host
     const size_t C = c.n_ch > 0 ? (size_t)c.n_ch : 3;          // values per unit in out_rgb / out_weight
     const size_t unit_bytes = 56 + 8 * C;
@@ -723,6 +886,11 @@ int mrl_destroy(mrl_ctx *ctx)
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     if (ctx->d_dummy) (void)hipFree(ctx->d_dummy);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    ctx->pipe.pool.stop();
+    for (int s = 0; s < 2; ++s) {
+        if (ctx->pipe.pin[s]) (void)hipHostFree(ctx->pipe.pin[s]);
+        if (ctx->pipe.done[s]) (void)hipEventDestroy(ctx->pipe.done[s]);
+    }
     if (ctx->d_queues) (void)hipFree(ctx->d_queues);
     if (ctx->d_part_work) (void)hipFree(ctx->d_part_work);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -742,6 +910,7 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
         case MRL_OPT_SAMPLING: if (value < 0 || value > 1) break; ctx->opts.sampling = value; return MRL_OK;
         case MRL_OPT_KERNEL:   if (value < 0 || value > 4) break; ctx->kernel_variant = value; return MRL_OK;
         case MRL_OPT_MEMORY_LIMIT_MB: if (value < 0) break; ctx->memory_limit = (size_t)value << 20; return MRL_OK;
+        case MRL_OPT_HOST_THREADS: if (value < 0 || value > 64) break; ctx->host_threads = value; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: if (value < 1) break; ctx->host_chunk = (size_t)value; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: {
             if (value < 0 || value > 1) break;
@@ -766,6 +935,7 @@ int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
         case MRL_OPT_SAMPLING: *value = ctx->opts.sampling; return MRL_OK;
         case MRL_OPT_KERNEL: *value = ctx->kernel_variant; return MRL_OK;
         case MRL_OPT_MEMORY_LIMIT_MB: *value = (int)(ctx->memory_limit >> 20); return MRL_OK;
+        case MRL_OPT_HOST_THREADS: *value = ctx->host_threads; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: *value = (int)ctx->host_chunk; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: *value = ctx->table_layout; return MRL_OK;
     }

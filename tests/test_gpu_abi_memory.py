@@ -66,3 +66,46 @@ def test_customized_table_file_with_f32_payload(tmp_path):
             f.write(b"\\0" * 8)
         with pytest.raises(host.MerlHipError):
             g.load_table(str(path))
+
+
+def test_pipelined_host_path_equals_staged_and_device_paths(oracle, tables):
+    """Plain numpy arrays in, numpy arrays out: the pipelined path (copy threads + pinned double buffers + zero-copy
+    kernel, MRL_OPT_HOST_THREADS > 0) against the staged hipMemcpy path (0) and the device-pointer path — bit for bit,
+    over several chunks with a ragged tail, every entry point, a mixed batch and an n-channel table."""
+    import torch
+    from mitsuba_customization_amd import host, synth
+    n = (1 << 21) + 12_345                                     # 3 pipeline chunks of 2^20, the last one ragged
+    wi, wo, u = oracle.generate_pairs(0x5EED, 31, n)
+    mat = oracle.generate_materials(0x5EED, 31, n, 3).astype(np.int32)
+    with host.MerlHip(0) as g:
+        ids = [g.upload_merl(tables("ggx_tab", s)) for s in range(3)]
+        nch = g.upload_table_nch(synth.make_table_nch("spectral", 6, 2, (16, 12, 20)))
+        assert g.get_option(host.OPT_HOST_THREADS) == 4
+        dwi, dwo, du, dmat = (torch.from_numpy(a).cuda() for a in (wi, wo, u, mat))
+        dev = [t.cpu().numpy() for t in g.eval_sample(dwi, dwo, du, mat=dmat)]
+        dev_nch = [t.cpu().numpy() for t in g.eval_sample_nch(dwi, dwo, du, 6, material=nch)]
+        results = {}
+        for threads in (4, 1, 0, 7):
+            g.set_option(host.OPT_HOST_THREADS, threads)
+            results[threads] = {
+                "fused": g.eval_sample(wi, wo, u, mat=mat),
+                "eval": g.eval(wi, wo, material=ids[1]),
+                "pdf": g.pdf(wi, wo, material=ids[1]),
+                "sample": g.sample(wi, u, mat=mat),
+                "eval_pdf": g.eval_pdf(wi, wo, material=ids[2]),
+                "nch": g.eval_sample_nch(wi, wo, u, 6, material=nch),
+            }
+        with pytest.raises(host.MerlHipError):
+            g.set_option(host.OPT_HOST_THREADS, 65)
+    for threads, r in results.items():
+        for a, b in zip(r["fused"], dev):
+            assert np.array_equal(a.view(np.int32), b.view(np.int32)), threads
+        for a, b in zip(r["nch"], dev_nch):
+            assert np.array_equal(a.view(np.int32), b.view(np.int32)), threads
+        for key in ("eval", "pdf"):
+            assert np.array_equal(r[key], results[0][key]), (threads, key)
+        for key in ("sample", "eval_pdf"):
+            assert all(np.array_equal(a, b) for a, b in zip(r[key], results[0][key])), (threads, key)
+    want = oracle.eval_sample_multi([oracle.OracleTable(tables("ggx_tab", s)) for s in range(3)], wi, wo, u, mat)
+    assert (np.abs(results[4]["fused"][0].astype(np.float64) - want[0]) <= 1e-6 * np.abs(want[0]) + 1e-30).all()
+    assert np.array_equal(results[4]["fused"][2], want[2])
