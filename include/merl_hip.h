@@ -166,6 +166,20 @@ int mrl_eval_sample_batch_nch(mrl_ctx *ctx, const float *wi, const float *wo, co
                               const int32_t *mat, int32_t single_id, size_t n, int n_channels,
                               float *out_values, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight);
 
+/* the same over a wavefront queue (see "wavefront queues" below): slots queue[0 .. min(*queue_count, capacity)); device pointers only */
+int mrl_eval_queue_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                       const uint32_t *queue, const uint32_t *queue_count, size_t capacity, int n_channels, float *out_values);
+int mrl_sample_queue_nch(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id,
+                         const uint32_t *queue, const uint32_t *queue_count, size_t capacity, int n_channels,
+                         float *out_wo, float *out_pdf, float *out_weight);
+int mrl_eval_pdf_queue_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
+                           const uint32_t *queue, const uint32_t *queue_count, size_t capacity, int n_channels,
+                           float *out_values, float *out_pdf);
+int mrl_eval_sample_queue_nch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u,
+                              const int32_t *mat, int32_t single_id,
+                              const uint32_t *queue, const uint32_t *queue_count, size_t capacity, int n_channels,
+                              float *out_values, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight);
+
 /* ---- "tensor_file" container (the RGL material database's *.bsdf files, read by upstream Mitsuba 3's `measured`
  * plugin).  LOADER ONLY: fields are listed and copied out; the adaptive parameterisation an RGL
  * *.bsdf describes is not evaluated by this library.  A customized_measurement table may be stored in the container

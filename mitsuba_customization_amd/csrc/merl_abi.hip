@@ -693,6 +693,10 @@ int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uin
     if (call_pointer_kind(c, queue, queue_count) != 1) return fail(ctx, MRL_ERR_POINTER_MIX, "queue calls take device pointers only");
     DeviceCall d = device_call(ctx, c);
     d.args.idx = queue; d.args.idx_count = queue_count;
+    if (c.n_ch > 0 && c.mode != 1) {                          // n-channel tables: the same kernels walk the queue
+        MRL_HIP(ctx, mrl::launch_batch_nch(c.mode, d.args, d.multi, c.n_ch, ctx->compute_units, ctx->stream));
+        return MRL_OK;
+    }
     MRL_HIP(ctx, mrl::launch_batch_indexed(c.mode, d.args, d.multi, ctx->table_layout, d.has_ggx, d.has_table, ctx->compute_units, ctx->stream));
     return MRL_OK;
 }
@@ -1286,6 +1290,43 @@ static int nch_call(mrl_ctx *ctx, BatchCall c, int n_channels)
     if (n_channels < 1 || n_channels > mrl::kMaxChannels) return fail(ctx, MRL_ERR_INVALID, "channel count must be 1.." + std::to_string(mrl::kMaxChannels));
     c.n_ch = n_channels == 3 ? 0 : n_channels;           // three channels: the RGB path, RGB materials
     return run_batch(ctx, c);
+}
+
+static int nch_queue_call(mrl_ctx *ctx, BatchCall c, int n_channels, const uint32_t *queue, const uint32_t *queue_count)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    if (n_channels < 1 || n_channels > mrl::kMaxChannels) return fail(ctx, MRL_ERR_INVALID, "channel count must be 1.." + std::to_string(mrl::kMaxChannels));
+    c.n_ch = n_channels == 3 ? 0 : n_channels;
+    return run_queue(ctx, c, queue, queue_count);
+}
+
+int mrl_eval_queue_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, const uint32_t *queue,
+                       const uint32_t *queue_count, size_t capacity, int n_channels, float *out_values)
+{
+    BatchCall c{ 0, wi, wo, nullptr, mat, single_id, capacity, out_values, nullptr, nullptr, nullptr, nullptr };
+    return nch_queue_call(ctx, c, n_channels, queue, queue_count);
+}
+
+int mrl_sample_queue_nch(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id, const uint32_t *queue,
+                         const uint32_t *queue_count, size_t capacity, int n_channels, float *out_wo, float *out_pdf, float *out_weight)
+{
+    BatchCall c{ 2, wi, nullptr, u, mat, single_id, capacity, nullptr, nullptr, out_wo, out_pdf, out_weight };
+    return nch_queue_call(ctx, c, n_channels, queue, queue_count);
+}
+
+int mrl_eval_pdf_queue_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, const uint32_t *queue,
+                           const uint32_t *queue_count, size_t capacity, int n_channels, float *out_values, float *out_pdf)
+{
+    BatchCall c{ 4, wi, wo, nullptr, mat, single_id, capacity, out_values, out_pdf, nullptr, nullptr, nullptr };
+    return nch_queue_call(ctx, c, n_channels, queue, queue_count);
+}
+
+int mrl_eval_sample_queue_nch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u, const int32_t *mat, int32_t single_id,
+                              const uint32_t *queue, const uint32_t *queue_count, size_t capacity, int n_channels,
+                              float *out_values, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
+{
+    BatchCall c{ 3, wi, wo, u, mat, single_id, capacity, out_values, out_pdf, out_wo, out_pdf2, out_weight };
+    return nch_queue_call(ctx, c, n_channels, queue, queue_count);
 }
 
 int mrl_eval_batch_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, int n_channels,

@@ -119,7 +119,14 @@ __device__ __forceinline__ void nch_blend(const float4 *lds_slots, unsigned lane
 
 // MODE as in merl_kernels.hip (pdf-only needs no table: the RGB pdf kernel serves every table kind).
 // a.out_rgb / a.out_weight hold n x n_ch values.
-template <int MODE, bool MULTI, int CPAD>
+// INDEXED: walk the caller's wavefront queue a.idx[0 .. min(*a.idx_count, a.n)) instead of the units [0, a.n)
+template <bool INDEXED> __device__ __forceinline__ size_t nch_item_count(const BatchArgs &a)
+{
+    if constexpr (INDEXED) { const size_t c = (size_t)*a.idx_count; return c < a.n ? c : a.n; }
+    else return a.n;
+}
+
+template <int MODE, bool MULTI, int CPAD, bool INDEXED = false>
 __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
 {
     static_assert(MODE != MODE_PDF, "pdf needs no table");
@@ -134,10 +141,12 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
     float4 *ldsB = lds[wave][LOOKUPS - 1];
     const int groups = CPAD == 4 ? (n_ch + 3) / 4 : 1;
     const size_t stride = (size_t)gridDim.x * kNchBlock;
-    for (size_t base = (size_t)blockIdx.x * kNchBlock + wave * 64u; base < a.n; base += stride) {
+    const size_t n_items = nch_item_count<INDEXED>(a);
+    for (size_t base = (size_t)blockIdx.x * kNchBlock + wave * 64u; base < n_items; base += stride) {
         const size_t j = base + lane;
-        const bool active = j < a.n;
-        const size_t i = active ? j : a.n - 1;               // tail lanes recompute the last unit, store nothing
+        const bool active = j < n_items;
+        const size_t jj = active ? j : n_items - 1;          // tail lanes recompute the last unit, store nothing
+        const size_t i = INDEXED ? (size_t)a.idx[jj] : jj;
 
         MaterialDev m;
         bool known = true;
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
 // row per unit (row stride n_ch + 1 floats: conflict-free), and once the lookup's groups are done the wave streams
 // the span out with 256-B contiguous stores.  The two lookups of a fused unit run one after the other, so that one
 // copy buffer (8 KB) and one staging area serve both: 2 blocks per CU up to 32 channels.
-template <int MODE, bool MULTI>
+template <int MODE, bool MULTI, bool INDEXED = false>
 __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n_ch)
 {
     static_assert(MODE != MODE_PDF, "pdf needs no table");
@@ -248,11 +257,13 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
     float *stage = (float *)(dma + 64 * S);
     const int groups = (n_ch + 3) / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t base = (size_t)blockIdx.x * blockDim.x + wave * 64u; base < a.n; base += stride) {
+    const size_t n_items = nch_item_count<INDEXED>(a);
+    for (size_t base = (size_t)blockIdx.x * blockDim.x + wave * 64u; base < n_items; base += stride) {
         const size_t j = base + lane;
-        const bool active = j < a.n;
-        const size_t i = active ? j : a.n - 1;               // tail lanes recompute the last unit, store nothing
-        const size_t span = (a.n - base < 64 ? a.n - base : 64) * (size_t)n_ch;      // floats this wave owns per output array
+        const bool active = j < n_items;
+        const size_t jj = active ? j : n_items - 1;          // tail lanes recompute the last unit, store nothing
+        const size_t i = INDEXED ? (size_t)a.idx[jj] : jj;
+        const size_t span = (n_items - base < 64 ? n_items - base : 64) * (size_t)n_ch;   // floats this wave owns per output array
 
         MaterialDev m;
         bool known = true;
@@ -288,6 +299,15 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
                 for (int ch = 0; ch < 4; ++ch)
                     if (4 * g + ch < n_ch) stage[lane * row + 4 * g + ch] = (float)(v[ch] * factor) / divide;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads of the copy buffer done before the next copy lands
+            }
+            if constexpr (INDEXED) {
+                // queued slots are scattered: every lane writes its own row (n_ch adjacent floats, back to back)
+                if (active) {
+                    float *mine = dst + i * (size_t)n_ch;
+                    for (int ch = 0; ch < n_ch; ++ch) mine[ch] = stage[lane * row + ch];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                return;
             }
             // the wave's span of this array: float t*64 + lane belongs to unit (t*64 + lane) / n_ch
             const int q = 64 / n_ch, r = 64 % n_ch;
@@ -371,16 +391,16 @@ __global__ __launch_bounds__(kNchBlock) void k_build_bricks_nch(const double *pl
     }
 }
 
-template <int MODE, bool MULTI>
+template <int MODE, bool MULTI, bool INDEXED>
 hipError_t launch_nch_cpad(const BatchArgs &a, int n_ch, int compute_units, hipStream_t stream)
 {
     size_t blocks = (a.n + kNchBlock - 1) / kNchBlock;
     const size_t cap = (size_t)compute_units * (MODE == MODE_EVAL_SAMPLE ? 2 : 4);
     if (blocks > cap) blocks = cap;
     const dim3 g((unsigned)blocks), b(kNchBlock);
-    if (n_ch == 1)      hipLaunchKernelGGL((k_table_nch<MODE, MULTI, 1>), g, b, 0, stream, a, n_ch);
-    else if (n_ch == 2) hipLaunchKernelGGL((k_table_nch<MODE, MULTI, 2>), g, b, 0, stream, a, n_ch);
-    else if (n_ch == 4) hipLaunchKernelGGL((k_table_nch<MODE, MULTI, 4>), g, b, 0, stream, a, n_ch);   // one line, dense 16-B stores: both lookups in flight
+    if (n_ch == 1)      hipLaunchKernelGGL((k_table_nch<MODE, MULTI, 1, INDEXED>), g, b, 0, stream, a, n_ch);
+    else if (n_ch == 2) hipLaunchKernelGGL((k_table_nch<MODE, MULTI, 2, INDEXED>), g, b, 0, stream, a, n_ch);
+    else if (n_ch == 4) hipLaunchKernelGGL((k_table_nch<MODE, MULTI, 4, INDEXED>), g, b, 0, stream, a, n_ch);   // one line, dense 16-B stores: both lookups in flight
     else {
         // per wave: one 8 KB copy buffer + 64 staging rows of n_ch + 1 floats (rounded up to float4s)
         const size_t wave_f4 = 64 * 8 + ((size_t)64 * (n_ch + 1) + 3) / 4;
@@ -390,15 +410,16 @@ hipError_t launch_nch_cpad(const BatchArgs &a, int n_ch, int compute_units, hipS
         size_t wide_blocks = (a.n + threads - 1) / threads;
         const size_t wide_cap = (size_t)compute_units * (threads == kNchBlock ? 2 : 4);       // 8 waves per CU either way
         if (wide_blocks > wide_cap) wide_blocks = wide_cap;
-        hipLaunchKernelGGL((k_table_nch_wide<MODE, MULTI>), dim3((unsigned)wide_blocks), dim3(threads), lds, stream, a, n_ch);
+        hipLaunchKernelGGL((k_table_nch_wide<MODE, MULTI, INDEXED>), dim3((unsigned)wide_blocks), dim3(threads), lds, stream, a, n_ch);
     }
     return hipGetLastError();
 }
 
 template <int MODE>
-hipError_t launch_nch_mode(const BatchArgs &a, bool multi, int n_ch, int compute_units, hipStream_t stream)
+hipError_t launch_nch_mode(const BatchArgs &a, bool multi, bool indexed, int n_ch, int compute_units, hipStream_t stream)
 {
-    return multi ? launch_nch_cpad<MODE, true>(a, n_ch, compute_units, stream) : launch_nch_cpad<MODE, false>(a, n_ch, compute_units, stream);
+    if (indexed) return multi ? launch_nch_cpad<MODE, true, true>(a, n_ch, compute_units, stream) : launch_nch_cpad<MODE, false, true>(a, n_ch, compute_units, stream);
+    return multi ? launch_nch_cpad<MODE, true, false>(a, n_ch, compute_units, stream) : launch_nch_cpad<MODE, false, false>(a, n_ch, compute_units, stream);
 }
 
 } // namespace
@@ -412,11 +433,12 @@ hipError_t launch_batch_nch(int mode, const BatchArgs &a, bool multi, int n_ch, 
 {
     if (a.n == 0) return hipSuccess;
     if (n_ch < 1 || n_ch > kMaxChannels || n_ch == 3) return hipErrorInvalidValue;
+    const bool indexed = a.idx != nullptr;                     // a caller's wavefront queue (a.n = its capacity)
     switch (mode) {
-        case MODE_EVAL:        return launch_nch_mode<MODE_EVAL>(a, multi, n_ch, compute_units, stream);
-        case MODE_SAMPLE:      return launch_nch_mode<MODE_SAMPLE>(a, multi, n_ch, compute_units, stream);
-        case MODE_EVAL_SAMPLE: return launch_nch_mode<MODE_EVAL_SAMPLE>(a, multi, n_ch, compute_units, stream);
-        case MODE_EVAL_PDF:    return launch_nch_mode<MODE_EVAL_PDF>(a, multi, n_ch, compute_units, stream);
+        case MODE_EVAL:        return launch_nch_mode<MODE_EVAL>(a, multi, indexed, n_ch, compute_units, stream);
+        case MODE_SAMPLE:      return launch_nch_mode<MODE_SAMPLE>(a, multi, indexed, n_ch, compute_units, stream);
+        case MODE_EVAL_SAMPLE: return launch_nch_mode<MODE_EVAL_SAMPLE>(a, multi, indexed, n_ch, compute_units, stream);
+        case MODE_EVAL_PDF:    return launch_nch_mode<MODE_EVAL_PDF>(a, multi, indexed, n_ch, compute_units, stream);
     }
     return hipErrorInvalidValue;
 }

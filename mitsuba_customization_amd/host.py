@@ -36,6 +36,7 @@ ABI_SYMBOLS = (
     "mrl_timer_start", "mrl_timer_stop",
     "mrl_material_upload_table_nch", "mrl_material_load_table_nch", "mrl_material_channels",
     "mrl_eval_batch_nch", "mrl_sample_batch_nch", "mrl_eval_pdf_batch_nch", "mrl_eval_sample_batch_nch",
+    "mrl_eval_queue_nch", "mrl_sample_queue_nch", "mrl_eval_pdf_queue_nch", "mrl_eval_sample_queue_nch",
     "mrl_tensor_file_open", "mrl_tensor_file_close", "mrl_tensor_file_last_error", "mrl_tensor_file_field_count", "mrl_tensor_file_find",
     "mrl_tensor_file_field_info", "mrl_tensor_file_field_data", "mrl_tensor_file_read_f64", "mrl_material_load_tensor_table",
     "mrl_group_init", "mrl_group_destroy", "mrl_group_size", "mrl_group_transport", "mrl_group_last_error", "mrl_group_context",
@@ -132,6 +133,10 @@ def load_library(path: Optional[str] = None):
     L.mrl_sample_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp, fp, fp]
     L.mrl_eval_pdf_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp, fp]
     L.mrl_eval_sample_batch_nch.argtypes = [vp, fp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp, fp, fp, fp, fp]
+    L.mrl_eval_queue_nch.argtypes = [vp, fp, fp, vp, C.c_int32, vp, vp, C.c_size_t, C.c_int, fp]
+    L.mrl_sample_queue_nch.argtypes = [vp, fp, fp, vp, C.c_int32, vp, vp, C.c_size_t, C.c_int, fp, fp, fp]
+    L.mrl_eval_pdf_queue_nch.argtypes = [vp, fp, fp, vp, C.c_int32, vp, vp, C.c_size_t, C.c_int, fp, fp]
+    L.mrl_eval_sample_queue_nch.argtypes = [vp, fp, fp, fp, vp, C.c_int32, vp, vp, C.c_size_t, C.c_int, fp, fp, fp, fp, fp]
     L.mrl_tensor_file_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.mrl_tensor_file_close.argtypes = [vp]
     L.mrl_tensor_file_last_error.argtypes = [vp]; L.mrl_tensor_file_last_error.restype = C.c_char_p
@@ -368,6 +373,47 @@ class MerlHip:
             detail = self._lib.mrl_tensor_file_last_error(None).decode() or self._lib.mrl_last_error(self._ctx).decode()
             raise MerlHipError(rc, "mrl_material_load_tensor_table", detail)
         return mid.value, ch.value
+
+    def eval_sample_queue_nch(self, wi, wo, u, queue, count, n_channels: int, mat=None, material: int = 0, capacity=None, out=None):
+        """Fused n-channel unit over a wavefront queue; unqueued slots of `out` stay as they are."""
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        if out is None:
+            out = (self._zeros(wi, (n, n_channels)), self._zeros(wi, (n,)), self._zeros(wi, (n, 3)), self._zeros(wi, (n,)),
+                   self._zeros(wi, (n, n_channels)))
+        val, pdf, wo2, pdf2, w = out
+        self._check(self._lib.mrl_eval_sample_queue_nch(
+            self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"), _addr(u, np.float32, 2, n, "u"),
+            _addr(mat, np.int32, None, n, "mat"), material, q, c, cap, n_channels,
+            _addr(val, np.float32, n_channels, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf"),
+            _addr(wo2, np.float32, 3, n, "out_wo"), _addr(pdf2, np.float32, None, n, "out_pdf2"),
+            _addr(w, np.float32, n_channels, n, "out_weight")), "mrl_eval_sample_queue_nch")
+        return out
+
+    def eval_queue_nch(self, wi, wo, queue, count, n_channels: int, mat=None, material: int = 0, capacity=None, out=None):
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        out = self._zeros(wi, (n, n_channels)) if out is None else out
+        self._check(self._lib.mrl_eval_queue_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                 _addr(mat, np.int32, None, n, "mat"), material, q, c, cap, n_channels,
+                                                 _addr(out, np.float32, n_channels, n, "out_values")), "mrl_eval_queue_nch")
+        return out
+
+    def sample_queue_nch(self, wi, u, queue, count, n_channels: int, mat=None, material: int = 0, capacity=None):
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        wo, pdf, w = self._zeros(wi, (n, 3)), self._zeros(wi, (n,)), self._zeros(wi, (n, n_channels))
+        self._check(self._lib.mrl_sample_queue_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(u, np.float32, 2, n, "u"),
+                                                   _addr(mat, np.int32, None, n, "mat"), material, q, c, cap, n_channels,
+                                                   _addr(wo, np.float32, 3, n, "out_wo"), _addr(pdf, np.float32, None, n, "out_pdf"),
+                                                   _addr(w, np.float32, n_channels, n, "out_weight")), "mrl_sample_queue_nch")
+        return wo, pdf, w
+
+    def eval_pdf_queue_nch(self, wi, wo, queue, count, n_channels: int, mat=None, material: int = 0, capacity=None):
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        val, pdf = self._zeros(wi, (n, n_channels)), self._zeros(wi, (n,))
+        self._check(self._lib.mrl_eval_pdf_queue_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                     _addr(mat, np.int32, None, n, "mat"), material, q, c, cap, n_channels,
+                                                     _addr(val, np.float32, n_channels, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf")),
+                    "mrl_eval_pdf_queue_nch")
+        return val, pdf
 
     def release_material(self, mid: int):
         """Frees the material's device memory; its id becomes a tombstone (batch calls render it as zeros)."""
@@ -718,6 +764,47 @@ class MerlGroup:
             detail = self._lib.mrl_tensor_file_last_error(None).decode() or self._lib.mrl_last_error(self._ctx).decode()
             raise MerlHipError(rc, "mrl_material_load_tensor_table", detail)
         return mid.value, ch.value
+
+    def eval_sample_queue_nch(self, wi, wo, u, queue, count, n_channels: int, mat=None, material: int = 0, capacity=None, out=None):
+        """Fused n-channel unit over a wavefront queue; unqueued slots of `out` stay as they are."""
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        if out is None:
+            out = (self._zeros(wi, (n, n_channels)), self._zeros(wi, (n,)), self._zeros(wi, (n, 3)), self._zeros(wi, (n,)),
+                   self._zeros(wi, (n, n_channels)))
+        val, pdf, wo2, pdf2, w = out
+        self._check(self._lib.mrl_eval_sample_queue_nch(
+            self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"), _addr(u, np.float32, 2, n, "u"),
+            _addr(mat, np.int32, None, n, "mat"), material, q, c, cap, n_channels,
+            _addr(val, np.float32, n_channels, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf"),
+            _addr(wo2, np.float32, 3, n, "out_wo"), _addr(pdf2, np.float32, None, n, "out_pdf2"),
+            _addr(w, np.float32, n_channels, n, "out_weight")), "mrl_eval_sample_queue_nch")
+        return out
+
+    def eval_queue_nch(self, wi, wo, queue, count, n_channels: int, mat=None, material: int = 0, capacity=None, out=None):
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        out = self._zeros(wi, (n, n_channels)) if out is None else out
+        self._check(self._lib.mrl_eval_queue_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                 _addr(mat, np.int32, None, n, "mat"), material, q, c, cap, n_channels,
+                                                 _addr(out, np.float32, n_channels, n, "out_values")), "mrl_eval_queue_nch")
+        return out
+
+    def sample_queue_nch(self, wi, u, queue, count, n_channels: int, mat=None, material: int = 0, capacity=None):
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        wo, pdf, w = self._zeros(wi, (n, 3)), self._zeros(wi, (n,)), self._zeros(wi, (n, n_channels))
+        self._check(self._lib.mrl_sample_queue_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(u, np.float32, 2, n, "u"),
+                                                   _addr(mat, np.int32, None, n, "mat"), material, q, c, cap, n_channels,
+                                                   _addr(wo, np.float32, 3, n, "out_wo"), _addr(pdf, np.float32, None, n, "out_pdf"),
+                                                   _addr(w, np.float32, n_channels, n, "out_weight")), "mrl_sample_queue_nch")
+        return wo, pdf, w
+
+    def eval_pdf_queue_nch(self, wi, wo, queue, count, n_channels: int, mat=None, material: int = 0, capacity=None):
+        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
+        val, pdf = self._zeros(wi, (n, n_channels)), self._zeros(wi, (n,))
+        self._check(self._lib.mrl_eval_pdf_queue_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                     _addr(mat, np.int32, None, n, "mat"), material, q, c, cap, n_channels,
+                                                     _addr(val, np.float32, n_channels, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf")),
+                    "mrl_eval_pdf_queue_nch")
+        return val, pdf
 
     def release_material(self, mid: int):
         self._check(self._lib.mrl_group_material_release(self._g, mid), "mrl_group_material_release")

@@ -226,3 +226,47 @@ def test_rgb_batches_never_read_a_narrow_table_as_bricks():
         cnt = torch.tensor([n], device=wi.device, dtype=torch.int32)
         outq = g.eval_sample_queue(wi, wo, u, q, cnt, mat=mat)
         assert float(outq[0][1::2].abs().max()) == 0.0 and torch.equal(outq[0][0::2], ref[0][0::2])
+
+
+@pytest.mark.parametrize("n_ch", [1, 4, 6, 16, 32])
+def test_nch_queue_calls_match_whole_array_calls(n_ch):
+    """mrl_*_queue_nch: queued slots equal the whole-array results bit for bit, every other slot keeps its sentinel;
+    ragged counts, a count above the capacity (clamped), an empty queue, a shuffled queue, mixed materials."""
+    import torch
+    from mitsuba_customization_amd import host, synth
+    n = 50_007
+    dims = (14, 12, 18)
+    with host.MerlHip(0) as g:
+        a = g.upload_table_nch(synth.make_table_nch("spectral", n_ch, 1, dims))
+        b = g.upload_table_nch(synth.make_table_nch("noise", n_ch, 2, dims))
+        other = g.upload_table_nch(synth.make_table_nch("noise", 2 if n_ch != 2 else 1, 3, dims))       # another width: zeros
+        wi, wo, u = g.generate_pairs(0x5EED, 7, n)
+        mat = torch.tensor([a, b, other], device=wi.device, dtype=torch.int32)[torch.arange(n, device=wi.device) % 3].contiguous()
+        whole = g.eval_sample_nch(wi, wo, u, n_ch, mat=mat)
+        perm = torch.randperm(n, device=wi.device, generator=torch.Generator(device=wi.device).manual_seed(5))
+        for queue, count in ((torch.arange(0, n, 3, device=wi.device), None), (perm[: n // 2], None), (torch.arange(0, n, 2, device=wi.device), 1000),
+                             (torch.arange(64, device=wi.device), 0), (torch.arange(100, device=wi.device), 10_000)):
+            queue = queue.to(torch.int32).contiguous()
+            k = queue.numel() if count is None else count
+            cnt = torch.tensor([k], device=wi.device, dtype=torch.int32)
+            live = queue[: min(k, queue.numel())].long()
+            sentinel = -7.0
+            out = (torch.full((n, n_ch), sentinel, device=wi.device), torch.full((n,), sentinel, device=wi.device), torch.full((n, 3), sentinel, device=wi.device),
+                   torch.full((n,), sentinel, device=wi.device), torch.full((n, n_ch), sentinel, device=wi.device))
+            g.eval_sample_queue_nch(wi, wo, u, queue, cnt, n_ch, mat=mat, out=out)
+            untouched = torch.ones(n, dtype=torch.bool, device=wi.device)
+            untouched[live] = False
+            for got, ref in zip(out, whole):
+                assert torch.equal(got[live].view(torch.int32), ref[live].view(torch.int32))
+                assert bool((got[untouched] == sentinel).all())
+        # the single-output calls, single material
+        q = torch.arange(0, n, 5, device=wi.device, dtype=torch.int32)
+        cnt = torch.tensor([q.numel()], device=wi.device, dtype=torch.int32)
+        ev = g.eval_queue_nch(wi, wo, q, cnt, n_ch, material=b)
+        ep = g.eval_pdf_queue_nch(wi, wo, q, cnt, n_ch, material=b)
+        sm = g.sample_queue_nch(wi, u, q, cnt, n_ch, material=b)
+        ref = g.eval_sample_nch(wi, wo, u, n_ch, material=b)
+        ql = q.long()
+        assert torch.equal(ev[ql], ref[0][ql]) and torch.equal(ep[0][ql], ref[0][ql]) and torch.equal(ep[1][ql], ref[1][ql])
+        assert torch.equal(sm[0][ql], ref[2][ql]) and torch.equal(sm[1][ql], ref[3][ql]) and torch.equal(sm[2][ql], ref[4][ql])
+        assert float(ev.abs().sum() - ev[ql].abs().sum()) == 0.0                     # unqueued slots of a zero-initialised output stay zero
