@@ -31,7 +31,7 @@ B_MAT = 4               # + the int32 material id of a mixed batch (SURVEY.md §
 B_GATHER = 192          # algorithmic table bytes per unit: 2 lookups x 8 texels x 12 B (reported beside)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW")
 HBM_COPY_GBS = 6290.0   # measured float4 copy on the same chip (same guide)
-GATHER_CEILING_GBS = 7000.0   # random 128-B lines -> LDS, nothing else (tools/microbench/gather128.hip, 187 MB table)
+GATHER_CEILING_GBS = 7000.0   # whole-line fabric bytes of the bare memory pattern (tools/microbench/gather128.hip, gather_streams.hip: 6.9-7.0 TB/s)
 SEED = 0x5EED
 EXIT_GATHER_FAILED = 3  # the N>1 result-gather leg raised or ran into its deadline (the bench line is still printed)
 
