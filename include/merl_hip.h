@@ -19,6 +19,13 @@
  *   mrl_eval_sample_batch                  the fused eval + pdf + sample unit (BASELINE metric)
  *   mrl_*_queue                            the same calls over a wavefront integrator's material queue
  *                                          (the caller side of the path)
+ *   mrl_material_release / mrl_memory_info plugin destructor (the host drops its last ref<BSDF>) / no counterpart
+ *   mrl_material_*_nch, mrl_*_batch_nch,   customized_measurement tables with 1..32 channels (the
+ *   mrl_*_queue_nch                        reference's own table format is unknown, Appendix B item 7)
+ *   mrl_tensor_file_*,                     the "tensor_file" container that upstream Mitsuba 3's `measured` plugin reads
+ *   mrl_material_load_tensor_table         (src/bsdfs/measured.cpp + src/core/tensor.cpp upstream; not in the snapshot)
+ *   mrl_group_*                            no counterpart in the reference (it has no multi-device path): the
+ *                                          data-parallel outer loop of SURVEY.md §8b/§8e, `mrl_init(n_devices, device_ids, …)`
  *
  * Conventions: every function returns 0 on success or a negative mrl_status; no exception
  * crosses the boundary.  All arrays are f32, direction arrays are xyzxyz… (n x 3), sample
