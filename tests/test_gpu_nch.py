@@ -271,3 +271,32 @@ def test_nch_queue_calls_match_whole_array_calls(n_ch):
         assert torch.equal(sm[0][ql], ref[2][ql]) and torch.equal(sm[1][ql], ref[3][ql]) and torch.equal(sm[2][ql], ref[4][ql])
         rest = ev.clone(); rest[ql] = 0.0
         assert float(rest.abs().max()) == 0.0                                        # unqueued slots of a zero-initialised output stay zero
+
+
+@pytest.mark.parametrize("n_ch", [4, 9])
+def test_nch_guards_unnormalised_and_nonfinite_inputs(oracle, n_ch):
+    """Below-horizon, zero, unnormalised, huge, NaN and inf directions through the narrow (4) and the wide (9 channels)
+    kernel: zeros where the oracle has zeros, NaN where it has NaN, equal values elsewhere — no trap, no hang."""
+    from mitsuba_customization_amd import host, synth
+    tab = synth.make_table_nch("spectral", n_ch, 4, (24, 20, 30))
+    wi = np.array([[0, 0, 1], [0.6, 0, 0.8], [0.6, 0, -0.8], [0.6, 0, 0.8], [1, 0, 0], [0.3, 0.4, 0.5], [3, 4, 5], [3e-5, 4e-5, 1e-6],
+                   [np.nan, 0, 1], [0, 0, np.inf], [0, 0, 0], [1e30, 0, 1e30], [0.1, 0.2, 0.97]], np.float32)
+    wo = np.array([[0, 0, 1], [-0.6, 0, 0.8], [0.6, 0, 0.8], [0.6, 0, -0.8], [0, 0, 1], [0.9, 1.2, 1.5], [0.09, 0.12, 0.15], [0, 1, 1e-3],
+                   [0, 0, 1], [0, 0, 1], [0, 0, 1], [0, 1e30, 1e30], [np.nan, np.nan, np.nan]], np.float32)
+    u = np.tile(np.array([[0.3, 0.7]], np.float32), (wi.shape[0], 1))
+    u[1] = (0.0, 0.0); u[2] = (1.0, 0.5); u[3] = (0.5, 0.5)
+    with host.MerlHip(0) as g:
+        mid = g.upload_table_nch(tab)
+        got = g.eval_sample_nch(wi, wo, u, n_ch, material=mid)          # host arrays
+        import torch
+        dev = [t.cpu().numpy() for t in g.eval_sample_nch(*(torch.from_numpy(a).cuda() for a in (wi, wo, u)), n_ch, material=mid)]
+    want = oracle.eval_sample_nch([oracle.OracleTableNch(tab)], wi, wo, u)
+    for a, b in zip(got, dev):
+        assert np.array_equal(a, b, equal_nan=True)
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(np.isnan(a), np.isnan(b)), k
+        fin = ~np.isnan(b)
+        assert (np.abs(a[fin].astype(np.float64) - b[fin]) <= 2e-6 * np.abs(b[fin]) + 1e-30).all(), k
+    for row in (2, 3, 4, 10):                                           # guards: everything of eval is zero
+        assert not got[0][row].any() and got[1][row] == 0
+    assert np.allclose(got[0][5] / 1.5, got[0][6] / 0.15, rtol=1e-6)    # f depends on the direction only
