@@ -287,7 +287,8 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
         const double k_th = (double)n_th * (double)n_th / kHalfPi, k_td = (double)n_td / kHalfPi, k_pd = (double)n_pd / kPi;
 
         // one lookup: copy + blend every group into the staging rows (scaled by `factor`), then stream the span out
-        auto lookup = [&](const fast::Vec3 &out_dir, double factor, float divide, float *dst) {
+        // (guards are selects on the finished value: a non-finite direction may have poisoned the blend)
+        auto lookup = [&](const fast::Vec3 &out_dir, bool keep, double factor, float divide, float *dst) {
             NchWeights w;
             const uint32_t cell = nch_cell(n_th, n_td, n_pd, fast::coords(in, out_dir, k_th, k_td, k_pd), a.opts, w);
             for (int g = 0; g < groups; ++g) {                // wave-uniform trip count
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
                 nch_blend<4>(dma, lane, w, v);
 #pragma unroll
                 for (int ch = 0; ch < 4; ++ch)
-                    if (4 * g + ch < n_ch) stage[lane * row + 4 * g + ch] = (float)(v[ch] * factor) / divide;
+                    if (4 * g + ch < n_ch) stage[lane * row + 4 * g + ch] = keep ? (float)(v[ch] * factor) / divide : 0.0f;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads of the copy buffer done before the next copy lands
             }
             if constexpr (INDEXED) {
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
         if constexpr (HAS_EVAL) {
             const bool valid = (wiz > 0.0f) && (woz > 0.0f);
             const double c = fast::cos_or_nan(wix, wiy, wiz, wox, woy, woz);
-            lookup(fast::normalize_f32(wox, woy, woz), valid ? c : 0.0, 1.0f, a.out_rgb);
+            lookup(fast::normalize_f32(wox, woy, woz), valid, c, 1.0f, a.out_rgb);
             if constexpr (mode_pdf(MODE)) {
                 float p = valid ? woz * kInvPiF : 0.0f;
                 if (a.opts.sampling && valid && known) p = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz);
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
             const bool valid = (wiz > 0.0f) && (!a.opts.sampling || sp > 0.0f);
             const bool has = valid && (sp > 0.0f);
             const double c = fast::cos_or_nan(wix, wiy, wiz, sx, sy, sz);
-            lookup(fast::normalize_f32(sx, sy, sz), has ? c : 0.0, has ? sp : 1.0f, a.out_weight);
+            lookup(fast::normalize_f32(sx, sy, sz), has, c, has ? sp : 1.0f, a.out_weight);
             if (active) {
                 const float wo2[3] = { valid ? sx : 0.0f, valid ? sy : 0.0f, valid ? sz : 0.0f };
                 store3(a.out_wo, i, wo2);
