@@ -300,3 +300,35 @@ def test_nch_guards_unnormalised_and_nonfinite_inputs(oracle, n_ch):
     for row in (2, 3, 4, 10):                                           # guards: everything of eval is zero
         assert not got[0][row].any() and got[1][row] == 0
     assert np.allclose(got[0][5] / 1.5, got[0][6] / 0.15, rtol=1e-6)    # f depends on the direction only
+
+
+@pytest.mark.parametrize("n_ch", [2, 8])
+def test_nch_table_sampling_in_a_mixed_batch(oracle, n_ch):
+    """MRL_OPT_SAMPLING = 1 over a batch of three n-channel tables (each with its own row marginal) and an unknown id:
+    cosine half bit-identical, half-vector half within one f32 ulp, pdf / weight to 3e-6 for >= 99.9 % (a direction one
+    ulp across a theta_h bin edge changes bins), sample().pdf == pdf(wi, sample().wo) on the device."""
+    import torch
+    from mitsuba_customization_amd import host, synth
+    dims = (30, 20, 36)
+    tabs = [synth.make_table_nch("spectral", n_ch, s, dims) for s in (1, 2, 3)]
+    n = 60_000
+    with host.MerlHip(0) as g:
+        g.set_option(host.OPT_SAMPLING, 1)
+        ids = [g.upload_table_nch(t) for t in tabs]
+        wi, wo, u = g.generate_pairs(0x5EED, 11, n)
+        mat = (torch.arange(n, device=wi.device) % 4).to(torch.int32)             # 3 = unknown
+        out = g.eval_sample_nch(wi, wo, u, n_ch, mat=mat)
+        back = g.pdf(wi, out[2].contiguous(), mat=mat)                            # pdf of the sampled direction, same option
+        assert torch.equal(back.view(torch.int32), out[3].view(torch.int32))
+        got = [t.cpu().numpy() for t in out]
+        hin = [t.cpu().numpy() for t in (wi, wo, u)]
+        hm = mat.cpu().numpy()
+    want = oracle.eval_sample_nch([oracle.OracleTableNch(t) for t in tabs], *hin, hm, table_sampling=True, n_ch=n_ch)
+    assert _close(got[0], want[0])
+    assert np.abs(got[2].astype(np.float64) - want[2]).max() <= 1.2e-7
+    cosine_half = hin[2][:, 0] < 0.5
+    assert np.array_equal(got[2][cosine_half], want[2][cosine_half])
+    for k in (1, 3, 4):
+        ok = np.abs(got[k].astype(np.float64) - want[k]) <= 3e-6 * np.abs(want[k]) + 1e-30
+        assert ok.mean() > 0.999, k
+    assert not got[0][hm == 3].any() and not got[4][hm == 3].any() and not got[3][hm == 3].any()
