@@ -102,7 +102,7 @@ def parse(argv=None):
     p.add_argument("--no-native-group", action="store_true",
                    help="N>1: skip the separately reported run of the native C++ host (lib/group_host: one process, mrl_group over the N GPUs, RCCL gather)")
     p.add_argument("--native-units", type=int, default=8 << 20, help="N>1: units per device of the native C++ host's run")
-    p.add_argument("--native-deadline", type=float, default=240.0, help="N>1: seconds before the native C++ host is killed")
+    p.add_argument("--native-deadline", type=float, default=90.0, help="N>1: seconds before the native C++ host is killed")
     return p.parse_args(argv)
 
 
