@@ -314,6 +314,13 @@ int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, in
 int mrl_group_eval_sample_batch(mrl_group *g, const float *wi, const float *wo, const float *u, const int32_t *mat,
                                 int32_t single_id, size_t n, float *out_rgb, float *out_pdf, float *out_wo,
                                 float *out_pdf2, float *out_weight);
+/* the other batch calls over host arrays, split the same way (BSDF::eval / pdf / eval_pdf / sample on every GPU of the node) */
+int mrl_group_eval_batch(mrl_group *g, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, float *out_rgb);
+int mrl_group_pdf_batch(mrl_group *g, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, float *out_pdf);
+int mrl_group_eval_pdf_batch(mrl_group *g, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n,
+                             float *out_rgb, float *out_pdf);
+int mrl_group_sample_batch(mrl_group *g, const float *wi, const float *u, const int32_t *mat, int32_t single_id, size_t n,
+                           float *out_wo, float *out_pdf, float *out_weight);
 int mrl_group_synchronize(mrl_group *g);
 /* device time of the last mrl_group_eval_sample_sharded per member (its first launch to its last launch or send),
  * valid after mrl_group_synchronize: ms_out[n_devices] */

@@ -487,12 +487,10 @@ int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, in
     return MRL_OK;
 }
 
-int mrl_group_eval_sample_batch(mrl_group *g, const float *wi, const float *wo, const float *u, const int32_t *mat, int32_t single_id, size_t n,
-                                float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
+// host arrays of n units split into tiles, one host thread per member; call(ctx, lo, hi) runs the member's tile
+template <typename F>
+static int host_split(mrl_group *g, size_t n, const char *what, F &&call)
 {
-    if (!g) return MRL_ERR_INVALID;
-    if (n == 0) return MRL_OK;
-    if (!wi || !wo || !u || !out_rgb || !out_pdf || !out_wo || !out_pdf2 || !out_weight) return gfail(g, MRL_ERR_INVALID, "null array argument");
     const int G = (int)g->members.size();
     std::vector<int> rcs((size_t)G, MRL_OK);
     std::vector<std::thread> pool;
@@ -500,17 +498,70 @@ int mrl_group_eval_sample_batch(mrl_group *g, const float *wi, const float *wo, 
         size_t lo, hi;
         mrl_tile_bounds(n, G, r, &lo, &hi);
         if (hi <= lo) continue;
-        pool.emplace_back([=, &rcs]() {
+        pool.emplace_back([=, &rcs, &call]() {
             mrl_ctx *c = g->members[(size_t)r].ctx;
-            rcs[(size_t)r] = mrl_eval_sample_batch(c, wi + 3 * lo, wo + 3 * lo, u + 2 * lo, mat ? mat + lo : nullptr, single_id, hi - lo,
-                                                   out_rgb + 3 * lo, out_pdf + lo, out_wo + 3 * lo, out_pdf2 + lo, out_weight + 3 * lo);
+            rcs[(size_t)r] = call(c, lo, hi);
             if (rcs[(size_t)r] == MRL_OK) rcs[(size_t)r] = mrl_synchronize(c);          // device-accessible (pinned) arrays are async
         });
     }
     for (auto &t : pool) t.join();
     for (int r = 0; r < G; ++r)
-        if (rcs[(size_t)r] != MRL_OK) return member_fail(g, r, rcs[(size_t)r], "mrl_eval_sample_batch");
+        if (rcs[(size_t)r] != MRL_OK) return member_fail(g, r, rcs[(size_t)r], what);
     return MRL_OK;
+}
+
+int mrl_group_eval_sample_batch(mrl_group *g, const float *wi, const float *wo, const float *u, const int32_t *mat, int32_t single_id, size_t n,
+                                float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
+{
+    if (!g) return MRL_ERR_INVALID;
+    if (n == 0) return MRL_OK;
+    if (!wi || !wo || !u || !out_rgb || !out_pdf || !out_wo || !out_pdf2 || !out_weight) return gfail(g, MRL_ERR_INVALID, "null array argument");
+    return host_split(g, n, "mrl_eval_sample_batch", [=](mrl_ctx *c, size_t lo, size_t hi) {
+        return mrl_eval_sample_batch(c, wi + 3 * lo, wo + 3 * lo, u + 2 * lo, mat ? mat + lo : nullptr, single_id, hi - lo,
+                                     out_rgb + 3 * lo, out_pdf + lo, out_wo + 3 * lo, out_pdf2 + lo, out_weight + 3 * lo);
+    });
+}
+
+int mrl_group_eval_batch(mrl_group *g, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, float *out_rgb)
+{
+    if (!g) return MRL_ERR_INVALID;
+    if (n == 0) return MRL_OK;
+    if (!wi || !wo || !out_rgb) return gfail(g, MRL_ERR_INVALID, "null array argument");
+    return host_split(g, n, "mrl_eval_batch", [=](mrl_ctx *c, size_t lo, size_t hi) {
+        return mrl_eval_batch(c, wi + 3 * lo, wo + 3 * lo, mat ? mat + lo : nullptr, single_id, hi - lo, out_rgb + 3 * lo);
+    });
+}
+
+int mrl_group_pdf_batch(mrl_group *g, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, float *out_pdf)
+{
+    if (!g) return MRL_ERR_INVALID;
+    if (n == 0) return MRL_OK;
+    if (!wi || !wo || !out_pdf) return gfail(g, MRL_ERR_INVALID, "null array argument");
+    return host_split(g, n, "mrl_pdf_batch", [=](mrl_ctx *c, size_t lo, size_t hi) {
+        return mrl_pdf_batch(c, wi + 3 * lo, wo + 3 * lo, mat ? mat + lo : nullptr, single_id, hi - lo, out_pdf + lo);
+    });
+}
+
+int mrl_group_eval_pdf_batch(mrl_group *g, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n,
+                             float *out_rgb, float *out_pdf)
+{
+    if (!g) return MRL_ERR_INVALID;
+    if (n == 0) return MRL_OK;
+    if (!wi || !wo || !out_rgb || !out_pdf) return gfail(g, MRL_ERR_INVALID, "null array argument");
+    return host_split(g, n, "mrl_eval_pdf_batch", [=](mrl_ctx *c, size_t lo, size_t hi) {
+        return mrl_eval_pdf_batch(c, wi + 3 * lo, wo + 3 * lo, mat ? mat + lo : nullptr, single_id, hi - lo, out_rgb + 3 * lo, out_pdf + lo);
+    });
+}
+
+int mrl_group_sample_batch(mrl_group *g, const float *wi, const float *u, const int32_t *mat, int32_t single_id, size_t n,
+                           float *out_wo, float *out_pdf, float *out_weight)
+{
+    if (!g) return MRL_ERR_INVALID;
+    if (n == 0) return MRL_OK;
+    if (!wi || !u || !out_wo || !out_pdf || !out_weight) return gfail(g, MRL_ERR_INVALID, "null array argument");
+    return host_split(g, n, "mrl_sample_batch", [=](mrl_ctx *c, size_t lo, size_t hi) {
+        return mrl_sample_batch(c, wi + 3 * lo, u + 2 * lo, mat ? mat + lo : nullptr, single_id, hi - lo, out_wo + 3 * lo, out_pdf + lo, out_weight + 3 * lo);
+    });
 }
 
 int mrl_group_synchronize(mrl_group *g)

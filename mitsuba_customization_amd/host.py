@@ -43,6 +43,7 @@ ABI_SYMBOLS = (
     "mrl_group_set_option", "mrl_group_material_load_merl", "mrl_group_material_upload_f64", "mrl_group_material_upload_table",
     "mrl_group_material_ggx", "mrl_group_material_release", "mrl_tile_bounds", "mrl_chunk_bounds", "mrl_chunk_steps",
     "mrl_group_generate_tiles", "mrl_group_eval_sample_sharded", "mrl_group_eval_sample_batch", "mrl_group_synchronize",
+    "mrl_group_eval_batch", "mrl_group_pdf_batch", "mrl_group_eval_pdf_batch", "mrl_group_sample_batch",
     "mrl_group_last_timing",
 )
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_PEER_COPY = 0, 1, 2
@@ -165,6 +166,10 @@ def load_library(path: Optional[str] = None):
     L.mrl_group_generate_tiles.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, C.POINTER(TileInputs)]
     L.mrl_group_eval_sample_sharded.argtypes = [vp, C.POINTER(TileInputs), C.c_int32, C.c_size_t, C.c_size_t, C.c_int, fp, fp, fp, fp, fp]
     L.mrl_group_eval_sample_batch.argtypes = [vp, fp, fp, fp, vp, C.c_int32, C.c_size_t, fp, fp, fp, fp, fp]
+    L.mrl_group_eval_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp]
+    L.mrl_group_pdf_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp]
+    L.mrl_group_eval_pdf_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp, fp]
+    L.mrl_group_sample_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp, fp, fp]
     L.mrl_group_synchronize.argtypes = [vp]
     L.mrl_group_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
     if path is None:
@@ -834,6 +839,36 @@ class MerlGroup:
             _addr(mat, np.int32, None, n, "mat"), material, n,
             *[_addr(o, np.float32, c, n, "out") for o, c in zip(out, (3, None, 3, None, 3))]), "mrl_group_eval_sample_batch")
         return out
+
+    def eval_host(self, wi, wo, mat=None, material: int = 0):
+        n = int(wi.shape[0]); out = np.empty((n, 3), np.float32)
+        self._check(self._lib.mrl_group_eval_batch(self._g, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                   _addr(mat, np.int32, None, n, "mat"), material, n, _addr(out, np.float32, 3, n, "out_rgb")),
+                    "mrl_group_eval_batch")
+        return out
+
+    def pdf_host(self, wi, wo, mat=None, material: int = 0):
+        n = int(wi.shape[0]); out = np.empty((n,), np.float32)
+        self._check(self._lib.mrl_group_pdf_batch(self._g, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                  _addr(mat, np.int32, None, n, "mat"), material, n, _addr(out, np.float32, None, n, "out_pdf")),
+                    "mrl_group_pdf_batch")
+        return out
+
+    def eval_pdf_host(self, wi, wo, mat=None, material: int = 0):
+        n = int(wi.shape[0]); rgb, pdf = np.empty((n, 3), np.float32), np.empty((n,), np.float32)
+        self._check(self._lib.mrl_group_eval_pdf_batch(self._g, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
+                                                       _addr(mat, np.int32, None, n, "mat"), material, n,
+                                                       _addr(rgb, np.float32, 3, n, "out_rgb"), _addr(pdf, np.float32, None, n, "out_pdf")),
+                    "mrl_group_eval_pdf_batch")
+        return rgb, pdf
+
+    def sample_host(self, wi, u, mat=None, material: int = 0):
+        n = int(wi.shape[0]); wo, pdf, w = np.empty((n, 3), np.float32), np.empty((n,), np.float32), np.empty((n, 3), np.float32)
+        self._check(self._lib.mrl_group_sample_batch(self._g, _addr(wi, np.float32, 3, n, "wi"), _addr(u, np.float32, 2, n, "u"),
+                                                     _addr(mat, np.int32, None, n, "mat"), material, n,
+                                                     _addr(wo, np.float32, 3, n, "out_wo"), _addr(pdf, np.float32, None, n, "out_pdf"),
+                                                     _addr(w, np.float32, 3, n, "out_weight")), "mrl_group_sample_batch")
+        return wo, pdf, w
 
     def synchronize(self):
         self._check(self._lib.mrl_group_synchronize(self._g), "mrl_group_synchronize")

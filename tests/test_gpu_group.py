@@ -82,6 +82,14 @@ def test_host_arrays_split_over_members(oracle, tables):
         out = grp.eval_sample_host(wi, wo, u, material=mid)
     for a, b in zip(out, ref):
         assert np.array_equal(a.view(np.int32), b.view(np.int32))
+    # the single-purpose calls split the same way
+    with host.MerlGroup([0, 0]) as grp:
+        mid = grp.upload_merl(tables("ggx_tab", 0))
+        ev, pd = grp.eval_host(wi, wo, material=mid), grp.pdf_host(wi, wo, material=mid)
+        ep = grp.eval_pdf_host(wi, wo, material=mid)
+        sm = grp.sample_host(wi, u, material=mid)
+    assert np.array_equal(ev, ref[0]) and np.array_equal(pd, ref[1]) and np.array_equal(ep[0], ref[0]) and np.array_equal(ep[1], ref[1])
+    assert np.array_equal(sm[0], ref[2]) and np.array_equal(sm[1], ref[3]) and np.array_equal(sm[2], ref[4])
     want = oracle.eval_sample_multi([oracle.OracleTable(tables("ggx_tab", 0))], wi, wo, u, None)
     assert (np.abs(out[0].astype(np.float64) - want[0]) <= 1e-6 * np.abs(want[0]) + 1e-30).all()
 
