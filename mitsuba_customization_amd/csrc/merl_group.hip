@@ -201,6 +201,29 @@ int replicated_material(mrl_group *g, const char *what, int *out_id, F &&call)
     return MRL_OK;
 }
 
+// host arrays of n units split into tiles, one host thread per member; call(ctx, lo, hi) runs the member's tile
+template <typename F>
+int host_split(mrl_group *g, size_t n, const char *what, F &&call)
+{
+    const int G = (int)g->members.size();
+    std::vector<int> rcs((size_t)G, MRL_OK);
+    std::vector<std::thread> pool;
+    for (int r = 0; r < G; ++r) {
+        size_t lo, hi;
+        mrl_tile_bounds(n, G, r, &lo, &hi);
+        if (hi <= lo) continue;
+        pool.emplace_back([=, &rcs, &call]() {
+            mrl_ctx *c = g->members[(size_t)r].ctx;
+            rcs[(size_t)r] = call(c, lo, hi);
+            if (rcs[(size_t)r] == MRL_OK) rcs[(size_t)r] = mrl_synchronize(c);          // device-accessible (pinned) arrays are async
+        });
+    }
+    for (auto &t : pool) t.join();
+    for (int r = 0; r < G; ++r)
+        if (rcs[(size_t)r] != MRL_OK) return member_fail(g, r, rcs[(size_t)r], what);
+    return MRL_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -484,29 +507,6 @@ int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, in
             MRL_GHIP(g, hipEventRecord(m.t1, m.compute));
         }
     }
-    return MRL_OK;
-}
-
-// host arrays of n units split into tiles, one host thread per member; call(ctx, lo, hi) runs the member's tile
-template <typename F>
-static int host_split(mrl_group *g, size_t n, const char *what, F &&call)
-{
-    const int G = (int)g->members.size();
-    std::vector<int> rcs((size_t)G, MRL_OK);
-    std::vector<std::thread> pool;
-    for (int r = 0; r < G; ++r) {
-        size_t lo, hi;
-        mrl_tile_bounds(n, G, r, &lo, &hi);
-        if (hi <= lo) continue;
-        pool.emplace_back([=, &rcs, &call]() {
-            mrl_ctx *c = g->members[(size_t)r].ctx;
-            rcs[(size_t)r] = call(c, lo, hi);
-            if (rcs[(size_t)r] == MRL_OK) rcs[(size_t)r] = mrl_synchronize(c);          // device-accessible (pinned) arrays are async
-        });
-    }
-    for (auto &t : pool) t.join();
-    for (int r = 0; r < G; ++r)
-        if (rcs[(size_t)r] != MRL_OK) return member_fail(g, r, rcs[(size_t)r], what);
     return MRL_OK;
 }
 
