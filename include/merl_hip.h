@@ -34,7 +34,10 @@
  * data_ptr) or host pointers; all pointers of one call must be of the same kind.  Device
  * pointer calls are asynchronous on the context's stream; host pointer calls return when the
  * outputs are written.  The caller owns every buffer; the context owns tables and streams.
- * A context is thread-compatible: one caller at a time.
+ * A context is thread-safe: every entry point takes the context's lock, so calls from several host threads serialise
+ * (device-pointer calls only enqueue — microseconds; host-array calls hold the lock for their duration).  What stays
+ * the caller's business is ordering: mrl_set_stream / mrl_timer_* / mrl_last_error describe "the last call", whoever
+ * made it, and a material must not be released while another thread still passes its id.
  *
  * There is NO CPU fallback: without a usable gfx950 device mrl_init fails.
  */

@@ -149,6 +149,9 @@ struct HostPipe {
 };
 
 struct mrl_ctx {
+    // every entry point that touches the context takes this lock: calls from several host threads are safe and serialise
+    // (device-pointer calls only enqueue, so the lock is held for microseconds; host-array calls hold it for their duration)
+    mutable std::recursive_mutex mu;
     int device = 0;
     int compute_units = 256;
     std::string device_name;
@@ -181,6 +184,8 @@ struct mrl_ctx {
 };
 
 namespace {
+
+#define MRL_GUARD(ctx) std::lock_guard<std::recursive_mutex> mrl_guard_((ctx)->mu)
 
 int fail(mrl_ctx *ctx, int status, const std::string &msg)
 {
@@ -325,7 +330,9 @@ int place_material(mrl_ctx *ctx, const MaterialHost &m, int *out_id)
 // neighbours never need a clamp or a wrap.  Scales applied and negatives clamped here, once.
 int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const double scale[3], int kind, int *out_id)
 {
-    if (!ctx || !planar || !dims || !scale || !out_id) return fail(ctx, MRL_ERR_INVALID, "null argument");
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
+    if (!planar || !dims || !scale || !out_id) return fail(ctx, MRL_ERR_INVALID, "null argument");
     const int n_th = dims[0], n_td = dims[1], n_pd = dims[2];
     if (n_th < 1 || n_td < 1 || n_pd < 1 || (long long)n_th * n_td * n_pd > (1LL << 28))
         return fail(ctx, MRL_ERR_INVALID, "table dims out of range");
@@ -628,6 +635,7 @@ int run_host_pipelined(mrl_ctx *ctx, const BatchCall &c)
 int run_batch(mrl_ctx *ctx, const BatchCall &c)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     if (c.n == 0) return MRL_OK;
     const bool has_eval = call_has_eval(c.mode), has_pdf = call_has_pdf(c.mode), has_sample = call_has_sample(c.mode);
     const bool needs_wo = has_eval || has_pdf, needs_u = has_sample;
@@ -684,6 +692,7 @@ int run_batch(mrl_ctx *ctx, const BatchCall &c)
 int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uint32_t *queue_count)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     if (c.n == 0) return MRL_OK;
     if (!queue || !queue_count) return fail(ctx, MRL_ERR_INVALID, "null array argument");
     int rc = check_call(ctx, c);
@@ -743,7 +752,9 @@ std::vector<double> build_sampling_nch(const double *planar, int n_th, int n_td,
 // planar f64, n_ch planes -> n-channel bricks in HBM (merl_nch.hip).  n_ch == 3 is the RGB path (packed 96-B bricks).
 int upload_table_nch(mrl_ctx *ctx, const double *planar, const int dims[3], int n_ch, const double *scale, int *out_id)
 {
-    if (!ctx || !planar || !dims || !out_id) return fail(ctx, MRL_ERR_INVALID, "null argument");
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
+    if (!planar || !dims || !out_id) return fail(ctx, MRL_ERR_INVALID, "null argument");
     if (n_ch < 1 || n_ch > mrl::kMaxChannels) return fail(ctx, MRL_ERR_INVALID, "channel count must be 1.." + std::to_string(mrl::kMaxChannels));
     std::vector<double> ones((size_t)n_ch, 1.0);
     if (!scale) scale = ones.data();
@@ -907,6 +918,7 @@ int mrl_destroy(mrl_ctx *ctx)
 int mrl_set_option(mrl_ctx *ctx, int option, int value)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     switch (option) {
         case MRL_OPT_LOOKUP:   if (value < 0 || value > 1) break; ctx->opts.lookup = value; return MRL_OK;
         case MRL_OPT_NODE:     if (value < 0 || value > 1) break; ctx->opts.node = value; return MRL_OK;
@@ -932,6 +944,7 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
 int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
 {
     if (!ctx || !value) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     switch (option) {
         case MRL_OPT_LOOKUP: *value = ctx->opts.lookup; return MRL_OK;
         case MRL_OPT_NODE: *value = ctx->opts.node; return MRL_OK;
@@ -949,6 +962,7 @@ int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
 int mrl_set_stream(mrl_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     ctx->stream = (hipStream_t)hip_stream;     // NULL = HIP's default stream
     return MRL_OK;
 }
@@ -956,6 +970,7 @@ int mrl_set_stream(mrl_ctx *ctx, void *hip_stream)
 int mrl_reset_stream(mrl_ctx *ctx)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     ctx->stream = ctx->own_stream;
     return MRL_OK;
 }
@@ -963,6 +978,7 @@ int mrl_reset_stream(mrl_ctx *ctx)
 int mrl_synchronize(mrl_ctx *ctx)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MRL_OK;
@@ -971,6 +987,7 @@ int mrl_synchronize(mrl_ctx *ctx)
 int mrl_device_info(const mrl_ctx *ctx, char *name, size_t name_len, int *compute_units, size_t *total_mem)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     if (name && name_len) { std::strncpy(name, ctx->device_name.c_str(), name_len - 1); name[name_len - 1] = 0; }
     if (compute_units) *compute_units = ctx->compute_units;
     if (total_mem) *total_mem = ctx->total_mem;
@@ -980,6 +997,7 @@ int mrl_device_info(const mrl_ctx *ctx, char *name, size_t name_len, int *comput
 int mrl_material_load_merl(mrl_ctx *ctx, const char *path, int *out_id)
 {
     if (!ctx || !out_id) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     std::vector<double> data; int dims[3];
     int rc = read_table_file(ctx, path, true, data, dims);
     if (rc != MRL_OK) return rc;
@@ -999,6 +1017,7 @@ int mrl_material_upload_table(mrl_ctx *ctx, const double *planar_rgb, const int 
 int mrl_material_load_table(mrl_ctx *ctx, const char *path, const double scale[3], int *out_id)
 {
     if (!ctx || !out_id || !scale) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     std::vector<double> data; int dims[3];
     int rc = read_table_file(ctx, path, false, data, dims);
     if (rc != MRL_OK) return rc;
@@ -1008,6 +1027,7 @@ int mrl_material_load_table(mrl_ctx *ctx, const char *path, const double scale[3
 int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float k[3], int *out_id)
 {
     if (!ctx || !eta || !k || !out_id) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     if (!(alpha > 0.0f)) return fail(ctx, MRL_ERR_INVALID, "alpha must be positive");
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     MaterialHost m;
@@ -1022,6 +1042,7 @@ int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float 
 int mrl_material_release(mrl_ctx *ctx, int id)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released)
         return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
     MRL_HIP(ctx, hipSetDevice(ctx->device));
@@ -1045,6 +1066,7 @@ int mrl_material_release(mrl_ctx *ctx, int id)
 int mrl_memory_info(const mrl_ctx *ctx, size_t *material_bytes, size_t *workspace_bytes, size_t *device_free, size_t *device_total)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     if (material_bytes) *material_bytes = ctx->material_bytes;
     if (workspace_bytes)
         *workspace_bytes = ctx->d_stage_bytes + (ctx->queue_cap ? (2 * ctx->queue_cap + 4 * kMaxSegments + 2) * sizeof(uint32_t) : 0) +
@@ -1059,11 +1081,17 @@ int mrl_memory_info(const mrl_ctx *ctx, size_t *material_bytes, size_t *workspac
     return MRL_OK;
 }
 
-int mrl_material_count(const mrl_ctx *ctx) { return ctx ? (int)ctx->materials.size() : MRL_ERR_INVALID; }
+int mrl_material_count(const mrl_ctx *ctx)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
+    return (int)ctx->materials.size();
+}
 
 int mrl_material_info(const mrl_ctx *ctx, int id, int *kind, int dims[3])
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return MRL_ERR_MATERIAL;
     const mrl::MaterialDev &d = ctx->materials[(size_t)id].dev;
     if (kind) *kind = d.kind;
@@ -1107,6 +1135,7 @@ int mrl_eval_pdf_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int
 int mrl_partition_by_material(mrl_ctx *ctx, const int32_t *mat, size_t n, uint32_t *queue_out, uint32_t *offsets_out, uint32_t *counts_out)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     if (!offsets_out || !counts_out || (n > 0 && (!mat || !queue_out))) return fail(ctx, MRL_ERR_INVALID, "null array argument");
     if (n > ((size_t)1 << 32)) return fail(ctx, MRL_ERR_INVALID, "more than 2^32 slots (queue entries are uint32)");
     const int K = (int)ctx->materials.size();
@@ -1172,7 +1201,9 @@ int mrl_eval_sample_queue(mrl_ctx *ctx, const float *wi, const float *wo, const 
 
 int mrl_generate_pairs(mrl_ctx *ctx, uint64_t seed, uint64_t first_index, size_t n, float *wi, float *wo, float *u)
 {
-    if (!ctx || !wi || !wo || !u) return fail(ctx, MRL_ERR_INVALID, "null argument");
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
+    if (!wi || !wo || !u) return fail(ctx, MRL_ERR_INVALID, "null argument");
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     if (common_kind({ wi, wo, u }) != 1) return fail(ctx, MRL_ERR_INVALID, "generator needs device pointers");
     MRL_HIP(ctx, mrl::launch_generate_pairs(seed, first_index, n, wi, wo, u, ctx->compute_units, ctx->stream));
@@ -1181,7 +1212,9 @@ int mrl_generate_pairs(mrl_ctx *ctx, uint64_t seed, uint64_t first_index, size_t
 
 int mrl_generate_materials(mrl_ctx *ctx, uint64_t seed, uint64_t first_index, size_t n, int n_materials, int32_t *mat)
 {
-    if (!ctx || !mat || n_materials < 1) return fail(ctx, MRL_ERR_INVALID, "bad argument");
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
+    if (!mat || n_materials < 1) return fail(ctx, MRL_ERR_INVALID, "bad argument");
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     if (pointer_kind(mat) != 1) return fail(ctx, MRL_ERR_INVALID, "generator needs device pointers");
     MRL_HIP(ctx, mrl::launch_generate_materials(seed, first_index, n, n_materials, mat, ctx->compute_units, ctx->stream));
@@ -1191,6 +1224,7 @@ int mrl_generate_materials(mrl_ctx *ctx, uint64_t seed, uint64_t first_index, si
 int mrl_device_alloc(mrl_ctx *ctx, size_t bytes, void **out)
 {
     if (!ctx || !out) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     MRL_ALLOC(ctx, hipMalloc(out, bytes ? bytes : 1));
     return MRL_OK;
@@ -1199,6 +1233,7 @@ int mrl_device_alloc(mrl_ctx *ctx, size_t bytes, void **out)
 int mrl_device_free(mrl_ctx *ctx, void *ptr)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     if (!ptr) return MRL_OK;
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1209,6 +1244,7 @@ int mrl_device_free(mrl_ctx *ctx, void *ptr)
 int mrl_copy_to_device(mrl_ctx *ctx, void *dst_device, const void *src_host, size_t bytes)
 {
     if (!ctx || (!dst_device && bytes) || (!src_host && bytes)) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     MRL_HIP(ctx, hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1218,6 +1254,7 @@ int mrl_copy_to_device(mrl_ctx *ctx, void *dst_device, const void *src_host, siz
 int mrl_copy_to_host(mrl_ctx *ctx, void *dst_host, const void *src_device, size_t bytes)
 {
     if (!ctx || (!dst_host && bytes) || (!src_device && bytes)) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     MRL_HIP(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1227,6 +1264,7 @@ int mrl_copy_to_host(mrl_ctx *ctx, void *dst_host, const void *src_device, size_
 int mrl_host_alloc(mrl_ctx *ctx, size_t bytes, void **out)
 {
     if (!ctx || !out) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     MRL_ALLOC(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable));
     return MRL_OK;
@@ -1235,6 +1273,7 @@ int mrl_host_alloc(mrl_ctx *ctx, size_t bytes, void **out)
 int mrl_host_free(mrl_ctx *ctx, void *ptr)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     if (!ptr) return MRL_OK;
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1245,6 +1284,7 @@ int mrl_host_free(mrl_ctx *ctx, void *ptr)
 int mrl_timer_start(mrl_ctx *ctx)
 {
     if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     MRL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     return MRL_OK;
@@ -1253,6 +1293,7 @@ int mrl_timer_start(mrl_ctx *ctx)
 int mrl_timer_stop(mrl_ctx *ctx, float *elapsed_ms)
 {
     if (!ctx || !elapsed_ms) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     MRL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     MRL_HIP(ctx, hipEventSynchronize(ctx->ev1));
@@ -1269,6 +1310,7 @@ int mrl_material_upload_table_nch(mrl_ctx *ctx, const double *planar, const int 
 int mrl_material_load_table_nch(mrl_ctx *ctx, const char *path, int n_channels, const double *scale, int *out_id)
 {
     if (!ctx || !out_id) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     if (n_channels < 1 || n_channels > mrl::kMaxChannels) return fail(ctx, MRL_ERR_INVALID, "channel count must be 1.." + std::to_string(mrl::kMaxChannels));
     std::vector<double> data; int dims[3];
     int rc = read_table_file_nch(ctx, path, n_channels, data, dims);
@@ -1279,6 +1321,7 @@ int mrl_material_load_table_nch(mrl_ctx *ctx, const char *path, int n_channels, 
 int mrl_material_channels(const mrl_ctx *ctx, int id, int *n_channels)
 {
     if (!ctx || !n_channels) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
     if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return MRL_ERR_MATERIAL;
     *n_channels = ctx->materials[(size_t)id].dev.n_ch;
     return MRL_OK;

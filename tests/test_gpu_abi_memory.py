@@ -109,3 +109,66 @@ def test_pipelined_host_path_equals_staged_and_device_paths(oracle, tables):
     want = oracle.eval_sample_multi([oracle.OracleTable(tables("ggx_tab", s)) for s in range(3)], wi, wo, u, mat)
     assert (np.abs(results[4]["fused"][0].astype(np.float64) - want[0]) <= 1e-6 * np.abs(want[0]) + 1e-30).all()
     assert np.array_equal(results[4]["fused"][2], want[2])
+
+
+def test_one_context_called_from_many_threads(oracle, tables):
+    """The context's internal lock: 8 host threads hammer ONE context with device-pointer calls, host-array calls,
+    queue calls and upload / release cycles (ctypes drops the GIL inside every call); every result equals the
+    single-threaded one bit for bit."""
+    import threading
+    import torch
+    from mitsuba_customization_amd import host
+    n = 200_000
+    wi, wo, u = oracle.generate_pairs(0x5EED, 77, n)
+    with host.MerlHip(0) as g:
+        g.use_own_stream()
+        keep = g.upload_merl(tables("ggx_tab", 0))
+        dwi, dwo, du = (torch.from_numpy(a).cuda() for a in (wi, wo, u))
+        torch.cuda.synchronize()
+        L, ctx = g._lib, g._ctx
+        ref = [t.cpu().numpy() for t in g.eval_sample(dwi, dwo, du, material=keep)]
+        g.use_own_stream()                                     # eval_sample() switched to torch's stream: back to the context's own
+        errors = []
+
+        def addr(t):
+            return t.data_ptr()
+
+        def worker(k):
+            try:
+                for it in range(12):
+                    kind = (k + it) % 4
+                    if kind == 0:                              # device pointers, raw ABI (no stream switching from this thread)
+                        outs = [torch.empty((n, 3), device="cuda"), torch.empty((n,), device="cuda"), torch.empty((n, 3), device="cuda"),
+                                torch.empty((n,), device="cuda"), torch.empty((n, 3), device="cuda")]
+                        rc = L.mrl_eval_sample_batch(ctx, addr(dwi), addr(dwo), addr(du), None, keep, n, *[addr(o) for o in outs])
+                        rc = rc or L.mrl_synchronize(ctx)
+                        if rc != 0 or any(not np.array_equal(o.cpu().numpy(), r) for o, r in zip(outs, ref)):
+                            errors.append(("device", k, it, rc))
+                    elif kind == 1:                            # host arrays: the pipelined path, lock held for the call
+                        outs = [np.empty((n, 3), np.float32), np.empty((n,), np.float32), np.empty((n, 3), np.float32),
+                                np.empty((n,), np.float32), np.empty((n, 3), np.float32)]
+                        rc = L.mrl_eval_sample_batch(ctx, wi.ctypes.data, wo.ctypes.data, u.ctypes.data, None, keep, n, *[o.ctypes.data for o in outs])
+                        if rc != 0 or any(not np.array_equal(o, r) for o, r in zip(outs, ref)):
+                            errors.append(("host", k, it, rc))
+                    elif kind == 2:                            # eval only on host arrays
+                        out = np.empty((n, 3), np.float32)
+                        rc = L.mrl_eval_batch(ctx, wi.ctypes.data, wo.ctypes.data, None, keep, n, out.ctypes.data)
+                        if rc != 0 or not np.array_equal(out, ref[0]):
+                            errors.append(("eval", k, it, rc))
+                    else:                                      # material churn beside the evaluations
+                        mid = C.c_int()
+                        tab = np.ascontiguousarray(tables("noise", 3, (8, 8, 16)), np.float64)
+                        rc = L.mrl_material_upload_table(ctx, tab.ctypes.data, (C.c_int * 3)(8, 8, 16), (C.c_double * 3)(1, 1, 1), C.byref(mid))
+                        rc = rc or L.mrl_material_release(ctx, mid.value)
+                        if rc != 0 or mid.value == keep:
+                            errors.append(("churn", k, it, rc))
+            except Exception as e:                             # pragma: no cover
+                errors.append(("exception", k, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors[:5]
+        assert g.material_count() >= 1 and g.material_info(keep)[0] == host.KIND_MERL
