@@ -262,7 +262,7 @@ int mrl_timer_stop(mrl_ctx *ctx, float *elapsed_ms);   /* records, synchronises,
  * keeps every material table replicated, and computes its tile alone on its own stream.  The only communication is
  * the delivery of per-tile RESULTS to a root device: peers send their chunk straight to the root (grouped
  * ncclSend / ncclRecv over RCCL: each peer's own xGMI link, not a ring), cut into chunks so that the send of chunk k
- * overlaps the compute of chunk k + 1.  A group is thread-compatible like a context.  A renderer host stays in
+ * overlaps the compute of chunk k + 1.  A group is thread-compatible (one caller at a time; its member contexts are thread-safe).  A renderer host stays in
  * C++ and reaches every GPU of the node through these calls; it replaces nothing in the reference (the reference
  * has no multi-device path), it is the data-parallel outer loop around mrl_eval_sample_batch. */
 typedef struct mrl_group mrl_group;

@@ -3,7 +3,7 @@
 // plumbing.  Host C++ only; everything that computes goes through the C ABI (include/merl_hip.h).
 //
 // Threading: the renderers call eval()/sample()/pdf() on a const BSDF from all render threads
-// (SURVEY.md §8b).  A libmerl_hip context is thread-compatible, so scalar calls are COMBINED:
+// (SURVEY.md §8b).  A libmerl_hip context serialises its callers (one GPU round trip each), so scalar calls are COMBINED:
 // a calling thread posts its request; whichever thread finds no round in flight becomes the
 // leader, takes every request posted so far (its own and other threads', up to 256), runs them
 // as ONE fused eval+sample batch on pinned, device-mapped memory (zero copy), and hands the
@@ -195,7 +195,7 @@ private:
         int rc;
         std::string what;
         {
-            std::lock_guard<std::mutex> call(m_mutex);      // the context itself is thread-compatible
+            std::lock_guard<std::mutex> call(m_mutex);      // one call sequence (launch + sync) at a time
             rc = mrl_eval_sample_batch(m_ctx, wi, wo, u, mat, 0, k, rgb, pdf, wo2, pdf2, weight);
             if (rc == MRL_OK) rc = mrl_synchronize(m_ctx);
             if (rc != MRL_OK) {
@@ -229,7 +229,7 @@ private:
 
     ContextKey m_key;
     mrl_ctx *m_ctx = nullptr;
-    std::mutex m_mutex;                    // serialises calls into the (thread-compatible) C context
+    std::mutex m_mutex;                    // keeps a launch and its synchronize together (the C context only locks per call)
     std::map<std::string, std::weak_ptr<Resident>> m_resident;     // guarded by m_mutex
     float *m_pin = nullptr;
     std::mutex m_post_mutex;               // guards the three members below
