@@ -88,6 +88,10 @@ enum mrl_option {
                                   and two pinned, device-mapped chunk buffers while the kernel of the previous / next chunk
                                   reads and writes those buffers over PCIe (default 4, counting the calling thread;
                                   0 = the staged hipMemcpy path of round 1, ~3x slower) */
+    MRL_OPT_BLOCK_MAP = 9,     /* how the LDS-DMA kernel's workgroups walk a batch: 0 interleaved (block b takes tiles b, b + G, ...),
+                                  1 XCD-contiguous: the workgroups of one XCD (its own 4 MB L2) walk one contiguous eighth of
+                                  the batch, so neighbouring units — pixels and scanlines of a render — share one L2 instead
+                                  of being fetched by all eight.  Same results either way; see DESIGN.md §6 for which is faster when */
     MRL_OPT_MEMORY_LIMIT_MB = 7 /* budget for the context's resident material data (tables + sampling marginals), in MiB;
                                   0 (default) = no budget, the device's free memory is the limit.  An upload that would
                                   exceed the budget — or the device — fails with MRL_ERR_OOM and leaves the context as it

@@ -176,6 +176,7 @@ struct mrl_ctx {
     int kernel_variant = 3;          // MRL_OPT_KERNEL default: cooperative LDS-DMA brick fetch
     int table_layout = 1;            // layout of tables uploaded from now on (mrl::Layout)
     size_t host_chunk = (size_t)1 << 22;
+    int block_map = 0;               // MRL_OPT_BLOCK_MAP
     int host_threads = 4;            // MRL_OPT_HOST_THREADS: copy threads of the pipelined host-array path; 0 = staged hipMemcpy path
     HostPipe pipe;
     void *d_stage = nullptr;
@@ -479,6 +480,7 @@ DeviceCall device_call(const mrl_ctx *ctx, const BatchCall &c)
     a.n_materials = (int)ctx->materials.size();
     a.opts = ctx->opts;
     a.safe = tombstone_dev(ctx);
+    a.block_map = ctx->block_map;
     d.multi = c.mat != nullptr;
     if (!d.multi) a.single = ctx->materials[(size_t)c.single_id].dev;
     d.has_ggx = d.has_table = false;
@@ -927,6 +929,7 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
         case MRL_OPT_KERNEL:   if (value < 0 || value > 4) break; ctx->kernel_variant = value; return MRL_OK;
         case MRL_OPT_MEMORY_LIMIT_MB: if (value < 0) break; ctx->memory_limit = (size_t)value << 20; return MRL_OK;
         case MRL_OPT_HOST_THREADS: if (value < 0 || value > 64) break; ctx->host_threads = value; return MRL_OK;
+        case MRL_OPT_BLOCK_MAP: if (value < 0 || value > 1) break; ctx->block_map = value; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: if (value < 1) break; ctx->host_chunk = (size_t)value; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: {
             if (value < 0 || value > 1) break;
@@ -953,6 +956,7 @@ int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
         case MRL_OPT_KERNEL: *value = ctx->kernel_variant; return MRL_OK;
         case MRL_OPT_MEMORY_LIMIT_MB: *value = (int)(ctx->memory_limit >> 20); return MRL_OK;
         case MRL_OPT_HOST_THREADS: *value = ctx->host_threads; return MRL_OK;
+        case MRL_OPT_BLOCK_MAP: *value = ctx->block_map; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: *value = (int)ctx->host_chunk; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: *value = ctx->table_layout; return MRL_OK;
     }

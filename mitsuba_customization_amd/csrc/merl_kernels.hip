@@ -374,9 +374,22 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float4 *ldsA = lds[wave][0];
     float4 *ldsB = lds[wave][LOOKUPS - 1];
-    const size_t stride = (size_t)gridDim.x * kDmaBlock;
     const size_t n_items = item_count<INDEXED>(a);
-    for (size_t base = (size_t)blockIdx.x * kDmaBlock + wave * 64u; base < n_items; base += stride) {
+    // Block -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (blocks b and b + 8 share one; observed, used
+    // for speed only).  a.block_map = 1: XCD x walks ITS contiguous eighth of the batch, so units that are neighbours in
+    // the batch — neighbouring pixels and scanlines of a render — meet in one XCD's L2 instead of being fetched by all
+    // eight; 0: the plain interleaved grid-stride walk (block b takes tiles b, b + G, ...).  Results do not depend on it.
+    const size_t tiles = (n_items + kDmaBlock - 1) / kDmaBlock;
+    size_t tile = blockIdx.x, tile_end = tiles, tile_step = gridDim.x;
+    if (a.block_map && (gridDim.x & 7u) == 0) {
+        const size_t x = blockIdx.x & 7u, per_xcd = gridDim.x >> 3;
+        tile = x * tiles / 8 + (blockIdx.x >> 3);
+        tile_end = (x + 1) * tiles / 8;
+        tile_step = per_xcd;
+    }
+    for (; tile < tile_end; tile += tile_step) {
+        const size_t base = tile * kDmaBlock + wave * 64u;
+        if (base >= n_items) break;                           // a wave beyond the tail of the last tile (wave-uniform)
         const size_t j_raw = base + lane;
         const bool active = j_raw < n_items;
         const size_t j = active ? j_raw : n_items - 1;        // tail lanes recompute the last unit, store nothing
@@ -774,6 +787,7 @@ hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, 
             constexpr int per_cu = ((MODE == MODE_EVAL_SAMPLE) ? 2 : 4) * (256 / kDmaBlock);
             size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;
             if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
+            blocks = (blocks + 7) / 8 * 8;                    // whole rounds over the 8 XCDs (BatchArgs::block_map)
             const dim3 g((unsigned)blocks), b(kDmaBlock);
             if (multi && has_ggx)      hipLaunchKernelGGL((k_table_dma<MODE, true, true, true>), g, b, 0, stream, a);
             else if (multi)            hipLaunchKernelGGL((k_table_dma<MODE, true, true, false>), g, b, 0, stream, a);
@@ -882,6 +896,7 @@ hipError_t launch_indexed_mode(const BatchArgs &a, bool multi, int layout, bool 
             constexpr int per_cu = ((MODE == MODE_EVAL_SAMPLE) ? 2 : 4) * (256 / kDmaBlock);
             size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;
             if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
+            blocks = (blocks + 7) / 8 * 8;
             const dim3 g((unsigned)blocks), b(kDmaBlock);
             if (multi && has_ggx)      hipLaunchKernelGGL((k_table_dma<MODE, true, true, true, true>), g, b, 0, stream, a);
             else if (multi)            hipLaunchKernelGGL((k_table_dma<MODE, true, true, false, true>), g, b, 0, stream, a);

@@ -15,7 +15,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRL_LIB_PATH") or os.path.join(_PKG, "lib", "libmerl_hip.so")   # env override: A/B builds
 
-OPT_LOOKUP, OPT_NODE, OPT_DISK_MAP, OPT_KERNEL, OPT_HOST_CHUNK, OPT_TABLE_LAYOUT, OPT_SAMPLING, OPT_MEMORY_LIMIT_MB, OPT_HOST_THREADS = 0, 1, 2, 3, 4, 5, 6, 7, 8
+OPT_LOOKUP, OPT_NODE, OPT_DISK_MAP, OPT_KERNEL, OPT_HOST_CHUNK, OPT_TABLE_LAYOUT, OPT_SAMPLING, OPT_MEMORY_LIMIT_MB, OPT_HOST_THREADS, OPT_BLOCK_MAP = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 SAMPLING_COSINE, SAMPLING_TABLE = 0, 1
 LAYOUT_ROWS, LAYOUT_BRICK = 0, 1
 LOOKUP_NEAREST, LOOKUP_TRILINEAR = 0, 1

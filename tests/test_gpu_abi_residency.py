@@ -130,6 +130,7 @@ def test_option_ranges():
             assert L.mrl_set_option(ctx, host.OPT_KERNEL, v) == host.ERR_INVALID
         assert g.get_option(host.OPT_KERNEL) == 4
         assert L.mrl_set_option(ctx, host.OPT_MEMORY_LIMIT_MB, -5) == host.ERR_INVALID
+        assert L.mrl_set_option(ctx, host.OPT_BLOCK_MAP, 2) == host.ERR_INVALID and L.mrl_set_option(ctx, host.OPT_BLOCK_MAP, 1) == 0
         assert L.mrl_material_release(ctx, 0) == host.ERR_MATERIAL and L.mrl_material_release(None, 0) == host.ERR_INVALID
         assert L.mrl_memory_info(None, None, None, None, None) == host.ERR_INVALID
         assert L.mrl_memory_info(ctx, None, None, None, None) == 0
