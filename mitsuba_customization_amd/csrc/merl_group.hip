@@ -459,7 +459,8 @@ int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, in
         const bool rccl = g->transport == MRL_TRANSPORT_RCCL;
         bool any = false;
         if (rccl) MRL_GNCCL(g, g->rccl.GroupStart());
-        for (int r = 0; r < G; ++r) {
+        int posted = MRL_OK;                                  // a failure inside the group must still close it
+        for (int r = 0; r < G && posted == MRL_OK; ++r) {
             if (r == root) continue;
             Member &m = g->members[(size_t)r];
             size_t a, b;
@@ -471,17 +472,23 @@ int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, in
             const float *from[5] = { src.rgb, src.pdf, src.wo, src.pdf2, src.weight };
             float *to[5] = { out_rgb + 3 * a, out_pdf + a, out_wo + 3 * a, out_pdf2 + a, out_weight + 3 * a };
             const size_t count[5] = { 3 * n, n, 3 * n, n, 3 * n };
-            for (int k = 0; k < 5; ++k) {
+            for (int k = 0; k < 5 && posted == MRL_OK; ++k) {
                 if (rccl) {
-                    MRL_GNCCL(g, g->rccl.Send(from[k], count[k], ncclFloat, root, m.comm, m.transfer));
-                    MRL_GNCCL(g, g->rccl.Recv(to[k], count[k], ncclFloat, r, R.comm, R.transfer));
+                    ncclResult_t nr = g->rccl.Send(from[k], count[k], ncclFloat, root, m.comm, m.transfer);
+                    if (nr == ncclSuccess) nr = g->rccl.Recv(to[k], count[k], ncclFloat, r, R.comm, R.transfer);
+                    if (nr != ncclSuccess) posted = gfail(g, MRL_ERR_COMM, std::string("ncclSend/ncclRecv: ") + g->rccl.GetErrorString(nr));
                 } else {
-                    MRL_GHIP(g, hipSetDevice(m.device));
-                    MRL_GHIP(g, hipMemcpyPeerAsync(to[k], R.device, from[k], m.device, count[k] * sizeof(float), m.transfer));
+                    hipError_t e = hipSetDevice(m.device);
+                    if (e == hipSuccess) e = hipMemcpyPeerAsync(to[k], R.device, from[k], m.device, count[k] * sizeof(float), m.transfer);
+                    if (e != hipSuccess) { (void)hipGetLastError(); posted = gfail(g, MRL_ERR_HIP, std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e)); }
                 }
             }
         }
-        if (rccl) MRL_GNCCL(g, g->rccl.GroupEnd());
+        if (rccl) {
+            const ncclResult_t nr = g->rccl.GroupEnd();
+            if (nr != ncclSuccess && posted == MRL_OK) posted = gfail(g, MRL_ERR_COMM, std::string("ncclGroupEnd: ") + g->rccl.GetErrorString(nr));
+        }
+        if (posted != MRL_OK) return posted;
         if (!any) continue;
         for (int r = 0; r < G; ++r) {
             if (r == root) continue;
@@ -495,17 +502,24 @@ int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, in
         }
     }
     // 3. order the root's context stream after everything that writes the caller's arrays, and close the timers
+    //    (every record / wait is issued with the stream's own device current)
+    const bool root_receives = g->transport == MRL_TRANSPORT_RCCL;
     for (int r = 0; r < G; ++r) {
         Member &m = g->members[(size_t)r];
-        MRL_GHIP(g, hipSetDevice(m.device));
-        if (r != root || g->transport == MRL_TRANSPORT_RCCL) {
+        if (r != root || root_receives) {
+            MRL_GHIP(g, hipSetDevice(m.device));
             MRL_GHIP(g, hipEventRecord(m.landed, m.transfer));
-            MRL_GHIP(g, hipStreamWaitEvent(R.compute, m.landed, 0));
         }
-        if (m.timed) {
-            if (r != root) MRL_GHIP(g, hipStreamWaitEvent(m.compute, m.landed, 0));     // a member's time includes its sends
-            MRL_GHIP(g, hipEventRecord(m.t1, m.compute));
-        }
+    }
+    MRL_GHIP(g, hipSetDevice(R.device));
+    for (int r = 0; r < G; ++r)
+        if (r != root || root_receives) MRL_GHIP(g, hipStreamWaitEvent(R.compute, g->members[(size_t)r].landed, 0));
+    for (int r = 0; r < G; ++r) {
+        Member &m = g->members[(size_t)r];
+        if (!m.timed) continue;
+        MRL_GHIP(g, hipSetDevice(m.device));
+        if (r != root) MRL_GHIP(g, hipStreamWaitEvent(m.compute, m.landed, 0));         // a member's time includes its sends
+        MRL_GHIP(g, hipEventRecord(m.t1, m.compute));
     }
     return MRL_OK;
 }
