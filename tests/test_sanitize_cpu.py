@@ -30,6 +30,13 @@ def test_scalar_call_combiner_is_clean_under_tsan(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-o", exe,
                            os.path.join(ROOT, "tests", "combiner_tsan.cpp"), "-lpthread"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    if "unexpected memory mapping" in r.stderr:
+        # this kernel randomises mappings beyond what the installed TSAN runtime accepts: retry without ASLR, else skip
+        setarch = shutil.which("setarch")
+        if setarch:
+            r = subprocess.run([setarch, "x86_64", "-R", exe], capture_output=True, text=True, timeout=600)
+        if "unexpected memory mapping" in r.stderr or (r.returncode != 0 and not r.stdout and "ThreadSanitizer" not in r.stderr):
+            pytest.skip("ThreadSanitizer cannot map its shadow memory on this host (ASLR): " + r.stderr.strip()[:120])
     assert r.returncode == 0 and "combiner ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
 
 
