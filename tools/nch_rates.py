@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the n-channel entry points beside the RGB path: fused eval+sample over 32M units,
-MERL-sized tables, 1 / 2 / 3 (RGB path) / 4 / 8 / 16 / 32 channels.   python tools/nch_rates.py"""
+MERL-sized tables, 1 / 2 / 3 (RGB path) / 4 / 8 / 16 / 32 channels.   python tools/nch_rates.py [widths...]"""
 import json
 import os
 import sys
@@ -14,7 +14,8 @@ from mitsuba_customization_amd import host, synth
 n = 32 << 20
 rows = []
 base = synth.make_table("ggx_tab", 0)
-for C in (1, 2, 3, 4, 8, 16, 32):
+widths = [int(x) for x in sys.argv[1:]] or [1, 2, 3, 4, 8, 16, 32]
+for C in widths:
     with host.MerlHip(0) as gpu:
         planes = np.stack([np.abs(base[c % 3]) * (1.0 + 0.01 * c) for c in range(C)])
         mid = gpu.upload_table_nch(planes, [1.0 / 1500.0] * C)

@@ -18,7 +18,7 @@ for d in sorted(glob.glob(os.path.join(out, "*_*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             acc[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
-            names[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0]
+            names[r["Dispatch_Id"]] = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
     per_kernel = defaultdict(lambda: defaultdict(list))
     for disp, cs in acc.items():
         for c, v in cs.items():
