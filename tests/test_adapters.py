@@ -97,7 +97,7 @@ def test_merl_plugin_scalar_and_batched_calls_match_oracle(built, merl_file, ora
         _check(batch, want)
     else:
         ok = np.abs(batch[:, 0:3].astype(np.float64) - want[0]) <= 1e-6 * np.abs(want[0]) + 1e-30
-        assert ok.mean() > 0.9999
+        assert (~ok.all(axis=1)).sum() <= 1                     # nearest: at most one bin-edge flip (measured: none in 67 M lookups)
 
 
 @pytest.mark.gpu

@@ -50,7 +50,7 @@ def test_nch_eval_sample_matches_oracle(oracle, n_ch, kind, dims, lookup, node, 
         _check(fused, want)
     else:                                                               # nearest: a coordinate on an exact bin edge may flip
         ok = np.abs(fused[0].cpu().numpy().astype(np.float64) - want[0]) <= 1e-6 * np.abs(want[0]) + 1e-30
-        assert ok.mean() > 0.9999
+        assert (~ok.all(axis=1)).sum() <= 1                             # measured: none
         assert np.array_equal(fused[2].cpu().numpy(), want[2]) and np.array_equal(fused[3].cpu().numpy(), want[3])
     import torch
     for a, b in ((ev, fused[0]), (ep[0], fused[0]), (ep[1], fused[1]), (sm[0], fused[2]), (sm[1], fused[3]), (sm[2], fused[4]), (pdf_only, fused[1])):

@@ -4,7 +4,8 @@ the C ABI (libmerl_hip.so) and is checked against the CPU oracle on identical in
 Tolerances (BASELINE.json north_star): eval RGB, sample direction, pdf, weight <= 1e-6 relative.
   * sampled directions and cosine pdfs are expected BIT-IDENTICAL (pinned f32 sequence);
   * rgb / weight: |gpu - oracle| <= 1e-6 * |oracle| + 1e-30 (trilinear);
-  * nearest lookup: a bin can flip on an exact boundary, so the bound must hold for >= 99.99 %.
+  * nearest lookup: a coordinate within ~1e-12 of an integer could land in the neighbouring texel, so ONE unit per test may
+    differ; measured: none in 2 x 16.7 M units on the GGX-shaped and the noise table (tools/nearest_flips.py).
 Parity is vs this repo's oracle; the reference ships no vectors (parity unpinned).
 """
 import numpy as np
@@ -91,7 +92,7 @@ def test_eval_nearest_matches_oracle(gpu, oracle, mats):
     got = gpu.eval(dwi, dwo, material=mid).cpu().numpy()
     want = T.eval(wi, wo, oracle.make_opts(lookup=0))
     ok = np.abs(got.astype(np.float64) - want) <= REL * np.abs(want) + 1e-30
-    assert ok.mean() >= 0.9999, f"nearest: {(~ok).sum()} mismatching values"
+    assert (~ok.all(axis=1)).sum() <= 1, f"nearest: {(~ok).sum()} mismatching values"      # at most one bin-edge flip (measured: none)
     set_opts(gpu)
 
 
@@ -381,7 +382,7 @@ def test_kernel_variants_and_layouts_match_oracle(gpu, oracle, tables, kind, see
                         assert_close(got[0], want[0], what=tag + " rgb"); assert_close(got[4], want[4], what=tag + " weight")
                     else:
                         ok = np.abs(got[0].astype(np.float64) - want[0]) <= REL * np.abs(want[0]) + 1e-30
-                        assert ok.mean() >= 0.9999, tag
+                        assert (~ok.reshape(ok.shape[0], -1).all(axis=1)).sum() <= 1, tag        # at most one bin-edge flip
                     assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
                     results[(layout, lookup, node, variant)] = got[0]
     base = results[(0, 1, 0, 1)]
