@@ -2,7 +2,8 @@
 oracle's definition (oracle/merl_oracle.h).  The cosine half of the mixture stays bit-identical; the
 half-vector half is f64 math rounded to Float, so a direction may differ by one f32 ulp, which then
 moves pdf / weight by ~1e-7 (and, for a direction within an ulp of a theta_h bin edge, by a bin step:
-such units must stay below 1 in 10,000)."""
+such units must stay below 1 in 10,000).  EVERY unit, however, must agree with the oracle evaluated at the direction the
+device returned (`at_returned_direction`): pdf to 2e-6 and weight to 3e-6, no exceptions."""
 import numpy as np
 import pytest
 
@@ -17,6 +18,16 @@ def to_dev(*arrs):
 def frac_close(got, want, rel):
     got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
     return (np.abs(got - want) <= rel * np.abs(want) + 1e-30).mean()
+
+
+def at_returned_direction(T, wi, s_wo, s_pdf, s_w, tag):
+    """Every unit: the device's pdf and weight against the oracle's pdf(wi, wo') and eval(wi, wo') / pdf at the device's wo'."""
+    live = s_pdf > 0
+    c_pdf = T.pdf_table(wi[live], s_wo[live]).astype(np.float64)
+    assert frac_close(s_pdf[live], c_pdf, 2e-6) == 1.0, tag + ": pdf at the returned direction"
+    c_w = T.eval(wi[live], s_wo[live]).astype(np.float64) / c_pdf[:, None]
+    assert frac_close(s_w[live], c_w, 3e-6) == 1.0, tag + ": weight at the returned direction"
+    assert not s_w[~live].any(), tag
 
 
 @pytest.mark.parametrize("layout", [0, 1])
@@ -49,6 +60,7 @@ def test_table_sampling_matches_oracle(oracle, tables, layout, kind, seed):
             same = (s_wo == c_wo).all(axis=1)
             assert same.mean() > 0.99
             assert frac_close(s_w[same], c_w[same], 1e-6) == 1.0, tag        # same direction -> same weight to 1e-6
+            at_returned_direction(T, wi, s_wo, s_pdf, s_w, tag)              # any direction -> every value
             # pdf queries
             q = g.pdf(dwi, dwo, material=mid).cpu().numpy()
             assert frac_close(q, c_pdf_q, 2e-6) == 1.0, tag
@@ -89,6 +101,7 @@ def test_table_sampling_mixed_batch_and_variance(oracle, tables):
         c_wo, c_pdf, c_w = ob.OracleTable(tabs[k]).sample_table(wi[sel], u[sel])
         assert np.abs(s_wo[sel].astype(np.float64) - c_wo).max() <= 1.2e-7
         assert frac_close(s_pdf[sel], c_pdf, 2e-6) > 0.9999 and frac_close(s_w[sel], c_w, 3e-6) > 0.9995
+        at_returned_direction(ob.OracleTable(tabs[k]), wi[sel], s_wo[sel], s_pdf[sel], s_w[sel], f"material {k}")
     assert float(tab_w.var(0).sum()) < 0.2 * float(cos_w.cpu().var(0).sum())
     # both estimators agree on the mean (albedo-like integral) within the cosine estimator's noise
     assert np.allclose(tab_w.mean(0).numpy(), cos_w.cpu().mean(0).numpy(), rtol=0.1)
