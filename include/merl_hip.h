@@ -66,6 +66,17 @@ enum mrl_status {
     MRL_ERR_COMM = -9          /* an RCCL call failed or librccl could not be loaded (see mrl_group_last_error) */
 };
 
+/* Which three angles index a customized_measurement table ("dims/parameterisation"); axis order
+ * in the file stays (0, 1, 2) = the order listed here, axis 2 fastest.
+ *   HALF_DIFF      theta_h (sqrt-warped), theta_d, phi_d mod pi — the MERL / Rusinkiewicz form (default);
+ *   STANDARD       theta_i, theta_o, |phi_o - phi_i| in [0, pi] — an isotropic, bilaterally symmetric gonioreflectometer grid;
+ *                  every axis linear in its angle, the azimuth axis clamped (0 and pi are its two ends);
+ *   STANDARD_FULL  theta_i, theta_o, (phi_o - phi_i) mod 2 pi — isotropic without the mirror symmetry; azimuth periodic.
+ * x = angle / range * n along each axis; nearest lookups truncate, trilinear lookups follow MRL_OPT_NODE, exactly as for
+ * MERL tables.  Table importance sampling (MRL_OPT_SAMPLING = 1) has no theta_h rows to learn from on the standard forms:
+ * its half-vector lobe is flat there (p_h = cos(theta_h) / pi) — valid, not variance-reducing. */
+enum mrl_param { MRL_PARAM_HALF_DIFF = 0, MRL_PARAM_STANDARD = 1, MRL_PARAM_STANDARD_FULL = 2 };
+
 enum mrl_option {
     MRL_OPT_LOOKUP = 0,        /* 0 nearest (BRDFRead), 1 trilinear (default) */
     MRL_OPT_NODE = 1,          /* trilinear node position: 0 integer coordinate (default), 1 texel centre */
@@ -92,6 +103,9 @@ enum mrl_option {
                                   1 XCD-contiguous: the workgroups of one XCD (its own 4 MB L2) walk one contiguous eighth of
                                   the batch, so neighbouring units — pixels and scanlines of a render — share one L2 instead
                                   of being fetched by all eight.  Same results either way; see DESIGN.md §6 for which is faster when */
+    MRL_OPT_TABLE_PARAM = 10,  /* parameterisation of the customized_measurement tables uploaded FROM NOW ON (enum mrl_param below;
+                                  recorded per material, so one context can hold tables of all three; MERL files are always
+                                  half/diff).  Same kernels, same HBM layouts: only the three lookup angles differ. */
     MRL_OPT_MEMORY_LIMIT_MB = 7 /* budget for the context's resident material data (tables + sampling marginals), in MiB;
                                   0 (default) = no budget, the device's free memory is the limit.  An upload that would
                                   exceed the budget — or the device — fails with MRL_ERR_OOM and leaves the context as it
@@ -131,6 +145,7 @@ int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float 
 /* number of material SLOTS (live + released); ids are slot indices */
 int mrl_material_count(const mrl_ctx *ctx);
 int mrl_material_info(const mrl_ctx *ctx, int id, int *kind, int dims[3]);
+int mrl_material_param(const mrl_ctx *ctx, int id, int *param);     /* enum mrl_param of a table material (GGX: MRL_ERR_MATERIAL) */
 /* Frees a material's device memory (plugin destructor).  Waits for the context's stream first.  The slot becomes a
  * tombstone: batch and queue calls treat its id like an unknown id (every output zero), single_id calls and
  * mrl_material_info return MRL_ERR_MATERIAL.  A later upload may reuse the slot (lowest free slot first), exactly like

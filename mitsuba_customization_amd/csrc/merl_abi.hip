@@ -35,7 +35,7 @@ struct MaterialHost {
 
 // Row marginal for table importance sampling (definition: oracle/merl_oracle.h):
 // s[n+1] = sin^2(theta_i), cdf[n+1], c[n]; computed on the host in f64, in the file's loop order.
-std::vector<double> build_sampling(const double *planar, int n_th, int n_td, int n_pd, const double scale[3])
+std::vector<double> build_sampling(const double *planar, int n_th, int n_td, int n_pd, const double scale[3], int param)
 {
     const size_t plane = (size_t)n_th * n_td * n_pd;
     std::vector<double> D((size_t)n_th), out(3 * (size_t)n_th + 2);
@@ -52,6 +52,7 @@ std::vector<double> build_sampling(const double *planar, int n_th, int n_td, int
         mean += D[(size_t)i];
     }
     mean /= (double)n_th;
+    if (param != mrl::PARAM_HALF_DIFF) mean = 0.0;                    // the rows are not theta_h: flat lobe (oracle/merl_oracle.h)
     for (int i = 0; i < n_th; ++i) D[(size_t)i] = mean > 0.0 ? D[(size_t)i] + 0.01 * mean : 1.0;
     const double kHalfPi = 3.14159265358979323846 / 2.0;
     for (int i = 0; i <= n_th; ++i) {
@@ -175,6 +176,7 @@ struct mrl_ctx {
     mrl::Options opts{ 1, 0, 0, 0 };
     int kernel_variant = 3;          // MRL_OPT_KERNEL default: cooperative LDS-DMA brick fetch
     int table_layout = 1;            // layout of tables uploaded from now on (mrl::Layout)
+    int table_param = 0;             // parameterisation of customized_measurement tables uploaded from now on (mrl::Param)
     size_t host_chunk = (size_t)1 << 22;
     int block_map = 0;               // MRL_OPT_BLOCK_MAP
     int host_threads = 4;            // MRL_OPT_HOST_THREADS: copy threads of the pipelined host-array path; 0 = staged hipMemcpy path
@@ -341,6 +343,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1;
     const size_t plane = (size_t)n_th * n_td * n_pd;
     const int layout = ctx->table_layout;
+    const int param = kind == mrl::KIND_MERL ? mrl::PARAM_HALF_DIFF : ctx->table_param;      // a MERL file is what it is
     const size_t out_texels = layout == mrl::LAYOUT_BRICK ? plane * 8 : H * D * P;
     const size_t sampling_doubles = 3 * (size_t)n_th + 2;
     MaterialHost m;
@@ -354,7 +357,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     hipError_t e = hipMalloc((void **)&m.d_texels, out_texels * sizeof(float4));
     const bool oom = e == hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMemcpyAsync(d_planar, planar, 3 * plane * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = mrl::launch_build_table(d_planar, dims, scale, layout, m.d_texels, ctx->compute_units, ctx->stream);
+    if (e == hipSuccess) e = mrl::launch_build_table(d_planar, dims, scale, layout, param, m.d_texels, ctx->compute_units, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_planar);
     if (e != hipSuccess) {
@@ -363,7 +366,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
         return fail(ctx, oom ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
     }
     {
-        const std::vector<double> sampling = build_sampling(planar, n_th, n_td, n_pd, scale);
+        const std::vector<double> sampling = build_sampling(planar, n_th, n_td, n_pd, scale, param);
         e = hipMalloc((void **)&m.d_sampling, sampling.size() * sizeof(double));
         const bool oom2 = e == hipErrorOutOfMemory;
         if (e == hipSuccess) e = hipMemcpy(m.d_sampling, sampling.data(), sampling.size() * sizeof(double), hipMemcpyHostToDevice);
@@ -383,6 +386,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     m.dev.texels = m.d_texels;
     m.dev.layout = layout;
     m.dev.n_ch = 3;
+    m.dev.param = param;
     rc = place_material(ctx, m, out_id);
     if (rc != MRL_OK) { (void)hipFree(m.d_texels); (void)hipFree(m.d_sampling); return rc; }
     return MRL_OK;
@@ -715,7 +719,7 @@ int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uin
 
 // n-channel row marginal for table importance sampling: as build_sampling, with the plain mean over the channels in
 // place of the RGB luminance (oracle: orc_build_sampling_nch)
-std::vector<double> build_sampling_nch(const double *planar, int n_th, int n_td, int n_pd, int n_ch, const double *scale)
+std::vector<double> build_sampling_nch(const double *planar, int n_th, int n_td, int n_pd, int n_ch, const double *scale, int param)
 {
     const size_t plane = (size_t)n_th * n_td * n_pd;
     std::vector<double> D((size_t)n_th), out(3 * (size_t)n_th + 2);
@@ -733,6 +737,7 @@ std::vector<double> build_sampling_nch(const double *planar, int n_th, int n_td,
         mean += D[(size_t)i];
     }
     mean /= (double)n_th;
+    if (param != mrl::PARAM_HALF_DIFF) mean = 0.0;                    // the rows are not theta_h: flat lobe (oracle/merl_oracle.h)
     for (int i = 0; i < n_th; ++i) D[(size_t)i] = mean > 0.0 ? D[(size_t)i] + 0.01 * mean : 1.0;
     const double kHalfPi = 3.14159265358979323846 / 2.0;
     for (int i = 0; i <= n_th; ++i) {
@@ -780,7 +785,7 @@ int upload_table_nch(mrl_ctx *ctx, const double *planar, const int dims[3], int 
     const bool oom = e == hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMemcpyAsync(d_planar, planar, (size_t)n_ch * plane * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_scale, scale, (size_t)n_ch * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = mrl::launch_build_table_nch(d_planar, d_scale, dims, n_ch, m.d_texels, ctx->compute_units, ctx->stream);
+    if (e == hipSuccess) e = mrl::launch_build_table_nch(d_planar, d_scale, dims, n_ch, ctx->table_param, m.d_texels, ctx->compute_units, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_planar);
     if (e != hipSuccess) {
@@ -788,7 +793,7 @@ int upload_table_nch(mrl_ctx *ctx, const double *planar, const int dims[3], int 
         if (m.d_texels) (void)hipFree(m.d_texels);
         return fail(ctx, oom ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("n-channel table upload: ") + hipGetErrorString(e));
     }
-    const std::vector<double> sampling = build_sampling_nch(planar, n_th, n_td, n_pd, n_ch, scale);
+    const std::vector<double> sampling = build_sampling_nch(planar, n_th, n_td, n_pd, n_ch, scale, ctx->table_param);
     e = hipMalloc((void **)&m.d_sampling, sampling.size() * sizeof(double));
     const bool oom2 = e == hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMemcpy(m.d_sampling, sampling.data(), sampling.size() * sizeof(double), hipMemcpyHostToDevice);
@@ -805,6 +810,7 @@ int upload_table_nch(mrl_ctx *ctx, const double *planar, const int dims[3], int 
     m.dev.texels = m.d_texels;
     m.dev.layout = mrl::LAYOUT_BRICK;
     m.dev.n_ch = n_ch;
+    m.dev.param = ctx->table_param;
     rc = place_material(ctx, m, out_id);
     if (rc != MRL_OK) { (void)hipFree(m.d_texels); (void)hipFree(m.d_sampling); return rc; }
     return MRL_OK;
@@ -931,6 +937,7 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
         case MRL_OPT_HOST_THREADS: if (value < 0 || value > 64) break; ctx->host_threads = value; return MRL_OK;
         case MRL_OPT_BLOCK_MAP: if (value < 0 || value > 1) break; ctx->block_map = value; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: if (value < 1) break; ctx->host_chunk = (size_t)value; return MRL_OK;
+        case MRL_OPT_TABLE_PARAM: if (value < 0 || value > 2) break; ctx->table_param = value; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: {
             if (value < 0 || value > 1) break;
             if (value != ctx->table_layout)
@@ -958,6 +965,7 @@ int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
         case MRL_OPT_HOST_THREADS: *value = ctx->host_threads; return MRL_OK;
         case MRL_OPT_BLOCK_MAP: *value = ctx->block_map; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: *value = (int)ctx->host_chunk; return MRL_OK;
+        case MRL_OPT_TABLE_PARAM: *value = ctx->table_param; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: *value = ctx->table_layout; return MRL_OK;
     }
     return MRL_ERR_INVALID;
@@ -1328,6 +1336,17 @@ int mrl_material_channels(const mrl_ctx *ctx, int id, int *n_channels)
     MRL_GUARD(ctx);
     if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return MRL_ERR_MATERIAL;
     *n_channels = ctx->materials[(size_t)id].dev.n_ch;
+    return MRL_OK;
+}
+
+int mrl_material_param(const mrl_ctx *ctx, int id, int *param)
+{
+    if (!ctx || !param) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
+    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return MRL_ERR_MATERIAL;
+    const mrl::MaterialDev &d = ctx->materials[(size_t)id].dev;
+    if (d.kind == mrl::KIND_GGX) return MRL_ERR_MATERIAL;
+    *param = d.param;
     return MRL_OK;
 }
 

@@ -27,6 +27,11 @@ enum Kind : int { KIND_MERL = 0, KIND_TABLE = 1, KIND_GGX = 2,
 // the RGB kernels evaluate kinds 0..2; anything above renders as an unknown id (every output zero)
 __host__ __device__ constexpr bool kind_is_rgb_path(int kind) { return kind >= KIND_MERL && kind <= KIND_GGX; }
 enum Layout : int { LAYOUT_ROWS = 0, LAYOUT_BRICK = 1 };
+// table parameterisation (include/merl_hip.h MRL_PARAM_*): which three angles index the table
+enum Param : int { PARAM_HALF_DIFF = 0,        // (theta_h sqrt-warped, theta_d, phi_d mod pi): MERL
+                   PARAM_STANDARD = 1,         // (theta_i, theta_o, |phi_o - phi_i| in [0,pi]): linear axes, azimuth clamped
+                   PARAM_STANDARD_FULL = 2 };  // (theta_i, theta_o, phi_o - phi_i in [0,2pi)): linear axes, azimuth periodic
+__host__ __device__ constexpr bool param_phi_periodic(int param) { return param != PARAM_STANDARD; }
 
 // One material as the kernels see it (array in device memory; single-material launches get it
 // by value, i.e. in SGPRs).
@@ -40,6 +45,7 @@ struct MaterialDev {
     int layout;                  // LAYOUT_ROWS / LAYOUT_BRICK
     int n_ch;                    // channels: 3 for the RGB kinds; KIND_TABLE_NCH: 1..32 (bricks of ceil(n_ch/4) x 128 B, or 32 / 64 B for 1 / 2 channels)
     const double *sampling;      // table importance sampling: s[n_th+1] | cdf[n_th+1] | c[n_th]  (see table_pdf below)
+    int param;                   // PARAM_*: the axes are (n_th, n_td, n_pd) whatever they mean
     double alpha;                // GGX
     double eta[3], k[3];
 };
@@ -85,6 +91,20 @@ __device__ __forceinline__ Coords half_diff_coords(const Vec3d &in, const Vec3d 
     return c;
 }
 
+// the standard parameterisations: polar angles of both directions and their azimuth difference, linear axes
+__device__ __forceinline__ Coords standard_coords(const Vec3d &in, const Vec3d &out, int param, int n_0, int n_1, int n_2)
+{
+    const double ti = atan2(sqrt(in.x * in.x + in.y * in.y), in.z);
+    const double to = atan2(sqrt(out.x * out.x + out.y * out.y), out.z);
+    double dp = atan2(in.x * out.y - in.y * out.x, in.x * out.x + in.y * out.y);          // atan2(0,0) = 0
+    Coords c;
+    c.xh = ti / kHalfPi * n_0;
+    c.xd = to / kHalfPi * n_1;
+    if (param == PARAM_STANDARD) c.xp = fabs(dp) / kPi * n_2;
+    else c.xp = (dp < 0.0 ? dp + 2.0 * kPi : dp) / (2.0 * kPi) * n_2;
+    return c;
+}
+
 // ---- a4: table fetch -------------------------------------------------------------------------
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -122,6 +142,16 @@ __device__ __forceinline__ void split_periodic(double x, int n, int &i0, double 
     i0 = i < 0 ? i + n : i;
 }
 
+// the azimuth axis: periodic, except for the mirrored standard form (0 and pi are its two ends)
+__device__ __forceinline__ void split_phi(bool periodic, double x, int n, int &i0, double &f)
+{
+    int ip, ic; double fp, fc;
+    split_periodic(x, n, ip, fp);
+    split_clamped(x, n, ic, fc);
+    i0 = periodic ? ip : ic;
+    f = periodic ? fp : fc;
+}
+
 template <int LAYOUT>
 __device__ __forceinline__ Rgbd lookup_trilinear_t(const MaterialDev &m, const Coords &c, int node)
 {
@@ -129,7 +159,7 @@ __device__ __forceinline__ Rgbd lookup_trilinear_t(const MaterialDev &m, const C
     int h0, d0, p0; double fh, fd, fp;
     split_clamped(c.xh - shift, m.n_th, h0, fh);
     split_clamped(c.xd - shift, m.n_td, d0, fd);
-    split_periodic(c.xp - shift, m.n_pd, p0, fp);
+    split_phi(param_phi_periodic(m.param), c.xp - shift, m.n_pd, p0, fp);
     const double gh = 1.0 - fh, gd = 1.0 - fd, gp = 1.0 - fp;
     const double w000 = gh * gd * gp, w001 = gh * gd * fp, w010 = gh * fd * gp, w011 = gh * fd * fp;
     const double w100 = fh * gd * gp, w101 = fh * gd * fp, w110 = fh * fd * gp, w111 = fh * fd * fp;
@@ -170,7 +200,8 @@ __device__ __forceinline__ Rgbd lookup_trilinear(const MaterialDev &m, const Coo
 // BRDF value (no cosine) of a table material for unit in/out
 __device__ __forceinline__ Rgbd table_brdf(const MaterialDev &m, const Options &o, const Vec3d &in, const Vec3d &out)
 {
-    Coords c = half_diff_coords(in, out, m.n_th, m.n_td, m.n_pd);
+    Coords c = m.param == PARAM_HALF_DIFF ? half_diff_coords(in, out, m.n_th, m.n_td, m.n_pd)
+                                          : standard_coords(in, out, m.param, m.n_th, m.n_td, m.n_pd);
     return o.lookup ? lookup_trilinear(m, c, o.node) : lookup_nearest(m, c);
 }
 

@@ -219,7 +219,7 @@ __device__ __forceinline__ uint32_t brick_cell(const MaterialDev &m, const Coord
     int h0, d0, p0;
     split_clamped(c.xh - shift, m.n_th, h0, w.fh);
     split_clamped(c.xd - shift, m.n_td, d0, w.fd);
-    split_periodic(c.xp - shift, m.n_pd, p0, w.fp);
+    split_phi(param_phi_periodic(m.param), c.xp - shift, m.n_pd, p0, w.fp);
     return (uint32_t)((h0 * m.n_td + d0) * m.n_pd + p0);
 }
 
@@ -261,7 +261,7 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
     float sx = 0.0f, sy = 0.0f, sz = 1.0f;
     if constexpr (HAS_EVAL) {
         const fast::Vec3 out = fast::normalize_f32(io.wox, io.woy, io.woz);
-        cellA = brick_cell(m, fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wA);
+        cellA = brick_cell(m, maps(in, out), a.opts.node, wA);
         if (GGX && !is_table) cellA = 0;
     }
     float sp = 0.0f;                                          // pdf of the sampled direction
@@ -276,7 +276,7 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
             sp = sz > 0.0f ? sz * kInvPiF : 0.0f;
         }
         const fast::Vec3 out = fast::normalize_f32(sx, sy, sz);
-        cellB = brick_cell(m, fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wB);
+        cellB = brick_cell(m, maps(in, out), a.opts.node, wB);
         if (GGX && !is_table) cellB = 0;
     }
     {
@@ -671,7 +671,7 @@ __device__ __forceinline__ float scaled_texel(const double *planar, size_t plane
     return v > 0.0 ? (float)v : 0.0f;                         // MERL's negative "below horizon" markers clamp to 0
 }
 
-__global__ __launch_bounds__(kBlock) void k_build_bricks(const double *planar, int n_th, int n_td, int n_pd,
+__global__ __launch_bounds__(kBlock) void k_build_bricks(const double *planar, int n_th, int n_td, int n_pd, int phi_periodic,
                                                         double s0, double s1, double s2, float4 *bricks)
 {
     const size_t cells = (size_t)n_th * n_td * n_pd, plane = cells;
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(kBlock) void k_build_bricks(const double *planar, i
         float v[32];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int sh = min(ih + (k >> 2), n_th - 1), sd = min(id + ((k >> 1) & 1), n_td - 1), sp = (ip + (k & 1)) % n_pd;
+            const int sh = min(ih + (k >> 2), n_th - 1), sd = min(id + ((k >> 1) & 1), n_td - 1), sp = phi_periodic ? (ip + (k & 1)) % n_pd : min(ip + (k & 1), n_pd - 1);
             const size_t src = ((size_t)sh * n_td + sd) * n_pd + sp;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) v[3 * k + ch] = scaled_texel(planar, plane, src, ch, scale[ch]);
@@ -695,14 +695,14 @@ __global__ __launch_bounds__(kBlock) void k_build_bricks(const double *planar, i
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_build_rows(const double *planar, int n_th, int n_td, int n_pd,
+__global__ __launch_bounds__(kBlock) void k_build_rows(const double *planar, int n_th, int n_td, int n_pd, int phi_periodic,
                                                       double s0, double s1, double s2, float4 *rows)
 {
     const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1, total = H * D * P, plane = (size_t)n_th * n_td * n_pd;
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
         const size_t ip = t % P, id = (t / P) % D, ih = t / (P * D);
-        const size_t sh = ih < (size_t)n_th ? ih : n_th - 1, sd = id < (size_t)n_td ? id : n_td - 1, sp = ip == (size_t)n_pd ? 0 : ip;
+        const size_t sh = ih < (size_t)n_th ? ih : n_th - 1, sd = id < (size_t)n_td ? id : n_td - 1, sp = ip == (size_t)n_pd ? (phi_periodic ? 0 : n_pd - 1) : ip;
         const size_t src = (sh * n_td + sd) * n_pd + sp;
         rows[t] = make_float4(scaled_texel(planar, plane, src, 0, s0), scaled_texel(planar, plane, src, 1, s1),
                               scaled_texel(planar, plane, src, 2, s2), 0.0f);
@@ -956,16 +956,16 @@ hipError_t launch_partition_materials(const int32_t *mat, size_t n, int K, uint3
     return hipGetLastError();
 }
 
-hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, float4 *d_out,
+hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, int param, float4 *d_out,
                               int compute_units, hipStream_t stream)
 {
     const size_t cells = (size_t)dims[0] * dims[1] * dims[2];
     if (layout == LAYOUT_BRICK)
         hipLaunchKernelGGL(k_build_bricks, dim3(grid_for(cells, compute_units)), dim3(kBlock), 0, stream, d_planar, dims[0], dims[1], dims[2],
-                           scale[0], scale[1], scale[2], d_out);
+                           (int)param_phi_periodic(param), scale[0], scale[1], scale[2], d_out);
     else
         hipLaunchKernelGGL(k_build_rows, dim3(grid_for((size_t)(dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1), compute_units)), dim3(kBlock), 0, stream,
-                           d_planar, dims[0], dims[1], dims[2], scale[0], scale[1], scale[2], d_out);
+                           d_planar, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), scale[0], scale[1], scale[2], d_out);
     return hipGetLastError();
 }
 

@@ -51,14 +51,14 @@ void material_partition_geometry(size_t n, int compute_units, uint32_t *chunks, 
 hipError_t launch_partition_materials(const int32_t *mat, size_t n, int K, uint32_t *queue, uint32_t *offsets, uint32_t *counts,
                                       uint32_t *work, uint32_t chunks, uint32_t chunk_len, int compute_units, hipStream_t stream);
 // a1: planar f64 table (device copy of the file payload) -> padded rows or bricks
-hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, float4 *d_out,
+hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, int param, float4 *d_out,
                               int compute_units, hipStream_t stream);
 // ---- n-channel tables (merl_nch.hip): a.out_rgb / a.out_weight hold n x n_ch values ----
 constexpr int kMaxChannels = 32;
 size_t nch_brick_float4s(int n_ch);                      // float4s per cell: 2 (1 ch), 4 (2 ch), 8 * ceil(n_ch / 4)
 // mode: 0 eval, 2 sample, 3 eval+sample, 4 eval+pdf (pdf alone: the RGB pdf kernel serves every table kind)
 hipError_t launch_batch_nch(int mode, const BatchArgs &a, bool multi, int n_ch, int compute_units, hipStream_t stream);
-hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale, const int dims[3], int n_ch, float4 *d_out,
+hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale, const int dims[3], int n_ch, int param, float4 *d_out,
                                   int compute_units, hipStream_t stream);
 hipError_t launch_generate_pairs(uint64_t seed, uint64_t first, size_t n, float *wi, float *wo, float *u,
                                  int compute_units, hipStream_t stream);

@@ -52,7 +52,7 @@ template <int S> __device__ __forceinline__ unsigned nch_swz(unsigned u)
 struct NchWeights { double w[8]; };
 
 // a3 tail: cell index + the 8 corner weights.  Nearest lookups are the trilinear blend with all weight on corner 0.
-__device__ __forceinline__ uint32_t nch_cell(int n_th, int n_td, int n_pd, const Coords &c, const Options &o, NchWeights &out)
+__device__ __forceinline__ uint32_t nch_cell(int n_th, int n_td, int n_pd, bool phi_periodic, const Coords &c, const Options &o, NchWeights &out)
 {
     int h0, d0, p0;
     double fh, fd, fp;
@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t nch_cell(int n_th, int n_td, int n_pd, const
         const double shift = o.node ? 0.5 : 0.0;
         split_clamped(c.xh - shift, n_th, h0, fh);
         split_clamped(c.xd - shift, n_td, d0, fd);
-        split_periodic(c.xp - shift, n_pd, p0, fp);
+        split_phi(phi_periodic, c.xp - shift, n_pd, p0, fp);
     } else {
         h0 = clampi((int)c.xh, 0, n_th - 1); d0 = clampi((int)c.xd, 0, n_td - 1); p0 = clampi((int)c.xp, 0, n_pd - 1);
         fh = fd = fp = 0.0;
@@ -168,13 +168,15 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
         if constexpr (HAS_EVAL) load3(a.wo, i, wox, woy, woz);
         if constexpr (HAS_SAMPLE) { u0 = a.u[2 * i]; u1 = a.u[2 * i + 1]; }
         const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
-        const double k_th = (double)n_th * (double)n_th / kHalfPi, k_td = (double)n_td / kHalfPi, k_pd = (double)n_pd / kPi;
+        const int param = known ? m.param : PARAM_HALF_DIFF;
+        const bool phi_periodic = param_phi_periodic(param);
+        const fast::TableMaps maps(n_th, n_td, n_pd, param);
 
         NchWeights wA, wB;
         uint32_t cellA = 0, cellB = 0;
         float sx = 0.0f, sy = 0.0f, sz = 1.0f, sp = 0.0f;
         if constexpr (HAS_EVAL)
-            cellA = nch_cell(n_th, n_td, n_pd, fast::coords(in, fast::normalize_f32(wox, woy, woz), k_th, k_td, k_pd), a.opts, wA);
+            cellA = nch_cell(n_th, n_td, n_pd, phi_periodic, maps(in, fast::normalize_f32(wox, woy, woz)), a.opts, wA);
         if constexpr (HAS_SAMPLE) {
             if (a.opts.sampling && known) {                   // option is wave-uniform
                 fast::table_sample_dir(m, a.opts.disk_map, in, u0, u1, sx, sy, sz);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
                 square_to_cosine_hemisphere(a.opts.disk_map, u0, u1, sx, sy, sz);
                 sp = sz > 0.0f ? sz * kInvPiF : 0.0f;
             }
-            cellB = nch_cell(n_th, n_td, n_pd, fast::coords(in, fast::normalize_f32(sx, sy, sz), k_th, k_td, k_pd), a.opts, wB);
+            cellB = nch_cell(n_th, n_td, n_pd, phi_periodic, maps(in, fast::normalize_f32(sx, sy, sz)), a.opts, wB);
         }
         const bool validA = (wiz > 0.0f) && (woz > 0.0f);
         const bool validB = (wiz > 0.0f) && (!a.opts.sampling || sp > 0.0f);
@@ -284,13 +286,15 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
         if constexpr (HAS_EVAL) load3(a.wo, i, wox, woy, woz);
         if constexpr (HAS_SAMPLE) { u0 = a.u[2 * i]; u1 = a.u[2 * i + 1]; }
         const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
-        const double k_th = (double)n_th * (double)n_th / kHalfPi, k_td = (double)n_td / kHalfPi, k_pd = (double)n_pd / kPi;
+        const int param = known ? m.param : PARAM_HALF_DIFF;
+        const bool phi_periodic = param_phi_periodic(param);
+        const fast::TableMaps maps(n_th, n_td, n_pd, param);
 
         // one lookup: copy + blend every group into the staging rows (scaled by `factor`), then stream the span out
         // (guards are selects on the finished value: a non-finite direction may have poisoned the blend)
         auto lookup = [&](const fast::Vec3 &out_dir, bool keep, double factor, float divide, float *dst) {
             NchWeights w;
-            const uint32_t cell = nch_cell(n_th, n_td, n_pd, fast::coords(in, out_dir, k_th, k_td, k_pd), a.opts, w);
+            const uint32_t cell = nch_cell(n_th, n_td, n_pd, phi_periodic, maps(in, out_dir), a.opts, w);
             for (int g = 0; g < groups; ++g) {                // wave-uniform trip count
                 nch_copy<S>((uint64_t)(texels + ((size_t)cell * groups + g) * S), dma, lane);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
 // ---- upload: planar f64 (n_ch planes, file order) -> n-channel bricks.  One thread per (cell, channel group). ----
 template <int CPAD>
 __global__ __launch_bounds__(kNchBlock) void k_build_bricks_nch(const double *planar, const double *scale, int n_th, int n_td, int n_pd,
-                                                               int n_ch, float4 *bricks)
+                                                               int phi_periodic, int n_ch, float4 *bricks)
 {
     constexpr int S = 2 * CPAD;
     const int groups = CPAD == 4 ? (n_ch + 3) / 4 : 1;
@@ -373,7 +377,8 @@ __global__ __launch_bounds__(kNchBlock) void k_build_bricks_nch(const double *pl
         float v[8 * CPAD];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int sh = min(ih + (k >> 2), n_th - 1), sd = min(id + ((k >> 1) & 1), n_td - 1), sp = (ip + (k & 1)) % n_pd;
+            const int sh = min(ih + (k >> 2), n_th - 1), sd = min(id + ((k >> 1) & 1), n_td - 1),
+                      sp = phi_periodic ? (ip + (k & 1)) % n_pd : min(ip + (k & 1), n_pd - 1);
             const size_t src = ((size_t)sh * n_td + sd) * n_pd + sp;
 #pragma unroll
             for (int ch = 0; ch < CPAD; ++ch) {
@@ -444,7 +449,7 @@ hipError_t launch_batch_nch(int mode, const BatchArgs &a, bool multi, int n_ch, 
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale, const int dims[3], int n_ch, float4 *d_out,
+hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale, const int dims[3], int n_ch, int param, float4 *d_out,
                                   int compute_units, hipStream_t stream)
 {
     const size_t cells = (size_t)dims[0] * dims[1] * dims[2];
@@ -453,9 +458,9 @@ hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale,
     if (blocks > (size_t)compute_units * 8) blocks = (size_t)compute_units * 8;
     if (blocks < 1) blocks = 1;
     const dim3 g((unsigned)blocks), b(kNchBlock);
-    if (n_ch == 1)      hipLaunchKernelGGL((k_build_bricks_nch<1>), g, b, 0, stream, d_planar, d_scale, dims[0], dims[1], dims[2], n_ch, d_out);
-    else if (n_ch == 2) hipLaunchKernelGGL((k_build_bricks_nch<2>), g, b, 0, stream, d_planar, d_scale, dims[0], dims[1], dims[2], n_ch, d_out);
-    else                hipLaunchKernelGGL((k_build_bricks_nch<4>), g, b, 0, stream, d_planar, d_scale, dims[0], dims[1], dims[2], n_ch, d_out);
+    if (n_ch == 1)      hipLaunchKernelGGL((k_build_bricks_nch<1>), g, b, 0, stream, d_planar, d_scale, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), n_ch, d_out);
+    else if (n_ch == 2) hipLaunchKernelGGL((k_build_bricks_nch<2>), g, b, 0, stream, d_planar, d_scale, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), n_ch, d_out);
+    else                hipLaunchKernelGGL((k_build_bricks_nch<4>), g, b, 0, stream, d_planar, d_scale, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), n_ch, d_out);
     return hipGetLastError();
 }
 

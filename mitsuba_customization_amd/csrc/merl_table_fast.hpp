@@ -124,11 +124,40 @@ __device__ __forceinline__ Coords coords(const Vec3 &in, const Vec3 &out, double
     return c;
 }
 
+// the standard parameterisations (merl_device.hpp::standard_coords): theta = atan2(|v_xy|, v_z) for both directions,
+// dphi = atan2(cross_z, dot_xy); all three axes linear.  k_0 = n_0 / (pi/2), k_1 = n_1 / (pi/2), k_2 = n_2 / pi (mirrored)
+// or n_2 / 2pi (full).  Directions below the horizon are discarded by the caller; |z| keeps atan2_q1 in its domain.
+__device__ __forceinline__ Coords coords_standard(const Vec3 &in, const Vec3 &out, bool full, double k_0, double k_1, double k_2)
+{
+    const double ti = atan2_q1(sqrt_fast(__builtin_fma(in.x, in.x, in.y * in.y)), __builtin_fabs(in.z));
+    const double to = atan2_q1(sqrt_fast(__builtin_fma(out.x, out.x, out.y * out.y)), __builtin_fabs(out.z));
+    const double cr = __builtin_fma(in.x, out.y, -(in.y * out.x));
+    const double dt = __builtin_fma(in.x, out.x, in.y * out.y);
+    const double t = (cr == 0.0 && dt == 0.0) ? 0.0 : atan2_q1(__builtin_fabs(cr), __builtin_fabs(dt));   // atan2(0,0) = 0
+    const double ap = dt < 0.0 ? kPi - t : t;                      // |dphi| in [0, pi]
+    Coords c;
+    c.xh = ti * k_0;
+    c.xd = to * k_1;
+    c.xp = ((full && cr < 0.0) ? 2.0 * kPi - ap : ap) * k_2;
+    return c;
+}
+
 // per-material constants of the coordinate maps
 struct TableMaps {
     double k_th, k_td, k_pd;
+    int param;
     __device__ __forceinline__ explicit TableMaps(const MaterialDev &m)
-        : k_th((double)m.n_th * (double)m.n_th / kHalfPi), k_td((double)m.n_td / kHalfPi), k_pd((double)m.n_pd / kPi) {}
+        : k_th((double)m.n_th * (m.param == PARAM_HALF_DIFF ? (double)m.n_th : 1.0) / kHalfPi), k_td((double)m.n_td / kHalfPi),
+          k_pd((double)m.n_pd / (m.param == PARAM_STANDARD_FULL ? 2.0 * kPi : kPi)), param(m.param) {}
+    __device__ __forceinline__ TableMaps(int n_th, int n_td, int n_pd, int prm)
+        : k_th((double)n_th * (prm == PARAM_HALF_DIFF ? (double)n_th : 1.0) / kHalfPi), k_td((double)n_td / kHalfPi),
+          k_pd((double)n_pd / (prm == PARAM_STANDARD_FULL ? 2.0 * kPi : kPi)), param(prm) {}
+    // a2 + a3 under the material's parameterisation (wave-uniform branch for a single-material launch)
+    __device__ __forceinline__ Coords operator()(const Vec3 &in, const Vec3 &out) const
+    {
+        return param == PARAM_HALF_DIFF ? coords(in, out, k_th, k_td, k_pd)
+                                        : coords_standard(in, out, param == PARAM_STANDARD_FULL, k_th, k_td, k_pd);
+    }
 };
 
 // BRDF value (no cosine).  LOOKUP and LAYOUT are compile-time so that the eval lookup and the
@@ -138,7 +167,7 @@ template <int LOOKUP, int LAYOUT>
 __device__ __forceinline__ Rgbd table_brdf(const MaterialDev &m, const Options &o, const Vec3 &in, const Vec3 &out)
 {
     const TableMaps k(m);
-    const Coords c = coords(in, out, k.k_th, k.k_td, k.k_pd);
+    const Coords c = k(in, out);
     if constexpr (LOOKUP) return lookup_trilinear_t<LAYOUT>(m, c, o.node);
     else return lookup_nearest_t<LAYOUT>(m, c);
 }

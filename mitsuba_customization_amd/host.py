@@ -16,6 +16,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRL_LIB_PATH") or os.path.join(_PKG, "lib", "libmerl_hip.so")   # env override: A/B builds
 
 OPT_LOOKUP, OPT_NODE, OPT_DISK_MAP, OPT_KERNEL, OPT_HOST_CHUNK, OPT_TABLE_LAYOUT, OPT_SAMPLING, OPT_MEMORY_LIMIT_MB, OPT_HOST_THREADS, OPT_BLOCK_MAP = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_TABLE_PARAM = 10
+PARAM_HALF_DIFF, PARAM_STANDARD, PARAM_STANDARD_FULL = 0, 1, 2          # enum mrl_param
 SAMPLING_COSINE, SAMPLING_TABLE = 0, 1
 LAYOUT_ROWS, LAYOUT_BRICK = 0, 1
 LOOKUP_NEAREST, LOOKUP_TRILINEAR = 0, 1
@@ -34,7 +36,7 @@ ABI_SYMBOLS = (
     "mrl_generate_pairs", "mrl_generate_materials",
     "mrl_device_alloc", "mrl_device_free", "mrl_copy_to_device", "mrl_copy_to_host", "mrl_host_alloc", "mrl_host_free",
     "mrl_timer_start", "mrl_timer_stop",
-    "mrl_material_upload_table_nch", "mrl_material_load_table_nch", "mrl_material_channels",
+    "mrl_material_upload_table_nch", "mrl_material_load_table_nch", "mrl_material_channels", "mrl_material_param",
     "mrl_eval_batch_nch", "mrl_sample_batch_nch", "mrl_eval_pdf_batch_nch", "mrl_eval_sample_batch_nch",
     "mrl_eval_queue_nch", "mrl_sample_queue_nch", "mrl_eval_pdf_queue_nch", "mrl_eval_sample_queue_nch",
     "mrl_tensor_file_open", "mrl_tensor_file_close", "mrl_tensor_file_last_error", "mrl_tensor_file_field_count", "mrl_tensor_file_find",
@@ -130,6 +132,7 @@ def load_library(path: Optional[str] = None):
     L.mrl_material_upload_table_nch.argtypes = [vp, vp, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.mrl_material_load_table_nch.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.mrl_material_channels.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+    L.mrl_material_param.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.mrl_eval_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp]
     L.mrl_sample_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp, fp, fp]
     L.mrl_eval_pdf_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp, fp]
@@ -328,6 +331,12 @@ class MerlHip:
     def material_channels(self, mid: int) -> int:
         c = C.c_int()
         self._check(self._lib.mrl_material_channels(self._ctx, mid, C.byref(c)), "mrl_material_channels")
+        return c.value
+
+    def material_param(self, mid: int) -> int:
+        """enum mrl_param of a table material (the MRL_OPT_TABLE_PARAM in force when it was uploaded)."""
+        c = C.c_int()
+        self._check(self._lib.mrl_material_param(self._ctx, mid, C.byref(c)), "mrl_material_param")
         return c.value
 
     def eval_nch(self, wi, wo, n_channels: int, mat=None, material: int = 0, out=None):

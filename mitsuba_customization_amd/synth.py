@@ -119,7 +119,48 @@ def ggx_tab_table(seed: int = 0, dims=MERL_DIMS) -> np.ndarray:
     return t
 
 
+def ggx_standard_table(seed: int = 0, dims=(32, 32, 64), full: bool = False) -> np.ndarray:
+    """The same analytic GGX + Lambert BRDF tabulated in the STANDARD parameterisation (include/merl_hip.h enum mrl_param):
+    texel (i,j,k) is the BRDF at theta_i = i/n_0 pi/2, theta_o = j/n_1 pi/2 and azimuth difference k/n_2 pi
+    (full = False, mirror-symmetric) or k/n_2 2 pi (full = True; a 1 + 0.3 sin(dphi) factor breaks the mirror symmetry so
+    that the two halves of the period differ).  Raw values in MERL file units (divide MERL_SCALE back in on lookup)."""
+    n_0, n_1, n_2 = dims
+    h = _mix64(np.array([seed * 3 + 1, seed * 3 + 2, seed * 3 + 3], dtype=np.uint64))
+    uu = (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    alpha = 0.05 + 0.25 * uu[0]
+    kd = np.array([0.05 + 0.5 * uu[1], 0.04 + 0.3 * uu[2], 0.02 + 0.2 * uu[0]])
+    f0 = np.array([0.9 - 0.3 * uu[2], 0.6 + 0.2 * uu[1], 0.2 + 0.3 * uu[0]])
+    i0, i1, i2 = _grid(dims)
+    ti, to = i0 / n_0 * (np.pi / 2), i1 / n_1 * (np.pi / 2)
+    dp = i2 / n_2 * (2 * np.pi if full else np.pi)
+    wi = (np.sin(ti) + 0 * to + 0 * dp, 0 * ti + 0 * to + 0 * dp, np.cos(ti) + 0 * to + 0 * dp)
+    wo = (np.sin(to) * np.cos(dp) + 0 * ti, np.sin(to) * np.sin(dp) + 0 * ti, np.cos(to) + 0 * dp + 0 * ti)
+    hx, hy, hz = wi[0] + wo[0], wi[1] + wo[1], wi[2] + wo[2]
+    hn = np.sqrt(hx * hx + hy * hy + hz * hz)
+    hx, hy, hz = hx / hn, hy / hn, hz / hn
+    ct = np.maximum(hz, 1e-9)
+    tan2h = (1 - ct * ct) / (ct * ct)
+    D = 1.0 / (np.pi * alpha**2 * ct**4 * (1 + tan2h / alpha**2) ** 2)
+    ci, co = np.maximum(wi[2], 1e-3), np.maximum(wo[2], 1e-3)
+
+    def g1(c):
+        return 2.0 / (1.0 + np.sqrt(1.0 + alpha**2 * (1 - c * c) / (c * c)))
+
+    spec = D * g1(ci) * g1(co) / (4 * ci * co)
+    cd = wi[0] * hx + wi[1] * hy + wi[2] * hz
+    skew = 1.0 + (0.3 * np.sin(dp) if full else 0.0)
+    t = np.empty((3,) + tuple(dims), dtype=np.float64)
+    for c in range(3):
+        F = f0[c] + (1 - f0[c]) * (1 - cd) ** 5
+        t[c] = (kd[c] / np.pi + F * spec) * skew / MERL_SCALE[c]
+    return t
+
+
 def make_table(kind: str, seed: int = 0, dims=MERL_DIMS) -> np.ndarray:
+    if kind == "ggx_std":
+        return ggx_standard_table(seed, dims=dims, full=False)
+    if kind == "ggx_std_full":
+        return ggx_standard_table(seed, dims=dims, full=True)
     if kind == "constant":
         return constant_table(dims=dims)
     if kind == "affine":

@@ -17,6 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libmerl_oracle.so")
 LOOKUP_NEAREST, LOOKUP_TRILINEAR = 0, 1
 NODE_INTEGER, NODE_CENTER = 0, 1
 DISK_MITSUBA06, DISK_MITSUBA3 = 0, 1
+PARAM_HALF_DIFF, PARAM_STANDARD, PARAM_STANDARD_FULL = 0, 1, 2
 
 
 class Opts(C.Structure):
@@ -25,7 +26,7 @@ class Opts(C.Structure):
 
 class Table(C.Structure):
     _fields_ = [("n_th", C.c_int), ("n_td", C.c_int), ("n_pd", C.c_int),
-                ("data", C.POINTER(C.c_double)), ("scale", C.c_double * 3)]
+                ("data", C.POINTER(C.c_double)), ("scale", C.c_double * 3), ("param", C.c_int)]
 
 
 class Sampling(C.Structure):
@@ -34,7 +35,7 @@ class Sampling(C.Structure):
 
 class TableNch(C.Structure):
     _fields_ = [("n_th", C.c_int), ("n_td", C.c_int), ("n_pd", C.c_int), ("n_ch", C.c_int),
-                ("data", C.POINTER(C.c_double)), ("scale", C.POINTER(C.c_double))]
+                ("data", C.POINTER(C.c_double)), ("scale", C.POINTER(C.c_double)), ("param", C.c_int)]
 
 
 class Ggx(C.Structure):
@@ -69,6 +70,7 @@ def lib():
         L.orc_write_table.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_half_diff.argtypes = [C.POINTER(C.c_double)] * 2 + [C.POINTER(C.c_double)] * 4
+        L.orc_standard_angles.argtypes = [C.POINTER(C.c_double)] * 2 + [C.POINTER(C.c_double)] * 3
         for nm in ("orc_theta_half_index", "orc_theta_diff_index", "orc_phi_diff_index"):
             getattr(L, nm).argtypes = [C.POINTER(Table), C.c_double]
             getattr(L, nm).restype = C.c_int
@@ -118,13 +120,14 @@ def make_opts(lookup=LOOKUP_TRILINEAR, node=NODE_INTEGER, disk_map=DISK_MITSUBA0
 class OracleTable:
     """A planar f64 table (3, n_th, n_td, n_pd) + channel scales, as the oracle sees it."""
 
-    def __init__(self, planar: np.ndarray, scale=None):
+    def __init__(self, planar: np.ndarray, scale=None, param=PARAM_HALF_DIFF):
         self.planar = np.ascontiguousarray(planar, dtype=np.float64)
         assert self.planar.ndim == 4 and self.planar.shape[0] == 3
         if scale is None:
             scale = (1.0 / 1500.0, 1.15 / 1500.0, 1.66 / 1500.0)
+        self.param = int(param)
         self.c = Table(self.planar.shape[1], self.planar.shape[2], self.planar.shape[3],
-                       _dp(self.planar), (C.c_double * 3)(*scale))
+                       _dp(self.planar), (C.c_double * 3)(*scale), self.param)
 
     def eval(self, wi, wo, opts=None):
         opts = opts or make_opts()
@@ -188,13 +191,14 @@ class OracleTable:
 class OracleTableNch:
     """A planar f64 table (n_ch, n_th, n_td, n_pd) + per-channel scales, as the oracle sees it."""
 
-    def __init__(self, planar: np.ndarray, scale=None):
+    def __init__(self, planar: np.ndarray, scale=None, param=PARAM_HALF_DIFF):
         self.planar = np.ascontiguousarray(planar, dtype=np.float64)
         assert self.planar.ndim == 4
+        self.param = int(param)
         self.n_ch = int(self.planar.shape[0])
         self.scale = np.ascontiguousarray(np.ones(self.n_ch) if scale is None else scale, dtype=np.float64)
         assert self.scale.shape == (self.n_ch,)
-        self.c = TableNch(self.planar.shape[1], self.planar.shape[2], self.planar.shape[3], self.n_ch, _dp(self.planar), _dp(self.scale))
+        self.c = TableNch(self.planar.shape[1], self.planar.shape[2], self.planar.shape[3], self.n_ch, _dp(self.planar), _dp(self.scale), self.param)
         self._sampling = None
 
     def sampling(self):
@@ -257,6 +261,13 @@ def eval_sample_multi(tables, wi, wo, u, mat, opts=None):
                                       rgb.ctypes.data_as(fp), p.ctypes.data_as(fp), wo2.ctypes.data_as(fp),
                                       p2.ctypes.data_as(fp), w.ctypes.data_as(fp))
     return rgb, p, wo2, p2, w
+
+
+def standard_angles(in_vec, out_vec):
+    a = np.ascontiguousarray(in_vec, np.float64); b = np.ascontiguousarray(out_vec, np.float64)
+    r = [C.c_double() for _ in range(3)]
+    lib().orc_standard_angles(_dp(a), _dp(b), *[C.byref(x) for x in r])
+    return tuple(x.value for x in r)  # theta_i, theta_o, dphi
 
 
 def half_diff(in_vec, out_vec):

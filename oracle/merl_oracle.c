@@ -63,6 +63,7 @@ void orc_merl_table(orc_table *t, const double *planar)
     t->scale[0] = 1.0 / 1500.0;      /* A.1 channel scales */
     t->scale[1] = 1.15 / 1500.0;
     t->scale[2] = 1.66 / 1500.0;
+    t->param = ORC_PARAM_HALF_DIFF;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -109,11 +110,30 @@ void orc_half_diff(const double in[3], const double out[3],
     *phi_diff = atan2(d[1], d[0]);
 }
 
+/* the standard parameterisations (merl_oracle.h): polar angles and the azimuth difference, atan2 forms */
+void orc_standard_angles(const double in[3], const double out[3], double *theta_i, double *theta_o, double *dphi)
+{
+    *theta_i = atan2(sqrt(in[0] * in[0] + in[1] * in[1]), in[2]);
+    *theta_o = atan2(sqrt(out[0] * out[0] + out[1] * out[1]), out[2]);
+    *dphi = atan2(in[0] * out[1] - in[1] * out[0], in[0] * out[0] + in[1] * out[1]);     /* atan2(0,0) = 0 */
+}
+
+void orc_table_angles(const orc_table *t, const double in[3], const double out[3], double a[3])
+{
+    if (t->param == ORC_PARAM_HALF_DIFF) {
+        double ph;
+        orc_half_diff(in, out, &a[0], &ph, &a[1], &a[2]);
+    } else
+        orc_standard_angles(in, out, &a[0], &a[1], &a[2]);
+}
+
 /* ------------------------------------------------------------------------------------------
- * a3 — index maps, generalised from 90/90/180 to the table's dims.
+ * a3 — index maps, generalised from 90/90/180 to the table's dims and, for the
+ * standard parameterisations, to linear axes (no sqrt warp; azimuth over [0,pi] or [0,2pi)).
  * ---------------------------------------------------------------------------------------- */
 static double x_theta_half(const orc_table *t, double theta_half)
 {
+    if (t->param != ORC_PARAM_HALF_DIFF) return theta_half / (M_PI * 0.5) * t->n_th;
     if (theta_half <= 0.0) return 0.0;
     double deg = (theta_half / (M_PI / 2.0)) * t->n_th;
     return sqrt(deg * t->n_th);
@@ -124,6 +144,8 @@ static double x_theta_diff(const orc_table *t, double theta_diff)
 }
 static double x_phi_diff(const orc_table *t, double phi_diff)
 {
+    if (t->param == ORC_PARAM_STANDARD) return fabs(phi_diff) / M_PI * t->n_pd;               /* mirror symmetry */
+    if (t->param == ORC_PARAM_STANDARD_FULL) return (phi_diff < 0.0 ? phi_diff + 2.0 * M_PI : phi_diff) / (2.0 * M_PI) * t->n_pd;
     if (phi_diff < 0.0) phi_diff += M_PI;       /* reciprocity fold: phi_d == phi_d + pi */
     return phi_diff / M_PI * t->n_pd;
 }
@@ -184,6 +206,13 @@ static void split_periodic(double x, int n, int *i0, int *i1, double *f)
     *i1 = (i + 1) % n;
 }
 
+/* azimuth axis: periodic, except for the mirrored standard form where 0 and pi are the two ends */
+static void split_phi(int param, double x, int n, int *i0, int *i1, double *f)
+{
+    if (param == ORC_PARAM_STANDARD) split_clamped(x, n, i0, i1, f);
+    else split_periodic(x, n, i0, i1, f);
+}
+
 void orc_lookup(const orc_table *t, const orc_opts *o, double th, double td, double pd, double rgb[3])
 {
     if (o->lookup == ORC_LOOKUP_NEAREST) {
@@ -196,7 +225,7 @@ void orc_lookup(const orc_table *t, const orc_opts *o, double th, double td, dou
     int h0, h1, d0, d1, p0, p1; double fh, fd, fp;
     split_clamped(xh - shift, t->n_th, &h0, &h1, &fh);
     split_clamped(xd - shift, t->n_td, &d0, &d1, &fd);
-    split_periodic(xp - shift, t->n_pd, &p0, &p1, &fp);
+    split_phi(t->param, xp - shift, t->n_pd, &p0, &p1, &fp);
     const int hs[2] = { h0, h1 }, ds[2] = { d0, d1 }, ps[2] = { p0, p1 };
     const double wh[2] = { 1.0 - fh, fh }, wd[2] = { 1.0 - fd, fd }, wp[2] = { 1.0 - fp, fp };
     rgb[0] = rgb[1] = rgb[2] = 0.0;
@@ -221,9 +250,9 @@ static void eval_f64(const orc_table *t, const orc_opts *o, const float wi[3], c
     if (!(wi[2] > 0.0f) || !(wo[2] > 0.0f)) return;
     double in[3] = { wi[0], wi[1], wi[2] }, out[3] = { wo[0], wo[1], wo[2] };
     unit3(in); unit3(out);
-    double th, ph, td, pd;
-    orc_half_diff(in, out, &th, &ph, &td, &pd);
-    orc_lookup(t, o, th, td, pd, rgb);
+    double a[3];
+    orc_table_angles(t, in, out, a);
+    orc_lookup(t, o, a[0], a[1], a[2], rgb);
     double c = (double)wo[2];
     rgb[0] *= c; rgb[1] *= c; rgb[2] *= c;
 }
@@ -323,6 +352,7 @@ int orc_build_sampling(const orc_table *t, orc_sampling *out)
         mean += D[i];
     }
     mean /= (double)n;
+    if (t->param != ORC_PARAM_HALF_DIFF) mean = 0.0;                  /* rows are not theta_h: flat lobe */
     for (int i = 0; i < n; ++i) D[i] = mean > 0.0 ? D[i] + 0.01 * mean : 1.0;
     for (int i = 0; i <= n; ++i) {
         double r = (double)i / (double)n;
@@ -460,6 +490,7 @@ static orc_table dims_view(const orc_table_nch *t)
     orc_table v;
     v.n_th = t->n_th; v.n_td = t->n_td; v.n_pd = t->n_pd; v.data = NULL;
     v.scale[0] = v.scale[1] = v.scale[2] = 1.0;
+    v.param = t->param;
     return v;
 }
 
@@ -488,7 +519,7 @@ void orc_lookup_nch(const orc_table_nch *t, const orc_opts *o, double th, double
     int h0, h1, d0, d1, p0, p1; double fh, fd, fp;
     split_clamped(xh - shift, t->n_th, &h0, &h1, &fh);
     split_clamped(xd - shift, t->n_td, &d0, &d1, &fd);
-    split_periodic(xp - shift, t->n_pd, &p0, &p1, &fp);
+    split_phi(t->param, xp - shift, t->n_pd, &p0, &p1, &fp);
     const int hs[2] = { h0, h1 }, ds[2] = { d0, d1 }, ps[2] = { p0, p1 };
     const double wh[2] = { 1.0 - fh, fh }, wd[2] = { 1.0 - fd, fd }, wp[2] = { 1.0 - fp, fp };
     for (int c = 0; c < t->n_ch; ++c) out[c] = 0.0;
@@ -508,9 +539,10 @@ void orc_eval_nch(const orc_table_nch *t, const orc_opts *o, const float wi[3], 
     if (!(wi[2] > 0.0f) || !(wo[2] > 0.0f)) return;
     double in[3] = { wi[0], wi[1], wi[2] }, od[3] = { wo[0], wo[1], wo[2] };
     unit3(in); unit3(od);
-    double th, ph, td, pd, v[ORC_MAX_CH];
-    orc_half_diff(in, od, &th, &ph, &td, &pd);
-    orc_lookup_nch(t, o, th, td, pd, v);
+    double a[3], v[ORC_MAX_CH];
+    const orc_table dv = dims_view(t);
+    orc_table_angles(&dv, in, od, a);
+    orc_lookup_nch(t, o, a[0], a[1], a[2], v);
     for (int c = 0; c < t->n_ch; ++c) out[c] = (float)(v[c] * (double)wo[2]);
 }
 
@@ -552,6 +584,7 @@ int orc_build_sampling_nch(const orc_table_nch *t, orc_sampling *out)
         mean += D[i];
     }
     mean /= (double)n;
+    if (t->param != ORC_PARAM_HALF_DIFF) mean = 0.0;                  /* rows are not theta_h: flat lobe */
     for (int i = 0; i < n; ++i) D[i] = mean > 0.0 ? D[i] + 0.01 * mean : 1.0;
     for (int i = 0; i <= n; ++i) {
         double r = (double)i / (double)n;

@@ -34,6 +34,16 @@ enum { ORC_LOOKUP_NEAREST = 0, ORC_LOOKUP_TRILINEAR = 1 };
 enum { ORC_NODE_INTEGER = 0, ORC_NODE_CENTER = 1 };   /* trilinear node position: i or i+1/2 */
 enum { ORC_DISK_MITSUBA06 = 0, ORC_DISK_MITSUBA3 = 1 }; /* concentric-disk flavour (A.5) */
 
+/* Table parameterisation ("generalise table dims/parameterisation"):
+ *   HALF_DIFF      (theta_h sqrt-warped, theta_d, phi_d mod pi)  — MERL, the default;
+ *   STANDARD       (theta_i, theta_o, |phi_o - phi_i| in [0, pi]) — an isotropic, bilaterally symmetric gonioreflectometer
+ *                  grid: all three axes linear in the angle, the azimuth axis CLAMPED (0 and pi are different samples);
+ *   STANDARD_FULL  (theta_i, theta_o, phi_o - phi_i in [0, 2 pi)) — isotropic without the mirror symmetry, azimuth PERIODIC.
+ * Angles of the standard forms come from cancellation-free atan2 expressions (this is the build's own definition, not
+ * BRDFRead's):  theta = atan2(|v_xy|, v_z),  dphi = atan2(wi_x wo_y - wi_y wo_x, wi_x wo_x + wi_y wo_y)  (0 when either
+ * direction is the normal).  Nearest lookup truncates, trilinear uses the node convention of orc_opts, as for MERL. */
+enum { ORC_PARAM_HALF_DIFF = 0, ORC_PARAM_STANDARD = 1, ORC_PARAM_STANDARD_FULL = 2 };
+
 typedef struct orc_opts {
     int lookup;       /* ORC_LOOKUP_* */
     int node;         /* ORC_NODE_*   */
@@ -44,9 +54,10 @@ typedef struct orc_opts {
  * layout, other dims/scales).  data is planar: channel c at data + c*n_th*n_td*n_pd, and
  * inside a plane ind = i_pd + n_pd*(i_td + n_td*i_th)  (A.1). */
 typedef struct orc_table {
-    int n_th, n_td, n_pd;
+    int n_th, n_td, n_pd;         /* axis 0, 1, 2 (theta_h, theta_d, phi_d for MERL; theta_i, theta_o, dphi for the standard forms) */
     const double *data;
     double scale[3];
+    int param;                    /* ORC_PARAM_* */
 } orc_table;
 
 /* ---- a1: file format ---- */
@@ -59,7 +70,11 @@ void orc_merl_table(orc_table *t, const double *planar);  /* dims 90/90/180, MER
 void orc_half_diff(const double in[3], const double out[3],
                    double *theta_half, double *phi_half, double *theta_diff, double *phi_diff);
 
-/* ---- a3: index maps ---- */
+/* the three lookup angles of a direction pair under the table's parameterisation (unit f64 vectors) */
+void orc_standard_angles(const double in[3], const double out[3], double *theta_i, double *theta_o, double *dphi);
+void orc_table_angles(const orc_table *t, const double in[3], const double out[3], double angles[3]);
+
+/* ---- a3: index maps (param-aware: the names are MERL's, the axes are the table's) ---- */
 int orc_theta_half_index(const orc_table *t, double theta_half);
 int orc_theta_diff_index(const orc_table *t, double theta_diff);
 int orc_phi_diff_index(const orc_table *t, double phi_diff);
@@ -97,7 +112,9 @@ void orc_eval_sample_batch_multi(const orc_table *tables, int n_tables, const or
  *   sample(): u1 < 1/2 -> cosine hemisphere with (2 u1, u2); else theta_h by inverting the bin CDF with
  *             2 u1 - 1 (exact: sin^2 theta_h is uniform inside a bin), phi_h = 2 pi u2, wo = reflect(wi, h);
  *   pdf(wi, wo) = 1/2 cos(theta_o)/pi + 1/2 p_h(h) / (4 wi.h), h = normalize(wi + wo);
- *   sample() reports pdf(wi, wo_rounded_to_Float), so pdf(wi, sample.wo) == sample.pdf exactly. */
+ *   sample() reports pdf(wi, wo_rounded_to_Float), so pdf(wi, sample.wo) == sample.pdf exactly.
+ * A table in one of the standard parameterisations has no theta_h rows to read D_i from: its lobe is flat (D_i = 1,
+ * p_h = cos(theta_h)/pi) — a valid mixture with nothing learnt from the table. */
 typedef struct orc_sampling {
     int n;            /* = n_th */
     double *s;        /* [n+1] sin^2(theta_i) */
@@ -122,6 +139,7 @@ typedef struct orc_table_nch {
     int n_th, n_td, n_pd, n_ch;
     const double *data;
     const double *scale;          /* n_ch factors */
+    int param;                    /* ORC_PARAM_* */
 } orc_table_nch;
 void  orc_lookup_nch(const orc_table_nch *t, const orc_opts *o, double theta_half, double theta_diff, double phi_diff, double *out);
 void  orc_eval_nch(const orc_table_nch *t, const orc_opts *o, const float wi[3], const float wo[3], float *out);

@@ -31,7 +31,26 @@ CASES = [
 ]
 
 
+def standard_param_cases():
+    """SURVEY.md §8f item 3, "parameterisation": tables indexed by (theta_i, theta_o, dphi) — enum mrl_param."""
+    for name, kind, seed, dims, param, lookup, node, first in (("std_ggx_trilinear", "ggx_std", 4, (24, 20, 48), 1, 1, 0, 110_000),
+                                                               ("std_full_noise_center", "noise", 6, (16, 12, 40), 2, 1, 1, 120_000),
+                                                               ("std_noise_nearest", "noise", 8, (20, 20, 30), 1, 0, 0, 130_000)):
+        tab = synth.make_table(kind, seed, dims)
+        T = ob.OracleTable(tab, synth.MERL_SCALE, param=param)
+        wi, wo, u = ob.generate_pairs(0x5EED, first, N)
+        s = np.float32(np.sqrt(0.5))
+        wi[:5] = [[0, 0, 1], [s, 0, s], [0.6, 0, 0.8], [0.6, 0, 0.8], [0, 0.6, 0.8]]         # normal incidence (dphi := 0), mirror,
+        wo[:5] = [[0.6, 0, 0.8], [-s, 0, s], [0.6, 0, 0.8], [0.6, -1e-3, 0.8], [0, 0, 1]]    # retro, just across the seam, normal exitance
+        rgb, pdf, wo2, pdf2, w = ob.eval_sample_multi([T], wi, wo, u, None, ob.make_opts(lookup, node, 0))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), table_kind=kind, table_seed=seed, dims=np.array(dims), scale=np.array(synth.MERL_SCALE),
+                            param=param, lookup=lookup, node=node, disk_map=0, wi=wi, wo=wo, u=u, rgb=rgb, pdf=pdf, wo2=wo2, pdf2=pdf2, weight=w)
+
+
 def main():
+    if "--standard-param-only" in sys.argv:            # the older fixtures stay byte-identical in git
+        return standard_param_cases()
+    standard_param_cases()
     for name, kind, seed, lookup, node, disk, first in CASES:
         tab = synth.make_table(kind, seed)
         T = ob.OracleTable(tab)

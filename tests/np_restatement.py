@@ -50,7 +50,7 @@ def scaled_table(planar, scale=MERL_SCALE):
     return np.maximum(t, 0.0)
 
 
-def lookup(planar, xh, xd, xp, trilinear=True, center=False, scale=MERL_SCALE):
+def lookup(planar, xh, xd, xp, trilinear=True, center=False, scale=MERL_SCALE, phi_clamped=False):
     t = scaled_table(planar, scale)
     _, n_th, n_td, n_pd = t.shape
     if not trilinear:
@@ -72,7 +72,7 @@ def lookup(planar, xh, xd, xp, trilinear=True, center=False, scale=MERL_SCALE):
 
     h0, h1, fh = split_c(xh - sh, n_th)
     d0, d1, fd = split_c(xd - sh, n_td)
-    p0, p1, fp = split_p(xp - sh, n_pd)
+    p0, p1, fp = split_c(xp - sh, n_pd) if phi_clamped else split_p(xp - sh, n_pd)
     out = 0.0
     for hi, wh in ((h0, 1 - fh), (h1, fh)):
         for di, wd in ((d0, 1 - fd), (d1, fd)):
@@ -86,5 +86,26 @@ def eval_merl(planar, wi, wo, trilinear=True, center=False, scale=MERL_SCALE):
     th, td, pd = half_diff(wi.astype(np.float64), wo.astype(np.float64))
     xh, xd, xp = coords(th, td, pd, np.asarray(planar).shape[1:])
     v = lookup(planar, xh, xd, xp, trilinear, center, scale) * wo[:, 2:3].astype(np.float64)
+    ok = (wi[:, 2] > 0) & (wo[:, 2] > 0)
+    return np.where(ok[:, None], v, 0.0)
+
+
+def eval_standard(planar, wi, wo, full=False, trilinear=True, center=False, scale=MERL_SCALE):
+    """The standard parameterisations (include/merl_hip.h enum mrl_param), formulated differently from the oracle:
+    theta = arccos(z) of the unit vector, dphi = phi_o - phi_i from the two azimuths, wrapped."""
+    wi = np.asarray(wi, np.float32); wo = np.asarray(wo, np.float32)
+    a, b = unit(wi.astype(np.float64)), unit(wo.astype(np.float64))
+    n0, n1, n2 = np.asarray(planar).shape[1:]
+    ti, to = np.arccos(np.clip(a[:, 2], -1, 1)), np.arccos(np.clip(b[:, 2], -1, 1))
+    pi_, po = np.arctan2(a[:, 1], a[:, 0]), np.arctan2(b[:, 1], b[:, 0])
+    flat = ((a[:, 0] == 0) & (a[:, 1] == 0)) | ((b[:, 0] == 0) & (b[:, 1] == 0))
+    dp = np.where(flat, 0.0, po - pi_)
+    dp = np.mod(dp, 2 * np.pi)                                   # [0, 2 pi)
+    x0, x1 = ti / (np.pi / 2) * n0, to / (np.pi / 2) * n1
+    if full:
+        x2 = dp / (2 * np.pi) * n2
+    else:
+        x2 = np.where(dp > np.pi, 2 * np.pi - dp, dp) / np.pi * n2
+    v = lookup(planar, x0, x1, x2, trilinear, center, scale, phi_clamped=not full) * wo[:, 2:3].astype(np.float64)
     ok = (wi[:, 2] > 0) & (wo[:, 2] > 0)
     return np.where(ok[:, None], v, 0.0)

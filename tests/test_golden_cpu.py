@@ -8,7 +8,7 @@ import numpy as np
 
 def test_oracle_reproduces_golden(oracle, tables):
     files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-    assert len(files) >= 11
+    assert len(files) >= 14
     for f in files:
         z = np.load(f)
         kind = str(z["table_kind"])
@@ -27,7 +27,8 @@ def test_oracle_reproduces_golden(oracle, tables):
                 assert np.array_equal(g, z[name]), (f, name)
             continue
         dims = tuple(int(d) for d in z["dims"]) if "dims" in z else (90, 90, 180)
-        T = oracle.OracleTable(tables(kind, int(z["table_seed"]), dims), tuple(z["scale"]) if "scale" in z else None)
+        T = oracle.OracleTable(tables(kind, int(z["table_seed"]), dims), tuple(z["scale"]) if "scale" in z else None,
+                               param=int(z["param"]) if "param" in z else 0)
         o = oracle.make_opts(int(z["lookup"]), int(z["node"]), int(z["disk_map"]))
         if "sampling" in z and int(z["sampling"]) == 1:
             wo2, pdf2, w = T.sample_table(z["wi"], z["u"], o)

@@ -1,0 +1,195 @@
+"""The STANDARD table parameterisations on the GPU (MRL_OPT_TABLE_PARAM, enum mrl_param; SURVEY.md §8f item 3,
+"dims/parameterisation") against the oracle's restatement (oracle/merl_oracle.h ORC_PARAM_*), through the C ABI.
+Tolerances as for MERL tables: sampled direction / pdf bit-identical, values and weights |gpu - oracle| <= 1e-6 |oracle|
+for EVERY value (trilinear), at most one flipped unit for nearest lookups.  PARITY UNPINNED: the reference's
+customized_measurement format is unknown; the definition is this repo's own."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6
+HALF, STD, FULL = 0, 1, 2
+
+
+def to_dev(*arrs):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
+
+
+def close(got, want, rel=REL):
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    return np.abs(got - want) <= rel * np.abs(want) + 1e-30
+
+
+def special_pairs(wi, wo):
+    """normal incidence / exitance (dphi := 0), retro-reflection, mirror direction, wo a hair either side of the plane of
+    incidence (the seam of the periodic form, the clamped end of the mirrored one), below-horizon guards, grazing."""
+    s = np.float32(np.sqrt(0.5))
+    wi[:10] = [[0, 0, 1], [0, 0.6, 0.8], [0.6, 0, 0.8], [s, 0, s], [0.6, 0, 0.8], [0.6, 0, 0.8], [0.6, 0, -0.8], [0.6, 0, 0.8], [0.9999, 0, 0.014142], [-0.6, 0, 0.8]]
+    wo[:10] = [[0.6, 0, 0.8], [0, 0, 1], [0.6, 0, 0.8], [-s, 0, s], [0.6, 1e-4, 0.8], [0.6, -1e-4, 0.8], [0.6, 0, 0.8], [0.6, 0, -0.8], [0, 0.9999, 0.014142], [0.6, 1e-6, 0.8]]
+
+
+@pytest.mark.parametrize("param,kind", [(STD, "ggx_std"), (STD, "noise"), (FULL, "ggx_std_full"), (FULL, "noise")])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_standard_tables_match_oracle(oracle, tables, param, kind, layout):
+    """Every kernel variant x lookup flavour, eval / pdf / sample / fused entry points."""
+    from mitsuba_customization_amd import host
+    dims = (24, 20, 48)
+    tab = tables(kind, 4, dims)
+    scale = (1.0 / 1500.0, 1.15 / 1500.0, 1.66 / 1500.0)
+    T = oracle.OracleTable(tab, scale, param=param)
+    n = 30_011
+    wi, wo, u = oracle.generate_pairs(0x5EED, 909, n)
+    special_pairs(wi, wo)
+    dwi, dwo, du = to_dev(wi, wo, u)
+    with host.MerlHip(0) as g:
+        g.set_option(host.OPT_TABLE_LAYOUT, layout)
+        g.set_option(host.OPT_TABLE_PARAM, param)
+        mid = g.upload_table(tab, scale)
+        assert g.material_param(mid) == param and g.get_option(host.OPT_TABLE_PARAM) == param
+        for lookup, node, disk in ((1, 0, 0), (1, 1, 1), (0, 0, 0)):
+            o = oracle.make_opts(lookup, node, disk)
+            want = oracle.eval_sample_multi([T], wi, wo, u, None, o)
+            g.set_option(host.OPT_LOOKUP, lookup); g.set_option(host.OPT_NODE, node); g.set_option(host.OPT_DISK_MAP, disk)
+            for variant in (0, 1, 2, 3):
+                g.set_option(host.OPT_KERNEL, variant)
+                got = [t.cpu().numpy() for t in g.eval_sample(dwi, dwo, du, material=mid)]
+                tag = f"param {param} {kind} layout {layout} lookup {lookup} node {node} variant {variant}"
+                for k in (0, 4):
+                    ok = close(got[k], want[k])
+                    if lookup:
+                        assert ok.all(), f"{tag}: {(~ok).sum()} values of output {k} off, max rel {np.max(np.abs(got[k] - want[k]) / np.maximum(np.abs(want[k]), 1e-30)):.2e}"
+                    else:
+                        assert (~ok.all(axis=1)).sum() <= 1, tag
+                assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]), tag
+                # the separate entry points are the same arithmetic
+                assert np.array_equal(g.eval(dwi, dwo, material=mid).cpu().numpy(), got[0]), tag
+                s_wo, s_pdf, s_w = [t.cpu().numpy() for t in g.sample(dwi, du, material=mid)]
+                assert np.array_equal(s_wo, got[2]) and np.array_equal(s_pdf, got[3]) and np.array_equal(s_w, got[4]), tag
+                e_rgb, e_pdf = [t.cpu().numpy() for t in g.eval_pdf(dwi, dwo, material=mid)]
+                assert np.array_equal(e_rgb, got[0]) and np.array_equal(e_pdf, got[1]), tag
+
+
+def test_mixed_batch_of_all_parameterisations(oracle, tables):
+    """One batch over a MERL table, a half/diff custom table, a mirrored and a full standard table and a GGX material;
+    host arrays (the staged path) and the wavefront queue call see the same numbers."""
+    import torch
+    from mitsuba_customization_amd import host
+    from oracle import binding as ob
+    dims = (20, 16, 32)
+    scale = (0.5, 1.0, 2.0)
+    tabs = [tables("ggx_tab", 1), tables("noise", 2, dims), tables("ggx_std", 3, dims), tables("noise", 4, dims)]
+    params = [HALF, HALF, STD, FULL]
+    eta, k = (0.143, 0.375, 1.442), (3.983, 2.386, 1.603)
+    n = 40_000
+    wi, wo, u = oracle.generate_pairs(0x5EED, 31, n)
+    special_pairs(wi, wo)
+    mat = oracle.generate_materials(0x5EED, 31, n, 6)                   # 5 = unknown id
+    with host.MerlHip(0) as g:
+        ids = [g.upload_merl(tabs[0])]
+        for t, p in zip(tabs[1:], params[1:]):
+            g.set_option(host.OPT_TABLE_PARAM, p)
+            ids.append(g.upload_table(t, scale))
+        g.set_option(host.OPT_TABLE_PARAM, STD)                         # a MERL upload ignores the option
+        again = g.upload_merl(tabs[0])
+        assert g.material_param(again) == HALF
+        g.release_material(again)
+        ids.append(g.ggx(0.2, eta, k))
+        assert ids == [0, 1, 2, 3, 4] and [g.material_param(i) for i in ids[:4]] == params
+        with pytest.raises(host.MerlHipError):
+            g.material_param(ids[4])
+        dwi, dwo, du = to_dev(wi, wo, u); (dmat,) = to_dev(mat)
+        got = [t.cpu().numpy() for t in g.eval_sample(dwi, dwo, du, mat=dmat)]
+        staged = g.eval_sample(wi, wo, u, mat=mat)                       # host arrays
+        for a, b in zip(staged, got):
+            assert np.array_equal(np.asarray(a), b)
+        # queue call over every third slot
+        q = torch.arange(0, n, 3, dtype=torch.int32, device="cuda")
+        cnt = torch.tensor([q.numel()], dtype=torch.int32, device="cuda")
+        outs = [torch.full_like(torch.from_numpy(x).cuda(), -7.0) for x in got]
+        g.eval_sample_queue(dwi, dwo, du, q, cnt, mat=dmat, out=outs)
+        g.synchronize()
+        for o_, ref in zip(outs, got):
+            o_ = o_.cpu().numpy()
+            assert np.array_equal(o_[::3], ref[::3]) and (o_[1::3] == -7.0).all()
+    want = [np.zeros_like(x) for x in got]
+    for i, (t, p) in enumerate(zip(tabs, params)):
+        sel = mat == i
+        T = ob.OracleTable(t, None if i == 0 else scale, param=p)
+        for a, b in zip(want, ob.eval_sample_multi([T], wi[sel], wo[sel], u[sel], None, ob.make_opts())):
+            a[sel] = b
+    sel = mat == 4
+    G = ob.OracleGgx(float(np.float32(0.2)), [float(np.float32(x)) for x in eta], [float(np.float32(x)) for x in k])
+    s_wo, s_pdf, s_w = G.sample(wi[sel], u[sel])
+    for a, b in zip(want, (G.eval(wi[sel], wo[sel]), G.pdf(wi[sel], wo[sel]), s_wo, s_pdf, s_w)):
+        a[sel] = b
+    tsel = mat < 4
+    assert close(got[0], want[0]).all() and close(got[4], want[4]).all()
+    assert np.array_equal(got[1][tsel], want[1][tsel]) and np.array_equal(got[2][tsel], want[2][tsel]) and np.array_equal(got[3][tsel], want[3][tsel])
+    assert close(got[1], want[1], 2e-6).all() and close(got[3], want[3], 2e-6).all() and np.abs(got[2].astype(np.float64) - want[2]).max() <= 1.2e-7
+    for arr in got:
+        assert not arr[mat == 5].any()
+
+
+@pytest.mark.parametrize("n_ch", [1, 4, 8])
+@pytest.mark.parametrize("param", [STD, FULL])
+def test_nch_tables_in_standard_form(oracle, n_ch, param):
+    from mitsuba_customization_amd import host, synth
+    dims = (14, 12, 20)
+    tab = synth.make_table_nch("noise", n_ch, 5, dims)
+    scale = [0.5 + 0.25 * c for c in range(n_ch)]
+    n = 20_003
+    wi, wo, u = oracle.generate_pairs(0x5EED, 606, n)
+    special_pairs(wi, wo)
+    T = oracle.OracleTableNch(tab, scale, param=param)
+    with host.MerlHip(0) as g:
+        g.set_option(host.OPT_TABLE_PARAM, param)
+        mid = g.upload_table_nch(tab, scale)
+        assert g.material_param(mid) == param
+        for lookup, node in ((1, 0), (1, 1), (0, 0)):
+            g.set_option(host.OPT_LOOKUP, lookup); g.set_option(host.OPT_NODE, node)
+            got = [np.asarray(t) for t in g.eval_sample_nch(wi, wo, u, n_ch, material=mid)]
+            want = oracle.eval_sample_nch([T], wi, wo, u, None, oracle.make_opts(lookup, node, 0))
+            for kk in (0, 4):
+                ok = close(got[kk], want[kk])
+                assert ok.all() if lookup else (~ok.all(axis=1)).sum() <= 1, (n_ch, param, lookup, node, kk)
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+
+
+@pytest.mark.parametrize("param", [STD, FULL])
+def test_table_sampling_uses_a_flat_lobe(oracle, tables, param):
+    """MRL_OPT_SAMPLING = 1 on a standard-form table: cosine half bit-identical, half-vector half within one f32 ulp, and
+    EVERY unit's pdf / weight against the oracle evaluated at the returned direction."""
+    from mitsuba_customization_amd import host
+    dims = (16, 16, 24)
+    tab = tables("ggx_std" if param == STD else "ggx_std_full", 2, dims)
+    scale = (1.0 / 1500.0, 1.15 / 1500.0, 1.66 / 1500.0)
+    T = oracle.OracleTable(tab, scale, param=param)
+    n = 30_000
+    wi, wo, u = oracle.generate_pairs(0x5EED, 4321, n)
+    c_wo, c_pdf, c_w = T.sample_table(wi, u)
+    dwi, dwo, du = to_dev(wi, wo, u)
+    with host.MerlHip(0) as g:
+        g.set_option(host.OPT_TABLE_PARAM, param)
+        g.set_option(host.OPT_SAMPLING, host.SAMPLING_TABLE)
+        mid = g.upload_table(tab, scale)
+        s_wo, s_pdf, s_w = [t.cpu().numpy() for t in g.sample(dwi, du, material=mid)]
+        q = g.pdf(dwi, dwo, material=mid).cpu().numpy()
+    lo = u[:, 0] < 0.5
+    assert np.array_equal(s_wo[lo], c_wo[lo]) and np.abs(s_wo.astype(np.float64) - c_wo).max() <= 1.2e-7
+    assert np.array_equal(s_pdf > 0, c_pdf > 0)
+    assert close(q, T.pdf_table(wi, wo), 2e-6).all()
+    live = s_pdf > 0
+    at_pdf = T.pdf_table(wi[live], s_wo[live]).astype(np.float64)
+    assert close(s_pdf[live], at_pdf, 2e-6).all()
+    assert close(s_w[live], T.eval(wi[live], s_wo[live]).astype(np.float64) / at_pdf[:, None], 3e-6).all()
+
+
+def test_bad_option_value():
+    from mitsuba_customization_amd import host
+    with host.MerlHip(0) as g:
+        for v in (-1, 3):
+            with pytest.raises(host.MerlHipError):
+                g.set_option(host.OPT_TABLE_PARAM, v)
+        assert g.get_option(host.OPT_TABLE_PARAM) == HALF

@@ -335,6 +335,7 @@ def test_golden_fixtures(tables, oracle):
             if kind == "ggx":
                 mid = g.ggx(float(z["alpha"]), z["eta"].tolist(), z["k"].tolist())
             elif "dims" in z:
+                g.set_option(host.OPT_TABLE_PARAM, int(z["param"]) if "param" in z else 0)
                 mid = g.upload_table(tables(kind, seed, tuple(int(d) for d in z["dims"])), tuple(z["scale"]))
             else:
                 mid = g.upload_merl(tables(kind, seed))

@@ -1,0 +1,144 @@
+"""Oracle known-answer tests for the STANDARD table parameterisations ("parameterisation";
+include/merl_hip.h enum mrl_param): tables indexed by (theta_i, theta_o, |dphi|) or (theta_i, theta_o, dphi mod 2 pi).
+PARITY UNPINNED — the reference's customized_measurement format is unknown; these pin the oracle's own definition
+with closed forms, symmetries and an independently formulated numpy restatement (tests/np_restatement.py)."""
+import numpy as np
+import pytest
+
+from tests import np_restatement as npr
+
+HALF, STD, FULL = 0, 1, 2
+
+
+def dirs(theta, phi):
+    return np.stack([np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)], -1)
+
+
+def test_standard_angles_closed_form(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        ti, to = rng.uniform(0.01, 1.55, 2)
+        pi_, dp = rng.uniform(-np.pi, np.pi, 2)
+        a, b = dirs(ti, pi_), dirs(to, pi_ + dp)
+        got = oracle.standard_angles(a, b)
+        assert abs(got[0] - ti) < 1e-14 and abs(got[1] - to) < 1e-14
+        assert abs(np.angle(np.exp(1j * (got[2] - dp)))) < 1e-13
+    # either direction at the normal: the azimuth difference is defined as 0
+    assert oracle.standard_angles([0, 0, 1], [0.6, 0, 0.8])[2] == 0.0
+    assert oracle.standard_angles([0, 0.6, 0.8], [0, 0, 1])[2] == 0.0
+
+
+@pytest.mark.parametrize("param", [STD, FULL])
+def test_affine_table_is_reproduced(oracle, param):
+    """raw = a0 + a1 i + a2 j + a3 k, scale 1: trilinear (integer nodes) returns a0 + a1 x0 + a2 x1 + a3 x2 away from the
+    clamped ends (and, for the periodic azimuth, away from the seam)."""
+    from mitsuba_customization_amd import synth
+    dims = (20, 16, 24)
+    tab = synth.affine_table(dims=dims)
+    T = oracle.OracleTable(tab, (1.0, 1.0, 1.0), param=param)
+    rng = np.random.default_rng(2)
+    n = 4000
+    ti, to = rng.uniform(0.05, 1.4, n), rng.uniform(0.05, 1.4, n)
+    rng_hi = np.pi * (1 - 1.5 / dims[2]) if param == STD else 2 * np.pi * (1 - 1.5 / dims[2])
+    dp = rng.uniform(0.05, rng_hi, n)
+    p0 = rng.uniform(-np.pi, np.pi, n)
+    wi, wo = dirs(ti, p0).astype(np.float32), dirs(to, p0 + dp).astype(np.float32)
+    got = T.eval(wi, wo).astype(np.float64)
+    a, b = npr.unit(wi.astype(np.float64)), npr.unit(wo.astype(np.float64))            # the f32-rounded directions' own angles
+    tif, tof = np.arctan2(np.hypot(a[:, 0], a[:, 1]), a[:, 2]), np.arctan2(np.hypot(b[:, 0], b[:, 1]), b[:, 2])
+    dpf = np.mod(np.arctan2(b[:, 1], b[:, 0]) - np.arctan2(a[:, 1], a[:, 0]), 2 * np.pi)
+    x0, x1 = tif / (np.pi / 2) * dims[0], tof / (np.pi / 2) * dims[1]
+    x2 = dpf / (np.pi if param == STD else 2 * np.pi) * dims[2]
+    inside = (x0 < dims[0] - 1) & (x1 < dims[1] - 1) & (x2 < dims[2] - 1)
+    assert inside.mean() > 0.8
+    coef = ((50.0, 3.0, 0.5, 0.25), (20.0, 1.0, 2.0, 0.125), (10.0, 0.25, 0.75, 1.5))
+    for c in range(3):
+        want = (coef[c][0] + coef[c][1] * x0 + coef[c][2] * x1 + coef[c][3] * x2) * wo[:, 2].astype(np.float64)
+        assert np.allclose(got[inside, c], want[inside], rtol=2e-7, atol=0)              # f32 output rounding
+
+
+def test_symmetries(oracle, tables):
+    """Isotropy: rotating both directions about the normal changes nothing (both forms).  STANDARD: mirroring wo across
+    the plane of incidence changes nothing; STANDARD_FULL tells the two sides apart."""
+    dims = (16, 12, 20)
+    rng = np.random.default_rng(3)
+    n = 2000
+    ti, to = rng.uniform(0.05, 1.5, n), rng.uniform(0.05, 1.5, n)
+    p0, dp = rng.uniform(-np.pi, np.pi, n), rng.uniform(0.1, np.pi - 0.1, n)
+    for param in (STD, FULL):
+        tab = tables("ggx_std" if param == STD else "ggx_std_full", 3, dims)      # smooth: the f32 inputs differ after a rotation
+        T = oracle.OracleTable(tab, (1, 1, 1), param=param)
+        base = T.eval(dirs(ti, p0), dirs(to, p0 + dp)).astype(np.float64)
+        rot = T.eval(dirs(ti, p0 + 1.234), dirs(to, p0 + dp + 1.234)).astype(np.float64)
+        assert np.allclose(base, rot, rtol=1e-4, atol=0)
+        mir = T.eval(dirs(ti, p0), dirs(to, p0 - dp)).astype(np.float64)
+        if param == STD:
+            assert np.allclose(base, mir, rtol=1e-4, atol=0)
+        else:
+            assert (np.abs(base - mir) > 1e-3 * np.abs(base)).mean() > 0.9
+
+
+def test_azimuth_ends_and_seam(oracle):
+    """One-hot texels: STANDARD clamps at dphi = pi (texel n-1 holds from x = n-1 to the end), STANDARD_FULL wraps
+    (texel 0 is reached again from x = n-1 upwards).  Nearest lookups truncate."""
+    from mitsuba_customization_amd import synth
+    dims = (4, 4, 8)
+    wi = dirs(np.array([0.5]), np.array([0.0])).astype(np.float32)
+    ti_idx = int(0.5 / (np.pi / 2) * 4)
+    def at(T, dphi, o=None):
+        return float(T.eval(wi, dirs(np.array([0.5]), np.array([dphi])).astype(np.float32), o)[0, 0]) / float(np.cos(np.float32(0.5)))
+    last = synth.onehot_table((ti_idx, ti_idx, 7), 1.0, dims)
+    first = synth.onehot_table((ti_idx, ti_idx, 0), 1.0, dims)
+    near = oracle.make_opts(0, 0, 0)
+    S_last, S_first = oracle.OracleTable(last, (1, 1, 1), param=STD), oracle.OracleTable(first, (1, 1, 1), param=STD)
+    F_last, F_first = oracle.OracleTable(last, (1, 1, 1), param=FULL), oracle.OracleTable(first, (1, 1, 1), param=FULL)
+    # nearest: STANDARD texel 7 covers dphi in [7/8 pi, pi]; FULL texel 7 covers [7/4 pi, 2 pi)
+    assert at(S_last, 0.95 * np.pi, near) == pytest.approx(1.0, rel=1e-6) and at(S_last, -0.95 * np.pi, near) == pytest.approx(1.0, rel=1e-6)
+    assert at(F_last, -0.1, near) == pytest.approx(1.0, rel=1e-6) and at(F_last, 0.95 * np.pi, near) == 0.0
+    # trilinear, the weights along the azimuth at theta_i = theta_o on a node row are partial; compare RATIOS along dphi
+    wS = [at(S_last, x / 8 * np.pi) for x in (6.5, 7.0, 7.5, 8.0)]
+    assert wS[1] == pytest.approx(2 * wS[0], rel=1e-5) and wS[2] == pytest.approx(wS[1], rel=1e-5) and wS[3] == pytest.approx(wS[1], rel=1e-5)
+    wF = [at(F_first, x / 8 * 2 * np.pi) for x in (7.0, 7.5, 7.999999, 0.0, 0.5)]
+    assert wF[0] == 0.0 and wF[1] == pytest.approx(0.5 * wF[3], rel=1e-5) and wF[2] == pytest.approx(wF[3], rel=1e-4) and wF[4] == pytest.approx(0.5 * wF[3], rel=1e-5)
+    assert at(S_first, np.pi) == 0.0                              # no wrap on the mirrored form
+
+
+@pytest.mark.parametrize("param", [STD, FULL])
+@pytest.mark.parametrize("lookup,center", [(1, False), (1, True), (0, False)])
+def test_agrees_with_numpy_restatement(oracle, tables, param, lookup, center):
+    dims = (18, 14, 22)
+    tab = tables("noise", 9, dims)
+    T = oracle.OracleTable(tab, npr.MERL_SCALE, param=param)
+    wi, wo, _ = oracle.generate_pairs(0x5EED, 4242, 20000)
+    got = T.eval(wi, wo, oracle.make_opts(lookup, int(center), 0)).astype(np.float64)
+    want = npr.eval_standard(tab, wi, wo, full=param == FULL, trilinear=bool(lookup), center=center)
+    ok = np.abs(got - want) <= 2e-7 * np.abs(want) + 1e-30
+    if lookup:
+        assert ok.all(), f"{(~ok).sum()} values differ, max rel {np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-30)):.2e}"
+    else:
+        assert (~ok.all(axis=1)).sum() <= 1
+
+
+def test_flat_lobe_for_table_sampling(oracle, tables):
+    """No theta_h rows to learn from: the half-vector lobe of MRL_OPT_SAMPLING = 1 is p_h = cos(theta_h) / pi."""
+    tab = tables("ggx_std", 1, (12, 12, 16))
+    T = oracle.OracleTable(tab, npr.MERL_SCALE, param=STD)
+    wi, wo, u = oracle.generate_pairs(0x5EED, 77, 5000)
+    p = T.pdf_table(wi, wo).astype(np.float64)
+    a, b = npr.unit(wi.astype(np.float64)), npr.unit(wo.astype(np.float64))
+    h = npr.unit(a + b)
+    want = 0.5 * wo[:, 2] / np.pi + 0.5 * (h[:, 2] / np.pi) / (4 * np.sum(a * h, -1))
+    assert np.allclose(p, want, rtol=1e-6)
+    s_wo, s_pdf, s_w = T.sample_table(wi, u)
+    live = s_pdf > 0
+    assert live.mean() > 0.7                                      # a flat half-vector lobe reflects a quarter of its samples below the horizon
+    assert np.allclose(T.pdf_table(wi[live], s_wo[live]), s_pdf[live], rtol=1e-6)
+    f = T.eval(wi[live], s_wo[live]).astype(np.float64)
+    assert np.allclose(s_w[live], f / s_pdf[live, None], rtol=2e-6, atol=1e-30)
+
+
+def test_half_diff_is_untouched(oracle, tables):
+    """param = 0 is the MERL form bit for bit (the default of every constructor)."""
+    tab = tables("noise", 5, (12, 10, 16))
+    wi, wo, _ = oracle.generate_pairs(0x5EED, 1, 3000)
+    assert np.array_equal(oracle.OracleTable(tab, (1, 1, 1)).eval(wi, wo), oracle.OracleTable(tab, (1, 1, 1), param=HALF).eval(wi, wo))
