@@ -96,7 +96,8 @@ __device__ __forceinline__ Coords standard_coords(const Vec3d &in, const Vec3d &
 {
     const double ti = atan2(sqrt(in.x * in.x + in.y * in.y), in.z);
     const double to = atan2(sqrt(out.x * out.x + out.y * out.y), out.z);
-    double dp = atan2(in.x * out.y - in.y * out.x, in.x * out.x + in.y * out.y);          // atan2(0,0) = 0
+    const double cr = in.x * out.y - in.y * out.x, dt = in.x * out.x + in.y * out.y;
+    const double dp = (cr == 0.0 && dt == 0.0) ? 0.0 : atan2(cr, dt);   // a direction AT the normal has no azimuth: 0
     Coords c;
     c.xh = ti / kHalfPi * n_0;
     c.xd = to / kHalfPi * n_1;

@@ -115,7 +115,8 @@ void orc_standard_angles(const double in[3], const double out[3], double *theta_
 {
     *theta_i = atan2(sqrt(in[0] * in[0] + in[1] * in[1]), in[2]);
     *theta_o = atan2(sqrt(out[0] * out[0] + out[1] * out[1]), out[2]);
-    *dphi = atan2(in[0] * out[1] - in[1] * out[0], in[0] * out[0] + in[1] * out[1]);     /* atan2(0,0) = 0 */
+    const double cr = in[0] * out[1] - in[1] * out[0], dt = in[0] * out[0] + in[1] * out[1];
+    *dphi = (cr == 0.0 && dt == 0.0) ? 0.0 : atan2(cr, dt);       /* a direction AT the normal has no azimuth: 0 (atan2 of signed zeros may say pi) */
 }
 
 void orc_table_angles(const orc_table *t, const double in[3], const double out[3], double a[3])

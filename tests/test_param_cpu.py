@@ -26,6 +26,8 @@ def test_standard_angles_closed_form(oracle):
     # either direction at the normal: the azimuth difference is defined as 0
     assert oracle.standard_angles([0, 0, 1], [0.6, 0, 0.8])[2] == 0.0
     assert oracle.standard_angles([0, 0.6, 0.8], [0, 0, 1])[2] == 0.0
+    for o in ([-0.6, 0, 0.8], [0, -0.6, 0.8], [-0.48, -0.36, 0.8], [0.48, -0.36, 0.8]):     # signed zeros must not turn into +-pi
+        assert oracle.standard_angles([0, 0, 1], o)[2] == 0.0 and oracle.standard_angles(o, [0, 0, 1])[2] == 0.0
 
 
 @pytest.mark.parametrize("param", [STD, FULL])
