@@ -18,8 +18,11 @@ def to_dev(*arrs):
 
 
 def close(got, want, rel=REL):
+    """|got - want| <= rel |want|, plus 1e-13 of the largest value around: the hand-picked pairs below land EXACTLY on table
+    nodes (theta = pi/4 on a 14-row axis is x = 7), where the oracle's weight on the neighbouring texel is exactly 0 and a
+    1-ulp different coordinate leaves 1e-16 of a neighbour in a texel whose own value is 0."""
     got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
-    return np.abs(got - want) <= rel * np.abs(want) + 1e-30
+    return np.abs(got - want) <= rel * np.abs(want) + 1e-13 * np.abs(want).max() + 1e-30
 
 
 def special_pairs(wi, wo):
@@ -86,6 +89,7 @@ def test_mixed_batch_of_all_parameterisations(oracle, tables):
     wi, wo, u = oracle.generate_pairs(0x5EED, 31, n)
     special_pairs(wi, wo)
     mat = oracle.generate_materials(0x5EED, 31, n, 6)                   # 5 = unknown id
+    mat[:10] = [2, 3] * 5       # the degenerate pairs go to the standard-form tables (half/diff has no phi_d at theta_d = 0: test_gpu_parity)
     with host.MerlHip(0) as g:
         ids = [g.upload_merl(tabs[0])]
         for t, p in zip(tabs[1:], params[1:]):
@@ -125,7 +129,9 @@ def test_mixed_batch_of_all_parameterisations(oracle, tables):
     for a, b in zip(want, (G.eval(wi[sel], wo[sel]), G.pdf(wi[sel], wo[sel]), s_wo, s_pdf, s_w)):
         a[sel] = b
     tsel = mat < 4
-    assert close(got[0], want[0]).all() and close(got[4], want[4]).all()
+    for kk in (0, 4):
+        bad = np.nonzero(~close(got[kk], want[kk]).all(axis=1))[0]
+        assert bad.size == 0, f"output {kk}: units {bad[:8]} (materials {mat[bad[:8]]}) differ"
     assert np.array_equal(got[1][tsel], want[1][tsel]) and np.array_equal(got[2][tsel], want[2][tsel]) and np.array_equal(got[3][tsel], want[3][tsel])
     assert close(got[1], want[1], 2e-6).all() and close(got[3], want[3], 2e-6).all() and np.abs(got[2].astype(np.float64) - want[2]).max() <= 1.2e-7
     for arr in got:
