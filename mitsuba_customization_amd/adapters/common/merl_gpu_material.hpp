@@ -258,26 +258,35 @@ public:
                                 [&](mrl_ctx *c, int *id) { return mrl_material_load_merl(c, path.c_str(), id); }, "mrl_material_load_merl");
         return Material(ctx, res);
     }
-    static Material load_table(const ContextKey &key, const std::string &path, const double scale[3])
+    // param: enum mrl_param — which three angles index the table.  The option is per upload; the loader runs under the
+    // context's lock, so setting it around the load cannot leak into another instance's upload.
+    static Material load_table(const ContextKey &key, const std::string &path, const double scale[3], int param = MRL_PARAM_HALF_DIFF)
     {
         auto ctx = Context::get(key);
-        char sc[128];
-        std::snprintf(sc, sizeof sc, "|%.17g|%.17g|%.17g", scale[0], scale[1], scale[2]);
+        char sc[160];
+        std::snprintf(sc, sizeof sc, "|%.17g|%.17g|%.17g|p%d", scale[0], scale[1], scale[2], param);
         auto res = ctx->acquire("table|" + canonical_path(path) + sc,
-                                [&](mrl_ctx *c, int *id) { return mrl_material_load_table(c, path.c_str(), scale, id); }, "mrl_material_load_table");
+                                [&](mrl_ctx *c, int *id) {
+                                    int rc = mrl_set_option(c, MRL_OPT_TABLE_PARAM, param);
+                                    if (rc == MRL_OK) rc = mrl_material_load_table(c, path.c_str(), scale, id);
+                                    (void)mrl_set_option(c, MRL_OPT_TABLE_PARAM, MRL_PARAM_HALF_DIFF);
+                                    return rc;
+                                }, "mrl_material_load_table");
         return Material(ctx, res);
     }
 
     // a customized_measurement table stored in a tensor_file container (the RGL *.bsdf container): field "table"
     // [3, n_theta_h, n_theta_d, n_phi_d] (+ optional "scale").  The renderers' RGB builds take three channels; wider
     // tables are reachable through the C ABI's *_nch calls, not through a Spectrum-returning plugin.
-    static Material load_tensor_table(const ContextKey &key, const std::string &path)
+    static Material load_tensor_table(const ContextKey &key, const std::string &path, int param = MRL_PARAM_HALF_DIFF)
     {
         auto ctx = Context::get(key);
-        auto res = ctx->acquire("tensor|" + canonical_path(path),
+        auto res = ctx->acquire("tensor|" + canonical_path(path) + "|p" + std::to_string(param),
                                 [&](mrl_ctx *c, int *id) {
                                     int channels = 0;
-                                    int rc = mrl_material_load_tensor_table(c, path.c_str(), nullptr, id, &channels);
+                                    int rc = mrl_set_option(c, MRL_OPT_TABLE_PARAM, param);
+                                    if (rc == MRL_OK) rc = mrl_material_load_tensor_table(c, path.c_str(), nullptr, id, &channels);
+                                    (void)mrl_set_option(c, MRL_OPT_TABLE_PARAM, MRL_PARAM_HALF_DIFF);
                                     if (rc == MRL_OK && channels != 3) {
                                         mrl_material_release(c, *id);
                                         throw Error(MRL_ERR_FORMAT, path + ": the table has " + std::to_string(channels) +
@@ -400,6 +409,13 @@ inline int parse_sampling(const std::string &s)
     if (s == "cosine") return 0;
     if (s == "table") return 1;
     throw Error(MRL_ERR_INVALID, "sampling must be \"cosine\" or \"table\", got \"" + s + "\"");
+}
+inline int parse_parameterization(const std::string &s)
+{
+    if (s == "half_diff" || s == "merl") return MRL_PARAM_HALF_DIFF;
+    if (s == "standard") return MRL_PARAM_STANDARD;
+    if (s == "standard_full") return MRL_PARAM_STANDARD_FULL;
+    throw Error(MRL_ERR_INVALID, "parameterization must be \"half_diff\", \"standard\" or \"standard_full\", got \"" + s + "\"");
 }
 inline int parse_node(const std::string &s)
 {

@@ -177,11 +177,15 @@ public:
     explicit CustomizedMeasurement(const Properties &props) : MeasuredBSDFBase(props)
     {
         m_scale[0] = props.getFloat("scaleR", 1.0f); m_scale[1] = props.getFloat("scaleG", 1.0f); m_scale[2] = props.getFloat("scaleB", 1.0f);
+        // which three angles index the table: "half_diff" (MERL's, default), "standard" (theta_i, theta_o, |dphi|),
+        // "standard_full" (theta_i, theta_o, dphi mod 2 pi) — include/merl_hip.h enum mrl_param
+        m_param = merl_gpu::parse_parameterization(props.getString("parameterization", "half_diff"));
         load();
     }
     CustomizedMeasurement(Stream *stream, InstanceManager *manager) : MeasuredBSDFBase(stream, manager)
     {
         for (int c = 0; c < 3; ++c) m_scale[c] = stream->readFloat();
+        m_param = stream->readInt();
         load();
         configure();
     }
@@ -189,6 +193,7 @@ public:
     {
         MeasuredBSDFBase::serialize(stream, manager);
         for (int c = 0; c < 3; ++c) stream->writeFloat(m_scale[c]);
+        stream->writeInt(m_param);
     }
     MTS_DECLARE_CLASS()
 protected:
@@ -198,10 +203,11 @@ private:
     {
         const double scale[3] = { m_scale[0], m_scale[1], m_scale[2] };
         // *.bsdf: the table sits in a tensor_file container and brings its own channel scales
-        m_material = merl_gpu::Material::is_tensor_file(m_filename) ? merl_gpu::Material::load_tensor_table(m_key, m_filename)
-                                                                    : merl_gpu::Material::load_table(m_key, m_filename, scale);
+        m_material = merl_gpu::Material::is_tensor_file(m_filename) ? merl_gpu::Material::load_tensor_table(m_key, m_filename, m_param)
+                                                                    : merl_gpu::Material::load_table(m_key, m_filename, scale, m_param);
     }
     Float m_scale[3];
+    int m_param = 0;
 };
 
 MTS_NAMESPACE_END

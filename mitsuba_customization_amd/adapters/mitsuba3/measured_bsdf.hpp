@@ -156,10 +156,13 @@ public:
     {
         const double scale[3] = { props.template get<double>("scale_r", 1.0), props.template get<double>("scale_g", 1.0),
                                   props.template get<double>("scale_b", 1.0) };
+        // which three angles index the table: "half_diff" (MERL's, default), "standard" (theta_i, theta_o, |dphi|),
+        // "standard_full" (theta_i, theta_o, dphi mod 2 pi) — include/merl_hip.h enum mrl_param
+        const int param = merl_gpu::parse_parameterization(props.string("parameterization", "half_diff"));
         // *.bsdf: the table sits in a tensor_file container and brings its own channel scales
         this->m_material = merl_gpu::Material::is_tensor_file(this->m_filename)
-                               ? merl_gpu::Material::load_tensor_table(this->m_key, this->m_filename)
-                               : merl_gpu::Material::load_table(this->m_key, this->m_filename, scale);
+                               ? merl_gpu::Material::load_tensor_table(this->m_key, this->m_filename, param)
+                               : merl_gpu::Material::load_table(this->m_key, this->m_filename, scale, param);
     }
     MI_DECLARE_CLASS()
 protected:

@@ -61,6 +61,7 @@ int main(int argc, char **argv)
     if (argc > 9) { props.setFloat("scaleR", (Float)atof(argv[7])); props.setFloat("scaleG", (Float)atof(argv[8])); props.setFloat("scaleB", (Float)atof(argv[9])); }
 
     if (argc > 10) props.setString("sampling", argv[10]);
+    if (argc > 11) props.setString("parameterization", argv[11]);
     BSDF *bsdf = nullptr;
     try {
         bsdf = static_cast<BSDF *>(create(props));

@@ -56,6 +56,7 @@ int main(int argc, char **argv)
     if (argc > 9) { props.set_float("scale_r", atof(argv[7])); props.set_float("scale_g", atof(argv[8])); props.set_float("scale_b", atof(argv[9])); }
 
     if (argc > 10) props.set_string("sampling", argv[10]);
+    if (argc > 11) props.set_string("parameterization", argv[11]);
     ScalarBSDF *bsdf = nullptr;
     try {
         bsdf = static_cast<ScalarBSDF *>(create(props));

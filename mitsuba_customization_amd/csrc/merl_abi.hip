@@ -488,13 +488,16 @@ DeviceCall device_call(const mrl_ctx *ctx, const BatchCall &c)
     d.multi = c.mat != nullptr;
     if (!d.multi) a.single = ctx->materials[(size_t)c.single_id].dev;
     d.has_ggx = d.has_table = false;
+    a.any_standard = 0;
     for (const auto &m : ctx->materials) {
         if (m.released) continue;
+        if (d.multi && m.dev.kind != mrl::KIND_GGX && m.dev.param != mrl::PARAM_HALF_DIFF) a.any_standard = 1;
         d.has_ggx = d.has_ggx || m.dev.kind == mrl::KIND_GGX;
         d.has_table = d.has_table || m.dev.kind == mrl::KIND_MERL || m.dev.kind == mrl::KIND_TABLE ||
                       (c.mode == 1 && m.dev.kind == mrl::KIND_TABLE_NCH);       // pdf serves n-channel tables too
     }
     if (!d.has_ggx && !d.has_table) d.has_table = true;        // only tombstones left: the table path renders them as zeros
+    if (!d.multi && a.single.kind != mrl::KIND_GGX && a.single.param != mrl::PARAM_HALF_DIFF) a.any_standard = 1;
     return d;
 }
 

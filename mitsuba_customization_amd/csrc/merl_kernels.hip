@@ -213,13 +213,16 @@ struct BrickSources {
 struct BrickWeights { double fh, fd, fp; };
 
 // a3 tail for the brick layout: cell index + interpolation fractions
+// STD = false: every table of the launch is in MERL's half/diff form (periodic phi_d), the branch is compiled out
+template <bool STD>
 __device__ __forceinline__ uint32_t brick_cell(const MaterialDev &m, const Coords &c, int node, BrickWeights &w)
 {
     const double shift = node ? 0.5 : 0.0;
     int h0, d0, p0;
     split_clamped(c.xh - shift, m.n_th, h0, w.fh);
     split_clamped(c.xd - shift, m.n_td, d0, w.fd);
-    split_phi(param_phi_periodic(m.param), c.xp - shift, m.n_pd, p0, w.fp);
+    if constexpr (STD) split_phi(param_phi_periodic(m.param), c.xp - shift, m.n_pd, p0, w.fp);
+    else split_periodic(c.xp - shift, m.n_pd, p0, w.fp);
     return (uint32_t)((h0 * m.n_td + d0) * m.n_pd + p0);
 }
 
@@ -247,7 +250,9 @@ struct UnitIO {
 // Table lanes of one wave: transform, cooperative brick copy, blend.  EVERY lane of the wave must call
 // it (the copy is wave-wide); lanes whose material is not a table pass is_table = false, take part with
 // a harmless source and keep their outputs untouched.
-template <int MODE, bool MULTI, bool GGX>
+// STD: the launch may meet tables in one of the standard parameterisations (BatchArgs::any_standard); without it the kernel
+// is the half/diff-only code (A/B on one box: the wave-uniform parameterisation branch costs the headline launch 0.5 %).
+template <int MODE, bool MULTI, bool GGX, bool STD>
 __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDev &m, bool is_table, UnitIO &io,
                                             const fast::Vec3 &in, float4 *ldsA, float4 *ldsB, unsigned lane)
 {
@@ -255,13 +260,13 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
     constexpr bool HAS_SAMPLE = mode_sample(MODE);
     // a valid 128-B source for lanes without a table: the material array itself, cell 0
     const float4 *lane_base = (GGX && !is_table) ? (const float4 *)a.materials : m.texels;
-    const fast::TableMaps maps(m);
+    const fast::TableMaps maps = STD ? fast::TableMaps(m) : fast::TableMaps(m.n_th, m.n_td, m.n_pd, PARAM_HALF_DIFF);   // STD = false never reads m.param
     BrickWeights wA, wB;
     uint32_t cellA = 0, cellB = 0;
     float sx = 0.0f, sy = 0.0f, sz = 1.0f;
     if constexpr (HAS_EVAL) {
         const fast::Vec3 out = fast::normalize_f32(io.wox, io.woy, io.woz);
-        cellA = brick_cell(m, maps(in, out), a.opts.node, wA);
+        cellA = brick_cell<STD>(m, STD ? maps(in, out) : fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wA);
         if (GGX && !is_table) cellA = 0;
     }
     float sp = 0.0f;                                          // pdf of the sampled direction
@@ -276,7 +281,7 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
             sp = sz > 0.0f ? sz * kInvPiF : 0.0f;
         }
         const fast::Vec3 out = fast::normalize_f32(sx, sy, sz);
-        cellB = brick_cell(m, maps(in, out), a.opts.node, wB);
+        cellB = brick_cell<STD>(m, STD ? maps(in, out) : fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wB);
         if (GGX && !is_table) cellB = 0;
     }
     {
@@ -361,7 +366,7 @@ __device__ __forceinline__ void store_unit(const BatchArgs &a, size_t i, const U
 // it wins only when most units are analytic, because a sparse queue reads whole 128-B lines
 // of the stream arrays for 12 B of payload.
 // INDEXED: the kernel walks a list of unit indices (one kind's queue built by k_partition_kinds) instead of [0, n).
-template <int MODE, bool MULTI, bool NT, bool GGX, bool INDEXED = false>
+template <int MODE, bool MULTI, bool NT, bool GGX, bool INDEXED = false, bool STD = false>
 __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
 {
     static_assert(MODE != MODE_PDF, "pdf needs no table");
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
         const fast::Vec3 in = fast::normalize_f32(io.wix, io.wiy, io.wiz);
 
         if (!GGX || __ballot(is_table) != 0ull)               // wave-uniform
-            table_lanes<MODE, MULTI, GGX>(a, m, is_table, io, in, ldsA, ldsB, lane);
+            table_lanes<MODE, MULTI, GGX, STD>(a, m, is_table, io, in, ldsA, ldsB, lane);
         if constexpr (GGX) {
             if (!is_table) ggx_lane<MODE>(m, io, in);
         }
@@ -758,6 +763,13 @@ void launch_table2(const BatchArgs &a, int lookup, int layout, dim3 grid, dim3 b
     if (lookup) launch_table3<MODE, MULTI, NT, 1>(a, layout, grid, block, stream);
     else        launch_table3<MODE, MULTI, NT, 0>(a, layout, grid, block, stream);
 }
+// the LDS-DMA kernel in its half/diff-only or its every-parameterisation build (BatchArgs::any_standard); MODE, g, b, stream, a in scope
+#define MRL_DMA_LAUNCH(MULTI_, GGX_, INDEXED_)                                                                         \
+    do {                                                                                                               \
+        if (a.any_standard) hipLaunchKernelGGL((k_table_dma<MODE, MULTI_, true, GGX_, INDEXED_, true>), g, b, 0, stream, a);  \
+        else                hipLaunchKernelGGL((k_table_dma<MODE, MULTI_, true, GGX_, INDEXED_, false>), g, b, 0, stream, a); \
+    } while (0)
+
 template <int MODE>
 void launch_table(const BatchArgs &a, bool multi, bool nt, int lookup, int layout, dim3 grid, dim3 block, hipStream_t stream)
 {
@@ -789,9 +801,9 @@ hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, 
             if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
             blocks = (blocks + 7) / 8 * 8;                    // whole rounds over the 8 XCDs (BatchArgs::block_map)
             const dim3 g((unsigned)blocks), b(kDmaBlock);
-            if (multi && has_ggx)      hipLaunchKernelGGL((k_table_dma<MODE, true, true, true>), g, b, 0, stream, a);
-            else if (multi)            hipLaunchKernelGGL((k_table_dma<MODE, true, true, false>), g, b, 0, stream, a);
-            else                       hipLaunchKernelGGL((k_table_dma<MODE, false, true, false>), g, b, 0, stream, a);
+            if (multi && has_ggx)      MRL_DMA_LAUNCH(true, true, false);
+            else if (multi)            MRL_DMA_LAUNCH(true, false, false);
+            else                       MRL_DMA_LAUNCH(false, false, false);
             return hipGetLastError();
         }
     }
@@ -858,7 +870,8 @@ hipError_t launch_queue_mode(const BatchArgs &a, bool ggx_queue, int compute_uni
             constexpr int per_cu = ((MODE == MODE_EVAL_SAMPLE) ? 2 : 4) * (256 / kDmaBlock);
             size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;
             if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
-            hipLaunchKernelGGL((k_table_dma<MODE, true, true, false, true>), dim3((unsigned)blocks), dim3(kDmaBlock), 0, stream, a);
+            const dim3 g((unsigned)blocks), b(kDmaBlock);
+            MRL_DMA_LAUNCH(true, false, true);
         }
         return hipGetLastError();
     }
@@ -898,9 +911,9 @@ hipError_t launch_indexed_mode(const BatchArgs &a, bool multi, int layout, bool 
             if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
             blocks = (blocks + 7) / 8 * 8;
             const dim3 g((unsigned)blocks), b(kDmaBlock);
-            if (multi && has_ggx)      hipLaunchKernelGGL((k_table_dma<MODE, true, true, true, true>), g, b, 0, stream, a);
-            else if (multi)            hipLaunchKernelGGL((k_table_dma<MODE, true, true, false, true>), g, b, 0, stream, a);
-            else                       hipLaunchKernelGGL((k_table_dma<MODE, false, true, false, true>), g, b, 0, stream, a);
+            if (multi && has_ggx)      MRL_DMA_LAUNCH(true, true, true);
+            else if (multi)            MRL_DMA_LAUNCH(true, false, true);
+            else                       MRL_DMA_LAUNCH(false, false, true);
             return hipGetLastError();
         }
     }

@@ -22,6 +22,7 @@ struct BatchArgs {
     // forced to zero anyway, but its lookups run (the code is branch-free) and must touch memory that exists — an
     // n-channel table's cells are narrower than the 128-B bricks these kernels read.
     MaterialDev safe;
+    int any_standard;                // some table this launch may meet is in a standard parameterisation (MaterialDev::param != 0)
     int block_map;                   // k_table_dma: 0 interleaved grid-stride tiles, 1 one contiguous eighth of the batch per XCD
     Options opts;
     // queue launches: a queue of unit indices (a caller's wavefront queue, or one kind's queue built by k_partition_kinds)

@@ -123,6 +123,38 @@ def test_customized_measurement_plugin(built, oracle, tables, tmp_path, host, di
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("host,disk", [("06", 0), ("3", 1)])
+@pytest.mark.parametrize("name,param", [("standard", 1), ("standard_full", 2)])
+def test_customized_measurement_parameterization_property(built, oracle, tables, tmp_path, host, disk, name, param):
+    """<string name="parameterization" value="standard"/>: the table is indexed by (theta_i, theta_o, dphi) — enum mrl_param.
+    The 0.6 driver also serialises the instance and evaluates the unserialised copy (the property travels with it)."""
+    dims, scale = (20, 16, 36), (0.5 / 1024, 2.0 / 1024, 1.25 / 1024)          # exact in Float: 0.6 keeps its scales as Float
+    tab = tables("ggx_std" if param == 1 else "ggx_std_full", 6, dims)
+    tfile = str(tmp_path / "custom.binary")
+    synth.write_merl_binary(tfile, tab)
+    n, m = 6000, 60
+    wi, wo, u = oracle.generate_pairs(0x5EED, 123, n)
+    pairs, out = str(tmp_path / "pairs.bin"), str(tmp_path / "out.bin")
+    _write_pairs(pairs, wi, wo, u)
+    drv = os.path.join(built, "driver06" if host == "06" else "driver3")
+    plug = os.path.join(built, "plugins06" if host == "06" else "plugins3", "customized_measurement.so")
+    r = subprocess.run([drv, plug, tfile, pairs, out, str(m), "trilinear"] + [repr(float(s)) for s in scale] + ["cosine", name],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    scalar, batch = _read_out(out, m, n)
+    assert np.array_equal(scalar, batch[:m])
+    want = oracle.eval_sample_multi([oracle.OracleTable(tab, scale, param=param)], wi, wo, u, None, oracle.make_opts(disk_map=disk))
+    _check(batch, want)
+    # the same file under the default parameterisation is a different material (and a different resident table)
+    r = subprocess.run([drv, plug, tfile, pairs, out, str(m), "trilinear"] + [repr(float(s)) for s in scale], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _, other = _read_out(out, m, n)
+    assert not np.array_equal(other[0], batch[0])
+    r = subprocess.run([drv, plug, tfile, pairs, out, str(m), "trilinear"] + [repr(float(s)) for s in scale] + ["cosine", "polar"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "parameterization" in r.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("host", ["06", "3"])
 def test_customized_measurement_reads_a_tensor_file_table(built, oracle, tables, tmp_path, host):
     """filename="*.bsdf": the table comes out of a tensor_file container (field "table" [3, h, d, p] + "scale")."""
