@@ -9,7 +9,8 @@
  * snapshot, so each entry point below cites the public upstream method it stands in for:
  *
  *   mrl_material_load_merl / _upload_f64   plugin constructor (Properties "filename" -> table load)
- *   mrl_material_upload_table / _load_table  customized_measurement constructor (free dims/scales)
+ *   mrl_material_upload_table / _load_table  customized_measurement constructor (free dims/scales; MRL_OPT_TABLE_PARAM
+ *                                          = the plugin's "parameterization" property, mrl_material_param reads it back)
  *   mrl_material_ggx                       upstream roughconductor constructor (BASELINE config 3)
  *   mrl_eval_batch                         BSDF::eval(bRec, ESolidAngle)   / M3 BSDF::eval
  *   mrl_pdf_batch                          BSDF::pdf(bRec, ESolidAngle)    / M3 BSDF::pdf
