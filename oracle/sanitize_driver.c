@@ -37,10 +37,12 @@ int main(int argc, char **argv)
     wo[3 * 7] = -wi[3 * 7]; wo[3 * 7 + 1] = -wi[3 * 7 + 1]; wo[3 * 7 + 2] = wi[3 * 7 + 2];
     u[0] = 0.0f; u[1] = 0.0f; u[2] = 1.0f; u[3] = 0.5f; u[4] = 0.5f; u[5] = 0.5f;
     mat[9] = -3; mat[10] = 7;
+    for (int param = 0; param < 3; ++param)                       /* half/diff, standard, standard-full axes */
     for (int lookup = 0; lookup < 2; ++lookup)
         for (int node = 0; node < 2; ++node)
             for (int disk = 0; disk < 2; ++disk) {
                 orc_opts o = { lookup, node, disk };
+                t.param = param;
                 orc_eval_sample_batch_multi(&t, 1, &o, wi, wo, u, mat, N, rgb, pdf, wo2, pdf2, w);
                 orc_sample_table_batch(&t, &o, &sp, wi, u, N, wo2, pdf2, w);
                 orc_pdf_table_batch(&sp, wi, wo, N, pdf);
@@ -66,6 +68,7 @@ int main(int argc, char **argv)
             for (int i = 0; i < N; ++i) mat[i] = (i % 5) - 1;                        /* -1, 0, 1 (other width), 2, 3 (unknown) */
             for (int lookup = 0; lookup < 2; ++lookup) {
                 orc_opts on = { lookup, lookup, 1 - lookup };
+                tabs[0].param = (k + lookup) % 3; tabs[1].param = (k + lookup + 1) % 3;
                 orc_eval_sample_batch_nch(tabs, 2, C, &on, NULL, wi, wo, u, mat, N, val, pdf, wo2, pdf2, wgt);
                 orc_eval_sample_batch_nch(tabs, 2, C, &on, sps, wi, wo, u, mat, N, val, pdf, wo2, pdf2, wgt);
                 orc_eval_sample_batch_nch(tabs, 1, C, &on, NULL, wi, wo, u, NULL, N, val, pdf, wo2, pdf2, wgt);
