@@ -183,6 +183,9 @@ int mrl_eval_sample_batch(mrl_ctx *ctx, const float *wi, const float *wo, const 
  * channels equally (the RGB path uses luminance).  Host or device pointers, like the RGB calls. ---- */
 int mrl_material_upload_table_nch(mrl_ctx *ctx, const double *planar, const int dims[3], int n_channels,
                                   const double *scale, int *out_id);
+/* the same with the parameterisation (enum mrl_param) named in the call instead of taken from MRL_OPT_TABLE_PARAM */
+int mrl_material_upload_table_param(mrl_ctx *ctx, const double *planar, const int dims[3], int n_channels,
+                                    const double *scale, int param, int *out_id);
 /* file: int32 dims[3], then n_channels planes as f64 or f32 (told apart by the file length) */
 int mrl_material_load_table_nch(mrl_ctx *ctx, const char *path, int n_channels, const double *scale, int *out_id);
 int mrl_material_channels(const mrl_ctx *ctx, int id, int *n_channels);
@@ -224,7 +227,9 @@ int mrl_tensor_file_find(const mrl_tensor_file *f, const char *name);           
 int mrl_tensor_file_field_info(const mrl_tensor_file *f, int index, const char **name, int *dtype, int *ndim, const uint64_t **shape);
 const void *mrl_tensor_file_field_data(const mrl_tensor_file *f, int index, size_t *bytes);   /* raw payload, valid until close */
 int mrl_tensor_file_read_f64(const mrl_tensor_file *f, int index, double *out, size_t capacity);   /* float fields, converted */
-/* field == NULL: "table".  The material is an RGB table for 3 channels, an n-channel table otherwise. */
+/* field == NULL: "table".  The material is an RGB table for 3 channels, an n-channel table otherwise.  Optional fields of
+ * the container: "scale" (one factor per channel) and "parameterization" (one integer, enum mrl_param: the file says which
+ * angles index it; without the field MRL_OPT_TABLE_PARAM decides). */
 int mrl_material_load_tensor_table(mrl_ctx *ctx, const char *path, const char *field, int *out_id, int *out_channels);
 
 /* ---- wavefront queues.  A wavefront path tracer keeps its path state in arrays

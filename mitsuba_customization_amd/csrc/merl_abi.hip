@@ -1322,6 +1322,19 @@ int mrl_material_upload_table_nch(mrl_ctx *ctx, const double *planar, const int 
     return upload_table_nch(ctx, planar, dims, n_channels, scale, out_id);
 }
 
+// the same upload with the parameterisation named in the call (the context's MRL_OPT_TABLE_PARAM is left as it was)
+int mrl_material_upload_table_param(mrl_ctx *ctx, const double *planar, const int dims[3], int n_channels, const double *scale, int param, int *out_id)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);                                    // recursive: the option cannot be seen half-way by another thread's upload
+    if (param < mrl::PARAM_HALF_DIFF || param > mrl::PARAM_STANDARD_FULL) return fail(ctx, MRL_ERR_INVALID, "unknown parameterisation");
+    const int before = ctx->table_param;
+    ctx->table_param = param;
+    const int rc = upload_table_nch(ctx, planar, dims, n_channels, scale, out_id);
+    ctx->table_param = before;
+    return rc;
+}
+
 int mrl_material_load_table_nch(mrl_ctx *ctx, const char *path, int n_channels, const double *scale, int *out_id)
 {
     if (!ctx || !out_id) return MRL_ERR_INVALID;

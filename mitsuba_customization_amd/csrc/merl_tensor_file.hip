@@ -15,7 +15,8 @@
 // LOADER ONLY: the adaptive parameterisation the RGL *.bsdf fields describe (ndf / vndf / luminance warps) is a
 // different model from the MERL-parameterised tables this library evaluates and is not built.  What the loader feeds
 // the hot path is a customized_measurement table stored in this container: a float field of shape
-// [channels, n_theta_h, n_theta_d, n_phi_d] (default name "table"), optionally with a "scale" field [channels].
+// [channels, n_0, n_1, n_2] (default name "table"), optionally with a "scale" field [channels] and a "parameterization"
+// field (one integer, enum mrl_param: which three angles the axes are — half/diff by default).
 #include "../../include/merl_hip.h"
 
 #include <cstdio>
@@ -214,9 +215,27 @@ int mrl_material_load_tensor_table(mrl_ctx *ctx, const char *path, const char *f
         if (sf.count != (uint64_t)n_ch) { t_open_error = "field \"scale\" must hold one factor per channel"; rc = MRL_ERR_FORMAT; }
         else rc = mrl_tensor_file_read_f64(f, sc, scale.data(), scale.size());
     }
+    // optional: the file names its own parameterisation (one integer of any integer or float type)
+    int param = -1;
+    const int pf = mrl_tensor_file_find(f, "parameterization");
+    if (rc == MRL_OK && pf >= 0) {
+        const Field &q = f->fields[(size_t)pf];
+        const unsigned char *b = f->bytes.data() + q.offset;
+        long long v = -1;
+        double dv = 0.0;
+        if (q.count != 1) v = -1;
+        else if (q.dtype == 1 || q.dtype == 2) v = q.dtype == 1 ? (long long)*b : (long long)*(const signed char *)b;
+        else if (q.dtype == 3 || q.dtype == 4) { int16_t t; std::memcpy(&t, b, 2); v = q.dtype == 3 ? (long long)(uint16_t)t : (long long)t; }
+        else if (q.dtype == 5 || q.dtype == 6) { int32_t t; std::memcpy(&t, b, 4); v = q.dtype == 5 ? (long long)(uint32_t)t : (long long)t; }
+        else if (q.dtype == 7 || q.dtype == 8) { int64_t t; std::memcpy(&t, b, 8); v = (long long)t; }
+        else if (mrl_tensor_file_read_f64(f, pf, &dv, 1) == MRL_OK && dv == (double)(long long)dv) v = (long long)dv;
+        if (v < MRL_PARAM_HALF_DIFF || v > MRL_PARAM_STANDARD_FULL) { t_open_error = "field \"parameterization\" must hold one integer 0..2 (enum mrl_param)"; rc = MRL_ERR_FORMAT; }
+        else param = (int)v;
+    }
     mrl_tensor_file_close(f);
     if (rc != MRL_OK) return rc;
-    rc = mrl_material_upload_table_nch(ctx, data.data(), dims, n_ch, scale.data(), out_id);
+    rc = param >= 0 ? mrl_material_upload_table_param(ctx, data.data(), dims, n_ch, scale.data(), param, out_id)
+                    : mrl_material_upload_table_nch(ctx, data.data(), dims, n_ch, scale.data(), out_id);
     if (rc == MRL_OK && out_channels) *out_channels = n_ch;
     return rc;
 }

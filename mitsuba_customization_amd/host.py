@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mrl_generate_pairs", "mrl_generate_materials",
     "mrl_device_alloc", "mrl_device_free", "mrl_copy_to_device", "mrl_copy_to_host", "mrl_host_alloc", "mrl_host_free",
     "mrl_timer_start", "mrl_timer_stop",
-    "mrl_material_upload_table_nch", "mrl_material_load_table_nch", "mrl_material_channels", "mrl_material_param",
+    "mrl_material_upload_table_nch", "mrl_material_upload_table_param", "mrl_material_load_table_nch", "mrl_material_channels", "mrl_material_param",
     "mrl_eval_batch_nch", "mrl_sample_batch_nch", "mrl_eval_pdf_batch_nch", "mrl_eval_sample_batch_nch",
     "mrl_eval_queue_nch", "mrl_sample_queue_nch", "mrl_eval_pdf_queue_nch", "mrl_eval_sample_queue_nch",
     "mrl_tensor_file_open", "mrl_tensor_file_close", "mrl_tensor_file_last_error", "mrl_tensor_file_field_count", "mrl_tensor_file_find",
@@ -130,6 +130,7 @@ def load_library(path: Optional[str] = None):
     L.mrl_timer_start.argtypes = [vp]
     L.mrl_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     L.mrl_material_upload_table_nch.argtypes = [vp, vp, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.mrl_material_upload_table_param.argtypes = [vp, vp, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
     L.mrl_material_load_table_nch.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.mrl_material_channels.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.mrl_material_param.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
@@ -321,6 +322,18 @@ class MerlHip:
         dims = (C.c_int * 3)(*p.shape[1:]); mid = C.c_int()
         sc = None if scale is None else (C.c_double * c)(*scale)
         self._check(self._lib.mrl_material_upload_table_nch(self._ctx, p.ctypes.data, dims, c, sc, C.byref(mid)), "mrl_material_upload_table_nch")
+        return mid.value
+
+    def upload_table_param(self, planar: np.ndarray, param: int, scale: Optional[Sequence[float]] = None) -> int:
+        """planar: (n_channels, n_0, n_1, n_2) f64 indexed by the angles of `param` (PARAM_*); 3 channels = the RGB path.
+        The context's OPT_TABLE_PARAM stays as it is."""
+        p = np.ascontiguousarray(planar, dtype=np.float64)
+        if p.ndim != 4:
+            raise ValueError("upload_table_param needs a (n_channels, n_0, n_1, n_2) array")
+        c = int(p.shape[0])
+        dims = (C.c_int * 3)(*p.shape[1:]); mid = C.c_int()
+        sc = None if scale is None else (C.c_double * c)(*scale)
+        self._check(self._lib.mrl_material_upload_table_param(self._ctx, p.ctypes.data, dims, c, sc, int(param), C.byref(mid)), "mrl_material_upload_table_param")
         return mid.value
 
     def load_table_nch(self, path: str, n_channels: int, scale: Optional[Sequence[float]] = None) -> int:
@@ -707,118 +720,6 @@ class MerlGroup:
         mid = C.c_int()
         self._check(self._lib.mrl_group_material_ggx(self._g, alpha, (C.c_float * 3)(*eta), (C.c_float * 3)(*k), C.byref(mid)), "mrl_group_material_ggx")
         return mid.value
-
-    # ---- n-channel tables ----
-    def upload_table_nch(self, planar: np.ndarray, scale: Optional[Sequence[float]] = None) -> int:
-        """planar: (n_channels, n_th, n_td, n_pd) f64."""
-        p = np.ascontiguousarray(planar, dtype=np.float64)
-        if p.ndim != 4:
-            raise ValueError("upload_table_nch needs a (n_channels, n_th, n_td, n_pd) array")
-        c = int(p.shape[0])
-        dims = (C.c_int * 3)(*p.shape[1:]); mid = C.c_int()
-        sc = None if scale is None else (C.c_double * c)(*scale)
-        self._check(self._lib.mrl_material_upload_table_nch(self._ctx, p.ctypes.data, dims, c, sc, C.byref(mid)), "mrl_material_upload_table_nch")
-        return mid.value
-
-    def load_table_nch(self, path: str, n_channels: int, scale: Optional[Sequence[float]] = None) -> int:
-        sc = None if scale is None else (C.c_double * n_channels)(*scale); mid = C.c_int()
-        self._check(self._lib.mrl_material_load_table_nch(self._ctx, path.encode(), n_channels, sc, C.byref(mid)), "mrl_material_load_table_nch")
-        return mid.value
-
-    def material_channels(self, mid: int) -> int:
-        c = C.c_int()
-        self._check(self._lib.mrl_material_channels(self._ctx, mid, C.byref(c)), "mrl_material_channels")
-        return c.value
-
-    def eval_nch(self, wi, wo, n_channels: int, mat=None, material: int = 0, out=None):
-        n = int(wi.shape[0]); self._prep(wi)
-        out = self._empty(wi, (n, n_channels)) if out is None else out
-        self._check(self._lib.mrl_eval_batch_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
-                                                 _addr(mat, np.int32, None, n, "mat"), material, n, n_channels,
-                                                 _addr(out, np.float32, n_channels, n, "out_values")), "mrl_eval_batch_nch")
-        return out
-
-    def sample_nch(self, wi, u, n_channels: int, mat=None, material: int = 0):
-        n = int(wi.shape[0]); self._prep(wi)
-        wo, pdf, w = self._empty(wi, (n, 3)), self._empty(wi, (n,)), self._empty(wi, (n, n_channels))
-        self._check(self._lib.mrl_sample_batch_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(u, np.float32, 2, n, "u"),
-                                                   _addr(mat, np.int32, None, n, "mat"), material, n, n_channels,
-                                                   _addr(wo, np.float32, 3, n, "out_wo"), _addr(pdf, np.float32, None, n, "out_pdf"),
-                                                   _addr(w, np.float32, n_channels, n, "out_weight")), "mrl_sample_batch_nch")
-        return wo, pdf, w
-
-    def eval_pdf_nch(self, wi, wo, n_channels: int, mat=None, material: int = 0):
-        n = int(wi.shape[0]); self._prep(wi)
-        val, pdf = self._empty(wi, (n, n_channels)), self._empty(wi, (n,))
-        self._check(self._lib.mrl_eval_pdf_batch_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
-                                                     _addr(mat, np.int32, None, n, "mat"), material, n, n_channels,
-                                                     _addr(val, np.float32, n_channels, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf")),
-                    "mrl_eval_pdf_batch_nch")
-        return val, pdf
-
-    def eval_sample_nch(self, wi, wo, u, n_channels: int, mat=None, material: int = 0):
-        """Returns (values[n, C], pdf, wo', pdf', weight'[n, C])."""
-        n = int(wi.shape[0]); self._prep(wi)
-        out = (self._empty(wi, (n, n_channels)), self._empty(wi, (n,)), self._empty(wi, (n, 3)), self._empty(wi, (n,)),
-               self._empty(wi, (n, n_channels)))
-        val, pdf, wo2, pdf2, w = out
-        self._check(self._lib.mrl_eval_sample_batch_nch(
-            self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"), _addr(u, np.float32, 2, n, "u"),
-            _addr(mat, np.int32, None, n, "mat"), material, n, n_channels,
-            _addr(val, np.float32, n_channels, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf"),
-            _addr(wo2, np.float32, 3, n, "out_wo"), _addr(pdf2, np.float32, None, n, "out_pdf2"),
-            _addr(w, np.float32, n_channels, n, "out_weight")), "mrl_eval_sample_batch_nch")
-        return out
-
-    def load_tensor_table(self, path: str, field: Optional[str] = None):
-        """A customized_measurement table stored in a tensor_file container.  Returns (material id, channels)."""
-        mid, ch = C.c_int(), C.c_int()
-        rc = self._lib.mrl_material_load_tensor_table(self._ctx, path.encode(), None if field is None else field.encode(), C.byref(mid), C.byref(ch))
-        if rc != 0:
-            detail = self._lib.mrl_tensor_file_last_error(None).decode() or self._lib.mrl_last_error(self._ctx).decode()
-            raise MerlHipError(rc, "mrl_material_load_tensor_table", detail)
-        return mid.value, ch.value
-
-    def eval_sample_queue_nch(self, wi, wo, u, queue, count, n_channels: int, mat=None, material: int = 0, capacity=None, out=None):
-        """Fused n-channel unit over a wavefront queue; unqueued slots of `out` stay as they are."""
-        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
-        if out is None:
-            out = (self._zeros(wi, (n, n_channels)), self._zeros(wi, (n,)), self._zeros(wi, (n, 3)), self._zeros(wi, (n,)),
-                   self._zeros(wi, (n, n_channels)))
-        val, pdf, wo2, pdf2, w = out
-        self._check(self._lib.mrl_eval_sample_queue_nch(
-            self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"), _addr(u, np.float32, 2, n, "u"),
-            _addr(mat, np.int32, None, n, "mat"), material, q, c, cap, n_channels,
-            _addr(val, np.float32, n_channels, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf"),
-            _addr(wo2, np.float32, 3, n, "out_wo"), _addr(pdf2, np.float32, None, n, "out_pdf2"),
-            _addr(w, np.float32, n_channels, n, "out_weight")), "mrl_eval_sample_queue_nch")
-        return out
-
-    def eval_queue_nch(self, wi, wo, queue, count, n_channels: int, mat=None, material: int = 0, capacity=None, out=None):
-        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
-        out = self._zeros(wi, (n, n_channels)) if out is None else out
-        self._check(self._lib.mrl_eval_queue_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
-                                                 _addr(mat, np.int32, None, n, "mat"), material, q, c, cap, n_channels,
-                                                 _addr(out, np.float32, n_channels, n, "out_values")), "mrl_eval_queue_nch")
-        return out
-
-    def sample_queue_nch(self, wi, u, queue, count, n_channels: int, mat=None, material: int = 0, capacity=None):
-        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
-        wo, pdf, w = self._zeros(wi, (n, 3)), self._zeros(wi, (n,)), self._zeros(wi, (n, n_channels))
-        self._check(self._lib.mrl_sample_queue_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(u, np.float32, 2, n, "u"),
-                                                   _addr(mat, np.int32, None, n, "mat"), material, q, c, cap, n_channels,
-                                                   _addr(wo, np.float32, 3, n, "out_wo"), _addr(pdf, np.float32, None, n, "out_pdf"),
-                                                   _addr(w, np.float32, n_channels, n, "out_weight")), "mrl_sample_queue_nch")
-        return wo, pdf, w
-
-    def eval_pdf_queue_nch(self, wi, wo, queue, count, n_channels: int, mat=None, material: int = 0, capacity=None):
-        n = int(wi.shape[0]); q, c, cap = self._queue(wi, queue, count, capacity)
-        val, pdf = self._zeros(wi, (n, n_channels)), self._zeros(wi, (n,))
-        self._check(self._lib.mrl_eval_pdf_queue_nch(self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"),
-                                                     _addr(mat, np.int32, None, n, "mat"), material, q, c, cap, n_channels,
-                                                     _addr(val, np.float32, n_channels, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf")),
-                    "mrl_eval_pdf_queue_nch")
-        return val, pdf
 
     def release_material(self, mid: int):
         self._check(self._lib.mrl_group_material_release(self._g, mid), "mrl_group_material_release")
