@@ -24,6 +24,15 @@ extern "C" int mrl_material_upload_table_nch(mrl_ctx *, const double *planar, co
     return MRL_OK;
 }
 
+// a file that names its parameterisation goes through the explicit-parameterisation upload
+static int g_param_uploads = 0;
+extern "C" int mrl_material_upload_table_param(mrl_ctx *c, const double *planar, const int dims[3], int n_channels, const double *scale, int param, int *out_id)
+{
+    if (param < 0 || param > 2) std::abort();                     // the reader validates the field before it gets here
+    ++g_param_uploads;
+    return mrl_material_upload_table_nch(c, planar, dims, n_channels, scale, out_id);
+}
+
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
 
@@ -34,23 +43,24 @@ static std::vector<unsigned char> good_file()
     std::vector<unsigned char> b;
     put(b, "tensor_file", 12);
     const uint8_t ver[2] = { 1, 0 }; put(b, ver, 2);
-    const uint32_t nf = 3; put(b, &nf, 4);
+    const uint32_t nf = 4; put(b, &nf, 4);
     struct F { const char *name; uint16_t ndim; uint8_t dtype; std::vector<uint64_t> shape; size_t bytes; };
-    const F fs[3] = { { "table", 4, 10, { 2, 3, 2, 4 }, 2 * 3 * 2 * 4 * 4 }, { "scale", 1, 11, { 2 }, 16 }, { "description", 1, 1, { 9 }, 9 } };
+    const F fs[4] = { { "table", 4, 10, { 2, 3, 2, 4 }, 2 * 3 * 2 * 4 * 4 }, { "scale", 1, 11, { 2 }, 16 }, { "description", 1, 1, { 9 }, 9 },
+                      { "parameterization", 0, 1, {}, 1 } };
     size_t head = b.size();
     for (const F &f : fs) head += 2 + std::strlen(f.name) + 2 + 1 + 8 + 8 * f.ndim;
     uint64_t off = (head + 7) / 8 * 8;
     std::vector<uint64_t> offs;
     for (const F &f : fs) { offs.push_back(off); off = (off + f.bytes + 7) / 8 * 8; }
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         const F &f = fs[i];
         const uint16_t nl = (uint16_t)std::strlen(f.name); put(b, &nl, 2); put(b, f.name, nl);
         put(b, &f.ndim, 2); put(b, &f.dtype, 1); put(b, &offs[i], 8);
         for (uint64_t e : f.shape) put(b, &e, 8);
     }
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         b.resize(offs[i], 0);
-        for (size_t k = 0; k < fs[i].bytes; ++k) b.push_back((unsigned char)(k * 7 + i));
+        for (size_t k = 0; k < fs[i].bytes; ++k) b.push_back(i == 3 ? (unsigned char)1 : (unsigned char)(k * 7 + i));    // parameterization = 1
     }
     return b;
 }
@@ -94,18 +104,18 @@ int main(int argc, char **argv)
 {
     const std::string path = argc > 1 ? argv[1] : "/tmp/tensor_fuzz.bsdf";
     const std::vector<unsigned char> good = good_file();
-    if (probe(path, good) != MRL_OK || g_uploads != 1) { std::fprintf(stderr, "the well-formed file was rejected\n"); return 1; }
+    if (probe(path, good) != MRL_OK || g_uploads != 1 || g_param_uploads != 1) { std::fprintf(stderr, "the well-formed file was rejected\n"); return 1; }
     int opened = 0, refused = 0;
     for (int round = 0; round < 6000; ++round) {
         std::vector<unsigned char> b = good;
         const int kind = (int)(rnd() % 5);
         if (kind == 0) {                                               // flip 1..4 bytes of the header / field table
-            for (int k = 0, m = 1 + (int)(rnd() % 4); k < m; ++k) b[rnd() % 120] ^= (unsigned char)(1u << (rnd() % 8));
+            for (int k = 0, m = 1 + (int)(rnd() % 4); k < m; ++k) b[rnd() % 150] ^= (unsigned char)(1u << (rnd() % 8));
         } else if (kind == 1) {                                        // truncate anywhere
             b.resize(rnd() % b.size());
         } else if (kind == 2) {                                        // overwrite 8 bytes of the field table with a huge or random value
             const uint64_t v = (rnd() % 2) ? ~0ull >> (rnd() % 40) : rnd();
-            std::memcpy(&b[18 + rnd() % 100], &v, 8);
+            std::memcpy(&b[18 + rnd() % 130], &v, 8);
         } else if (kind == 3) {                                        // random byte anywhere
             b[rnd() % b.size()] = (unsigned char)rnd();
         } else {                                                       // grow the field count
