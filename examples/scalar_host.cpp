@@ -1,0 +1,126 @@
+// scalar_host.cpp — a C++ host that makes ONE-unit calls from many threads, the way the render threads of a stock per-ray
+// integrator call a BSDF plugin:  mrl_scalar_eval_sample(ctx, material, wi, wo, u, out[11]).
+//
+//   scalar_host [--threads T] [--calls K] [--table file.binary] [--churn]
+//
+// It (1) checks every answer bit for bit against mrl_eval_sample_batch on the same inputs, (2) times the calls — one
+// thread alone (the latency of a call) and T threads together (what a render sees) —, (3) with --churn lets another
+// thread upload and release tables and flip an option meanwhile (the calls must keep returning the right numbers: the
+// service pauses around every change).  Prints one JSON line; exit code 0 = all answers right.
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "merl_hip.h"
+
+static uint64_t mix(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static float uni(uint64_t &s) { s = mix(s); return (float)(s >> 40) * (1.0f / 16777216.0f); }
+static void hemi(uint64_t &s, float v[3])
+{
+    const float z = 0.02f + 0.98f * uni(s), ph = 6.2831853f * uni(s), r = std::sqrt(1.0f - z * z);
+    v[0] = r * std::cos(ph); v[1] = r * std::sin(ph); v[2] = z;
+}
+
+#define CHECK(expr)                                                                                          \
+    do { const int rc_ = (expr); if (rc_ != MRL_OK) { std::fprintf(stderr, "%s: %s (%s)\n", #expr, mrl_strerror(rc_), mrl_last_error(ctx)); return 2; } } while (0)
+
+int main(int argc, char **argv)
+{
+    int threads = 16; long calls = 20000; bool churn = false; const char *table = nullptr;
+    for (int i = 1; i < argc; ++i) {
+        if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--calls") && i + 1 < argc) calls = std::atol(argv[++i]);
+        else if (!std::strcmp(argv[i], "--table") && i + 1 < argc) table = argv[++i];
+        else if (!std::strcmp(argv[i], "--churn")) churn = true;
+        else { std::fprintf(stderr, "usage: scalar_host [--threads T] [--calls K] [--table file.binary] [--churn]\n"); return 64; }
+    }
+    mrl_ctx *ctx = nullptr;
+    { const int rc = mrl_init(0, &ctx); if (rc != MRL_OK) { std::fprintf(stderr, "mrl_init: %s\n", mrl_strerror(rc)); return 2; } }
+    // materials: a table (from a file, or a small smooth synthetic one) and a GGX conductor
+    const int dims[3] = { 24, 20, 36 };
+    std::vector<double> planar((size_t)3 * dims[0] * dims[1] * dims[2]);
+    for (size_t i = 0; i < planar.size(); ++i) planar[i] = 40.0 + 30.0 * std::sin(0.37 * (double)(i % 9973)) + 0.001 * (double)(i % 4099);
+    const double scale[3] = { 0.01, 0.012, 0.016 };
+    int tab = -1, ggx = -1;
+    if (table) CHECK(mrl_material_load_merl(ctx, table, &tab));
+    else CHECK(mrl_material_upload_table(ctx, planar.data(), dims, scale, &tab));
+    const float eta[3] = { 0.143f, 0.375f, 1.442f }, kk[3] = { 3.983f, 2.386f, 1.603f };
+    CHECK(mrl_material_ggx(ctx, 0.2f, eta, kk, &ggx));
+
+    // the reference answers: one batch call over every request of every thread
+    const size_t n = (size_t)threads * (size_t)calls;
+    std::vector<float> wi(3 * n), wo(3 * n), u(2 * n), want(11 * n);
+    std::vector<int32_t> mat(n);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t s = 0x5EEDull * (i + 1);
+        hemi(s, &wi[3 * i]); hemi(s, &wo[3 * i]); u[2 * i] = uni(s); u[2 * i + 1] = uni(s);
+        mat[i] = (i % 5 == 4) ? ggx : tab;
+        if (i % 97 == 0) wi[3 * i + 2] = -wi[3 * i + 2];                // below the horizon: zeros
+    }
+    {
+        std::vector<float> rgb(3 * n), pdf(n), wo2(3 * n), pdf2(n), w(3 * n);
+        CHECK(mrl_eval_sample_batch(ctx, wi.data(), wo.data(), u.data(), mat.data(), 0, n, rgb.data(), pdf.data(), wo2.data(), pdf2.data(), w.data()));
+        CHECK(mrl_synchronize(ctx));
+        for (size_t i = 0; i < n; ++i) {
+            float *o = &want[11 * i];
+            std::memcpy(o, &rgb[3 * i], 12); o[3] = pdf[i]; std::memcpy(o + 4, &wo2[3 * i], 12); o[7] = pdf2[i]; std::memcpy(o + 8, &w[3 * i], 12);
+        }
+    }
+    using Clock = std::chrono::steady_clock;
+    std::atomic<long> wrong{ 0 }, failed{ 0 };
+    auto worker = [&](int t, long k0, long k1) {
+        for (long k = k0; k < k1; ++k) {
+            const size_t i = (size_t)t * (size_t)calls + (size_t)k;
+            float out[11];
+            const int rc = mrl_scalar_eval_sample(ctx, mat[i], &wi[3 * i], &wo[3 * i], &u[2 * i], out);
+            if (rc != MRL_OK) { ++failed; continue; }
+            if (std::memcmp(out, &want[11 * i], sizeof out) != 0) ++wrong;
+        }
+    };
+    // 1. one thread alone: the latency of a call (after a short warm-up that starts the service)
+    worker(0, 0, std::min<long>(calls, 200));
+    const long solo = std::min<long>(calls, 5000);
+    auto t0 = Clock::now();
+    worker(0, 0, solo);
+    const double solo_us = std::chrono::duration<double, std::micro>(Clock::now() - t0).count() / (double)solo;
+    // 2. all threads together (+ the churn thread)
+    std::atomic<bool> stop{ false };
+    long churn_rounds = 0;
+    std::thread churner;
+    if (churn) churner = std::thread([&] {
+        while (!stop.load()) {
+            int extra = -1;
+            if (mrl_material_upload_table(ctx, planar.data(), dims, scale, &extra) != MRL_OK) { ++failed; break; }
+            (void)mrl_set_option(ctx, MRL_OPT_BLOCK_MAP, (int)(churn_rounds & 1));      // any option change pauses the service
+            if (mrl_material_release(ctx, extra) != MRL_OK) { ++failed; break; }
+            ++churn_rounds;
+            std::this_thread::sleep_for(std::chrono::microseconds(300));
+        }
+    });
+    t0 = Clock::now();
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) pool.emplace_back(worker, t, 0L, calls);
+    for (auto &th : pool) th.join();
+    const double all_s = std::chrono::duration<double>(Clock::now() - t0).count();
+    stop.store(true);
+    if (churner.joinable()) churner.join();
+    // an id the scalar path refuses
+    float out[11];
+    const int bad = mrl_scalar_eval_sample(ctx, 99, &wi[0], &wo[0], &u[0], out);
+    std::printf("{\"threads\": %d, \"calls_per_thread\": %ld, \"solo_us_per_call\": %.3f, \"all_threads_Mcalls_per_s\": %.4f, "
+                "\"all_threads_us_per_call_amortised\": %.4f, \"wrong\": %ld, \"failed\": %ld, \"churn_rounds\": %ld, \"unknown_id_status\": %d}\n",
+                threads, calls, solo_us, (double)n / all_s / 1e6, all_s * 1e6 / (double)n, wrong.load(), failed.load(), churn_rounds, bad);
+    mrl_destroy(ctx);
+    return (wrong.load() == 0 && failed.load() == 0 && bad == MRL_ERR_MATERIAL) ? 0 : 1;
+}

@@ -18,6 +18,7 @@
  *   mrl_eval_pdf_batch                     M3 BSDF::eval_pdf (one table lookup for both; what a light-sampling
  *                                          integrator calls for its MIS weight)
  *   mrl_eval_sample_batch                  the fused eval + pdf + sample unit (BASELINE metric)
+ *   mrl_scalar_eval_sample                 ONE virtual BSDF::eval / sample / pdf call of a per-ray integrator
  *   mrl_*_queue                            the same calls over a wavefront integrator's material queue
  *                                          (the caller side of the path)
  *   mrl_material_release / mrl_memory_info plugin destructor (the host drops its last ref<BSDF>) / no counterpart
@@ -170,6 +171,17 @@ int mrl_eval_pdf_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int
 int mrl_eval_sample_batch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u,
                           const int32_t *mat, int32_t single_id, size_t n,
                           float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight);
+
+/* ---- one-unit calls: the virtual BSDF::eval / sample / pdf of a stock per-ray integrator ----
+ * The same fused unit for ONE (wi, wo, u), for callers that cannot batch.  out[11] = rgb[3] pdf wo'[3] pdf' weight'[3];
+ * the numbers are those mrl_eval_sample_batch returns for the unit (the service runs the batch kernels' own per-lane
+ * functions).  No launch and no stream synchronisation on the call path: the caller writes its request into a mailbox in
+ * pinned host memory and a resident wave — one lane per calling thread, so concurrent callers are answered side by
+ * side — writes the result back.  Service instances have a bounded lifetime (500 us) and are relaunched by the callers,
+ * so a device-wide synchronisation elsewhere in the process waits a bounded time and nothing spins once calls stop.
+ * Thread-safe and lock-free between callers; uploads, releases and option changes wait for calls in flight.
+ * Table materials with three channels and GGX materials; other ids are MRL_ERR_MATERIAL. */
+int mrl_scalar_eval_sample(mrl_ctx *ctx, int32_t material, const float wi[3], const float wo[3], const float u[2], float out[11]);
 
 /* ---- n-channel tables: customized_measurement beyond RGB (monochrome, RGB + alpha, spectral bins; SURVEY.md §8f
  * item 3).  Same MERL parameterisation, same transform and trilinear blend; a texel has n_channels values, 1..32.

@@ -67,6 +67,14 @@ def build_all(force: bool = False):
                                "-o", gh, gh_src, "-L", LIBDIR, "-lmerl_hip", "-Wl,-rpath,$ORIGIN"])
     if os.path.exists(gh):
         outs.append(gh)
+    # a host that makes one-unit calls from many threads (examples/scalar_host.cpp): the scalar service end to end
+    sh_src = os.path.join(os.path.dirname(PKG), "examples", "scalar_host.cpp")
+    sh = os.path.join(LIBDIR, "scalar_host")
+    if os.path.exists(sh_src) and (force or _stale(sh, [sh_src, os.path.join(os.path.dirname(PKG), "include", "merl_hip.h")])):
+        subprocess.check_call([CXX, "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", os.path.join(os.path.dirname(PKG), "include"),
+                               "-o", sh, sh_src, "-L", LIBDIR, "-lmerl_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"])
+    if os.path.exists(sh):
+        outs.append(sh)
     return outs
 
 

@@ -3,17 +3,14 @@
 // plumbing.  Host C++ only; everything that computes goes through the C ABI (include/merl_hip.h).
 //
 // Threading: the renderers call eval()/sample()/pdf() on a const BSDF from all render threads
-// (SURVEY.md §8b).  A libmerl_hip context serialises its callers (one GPU round trip each), so scalar calls are COMBINED:
-// a calling thread posts its request; whichever thread finds no round in flight becomes the
-// leader, takes every request posted so far (its own and other threads', up to 256), runs them
-// as ONE fused eval+sample batch on pinned, device-mapped memory (zero copy), and hands the
-// results back.  One thread alone pays the launch + sync latency (~16 us) per call; T render
-// threads share it, so throughput grows with T instead of serialising on a mutex.  Scalar calls
-// remain plumbing for existing integrators; the fast path is the batch / wavefront entry
-// points, which take whole arrays.
+// (SURVEY.md §8b).  A scalar call goes to the library's one-unit call service (mrl_scalar_eval_sample):
+// the calling thread writes its request into a mailbox slot of its own in pinned memory and a resident
+// wave on the GPU — one lane per calling thread — answers it; no kernel launch, no stream synchronisation
+// and no lock shared between render threads on the call path.  A call still costs a PCIe round trip plus
+// the evaluation (~10 us alone, ~1.5 us amortised over 16 threads: INTEGRATION.md §2) against ~0.3 us for a
+// CPU plugin — scalar calls remain plumbing for existing integrators; the fast path is the batch /
+// wavefront entry points, which take whole arrays.
 #pragma once
-#include <atomic>
-#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -23,8 +20,6 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
-#include <thread>
-#include <vector>
 
 #include "../../../include/merl_hip.h"
 
@@ -58,19 +53,8 @@ struct ContextKey {
     }
 };
 
-// One scalar plugin call: inputs, the material it addresses, and every output of the fused unit.
-struct ScalarRequest {
-    float wi[3] = { 0.0f, 0.0f, 1.0f }, wo[3] = { 0.0f, 0.0f, 1.0f }, u[2] = { 0.5f, 0.5f };
-    int material = 0;
-    float rgb[3], pdf, wo2[3], pdf2, weight[3];
-    std::atomic<bool> done{ false };        // set by the round's leader, last thing it does with the request
-    int status = MRL_OK;
-    std::string error;
-};
-
 class Context {
 public:
-    static constexpr size_t kSlots = 256;          // requests per combined round
     explicit Context(const ContextKey &key) : m_key(key)
     {
         int rc = mrl_init(key.device, &m_ctx);
@@ -83,14 +67,10 @@ public:
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_NODE, key.node), "mrl_set_option(node)");
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_DISK_MAP, key.disk_map), "mrl_set_option(disk_map)");
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_SAMPLING, key.sampling), "mrl_set_option(sampling)");
-        // scalar-call staging for kSlots requests: wi[3K] wo[3K] u[2K] mat[K] | rgb[3K] pdf[K] wo2[3K] pdf2[K] weight[3K]
-        void *p = nullptr;
-        check(m_ctx, mrl_host_alloc(m_ctx, 20 * kSlots * sizeof(float), &p), "mrl_host_alloc");
-        m_pin = static_cast<float *>(p);
     }
     ~Context()
     {
-        if (m_ctx) { mrl_host_free(m_ctx, m_pin); mrl_destroy(m_ctx); }
+        if (m_ctx) mrl_destroy(m_ctx);
     }
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
@@ -133,36 +113,20 @@ public:
         return m_resident.size();
     }
 
-    // Post one scalar request and return when its outputs are filled in (throws what the round's call reported).
-    // A GPU round lasts ~16 us, so a waiting thread spins for about that long before it sleeps on the condition
-    // variable (a render thread has nothing else to do until its BSDF value arrives).
-    void submit(ScalarRequest &r)
+    // One virtual BSDF call = one fused unit through the library's scalar service (include/merl_hip.h, "one-unit calls"):
+    // the request goes into a mailbox in pinned memory, a resident wave answers it — no launch, no synchronisation, no lock
+    // shared with the other render threads, whose calls are answered side by side by the wave's other lanes.
+    // out[11] = rgb[3] pdf wo'[3] pdf' weight'[3].
+    void scalar(int material, const float wi[3], const float *wo, const float *u, float out[11])
     {
-        {
-            std::lock_guard<std::mutex> lk(m_post_mutex);
-            m_posted.push_back(&r);
+        static const float up[3] = { 0.0f, 0.0f, 1.0f }, centre[2] = { 0.5f, 0.5f };
+        const int rc = mrl_scalar_eval_sample(m_ctx, material, wi, wo ? wo : up, u ? u : centre, out);
+        if (rc != MRL_OK) {
+            std::string what = std::string("scalar call: ") + mrl_strerror(rc);
+            const char *d = mrl_last_error(m_ctx);
+            if (d && *d) what += std::string(" (") + d + ")";
+            throw Error(rc, what);
         }
-        for (unsigned spins = 0; !r.done.load(std::memory_order_acquire); ++spins) {
-            if (!m_round_in_flight.load(std::memory_order_relaxed)) {
-                std::unique_lock<std::mutex> lk(m_post_mutex);
-                if (m_round_in_flight.load(std::memory_order_relaxed) || r.done.load(std::memory_order_acquire)) continue;
-                // lead a round over everything posted so far (this thread's request is among it or already served)
-                m_round_in_flight.store(true, std::memory_order_relaxed);
-                const size_t k = m_posted.size() < kSlots ? m_posted.size() : kSlots;
-                std::vector<ScalarRequest *> round(m_posted.begin(), m_posted.begin() + (std::ptrdiff_t)k);
-                m_posted.erase(m_posted.begin(), m_posted.begin() + (std::ptrdiff_t)k);
-                lk.unlock();
-                run_round(round);                       // ends by publishing done on every request: they are gone after that
-                lk.lock();
-                m_round_in_flight.store(false, std::memory_order_relaxed);
-                m_round_done.notify_all();
-                continue;
-            }
-            if (spins < kSpinsBeforeSleep) { relax(); continue; }
-            std::unique_lock<std::mutex> lk(m_post_mutex);
-            if (m_round_in_flight.load(std::memory_order_relaxed) && !r.done.load(std::memory_order_acquire)) m_round_done.wait(lk);
-        }
-        if (r.status != MRL_OK) throw Error(r.status, r.error);
     }
 
     static std::shared_ptr<Context> get(const ContextKey &key)
@@ -179,63 +143,10 @@ public:
     }
 
 private:
-    // one fused eval+sample launch over the round's requests, per-request material ids
-    void run_round(const std::vector<ScalarRequest *> &round) noexcept
-    {
-        const size_t k = round.size(), K = kSlots;
-        float *wi = m_pin, *wo = wi + 3 * K, *u = wo + 3 * K;
-        int32_t *mat = reinterpret_cast<int32_t *>(u + 2 * K);
-        float *rgb = u + 2 * K + K, *pdf = rgb + 3 * K, *wo2 = pdf + K, *pdf2 = wo2 + 3 * K, *weight = pdf2 + K;
-        for (size_t i = 0; i < k; ++i) {
-            const ScalarRequest &q = *round[i];
-            for (int c = 0; c < 3; ++c) { wi[3 * i + c] = q.wi[c]; wo[3 * i + c] = q.wo[c]; }
-            u[2 * i] = q.u[0]; u[2 * i + 1] = q.u[1];
-            mat[i] = q.material;
-        }
-        int rc;
-        std::string what;
-        {
-            std::lock_guard<std::mutex> call(m_mutex);      // one call sequence (launch + sync) at a time
-            rc = mrl_eval_sample_batch(m_ctx, wi, wo, u, mat, 0, k, rgb, pdf, wo2, pdf2, weight);
-            if (rc == MRL_OK) rc = mrl_synchronize(m_ctx);
-            if (rc != MRL_OK) {
-                what = std::string("scalar call: ") + mrl_strerror(rc);
-                const char *d = mrl_last_error(m_ctx);
-                if (d && *d) what += std::string(" (") + d + ")";
-            }
-        }
-        for (size_t i = 0; i < k; ++i) {
-            ScalarRequest &q = *round[i];
-            q.status = rc;
-            if (rc != MRL_OK) {
-                q.error = what;
-            } else {
-                for (int c = 0; c < 3; ++c) { q.rgb[c] = rgb[3 * i + c]; q.wo2[c] = wo2[3 * i + c]; q.weight[c] = weight[3 * i + c]; }
-                q.pdf = pdf[i]; q.pdf2 = pdf2[i];
-            }
-            q.done.store(true, std::memory_order_release);   // the owner may return and destroy q from here on
-        }
-    }
-
-    static void relax()
-    {
-#if defined(__x86_64__) || defined(__i386__)
-        __builtin_ia32_pause();
-#else
-        std::this_thread::yield();
-#endif
-    }
-    static constexpr unsigned kSpinsBeforeSleep = 4000;      // ~40 ns per pause: a few GPU rounds
-
     ContextKey m_key;
     mrl_ctx *m_ctx = nullptr;
     std::mutex m_mutex;                    // keeps a launch and its synchronize together (the C context only locks per call)
     std::map<std::string, std::weak_ptr<Resident>> m_resident;     // guarded by m_mutex
-    float *m_pin = nullptr;
-    std::mutex m_post_mutex;               // guards the three members below
-    std::condition_variable m_round_done;
-    std::vector<ScalarRequest *> m_posted;
-    std::atomic<bool> m_round_in_flight{ false };
 };
 
 // Canonical name of a table file for the residency map: the resolved absolute path when the file exists.
@@ -307,37 +218,33 @@ public:
     int id() const { return m_id; }
     mrl_ctx *ctx() const { return m_ctx->raw(); }
 
-    // ---- scalar calls: combined with the other render threads' calls into one GPU round ----
+    // ---- scalar calls (the virtual per-ray BSDF::eval / sample / pdf): one fused unit each, through the scalar service ----
     void eval1(const float wi[3], const float wo[3], float rgb[3]) const
     {
-        ScalarRequest r;
-        fill(r, wi, wo, nullptr);
-        m_ctx->submit(r);
-        for (int k = 0; k < 3; ++k) rgb[k] = r.rgb[k];
+        float o[11];
+        m_ctx->scalar(m_id, wi, wo, nullptr, o);
+        for (int k = 0; k < 3; ++k) rgb[k] = o[k];
     }
     float pdf1(const float wi[3], const float wo[3]) const
     {
-        ScalarRequest r;
-        fill(r, wi, wo, nullptr);
-        m_ctx->submit(r);
-        return r.pdf;
+        float o[11];
+        m_ctx->scalar(m_id, wi, wo, nullptr, o);
+        return o[3];
     }
     void sample1(const float wi[3], const float u[2], float wo[3], float &pdf, float weight[3]) const
     {
-        ScalarRequest r;
-        fill(r, wi, nullptr, u);
-        m_ctx->submit(r);
-        for (int k = 0; k < 3; ++k) { wo[k] = r.wo2[k]; weight[k] = r.weight[k]; }
-        pdf = r.pdf2;
+        float o[11];
+        m_ctx->scalar(m_id, wi, nullptr, u, o);
+        for (int k = 0; k < 3; ++k) { wo[k] = o[4 + k]; weight[k] = o[8 + k]; }
+        pdf = o[7];
     }
     // eval + pdf of the same pair (Mitsuba 3's eval_pdf)
     void eval_pdf1(const float wi[3], const float wo[3], float rgb[3], float &pdf) const
     {
-        ScalarRequest r;
-        fill(r, wi, wo, nullptr);
-        m_ctx->submit(r);
-        for (int k = 0; k < 3; ++k) rgb[k] = r.rgb[k];
-        pdf = r.pdf;
+        float o[11];
+        m_ctx->scalar(m_id, wi, wo, nullptr, o);
+        for (int k = 0; k < 3; ++k) rgb[k] = o[k];
+        pdf = o[3];
     }
 
     // ---- batch / wavefront calls: host or device arrays, n units (see include/merl_hip.h) ----
@@ -382,13 +289,6 @@ public:
     }
 
 private:
-    void fill(ScalarRequest &r, const float wi[3], const float *wo, const float *u) const
-    {
-        r.material = m_id;
-        for (int k = 0; k < 3; ++k) { r.wi[k] = wi[k]; if (wo) r.wo[k] = wo[k]; }
-        if (u) { r.u[0] = u[0]; r.u[1] = u[1]; }
-    }
-
     Material(std::shared_ptr<Context> ctx, std::shared_ptr<Context::Resident> res)
         : m_ctx(std::move(ctx)), m_res(std::move(res)), m_id(m_res->id) {}
 

@@ -13,12 +13,14 @@
 #include <thread>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "merl_kernels.hpp"
+#include "merl_scalar_host.hpp"
 
 namespace {
 
@@ -149,6 +151,21 @@ struct HostPipe {
     int threads = -1;                                // workers the pool was started with
 };
 
+// the device side of the one-unit call service (merl_scalar_host.hpp): where the mailbox lives and how an instance of
+// the service kernel is put on its own stream
+struct ScalarDevice {
+    mrl_ctx *ctx = nullptr;
+    mrl::ScalarBoard *b = nullptr;           // pinned, coherent host memory; nullptr until the first scalar call
+    mrl::ScalarBoard *b_dev = nullptr;       // the same memory as the device addresses it
+    hipStream_t stream = nullptr;            // non-blocking: batch launches on the context's stream never queue behind an instance
+    uint64_t lifetime_ticks = 50000;         // 500 us of the 100 MHz wall clock
+    std::atomic<bool> ok{ true };
+    mrl::ScalarBoard *board() { return b; }
+    bool launch(uint32_t gen);
+    bool healthy() { return ok.load(std::memory_order_relaxed); }
+};
+using ScalarSvc = mrl::ScalarService<ScalarDevice>;
+
 struct mrl_ctx {
     // every entry point that touches the context takes this lock: calls from several host threads are safe and serialise
     // (device-pointer calls only enqueue, so the lock is held for microseconds; host-array calls hold it for their duration)
@@ -183,6 +200,8 @@ struct mrl_ctx {
     HostPipe pipe;
     void *d_stage = nullptr;
     size_t d_stage_bytes = 0;
+    ScalarDevice scalar_dev;
+    std::atomic<ScalarSvc *> scalar{ nullptr };      // created by the first mrl_scalar_eval_sample
     std::string last_error;
 };
 
@@ -294,6 +313,19 @@ mrl::MaterialDev tombstone_dev(const mrl_ctx *ctx)
     return d;
 }
 
+// Whoever changes what a running service instance reads (the material array, the tables behind it, the options) holds one
+// of these: no scalar call is in flight and no instance is running while it lives (merl_scalar_host.hpp, "writer").
+struct ScalarPause {
+    ScalarSvc *svc;
+    explicit ScalarPause(mrl_ctx *ctx) : svc(ctx->scalar.load(std::memory_order_acquire))
+    {
+        if (svc && !svc->pause()) ctx->scalar_dev.ok.store(false, std::memory_order_relaxed);
+    }
+    ~ScalarPause() { if (svc) svc->resume(); }
+    ScalarPause(const ScalarPause &) = delete;
+    ScalarPause &operator=(const ScalarPause &) = delete;
+};
+
 // MRL_ERR_OOM when `need` more bytes of material data would exceed the context's budget or the device's free memory
 int budget_check(mrl_ctx *ctx, size_t need)
 {
@@ -310,6 +342,7 @@ int budget_check(mrl_ctx *ctx, size_t need)
 // puts a finished material into the lowest released slot (or a new one) and refreshes the device array
 int place_material(mrl_ctx *ctx, const MaterialHost &m, int *out_id)
 {
+    const ScalarPause quiet(ctx);                 // the material vector and the device array change under a running service otherwise
     size_t slot = ctx->materials.size();
     for (size_t i = 0; i < ctx->materials.size(); ++i)
         if (ctx->materials[i].released) { slot = i; break; }
@@ -853,7 +886,80 @@ int read_table_file_nch(mrl_ctx *ctx, const char *path, int n_ch, std::vector<do
 
 } // namespace
 
+bool ScalarDevice::launch(uint32_t gen)
+{
+    // called by a scalar caller between enter() and leave(): no writer is active, the context's state is stable
+    if (hipSetDevice(ctx->device) != hipSuccess) { (void)hipGetLastError(); ok.store(false, std::memory_order_relaxed); return false; }
+    mrl::ScalarArgs a;
+    a.materials = ctx->d_materials;
+    a.n_materials = (int)ctx->materials.size();
+    a.safe = tombstone_dev(ctx);
+    a.opts = ctx->opts;
+    a.board = b_dev;
+    a.gen = gen;
+    a.max_polls = 1u << 20;
+    a.lifetime_ticks = lifetime_ticks;
+    if (mrl::launch_scalar_service(a, stream) != hipSuccess) { (void)hipGetLastError(); ok.store(false, std::memory_order_relaxed); return false; }
+    return true;
+}
+
+namespace {
+
+// first scalar call of a context: the mailbox (pinned, coherent, device-mapped), the service's own stream, the protocol object
+int scalar_open(mrl_ctx *ctx)
+{
+    MRL_GUARD(ctx);
+    if (ctx->scalar.load(std::memory_order_acquire)) return MRL_OK;
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_dummy(ctx);
+    if (rc != MRL_OK) return rc;
+    ScalarDevice &d = ctx->scalar_dev;
+    d.ctx = ctx;
+    if (!d.b) {
+        MRL_ALLOC(ctx, hipHostMalloc((void **)&d.b, sizeof(mrl::ScalarBoard), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(d.b, 0, sizeof(mrl::ScalarBoard));
+        MRL_HIP(ctx, hipHostGetDevicePointer((void **)&d.b_dev, d.b, 0));
+    }
+    if (!d.stream) MRL_HIP(ctx, hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    long life_us = 500;                                          // bounded lifetime of one service instance
+    if (const char *e = std::getenv("MRL_SCALAR_LIFETIME_US")) { const long v = std::atol(e); if (v >= 20 && v <= 100000) life_us = v; }
+    d.lifetime_ticks = (uint64_t)life_us * 100;
+    ScalarSvc *svc = new (std::nothrow) ScalarSvc(&d, std::chrono::microseconds(life_us));
+    if (!svc) return fail(ctx, MRL_ERR_OOM, "scalar service");
+    ctx->scalar.store(svc, std::memory_order_release);
+    return MRL_OK;
+}
+
+} // namespace
+
 extern "C" {
+
+int mrl_scalar_eval_sample(mrl_ctx *ctx, int32_t material, const float wi[3], const float wo[3], const float u[2], float out[11])
+{
+    if (!ctx || !wi || !wo || !u || !out) return MRL_ERR_INVALID;
+    ScalarSvc *svc = ctx->scalar.load(std::memory_order_acquire);
+    if (!svc) {
+        const int rc = scalar_open(ctx);
+        if (rc != MRL_OK) return rc;
+        svc = ctx->scalar.load(std::memory_order_acquire);
+    }
+    const int slot = svc->enter();                               // from here to leave() no upload / release / option change runs
+    int rc = MRL_OK, st = mrl::SCALAR_OK;
+    if (material < 0 || (size_t)material >= ctx->materials.size() || ctx->materials[(size_t)material].released ||
+        !mrl::kind_is_rgb_path(ctx->materials[(size_t)material].dev.kind))
+        rc = MRL_ERR_MATERIAL;
+    else if ((st = svc->roundtrip(slot, material, wi, wo, u, out)) != mrl::SCALAR_OK)
+        rc = MRL_ERR_HIP;
+    svc->leave(slot);
+    if (rc != MRL_OK) {
+        MRL_GUARD(ctx);
+        (void)fail(ctx, rc, rc == MRL_ERR_MATERIAL ? "scalar call: unknown material id (or not an RGB material)"
+                            : st == mrl::SCALAR_LAUNCH_FAILED ? "scalar call: the service kernel could not be launched"
+                                                               : "scalar call: the service kernel did not answer");
+    }
+    return rc;
+}
+
 
 const char *mrl_strerror(int status)
 {
@@ -907,6 +1013,12 @@ int mrl_destroy(mrl_ctx *ctx)
 {
     if (!ctx) return MRL_OK;
     (void)hipSetDevice(ctx->device);
+    if (ScalarSvc *svc = ctx->scalar.load(std::memory_order_acquire)) {
+        (void)svc->pause();                                      // no caller inside, the running instance told to stop
+        if (ctx->scalar_dev.stream) { (void)hipStreamSynchronize(ctx->scalar_dev.stream); (void)hipStreamDestroy(ctx->scalar_dev.stream); }
+        delete svc;
+        if (ctx->scalar_dev.b) (void)hipHostFree(ctx->scalar_dev.b);
+    }
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &m : ctx->materials) { if (m.d_texels) (void)hipFree(m.d_texels); if (m.d_sampling) (void)hipFree(m.d_sampling); }
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
@@ -930,6 +1042,7 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
 {
     if (!ctx) return MRL_ERR_INVALID;
     MRL_GUARD(ctx);
+    const ScalarPause quiet(ctx);                 // a service instance carries the options it was launched with
     switch (option) {
         case MRL_OPT_LOOKUP:   if (value < 0 || value > 1) break; ctx->opts.lookup = value; return MRL_OK;
         case MRL_OPT_NODE:     if (value < 0 || value > 1) break; ctx->opts.node = value; return MRL_OK;
@@ -1061,6 +1174,7 @@ int mrl_material_release(mrl_ctx *ctx, int id)
     if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released)
         return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
     MRL_HIP(ctx, hipSetDevice(ctx->device));
+    const ScalarPause quiet(ctx);                                // a service instance may be reading the table
     int rc = ensure_dummy(ctx);
     if (rc != MRL_OK) return rc;
     MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));             // launches in flight may still read the table

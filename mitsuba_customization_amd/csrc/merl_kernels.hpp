@@ -61,6 +61,19 @@ size_t nch_brick_float4s(int n_ch);                      // float4s per cell: 2 
 hipError_t launch_batch_nch(int mode, const BatchArgs &a, bool multi, int n_ch, int compute_units, hipStream_t stream);
 hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale, const int dims[3], int n_ch, int param, float4 *d_out,
                                   int compute_units, hipStream_t stream);
+// ---- one-unit calls (merl_scalar.hip): a bounded-lifetime service kernel answers requests posted in pinned host memory ----
+struct ScalarBoard;
+struct ScalarArgs {
+    const MaterialDev *materials;    // the context's material array (the host stops the service before it changes)
+    int n_materials;
+    MaterialDev safe;
+    Options opts;
+    ScalarBoard *board;              // pinned, coherent host memory (device-visible address)
+    uint32_t gen;                    // this instance's generation: written to board->started_gen / exited_gen
+    uint32_t max_polls;              // hard bound on the poll loop, whatever the clock says
+    uint64_t lifetime_ticks;         // of wall_clock64() (100 MHz)
+};
+hipError_t launch_scalar_service(const ScalarArgs &a, hipStream_t stream);
 hipError_t launch_generate_pairs(uint64_t seed, uint64_t first, size_t n, float *wi, float *wo, float *u,
                                  int compute_units, hipStream_t stream);
 hipError_t launch_generate_materials(uint64_t seed, uint64_t first, size_t n, int n_materials, int32_t *mat,

@@ -1,0 +1,105 @@
+// merl_scalar.hip — the service kernel behind mrl_scalar_eval_sample (one-unit calls without a launch per call).
+//
+// One lane per mailbox slot (merl_scalar_board.hpp).  A lane polls its slot's sequence number in pinned host memory
+// with system-scope loads; when it changes the lane reads the request, evaluates the fused unit — eval(wi, wo),
+// pdf(wi, wo), sample(wi, u) — with the SAME per-lane functions the batch kernels use (merl_table_fast.hpp /
+// merl_ggx_fast.hpp: k_table's and k_ggx's arithmetic, so a scalar call returns what a batch call returns), writes the
+// eleven floats back and publishes the sequence number it served.  Requests of concurrent callers sit in different
+// lanes and are served side by side.
+// Every wave reaches the exit: the loop ends after `lifetime_ticks` of the 100 MHz wall clock, when the host raises
+// `stop`, or after a fixed number of polls, whichever comes first; the host launches the successor.
+#include "merl_kernels.hpp"
+#include "merl_scalar_board.hpp"
+#include "merl_table_fast.hpp"
+#include "merl_ggx_fast.hpp"
+
+namespace mrl {
+
+namespace {
+
+__device__ __forceinline__ uint32_t sys_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ float sys_loadf(const float *p) { return __uint_as_float(__hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
+__device__ __forceinline__ void sys_storef(float *p, float v) { __hip_atomic_store((uint32_t *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+template <int LOOKUP, int LAYOUT>
+__device__ __forceinline__ void table_unit(const MaterialDev &m, const Options &o, float wix, float wiy, float wiz, float wox, float woy, float woz,
+                                           float u0, float u1, float out[11])
+{
+    // k_table<MODE_EVAL_SAMPLE>'s lane, verbatim
+    const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
+    fast::unit_eval<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, wox, woy, woz, out);
+    float pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
+    if (o.sampling && pdf > 0.0f) pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz);
+    out[3] = pdf;
+    fast::unit_sample<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, u0, u1, out + 4, out[7], out + 8);
+}
+
+__device__ __forceinline__ void ggx_unit(const MaterialDev &m, float wix, float wiy, float wiz, float wox, float woy, float woz,
+                                         float u0, float u1, float out[11])
+{
+    // k_ggx<MODE_EVAL_SAMPLE>'s lane, verbatim
+    const fast::GgxConsts g(m);
+    const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
+    const fast::Vec3 o = fast::normalize_f32(wox, woy, woz);
+    double v[3], p;
+    fast::ggx_eval_pdf(g, in, o, v, p);
+    const bool valid = (wiz > 0.0f) && (woz > 0.0f);
+    const double poison = fast::cos_or_nan(wix, wiy, wiz, wox, woy, 1.0f);
+    out[0] = valid ? (float)(v[0] * poison) : 0.0f; out[1] = valid ? (float)(v[1] * poison) : 0.0f; out[2] = valid ? (float)(v[2] * poison) : 0.0f;
+    out[3] = valid ? (float)(p * poison) : 0.0f;
+    fast::ggx_sample(g, in, u0, u1, out + 4, out[7], out + 8);
+    if (!(wiz > 0.0f)) { out[4] = out[5] = out[6] = 0.0f; out[7] = 0.0f; out[8] = out[9] = out[10] = 0.0f; }
+}
+
+__global__ __launch_bounds__(kScalarSlots) void k_scalar_service(ScalarArgs a)
+{
+    ScalarBoard *b = a.board;
+    const unsigned i = threadIdx.x;
+    if (i == 0) __hip_atomic_store(&b->started_gen, a.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    ScalarSlot *s = &b->slot[i];
+    uint32_t last = sys_load(&s->done);                       // what this slot's caller has already been answered
+    const uint64_t t0 = wall_clock64();
+    for (uint32_t it = 0; it < a.max_polls; ++it) {
+        const uint32_t q = sys_load(&b->seq[i]);
+        if (q != last) {
+            __threadfence_system();                           // acquire: the request published with q
+            float wix = sys_loadf(&s->wi[0]), wiy = sys_loadf(&s->wi[1]), wiz = sys_loadf(&s->wi[2]);
+            const float wox = sys_loadf(&s->wo[0]), woy = sys_loadf(&s->wo[1]), woz = sys_loadf(&s->wo[2]);
+            const float u0 = sys_loadf(&s->u[0]), u1 = sys_loadf(&s->u[1]);
+            const int id = (int)sys_load((const uint32_t *)&s->material);
+            bool known = id >= 0 && id < a.n_materials;
+            MaterialDev m = a.materials[known ? id : 0];
+            known = known && kind_is_rgb_path(m.kind);
+            if (!known) { m = a.safe; wiz = 0.0f; }           // the host refuses such ids before they get here; zeros if one does
+            float out[11];
+            if (m.kind == KIND_GGX) {
+                ggx_unit(m, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+            } else if (a.opts.lookup) {
+                if (m.layout == LAYOUT_BRICK) table_unit<1, LAYOUT_BRICK>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+                else table_unit<1, LAYOUT_ROWS>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+            } else {
+                if (m.layout == LAYOUT_BRICK) table_unit<0, LAYOUT_BRICK>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+                else table_unit<0, LAYOUT_ROWS>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+            }
+#pragma unroll
+            for (int k = 0; k < 11; ++k) sys_storef(&s->out[k], out[k]);
+            __threadfence_system();                           // release: the result before its sequence number
+            __hip_atomic_store(&s->done, q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            last = q;
+        }
+        if (wall_clock64() - t0 > a.lifetime_ticks) break;
+        if ((it & 7u) == 7u && sys_load(&b->stop)) break;
+    }
+    __syncthreads();
+    if (i == 0) __hip_atomic_store(&b->exited_gen, a.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+} // namespace
+
+hipError_t launch_scalar_service(const ScalarArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_scalar_service, dim3(1), dim3(kScalarSlots), 0, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace mrl

@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "mrl_init", "mrl_destroy", "mrl_strerror", "mrl_last_error", "mrl_set_option", "mrl_get_option",
     "mrl_set_stream", "mrl_reset_stream", "mrl_synchronize", "mrl_device_info",
     "mrl_material_load_merl", "mrl_material_upload_f64", "mrl_material_upload_table", "mrl_material_load_table",
-    "mrl_material_ggx", "mrl_material_count", "mrl_material_info", "mrl_material_release", "mrl_memory_info",
+    "mrl_scalar_eval_sample", "mrl_material_ggx", "mrl_material_count", "mrl_material_info", "mrl_material_release", "mrl_memory_info",
     "mrl_eval_batch", "mrl_pdf_batch", "mrl_sample_batch", "mrl_eval_pdf_batch", "mrl_eval_sample_batch",
     "mrl_partition_by_material", "mrl_eval_queue", "mrl_pdf_queue", "mrl_eval_pdf_queue", "mrl_sample_queue", "mrl_eval_sample_queue",
     "mrl_generate_pairs", "mrl_generate_materials",
@@ -133,6 +133,7 @@ def load_library(path: Optional[str] = None):
     L.mrl_material_upload_table_param.argtypes = [vp, vp, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
     L.mrl_material_load_table_nch.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.mrl_material_channels.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+    L.mrl_scalar_eval_sample.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.mrl_material_param.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.mrl_eval_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp]
     L.mrl_sample_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp, fp, fp]
@@ -311,6 +312,14 @@ class MerlHip:
         kind = C.c_int(); dims = (C.c_int * 3)()
         self._check(self._lib.mrl_material_info(self._ctx, mid, C.byref(kind), dims), "mrl_material_info")
         return kind.value, tuple(dims)
+
+    def scalar_eval_sample(self, wi, wo, u, material: int = 0) -> np.ndarray:
+        """ONE fused unit through the scalar service (mrl_scalar_eval_sample): no launch per call.  Returns 11 floats:
+        rgb[3] pdf wo'[3] pdf' weight'[3] — what eval_sample returns for the unit."""
+        a = (C.c_float * 3)(*[float(x) for x in wi]); b = (C.c_float * 3)(*[float(x) for x in wo]); c = (C.c_float * 2)(*[float(x) for x in u])
+        out = (C.c_float * 11)()
+        self._check(self._lib.mrl_scalar_eval_sample(self._ctx, int(material), a, b, c, out), "mrl_scalar_eval_sample")
+        return np.frombuffer(out, dtype=np.float32).copy()
 
     # ---- n-channel tables ----
     def upload_table_nch(self, planar: np.ndarray, scale: Optional[Sequence[float]] = None) -> int:

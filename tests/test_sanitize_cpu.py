@@ -23,12 +23,14 @@ def test_oracle_is_clean_under_asan_ubsan(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ missing")
-def test_scalar_call_combiner_is_clean_under_tsan(tmp_path):
-    """The adapters' combining of concurrent scalar plugin calls (host C++, no GPU involved): ThreadSanitizer over
-    12 threads x 4500 calls against a test double of the C ABI; every call answered once with its own result."""
-    exe = str(tmp_path / "combiner_tsan")
+def test_scalar_service_protocol_is_clean_under_tsan(tmp_path):
+    """The host protocol of the one-unit call service (csrc/merl_scalar_host.hpp; no GPU involved): ThreadSanitizer over
+    12 caller threads x 3000 calls against a std::thread that stands in for the service kernel, while a writer thread
+    pauses the service (uploads / releases / option changes) — every call answered with its own result, no instance
+    running during a pause, instances expiring and being relaunched, never more than one queued behind the running one."""
+    exe = str(tmp_path / "scalar_service_tsan")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-o", exe,
-                           os.path.join(ROOT, "tests", "combiner_tsan.cpp"), "-lpthread"])
+                           os.path.join(ROOT, "tests", "scalar_service_tsan.cpp"), "-lpthread"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     if "unexpected memory mapping" in r.stderr:
         # this kernel randomises mappings beyond what the installed TSAN runtime accepts: retry without ASLR, else skip
@@ -37,7 +39,7 @@ def test_scalar_call_combiner_is_clean_under_tsan(tmp_path):
             r = subprocess.run([setarch, "x86_64", "-R", exe], capture_output=True, text=True, timeout=600)
         if "unexpected memory mapping" in r.stderr or (r.returncode != 0 and not r.stdout and "ThreadSanitizer" not in r.stderr):
             pytest.skip("ThreadSanitizer cannot map its shadow memory on this host (ASLR): " + r.stderr.strip()[:120])
-    assert r.returncode == 0 and "combiner ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
+    assert r.returncode == 0 and "scalar service ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ missing")
