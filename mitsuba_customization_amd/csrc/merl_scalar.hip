@@ -1,11 +1,11 @@
 // merl_scalar.hip — the service kernel behind mrl_scalar_eval_sample (one-unit calls without a launch per call).
 //
-// One lane per mailbox slot (merl_scalar_board.hpp).  A lane polls its slot's sequence number in pinned host memory
-// with system-scope loads; when it changes the lane reads the request, evaluates the fused unit — eval(wi, wo),
-// pdf(wi, wo), sample(wi, u) — with the SAME per-lane functions the batch kernels use (merl_table_fast.hpp /
-// merl_ggx_fast.hpp: k_table's and k_ggx's arithmetic, so a scalar call returns what a batch call returns), writes the
-// eleven floats back and publishes the sequence number it served.  Requests of concurrent callers sit in different
-// lanes and are served side by side.
+// One lane per mailbox slot (merl_scalar_board.hpp).  A lane polls its slot in pinned host memory with three 16-byte
+// system-scope loads — the whole request, each chunk carrying the call's sequence number; when all three carry a new
+// number the lane evaluates the fused unit — eval(wi, wo), pdf(wi, wo), sample(wi, u) — with the SAME per-lane functions
+// the batch kernels use (merl_table_fast.hpp / merl_ggx_fast.hpp: k_table's and k_ggx's arithmetic, so a scalar call
+// returns what a batch call returns) and writes the eleven floats back as four 16-byte stores, each carrying the number.
+// Requests of concurrent callers sit in different lanes and are served side by side.
 // Every wave reaches the exit: the loop ends after `lifetime_ticks` of the 100 MHz wall clock, when the host raises
 // `stop`, or after a fixed number of polls, whichever comes first; the host launches the successor.
 #include "merl_kernels.hpp"
@@ -17,9 +17,28 @@ namespace mrl {
 
 namespace {
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ uint32_t sys_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ float sys_loadf(const float *p) { return __uint_as_float(__hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
-__device__ __forceinline__ void sys_storef(float *p, float v) { __hip_atomic_store((uint32_t *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// the three request chunks of a slot: 16-byte loads that bypass every cache (sc0 sc1), all in flight together
+__device__ __forceinline__ void load_request(const ScalarSlot *s, v4f &a, v4f &b, v4f &c)
+{
+    asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16 sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32 sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(s) : "memory");
+}
+// the four result chunks: 16-byte write-through stores; each arrives whole, so no fence separates payload and number
+__device__ __forceinline__ void store_result(ScalarSlot *s, v4f r0, v4f r1, v4f r2, v4f r3)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off offset:64 sc0 sc1\n\t"
+                 "global_store_dwordx4 %0, %2, off offset:80 sc0 sc1\n\t"
+                 "global_store_dwordx4 %0, %3, off offset:96 sc0 sc1\n\t"
+                 "global_store_dwordx4 %0, %4, off offset:112 sc0 sc1"
+                 :: "v"(s), "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
+}
 
 template <int LOOKUP, int LAYOUT>
 __device__ __forceinline__ void table_unit(const MaterialDev &m, const Options &o, float wix, float wiy, float wiz, float wox, float woy, float woz,
@@ -57,39 +76,43 @@ __global__ __launch_bounds__(kScalarSlots) void k_scalar_service(ScalarArgs a)
     const unsigned i = threadIdx.x;
     if (i == 0) __hip_atomic_store(&b->started_gen, a.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     ScalarSlot *s = &b->slot[i];
-    uint32_t last = sys_load(&s->done);                       // what this slot's caller has already been answered
+    uint32_t last = sys_load(&s->res[3].seq);                 // what this slot's caller has already been answered
     const uint64_t t0 = wall_clock64();
     for (uint32_t it = 0; it < a.max_polls; ++it) {
-        const uint32_t q = sys_load(&b->seq[i]);
-        if (q != last) {
-            __threadfence_system();                           // acquire: the request published with q
-            float wix = sys_loadf(&s->wi[0]), wiy = sys_loadf(&s->wi[1]), wiz = sys_loadf(&s->wi[2]);
-            const float wox = sys_loadf(&s->wo[0]), woy = sys_loadf(&s->wo[1]), woz = sys_loadf(&s->wo[2]);
-            const float u0 = sys_loadf(&s->u[0]), u1 = sys_loadf(&s->u[1]);
-            const int id = (int)sys_load((const uint32_t *)&s->material);
-            bool known = id >= 0 && id < a.n_materials;
-            MaterialDev m = a.materials[known ? id : 0];
-            known = known && kind_is_rgb_path(m.kind);
-            if (!known) { m = a.safe; wiz = 0.0f; }           // the host refuses such ids before they get here; zeros if one does
-            float out[11];
-            if (m.kind == KIND_GGX) {
-                ggx_unit(m, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
-            } else if (a.opts.lookup) {
-                if (m.layout == LAYOUT_BRICK) table_unit<1, LAYOUT_BRICK>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
-                else table_unit<1, LAYOUT_ROWS>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
-            } else {
-                if (m.layout == LAYOUT_BRICK) table_unit<0, LAYOUT_BRICK>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
-                else table_unit<0, LAYOUT_ROWS>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+        const uint32_t active = sys_load(&b->active);         // slots beyond it have never carried a request: do not poll them
+        if (i < active) {
+            v4f ra, rb, rc;
+            load_request(s, ra, rb, rc);
+            const uint32_t q = __float_as_uint(ra.w);
+            if (q != last && __float_as_uint(rb.w) == q && __float_as_uint(rc.w) == q) {      // a new request, all of it
+                float wix = ra.x, wiy = ra.y, wiz = ra.z;
+                const float wox = rb.x, woy = rb.y, woz = rb.z, u0 = rc.x, u1 = rc.y;
+                const int id = (int)__float_as_uint(rc.z);
+                bool known = id >= 0 && id < a.n_materials;
+                MaterialDev m = a.materials[known ? id : 0];
+                known = known && kind_is_rgb_path(m.kind);
+                if (!known) { m = a.safe; wiz = 0.0f; }       // the host refuses such ids before they get here; zeros if one does
+                float out[11];
+                if (m.kind == KIND_GGX) {
+                    ggx_unit(m, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+                } else if (a.opts.lookup) {
+                    if (m.layout == LAYOUT_BRICK) table_unit<1, LAYOUT_BRICK>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+                    else table_unit<1, LAYOUT_ROWS>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+                } else {
+                    if (m.layout == LAYOUT_BRICK) table_unit<0, LAYOUT_BRICK>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+                    else table_unit<0, LAYOUT_ROWS>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+                }
+                const float qf = __uint_as_float(q);
+                const v4f r0 = { out[0], out[1], out[2], qf }, r1 = { out[3], out[4], out[5], qf }, r2 = { out[6], out[7], out[8], qf },
+                          r3 = { out[9], out[10], 0.0f, qf };
+                store_result(s, r0, r1, r2, r3);
+                last = q;
             }
-#pragma unroll
-            for (int k = 0; k < 11; ++k) sys_storef(&s->out[k], out[k]);
-            __threadfence_system();                           // release: the result before its sequence number
-            __hip_atomic_store(&s->done, q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            last = q;
         }
         if (wall_clock64() - t0 > a.lifetime_ticks) break;
         if ((it & 7u) == 7u && sys_load(&b->stop)) break;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last answers have left before the instance reports its exit
     __syncthreads();
     if (i == 0) __hip_atomic_store(&b->exited_gen, a.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

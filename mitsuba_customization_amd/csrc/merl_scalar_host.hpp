@@ -64,14 +64,25 @@ public:
     {
         ScalarBoard *b = m_dev->board();
         ScalarSlot &s = b->slot[slot];
-        std::memcpy(s.wi, wi, 12); std::memcpy(s.wo, wo, 12); std::memcpy(s.u, u, 8);
-        s.material = material;
+        if ((uint32_t)slot >= __atomic_load_n(&b->active, __ATOMIC_RELAXED)) {          // first call from this slot: let the device poll it
+            uint32_t seen = __atomic_load_n(&b->active, __ATOMIC_RELAXED);
+            while (seen <= (uint32_t)slot && !__atomic_compare_exchange_n(&b->active, &seen, (uint32_t)slot + 1, false, __ATOMIC_RELEASE, __ATOMIC_RELAXED)) {}
+        }
         const uint32_t seq = ++m_gate[slot].seq;
-        __atomic_store_n(&b->seq[slot], seq, __ATOMIC_RELEASE);
+        float mat_bits;
+        std::memcpy(&mat_bits, &material, 4);
+        const float words[3][3] = { { wi[0], wi[1], wi[2] }, { wo[0], wo[1], wo[2] }, { u[0], u[1], mat_bits } };
+        for (int c = 0; c < 3; ++c) {                              // payload first, the chunk's sequence number last
+            std::memcpy(s.req[c].v, words[c], 12);
+            __atomic_store_n(&s.req[c].seq, seq, __ATOMIC_RELEASE);
+        }
         int rc = keep_alive();
         if (rc != SCALAR_OK) return rc;
         const Clock::time_point t0 = Clock::now();
-        for (unsigned spins = 1; __atomic_load_n(&s.done, __ATOMIC_ACQUIRE) != seq; ++spins) {
+        for (unsigned spins = 1;; ++spins) {
+            bool all = true;
+            for (int c = 0; c < 4; ++c) all = all && __atomic_load_n(&s.res[c].seq, __ATOMIC_ACQUIRE) == seq;
+            if (all) break;
             relax();
             if ((spins & 255u) == 0) {                         // every few microseconds: is an instance still there?
                 rc = keep_alive();
@@ -79,7 +90,7 @@ public:
                 if (!m_dev->healthy() || Clock::now() - t0 > m_stall) return SCALAR_STALLED;
             }
         }
-        std::memcpy(out, s.out, sizeof s.out);
+        std::memcpy(out, s.res[0].v, 12); std::memcpy(out + 3, s.res[1].v, 12); std::memcpy(out + 6, s.res[2].v, 12); std::memcpy(out + 9, s.res[3].v, 8);
         return SCALAR_OK;
     }
 

@@ -52,21 +52,35 @@ struct FakeDevice {
         if (paused_flag.load()) ++ran_while_paused;
         __atomic_store_n(&b->started_gen, gen, __ATOMIC_RELEASE);
         uint32_t last[kScalarSlots];
-        for (int i = 0; i < kScalarSlots; ++i) last[i] = __atomic_load_n(&b->slot[i].done, __ATOMIC_RELAXED);
+        for (int i = 0; i < kScalarSlots; ++i) last[i] = __atomic_load_n(&b->slot[i].res[3].seq, __ATOMIC_RELAXED);
         const Clock::time_point t0 = Clock::now();
         for (;;) {
-            for (int i = 0; i < kScalarSlots; ++i) {
-                const uint32_t q = __atomic_load_n(&b->seq[i], __ATOMIC_ACQUIRE);
-                if (q == last[i]) continue;
+            const uint32_t active = __atomic_load_n(&b->active, __ATOMIC_ACQUIRE);
+            for (uint32_t i = 0; i < active; ++i) {
                 ScalarSlot &s = b->slot[i];
+                // a chunk = payload + sequence number, one 16-byte transaction on the device; here: acquire, then the payload
+                uint32_t q[3];
+                float w[3][3];
+                for (int c = 0; c < 3; ++c) {
+                    q[c] = __atomic_load_n(&s.req[c].seq, __ATOMIC_ACQUIRE);
+                    if (q[c] != last[i] && q[c] == q[0]) std::memcpy(w[c], s.req[c].v, 12);      // only a complete, new chunk is read
+                }
+                if (q[0] == last[i] || q[1] != q[0] || q[2] != q[0]) continue;
+                int32_t material;
+                std::memcpy(&material, &w[2][2], 4);
                 // the "evaluation": something the caller can verify, mixed with the state the instance was launched with
-                for (int k = 0; k < 3; ++k) s.out[k] = s.wi[k] + 2.0f * s.wo[k];
-                s.out[3] = s.u[0] * 10.0f + s.u[1];
-                s.out[4] = (float)s.material;
-                s.out[5] = (float)(a + bb);              // 0 unless the state was torn
-                for (int k = 6; k < 11; ++k) s.out[k] = 0.0f;
-                __atomic_store_n(&s.done, q, __ATOMIC_RELEASE);
-                last[i] = q;
+                float out[11];
+                for (int k = 0; k < 3; ++k) out[k] = w[0][k] + 2.0f * w[1][k];
+                out[3] = w[2][0] * 10.0f + w[2][1];
+                out[4] = (float)material;
+                out[5] = (float)(a + bb);                // 0 unless the state was torn
+                for (int k = 6; k < 11; ++k) out[k] = (float)k;
+                const float padded[12] = { out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], out[8], out[9], out[10], 0.0f };
+                for (int c = 0; c < 4; ++c) {
+                    std::memcpy(s.res[c].v, padded + 3 * c, 12);
+                    __atomic_store_n(&s.res[c].seq, q[0], __ATOMIC_RELEASE);
+                }
+                last[i] = q[0];
             }
             if (Clock::now() - t0 > lifetime || __atomic_load_n(&b->stop, __ATOMIC_ACQUIRE)) break;
         }
@@ -111,6 +125,7 @@ int main()
                 if (rc != SCALAR_OK) { ++failed; continue; }
                 bool ok = out[3] == u[0] * 10.0f + u[1] && out[4] == (float)(100 * t + (k % 100)) && out[5] == 0.0f;
                 for (int c = 0; c < 3; ++c) ok = ok && out[c] == wi[c] + 2.0f * wo[c];
+                for (int c = 6; c < 11; ++c) ok = ok && out[c] == (float)c;
                 if (!ok) ++wrong;
                 if ((k & 255) == 255) std::this_thread::sleep_for(std::chrono::microseconds(700));    // let instances expire: relaunch path
             }
