@@ -88,6 +88,7 @@ public:
                 rc = keep_alive();
                 if (rc != SCALAR_OK) return rc;
                 if (!m_dev->healthy() || Clock::now() - t0 > m_stall) return SCALAR_STALLED;
+                if (spins > 4096u) std::this_thread::yield();  // far beyond a round trip: more callers than cores? let the others run
             }
         }
         std::memcpy(out, s.res[0].v, 12); std::memcpy(out + 3, s.res[1].v, 12); std::memcpy(out + 6, s.res[2].v, 12); std::memcpy(out + 9, s.res[3].v, 8);
