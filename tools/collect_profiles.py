@@ -7,8 +7,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = {"merl64m": "void mrl::<3, false, true, false, false>", "ggx64m": "void mrl::<3, true, false, false>",
-          "mixed16_256m": "void mrl::<3, true, true, false, false>", "resident100": "void mrl::<3, true, true, false, false>"}
+KERNEL = {"merl64m": "void mrl::<3, false, true, false, false, false>", "ggx64m": "void mrl::<3, true, false, false>",
+          "mixed16_256m": "void mrl::<3, true, true, false, false, false>", "resident100": "void mrl::<3, true, true, false, false, false>"}
 tag, dirs = sys.argv[1], sys.argv[2:]
 rows = []
 for d in dirs:
