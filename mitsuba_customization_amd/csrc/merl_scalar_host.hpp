@@ -76,9 +76,14 @@ public:
             std::memcpy(s.req[c].v, words[c], 12);
             __atomic_store_n(&s.req[c].seq, seq, __ATOMIC_RELEASE);
         }
-        int rc = keep_alive();
-        if (rc != SCALAR_OK) return rc;
+        // Somebody must look after the instance chain every quarter lifetime; everybody else goes straight to waiting
+        // (no shared line is written on the way).  A caller that waits longer than a round trip looks again below.
         const Clock::time_point t0 = Clock::now();
+        int rc = SCALAR_OK;
+        if (t0.time_since_epoch().count() >= m_next_look.load(std::memory_order_relaxed)) {
+            rc = keep_alive();
+            if (rc != SCALAR_OK) return rc;
+        }
         for (unsigned spins = 1;; ++spins) {
             bool all = true;
             for (int c = 0; c < 4; ++c) all = all && __atomic_load_n(&s.res[c].seq, __ATOMIC_ACQUIRE) == seq;
@@ -116,7 +121,11 @@ public:
         }
         return ok;
     }
-    void resume() { m_paused.store(0, std::memory_order_release); }
+    void resume()
+    {
+        m_next_look.store(0, std::memory_order_relaxed);       // the next caller launches an instance (with the new state) at once
+        m_paused.store(0, std::memory_order_release);
+    }
 
     uint32_t launched() { std::lock_guard<std::mutex> lk(m_launch); return m_launched; }
 
@@ -160,6 +169,7 @@ private:
             ++m_launched;
             if (!m_dev->launch(m_launched)) { --m_launched; return SCALAR_LAUNCH_FAILED; }
         }
+        m_next_look.store((now + m_lifetime / 4).time_since_epoch().count(), std::memory_order_relaxed);
         return SCALAR_OK;
     }
 
@@ -168,6 +178,7 @@ private:
     const std::chrono::milliseconds m_stall;
     Gate m_gate[kScalarSlots];
     std::atomic<uint32_t> m_paused{ 0 };
+    std::atomic<Clock::rep> m_next_look{ 0 };                  // steady-clock count before which a posting caller need not call keep_alive()
     std::mutex m_launch;                                       // guards the four members below
     uint32_t m_launched = 0;                                   // generation of the newest instance handed to the device
     uint32_t m_seen_started = 0;
