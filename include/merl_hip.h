@@ -182,6 +182,10 @@ int mrl_eval_sample_batch(mrl_ctx *ctx, const float *wi, const float *wo, const 
  * Thread-safe and lock-free between callers; uploads, releases and option changes wait for calls in flight.
  * Table materials with three channels and GGX materials; other ids are MRL_ERR_MATERIAL. */
 int mrl_scalar_eval_sample(mrl_ctx *ctx, int32_t material, const float wi[3], const float wo[3], const float u[2], float out[11]);
+/* the two halves on their own — what one virtual eval() / pdf() / eval_pdf(), resp. one sample(), needs: one table lookup
+ * instead of two on the device */
+int mrl_scalar_eval_pdf(mrl_ctx *ctx, int32_t material, const float wi[3], const float wo[3], float out_rgb[3], float *out_pdf);
+int mrl_scalar_sample(mrl_ctx *ctx, int32_t material, const float wi[3], const float u[2], float out_wo[3], float *out_pdf, float out_weight[3]);
 
 /* ---- n-channel tables: customized_measurement beyond RGB (monochrome, RGB + alpha, spectral bins; SURVEY.md §8f
  * item 3).  Same MERL parameterisation, same transform and trilinear blend; a texel has n_channels values, 1..32.

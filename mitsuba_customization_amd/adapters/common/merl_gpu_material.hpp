@@ -113,20 +113,16 @@ public:
         return m_resident.size();
     }
 
-    // One virtual BSDF call = one fused unit through the library's scalar service (include/merl_hip.h, "one-unit calls"):
+    // One virtual BSDF call = one request to the library's scalar service (include/merl_hip.h, "one-unit calls"):
     // the request goes into a mailbox in pinned memory, a resident wave answers it — no launch, no synchronisation, no lock
     // shared with the other render threads, whose calls are answered side by side by the wave's other lanes.
-    // out[11] = rgb[3] pdf wo'[3] pdf' weight'[3].
-    void scalar(int material, const float wi[3], const float *wo, const float *u, float out[11])
+    void scalar_eval_pdf(int material, const float wi[3], const float wo[3], float rgb[3], float &pdf)
     {
-        static const float up[3] = { 0.0f, 0.0f, 1.0f }, centre[2] = { 0.5f, 0.5f };
-        const int rc = mrl_scalar_eval_sample(m_ctx, material, wi, wo ? wo : up, u ? u : centre, out);
-        if (rc != MRL_OK) {
-            std::string what = std::string("scalar call: ") + mrl_strerror(rc);
-            const char *d = mrl_last_error(m_ctx);
-            if (d && *d) what += std::string(" (") + d + ")";
-            throw Error(rc, what);
-        }
+        scalar_check(mrl_scalar_eval_pdf(m_ctx, material, wi, wo, rgb, &pdf));
+    }
+    void scalar_sample(int material, const float wi[3], const float u[2], float wo[3], float &pdf, float weight[3])
+    {
+        scalar_check(mrl_scalar_sample(m_ctx, material, wi, u, wo, &pdf, weight));
     }
 
     static std::shared_ptr<Context> get(const ContextKey &key)
@@ -143,6 +139,15 @@ public:
     }
 
 private:
+    void scalar_check(int rc)
+    {
+        if (rc == MRL_OK) return;
+        std::string what = std::string("scalar call: ") + mrl_strerror(rc);
+        const char *d = mrl_last_error(m_ctx);
+        if (d && *d) what += std::string(" (") + d + ")";
+        throw Error(rc, what);
+    }
+
     ContextKey m_key;
     mrl_ctx *m_ctx = nullptr;
     std::mutex m_mutex;                    // keeps a launch and its synchronize together (the C context only locks per call)
@@ -218,33 +223,26 @@ public:
     int id() const { return m_id; }
     mrl_ctx *ctx() const { return m_ctx->raw(); }
 
-    // ---- scalar calls (the virtual per-ray BSDF::eval / sample / pdf): one fused unit each, through the scalar service ----
+    // ---- scalar calls (the virtual per-ray BSDF::eval / sample / pdf): one half of the unit each, through the scalar service ----
     void eval1(const float wi[3], const float wo[3], float rgb[3]) const
     {
-        float o[11];
-        m_ctx->scalar(m_id, wi, wo, nullptr, o);
-        for (int k = 0; k < 3; ++k) rgb[k] = o[k];
+        float pdf;
+        m_ctx->scalar_eval_pdf(m_id, wi, wo, rgb, pdf);
     }
     float pdf1(const float wi[3], const float wo[3]) const
     {
-        float o[11];
-        m_ctx->scalar(m_id, wi, wo, nullptr, o);
-        return o[3];
+        float rgb[3], pdf;
+        m_ctx->scalar_eval_pdf(m_id, wi, wo, rgb, pdf);
+        return pdf;
     }
     void sample1(const float wi[3], const float u[2], float wo[3], float &pdf, float weight[3]) const
     {
-        float o[11];
-        m_ctx->scalar(m_id, wi, nullptr, u, o);
-        for (int k = 0; k < 3; ++k) { wo[k] = o[4 + k]; weight[k] = o[8 + k]; }
-        pdf = o[7];
+        m_ctx->scalar_sample(m_id, wi, u, wo, pdf, weight);
     }
     // eval + pdf of the same pair (Mitsuba 3's eval_pdf)
     void eval_pdf1(const float wi[3], const float wo[3], float rgb[3], float &pdf) const
     {
-        float o[11];
-        m_ctx->scalar(m_id, wi, wo, nullptr, o);
-        for (int k = 0; k < 3; ++k) rgb[k] = o[k];
-        pdf = o[3];
+        m_ctx->scalar_eval_pdf(m_id, wi, wo, rgb, pdf);
     }
 
     // ---- batch / wavefront calls: host or device arrays, n units (see include/merl_hip.h) ----

@@ -934,9 +934,9 @@ int scalar_open(mrl_ctx *ctx)
 
 extern "C" {
 
-int mrl_scalar_eval_sample(mrl_ctx *ctx, int32_t material, const float wi[3], const float wo[3], const float u[2], float out[11])
+// want: 0 the fused unit, 1 eval + pdf only, 2 sample only (bits 28-29 of the request's material word, merl_scalar.hip)
+static int scalar_call(mrl_ctx *ctx, int want, int32_t material, const float wi[3], const float wo[3], const float u[2], float out[11])
 {
-    if (!ctx || !wi || !wo || !u || !out) return MRL_ERR_INVALID;
     ScalarSvc *svc = ctx->scalar.load(std::memory_order_acquire);
     if (!svc) {
         const int rc = scalar_open(ctx);
@@ -945,10 +945,10 @@ int mrl_scalar_eval_sample(mrl_ctx *ctx, int32_t material, const float wi[3], co
     }
     const int slot = svc->enter();                               // from here to leave() no upload / release / option change runs
     int rc = MRL_OK, st = mrl::SCALAR_OK;
-    if (material < 0 || (size_t)material >= ctx->materials.size() || ctx->materials[(size_t)material].released ||
+    if (material < 0 || (size_t)material >= ctx->materials.size() || material >= (1 << 28) || ctx->materials[(size_t)material].released ||
         !mrl::kind_is_rgb_path(ctx->materials[(size_t)material].dev.kind))
         rc = MRL_ERR_MATERIAL;
-    else if ((st = svc->roundtrip(slot, material, wi, wo, u, out)) != mrl::SCALAR_OK)
+    else if ((st = svc->roundtrip(slot, material | (want << 28), wi, wo, u, out)) != mrl::SCALAR_OK)
         rc = MRL_ERR_HIP;
     svc->leave(slot);
     if (rc != MRL_OK) {
@@ -957,6 +957,32 @@ int mrl_scalar_eval_sample(mrl_ctx *ctx, int32_t material, const float wi[3], co
                             : st == mrl::SCALAR_LAUNCH_FAILED ? "scalar call: the service kernel could not be launched"
                                                                : "scalar call: the service kernel did not answer");
     }
+    return rc;
+}
+
+int mrl_scalar_eval_sample(mrl_ctx *ctx, int32_t material, const float wi[3], const float wo[3], const float u[2], float out[11])
+{
+    if (!ctx || !wi || !wo || !u || !out) return MRL_ERR_INVALID;
+    return scalar_call(ctx, 0, material, wi, wo, u, out);
+}
+
+int mrl_scalar_eval_pdf(mrl_ctx *ctx, int32_t material, const float wi[3], const float wo[3], float out_rgb[3], float *out_pdf)
+{
+    if (!ctx || !wi || !wo || !out_rgb || !out_pdf) return MRL_ERR_INVALID;
+    static const float centre[2] = { 0.5f, 0.5f };
+    float out[11];
+    const int rc = scalar_call(ctx, 1, material, wi, wo, centre, out);
+    if (rc == MRL_OK) { std::memcpy(out_rgb, out, 12); *out_pdf = out[3]; }
+    return rc;
+}
+
+int mrl_scalar_sample(mrl_ctx *ctx, int32_t material, const float wi[3], const float u[2], float out_wo[3], float *out_pdf, float out_weight[3])
+{
+    if (!ctx || !wi || !u || !out_wo || !out_pdf || !out_weight) return MRL_ERR_INVALID;
+    static const float up[3] = { 0.0f, 0.0f, 1.0f };
+    float out[11];
+    const int rc = scalar_call(ctx, 2, material, wi, up, u, out);
+    if (rc == MRL_OK) { std::memcpy(out_wo, out + 4, 12); *out_pdf = out[7]; std::memcpy(out_weight, out + 8, 12); }
     return rc;
 }
 

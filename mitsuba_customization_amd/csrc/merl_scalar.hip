@@ -43,34 +43,43 @@ __device__ __forceinline__ void store_result(ScalarSlot *s, v4f r0, v4f r1, v4f 
                  :: "v"(s), "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
 }
 
+// what a request asks for (bits 28-29 of the material word; 0 = both halves = the fused unit)
+constexpr int kWantEvalOnly = 1, kWantSampleOnly = 2;
+
 template <int LOOKUP, int LAYOUT>
-__device__ __forceinline__ void table_unit(const MaterialDev &m, const Options &o, float wix, float wiy, float wiz, float wox, float woy, float woz,
-                                           float u0, float u1, float out[11])
+__device__ __forceinline__ void table_unit(const MaterialDev &m, const Options &o, int want, float wix, float wiy, float wiz,
+                                           float wox, float woy, float woz, float u0, float u1, float out[11])
 {
-    // k_table<MODE_EVAL_SAMPLE>'s lane, verbatim
+    // k_table<MODE_EVAL_SAMPLE>'s lane, verbatim; a half the caller did not ask for is skipped (its outputs are zero)
     const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
-    fast::unit_eval<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, wox, woy, woz, out);
-    float pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
-    if (o.sampling && pdf > 0.0f) pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz);
-    out[3] = pdf;
-    fast::unit_sample<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, u0, u1, out + 4, out[7], out + 8);
+    if (want != kWantSampleOnly) {
+        fast::unit_eval<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, wox, woy, woz, out);
+        float pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
+        if (o.sampling && pdf > 0.0f) pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz);
+        out[3] = pdf;
+    }
+    if (want != kWantEvalOnly) fast::unit_sample<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, u0, u1, out + 4, out[7], out + 8);
 }
 
-__device__ __forceinline__ void ggx_unit(const MaterialDev &m, float wix, float wiy, float wiz, float wox, float woy, float woz,
+__device__ __forceinline__ void ggx_unit(const MaterialDev &m, int want, float wix, float wiy, float wiz, float wox, float woy, float woz,
                                          float u0, float u1, float out[11])
 {
     // k_ggx<MODE_EVAL_SAMPLE>'s lane, verbatim
     const fast::GgxConsts g(m);
     const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
-    const fast::Vec3 o = fast::normalize_f32(wox, woy, woz);
-    double v[3], p;
-    fast::ggx_eval_pdf(g, in, o, v, p);
-    const bool valid = (wiz > 0.0f) && (woz > 0.0f);
-    const double poison = fast::cos_or_nan(wix, wiy, wiz, wox, woy, 1.0f);
-    out[0] = valid ? (float)(v[0] * poison) : 0.0f; out[1] = valid ? (float)(v[1] * poison) : 0.0f; out[2] = valid ? (float)(v[2] * poison) : 0.0f;
-    out[3] = valid ? (float)(p * poison) : 0.0f;
-    fast::ggx_sample(g, in, u0, u1, out + 4, out[7], out + 8);
-    if (!(wiz > 0.0f)) { out[4] = out[5] = out[6] = 0.0f; out[7] = 0.0f; out[8] = out[9] = out[10] = 0.0f; }
+    if (want != kWantSampleOnly) {
+        const fast::Vec3 o = fast::normalize_f32(wox, woy, woz);
+        double v[3], p;
+        fast::ggx_eval_pdf(g, in, o, v, p);
+        const bool valid = (wiz > 0.0f) && (woz > 0.0f);
+        const double poison = fast::cos_or_nan(wix, wiy, wiz, wox, woy, 1.0f);
+        out[0] = valid ? (float)(v[0] * poison) : 0.0f; out[1] = valid ? (float)(v[1] * poison) : 0.0f; out[2] = valid ? (float)(v[2] * poison) : 0.0f;
+        out[3] = valid ? (float)(p * poison) : 0.0f;
+    }
+    if (want != kWantEvalOnly) {
+        fast::ggx_sample(g, in, u0, u1, out + 4, out[7], out + 8);
+        if (!(wiz > 0.0f)) { out[4] = out[5] = out[6] = 0.0f; out[7] = 0.0f; out[8] = out[9] = out[10] = 0.0f; }
+    }
 }
 
 __global__ __launch_bounds__(kScalarSlots) void k_scalar_service(ScalarArgs a)
@@ -90,20 +99,21 @@ __global__ __launch_bounds__(kScalarSlots) void k_scalar_service(ScalarArgs a)
             if (q != last && __float_as_uint(rb.w) == q && __float_as_uint(rc.w) == q) {      // a new request, all of it
                 float wix = ra.x, wiy = ra.y, wiz = ra.z;
                 const float wox = rb.x, woy = rb.y, woz = rb.z, u0 = rc.x, u1 = rc.y;
-                const int id = (int)__float_as_uint(rc.z);
+                const uint32_t word = __float_as_uint(rc.z);           // material id, and in bits 28-29 which half is wanted
+                const int id = (int)(word & 0x0FFFFFFFu), want = (int)((word >> 28) & 3u);
                 bool known = id >= 0 && id < a.n_materials;
                 MaterialDev m = a.materials[known ? id : 0];
                 known = known && kind_is_rgb_path(m.kind);
                 if (!known) { m = a.safe; wiz = 0.0f; }       // the host refuses such ids before they get here; zeros if one does
-                float out[11];
+                float out[11] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
                 if (m.kind == KIND_GGX) {
-                    ggx_unit(m, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+                    ggx_unit(m, want, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
                 } else if (a.opts.lookup) {
-                    if (m.layout == LAYOUT_BRICK) table_unit<1, LAYOUT_BRICK>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
-                    else table_unit<1, LAYOUT_ROWS>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+                    if (m.layout == LAYOUT_BRICK) table_unit<1, LAYOUT_BRICK>(m, a.opts, want, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+                    else table_unit<1, LAYOUT_ROWS>(m, a.opts, want, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
                 } else {
-                    if (m.layout == LAYOUT_BRICK) table_unit<0, LAYOUT_BRICK>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
-                    else table_unit<0, LAYOUT_ROWS>(m, a.opts, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+                    if (m.layout == LAYOUT_BRICK) table_unit<0, LAYOUT_BRICK>(m, a.opts, want, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
+                    else table_unit<0, LAYOUT_ROWS>(m, a.opts, want, wix, wiy, wiz, wox, woy, woz, u0, u1, out);
                 }
                 const float qf = __uint_as_float(q);
                 const v4f r0 = { out[0], out[1], out[2], qf }, r1 = { out[3], out[4], out[5], qf }, r2 = { out[6], out[7], out[8], qf },

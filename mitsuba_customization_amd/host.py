@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "mrl_init", "mrl_destroy", "mrl_strerror", "mrl_last_error", "mrl_set_option", "mrl_get_option",
     "mrl_set_stream", "mrl_reset_stream", "mrl_synchronize", "mrl_device_info",
     "mrl_material_load_merl", "mrl_material_upload_f64", "mrl_material_upload_table", "mrl_material_load_table",
-    "mrl_scalar_eval_sample", "mrl_material_ggx", "mrl_material_count", "mrl_material_info", "mrl_material_release", "mrl_memory_info",
+    "mrl_scalar_eval_sample", "mrl_scalar_eval_pdf", "mrl_scalar_sample", "mrl_material_ggx", "mrl_material_count", "mrl_material_info", "mrl_material_release", "mrl_memory_info",
     "mrl_eval_batch", "mrl_pdf_batch", "mrl_sample_batch", "mrl_eval_pdf_batch", "mrl_eval_sample_batch",
     "mrl_partition_by_material", "mrl_eval_queue", "mrl_pdf_queue", "mrl_eval_pdf_queue", "mrl_sample_queue", "mrl_eval_sample_queue",
     "mrl_generate_pairs", "mrl_generate_materials",
@@ -134,6 +134,8 @@ def load_library(path: Optional[str] = None):
     L.mrl_material_load_table_nch.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.mrl_material_channels.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.mrl_scalar_eval_sample.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.mrl_scalar_eval_pdf.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.mrl_scalar_sample.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.mrl_material_param.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.mrl_eval_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp]
     L.mrl_sample_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp, fp, fp]
@@ -320,6 +322,20 @@ class MerlHip:
         out = (C.c_float * 11)()
         self._check(self._lib.mrl_scalar_eval_sample(self._ctx, int(material), a, b, c, out), "mrl_scalar_eval_sample")
         return np.frombuffer(out, dtype=np.float32).copy()
+
+    def scalar_eval_pdf(self, wi, wo, material: int = 0):
+        """ONE eval + pdf through the scalar service (no sample half): (rgb[3], pdf)."""
+        a = (C.c_float * 3)(*[float(x) for x in wi]); b = (C.c_float * 3)(*[float(x) for x in wo])
+        rgb = (C.c_float * 3)(); pdf = C.c_float()
+        self._check(self._lib.mrl_scalar_eval_pdf(self._ctx, int(material), a, b, rgb, C.byref(pdf)), "mrl_scalar_eval_pdf")
+        return np.frombuffer(rgb, dtype=np.float32).copy(), float(pdf.value)
+
+    def scalar_sample(self, wi, u, material: int = 0):
+        """ONE sample through the scalar service (no eval half): (wo'[3], pdf', weight'[3])."""
+        a = (C.c_float * 3)(*[float(x) for x in wi]); c = (C.c_float * 2)(*[float(x) for x in u])
+        wo = (C.c_float * 3)(); pdf = C.c_float(); w = (C.c_float * 3)()
+        self._check(self._lib.mrl_scalar_sample(self._ctx, int(material), a, c, wo, C.byref(pdf), w), "mrl_scalar_sample")
+        return np.frombuffer(wo, dtype=np.float32).copy(), float(pdf.value), np.frombuffer(w, dtype=np.float32).copy()
 
     # ---- n-channel tables ----
     def upload_table_nch(self, planar: np.ndarray, scale: Optional[Sequence[float]] = None) -> int:

@@ -39,6 +39,12 @@ def test_scalar_calls_return_the_batch_answers(oracle, tables, lookup, layout, s
             # of values in a million (FMA contraction inside the blend); everything is within 1e-6 of the oracle either way
             assert (got != want).sum() <= 2, (mid, int((got != want).sum()))
             assert np.allclose(got, want, rtol=2e-6, atol=1e-30)
+            # the halves on their own (what one virtual eval() / sample() asks for) are the fused call's halves, bit for bit
+            for i in (0, 1, 5, 6, 17):
+                rgb, pdf = g.scalar_eval_pdf(wi[i], wo[i], material=mid)
+                s_wo, s_pdf, s_w = g.scalar_sample(wi[i], u[i], material=mid)
+                assert np.array_equal(rgb, got[i, 0:3]) and np.float32(pdf) == got[i, 3]
+                assert np.array_equal(s_wo, got[i, 4:7]) and np.float32(s_pdf) == got[i, 7] and np.array_equal(s_w, got[i, 8:11])
         assert not got[5].any() and not got[6][:4].any()
         with pytest.raises(host.MerlHipError):
             g.scalar_eval_sample(wi[0], wo[0], u[0], material=17)
