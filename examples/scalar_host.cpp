@@ -94,6 +94,23 @@ int main(int argc, char **argv)
     auto t0 = Clock::now();
     worker(0, 0, solo);
     const double solo_us = std::chrono::duration<double, std::micro>(Clock::now() - t0).count() / (double)solo;
+    // ... and the two halves on their own: what one virtual eval() / pdf(), resp. one sample(), asks for
+    double half_us[2] = { 0.0, 0.0 };
+    for (int half = 0; half < 2; ++half) {
+        t0 = Clock::now();
+        for (long k = 0; k < solo; ++k) {
+            const size_t i = (size_t)k;
+            float rgb[3], pdf, wo2[3], pdf2, w[3];
+            const int rc = half == 0 ? mrl_scalar_eval_pdf(ctx, mat[i], &wi[3 * i], &wo[3 * i], rgb, &pdf)
+                                     : mrl_scalar_sample(ctx, mat[i], &wi[3 * i], &u[2 * i], wo2, &pdf2, w);
+            if (rc != MRL_OK) { ++failed; continue; }
+            const float *ref = &want[11 * i];
+            const bool ok = half == 0 ? (!std::memcmp(rgb, ref, 12) && !std::memcmp(&pdf, ref + 3, 4))
+                                      : (!std::memcmp(wo2, ref + 4, 12) && !std::memcmp(&pdf2, ref + 7, 4) && !std::memcmp(w, ref + 8, 12));
+            if (!ok) ++wrong;
+        }
+        half_us[half] = std::chrono::duration<double, std::micro>(Clock::now() - t0).count() / (double)solo;
+    }
     // 2. all threads together (+ the churn thread)
     std::atomic<bool> stop{ false };
     long churn_rounds = 0;
@@ -118,9 +135,9 @@ int main(int argc, char **argv)
     // an id the scalar path refuses
     float out[11];
     const int bad = mrl_scalar_eval_sample(ctx, 99, &wi[0], &wo[0], &u[0], out);
-    std::printf("{\"threads\": %d, \"calls_per_thread\": %ld, \"solo_us_per_call\": %.3f, \"all_threads_Mcalls_per_s\": %.4f, "
+    std::printf("{\"threads\": %d, \"calls_per_thread\": %ld, \"solo_us_per_call\": %.3f, \"solo_eval_pdf_us\": %.3f, \"solo_sample_us\": %.3f, \"all_threads_Mcalls_per_s\": %.4f, "
                 "\"all_threads_us_per_call_amortised\": %.4f, \"wrong\": %ld, \"failed\": %ld, \"churn_rounds\": %ld, \"unknown_id_status\": %d}\n",
-                threads, calls, solo_us, (double)n / all_s / 1e6, all_s * 1e6 / (double)n, wrong.load(), failed.load(), churn_rounds, bad);
+                threads, calls, solo_us, half_us[0], half_us[1], (double)n / all_s / 1e6, all_s * 1e6 / (double)n, wrong.load(), failed.load(), churn_rounds, bad);
     mrl_destroy(ctx);
     return (wrong.load() == 0 && failed.load() == 0 && bad == MRL_ERR_MATERIAL) ? 0 : 1;
 }
