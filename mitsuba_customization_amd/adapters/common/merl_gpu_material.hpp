@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -85,6 +86,14 @@ public:
         Context *owner;                                 // kept alive by the Material's shared_ptr<Context>
         std::string key;
         int id;
+        unsigned long long serial = next_serial();     // never reused (a freed Resident's address and material id can be)
+        static unsigned long long next_serial()
+        {
+            static std::mutex mu;
+            static unsigned long long n = 0;
+            std::lock_guard<std::mutex> lk(mu);
+            return ++n;
+        }
         ~Resident()
         {
             std::lock_guard<std::mutex> call(owner->m_mutex);
@@ -103,7 +112,7 @@ public:
             if (auto sp = it->second.lock()) return sp;
         int id = -1;
         check(m_ctx, loader(m_ctx, &id), what);
-        auto sp = std::shared_ptr<Resident>(new Resident{ this, key, id });
+        auto sp = std::shared_ptr<Resident>(new Resident{ this, key, id });     // serial: its default member initialiser
         m_resident[key] = sp;
         return sp;
     }
@@ -224,27 +233,36 @@ public:
     mrl_ctx *ctx() const { return m_ctx->raw(); }
 
     // ---- scalar calls (the virtual per-ray BSDF::eval / sample / pdf): one half of the unit each, through the scalar service ----
+    // An integrator that weighs light samples asks eval(wi, wo) and then pdf(wi, wo) for the SAME pair (MIS): the device
+    // returns both at once, so the second question is answered from a one-entry, per-thread memo instead of a second trip.
     void eval1(const float wi[3], const float wo[3], float rgb[3]) const
     {
         float pdf;
-        m_ctx->scalar_eval_pdf(m_id, wi, wo, rgb, pdf);
+        eval_pdf1(wi, wo, rgb, pdf);
     }
     float pdf1(const float wi[3], const float wo[3]) const
     {
         float rgb[3], pdf;
-        m_ctx->scalar_eval_pdf(m_id, wi, wo, rgb, pdf);
+        eval_pdf1(wi, wo, rgb, pdf);
         return pdf;
+    }
+    // eval + pdf of the same pair (Mitsuba 3's eval_pdf)
+    void eval_pdf1(const float wi[3], const float wo[3], float rgb[3], float &pdf) const
+    {
+        Memo &m = memo();
+        if (m.table != m_res->serial || std::memcmp(m.wi, wi, 12) != 0 || std::memcmp(m.wo, wo, 12) != 0) {
+            m.table = 0;                                             // not valid while it is being refilled (an exception leaves it so)
+            m_ctx->scalar_eval_pdf(m_id, wi, wo, m.rgb, m.pdf);
+            std::memcpy(m.wi, wi, 12); std::memcpy(m.wo, wo, 12);
+            m.table = m_res->serial;
+        }
+        std::memcpy(rgb, m.rgb, 12);
+        pdf = m.pdf;
     }
     void sample1(const float wi[3], const float u[2], float wo[3], float &pdf, float weight[3]) const
     {
         m_ctx->scalar_sample(m_id, wi, u, wo, pdf, weight);
     }
-    // eval + pdf of the same pair (Mitsuba 3's eval_pdf)
-    void eval_pdf1(const float wi[3], const float wo[3], float rgb[3], float &pdf) const
-    {
-        m_ctx->scalar_eval_pdf(m_id, wi, wo, rgb, pdf);
-    }
-
     // ---- batch / wavefront calls: host or device arrays, n units (see include/merl_hip.h) ----
     void eval_batch(const float *wi, const float *wo, size_t n, float *rgb) const
     {
@@ -289,6 +307,17 @@ public:
 private:
     Material(std::shared_ptr<Context> ctx, std::shared_ptr<Context::Resident> res)
         : m_ctx(std::move(ctx)), m_res(std::move(res)), m_id(m_res->id) {}
+
+    // the last (table, wi, wo) -> (rgb, pdf) this thread asked for; the values are a pure function of the key
+    struct Memo {
+        unsigned long long table = 0;                   // Resident::serial, 0 = empty
+        float wi[3], wo[3], rgb[3], pdf;
+    };
+    static Memo &memo()
+    {
+        thread_local Memo m;
+        return m;
+    }
 
     // declaration order = reverse destruction order: the resident handle (which calls into the context) dies first
     std::shared_ptr<Context> m_ctx;
