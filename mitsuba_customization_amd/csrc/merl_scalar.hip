@@ -8,7 +8,9 @@
 // Requests of concurrent callers sit in different lanes and are served side by side.  (Tried: the slots dealt over eight
 // waves instead of two, so that callers do not wait for each other's evaluation — slower at every thread count, 0.84 vs
 // 0.59 us per call amortised over 16 threads: the PCIe transactions of the polls, not the evaluation, are what callers
-// queue behind, and more polling waves mean more of them.)
+// queue behind, and more polling waves mean more of them.  Also tried: chunk c of four neighbouring slots in one 64-byte
+// line, so that a quad's four accesses could cross PCIe as one transaction — no gain either, 0.76 us: the callers then
+// share cache lines on the host.)
 // Every wave reaches the exit: the loop ends after `lifetime_ticks` of the 100 MHz wall clock, when the host raises
 // `stop`, or after a fixed number of polls, whichever comes first; the host launches the successor.
 #include "merl_kernels.hpp"
