@@ -128,7 +128,7 @@ int main(int argc, char **argv)
         for (auto &th : pool) th.join();
         const double us_threads = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_threads).count() / (2.0 * m);
         std::cout << "scalar calls: " << us_single << " us/call from one thread, " << us_threads << " us/call amortised over " << T
-                  << " threads (combined rounds)\n";
+                  << " threads (one-unit call service)\n";
         for (unsigned t = 0; t < T; ++t) {
             size_t k = 0;
             for (size_t i = t; i < m; i += T, ++k) {
