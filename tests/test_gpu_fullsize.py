@@ -165,3 +165,76 @@ def test_1b_units_100_resident_tables(oracle, tables):
         small = g.eval_sample(wi[lo:].contiguous(), wo[lo:].contiguous(), u[lo:].contiguous(), mat=mat[lo:].contiguous())
         for a, b in zip(out, small):
             assert torch.equal(a[lo:], b)
+
+
+def test_one_table_beyond_four_gigabytes(oracle):
+    """A single customized_measurement table whose brick image exceeds 2^32 bytes (256 x 256 x 520 cells x 128 B = 4.36 GB):
+    every byte offset into it needs 64-bit arithmetic.  Lookups are compared with the oracle over the whole table, and in
+    particular in its last rows (the bytes beyond 4 GB)."""
+    from mitsuba_customization_amd import host, synth
+    dims = (256, 256, 520)
+    tab = synth.noise_table(77, dims=dims, decades=3.0, negative_fraction=0.0)
+    scale = (1.0, 1.0, 1.0)
+    n = 200_000
+    wi, wo, u = oracle.generate_pairs(0x5EED, 2468, n)
+    # half of the pairs with BOTH directions grazing and 0.3 .. 2 rad apart in azimuth: the half vector grazes too, i.e.
+    # theta_h near pi/2 = the table's last rows, with theta_d well away from 0
+    k = n // 2
+    rng = np.random.default_rng(5)
+    z1, z2 = rng.uniform(1e-3, 0.05, k), rng.uniform(1e-3, 0.05, k)
+    p1 = rng.uniform(0, 2 * np.pi, k); p2 = p1 + rng.uniform(0.3, 2.0, k)
+    wi[:k] = np.stack([np.sqrt(1 - z1 * z1) * np.cos(p1), np.sqrt(1 - z1 * z1) * np.sin(p1), z1], 1).astype(np.float32)
+    wo[:k] = np.stack([np.sqrt(1 - z2 * z2) * np.cos(p2), np.sqrt(1 - z2 * z2) * np.sin(p2), z2], 1).astype(np.float32)
+    T = oracle.OracleTable(tab, scale)
+    want = oracle.eval_sample_multi([T], wi, wo, u, None, oracle.make_opts())
+    with host.MerlHip(0) as g:
+        mid = g.upload_table(tab, scale)
+        assert g.memory_info()["table_bytes"] > (1 << 32)
+        got = [np.asarray(t) for t in g.eval_sample(wi, wo, u, material=mid)]
+        one = g.scalar_eval_sample(wi[5], wo[5], u[5], material=mid)
+    a = wi.astype(np.float64); b = wo.astype(np.float64)
+    a /= np.linalg.norm(a, axis=1, keepdims=True); b /= np.linalg.norm(b, axis=1, keepdims=True)
+    h = a + b
+    th = np.arctan2(np.hypot(h[:, 0], h[:, 1]), h[:, 2])
+    last_rows = np.sqrt(th / (np.pi / 2)) * dims[0] > 0.985 * dims[0]           # cells past byte offset 2^32
+    assert last_rows.sum() > 1000
+    td = np.arctan2(np.linalg.norm(a - b, axis=1), np.linalg.norm(h, axis=1))
+    well = (th > 0.02) & (td > 0.02)                                         # the noise table's ill-conditioned corner: test_gpu_parity
+    for kk in (0, 4):
+        ok = np.abs(got[kk].astype(np.float64) - want[kk]) <= 1e-6 * np.abs(want[kk]) + 1e-30
+        sel = well if kk == 0 else np.ones(n, bool)
+        assert ok[sel].all(), (kk, int((~ok[sel]).sum()))
+    assert (well & last_rows).sum() > 1000
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+    assert np.allclose(one[:3], got[0][5], rtol=2e-6, atol=1e-30)
+
+
+def test_one_wide_table_beyond_four_gigabytes(oracle):
+    """The same for the n-channel kernels: 8 channels x 160 x 160 x 680 cells x 256 B = 4.46 GB of bricks."""
+    from mitsuba_customization_amd import host, synth
+    dims, n_ch = (160, 160, 680), 8
+    planes = [synth.noise_table(100 + c, dims=dims, decades=3.0, negative_fraction=0.0)[0] for c in range(n_ch)]
+    tab = np.stack(planes, axis=0)
+    del planes
+    n = 100_000
+    wi, wo, u = oracle.generate_pairs(0x5EED, 1357, n)
+    k = n // 2
+    rng = np.random.default_rng(6)
+    z1, z2 = rng.uniform(1e-3, 0.05, k), rng.uniform(1e-3, 0.05, k)
+    p1 = rng.uniform(0, 2 * np.pi, k); p2 = p1 + rng.uniform(0.3, 2.0, k)
+    wi[:k] = np.stack([np.sqrt(1 - z1 * z1) * np.cos(p1), np.sqrt(1 - z1 * z1) * np.sin(p1), z1], 1).astype(np.float32)
+    wo[:k] = np.stack([np.sqrt(1 - z2 * z2) * np.cos(p2), np.sqrt(1 - z2 * z2) * np.sin(p2), z2], 1).astype(np.float32)
+    want = oracle.eval_sample_nch([oracle.OracleTableNch(tab)], wi, wo, u, None, oracle.make_opts())
+    with host.MerlHip(0) as g:
+        mid = g.upload_table_nch(tab)
+        assert g.memory_info()["table_bytes"] > (1 << 32)
+        got = [np.asarray(t) for t in g.eval_sample_nch(wi, wo, u, n_ch, material=mid)]
+    a = wi.astype(np.float64); b = wo.astype(np.float64)
+    a /= np.linalg.norm(a, axis=1, keepdims=True); b /= np.linalg.norm(b, axis=1, keepdims=True)
+    h = a + b
+    th = np.arctan2(np.hypot(h[:, 0], h[:, 1]), h[:, 2]); td = np.arctan2(np.linalg.norm(a - b, axis=1), np.linalg.norm(h, axis=1))
+    well = (th > 0.02) & (td > 0.02)
+    assert (well & (np.sqrt(th / (np.pi / 2)) * dims[0] > 0.985 * dims[0])).sum() > 1000
+    ok = np.abs(got[0].astype(np.float64) - want[0]) <= 1e-6 * np.abs(want[0]) + 1e-30
+    assert ok[well].all(), int((~ok[well]).sum())
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
