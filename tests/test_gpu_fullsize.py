@@ -101,6 +101,40 @@ def test_64m_linearity_in_the_table(gpu, batch64, tables):
     assert bool(((fab - (fa + fb)).abs() <= 5e-7 * fab.abs() + 1e-30).all())
 
 
+def test_64m_standard_parameterisation_properties(batch64, oracle, tables):
+    """A (theta_i, theta_o, |dphi|) table over all 64M units (MRL_OPT_TABLE_PARAM = standard): tile invariance; mirroring
+    BOTH directions in the plane y = 0 flips the sign of dphi and nothing else, so eval is bit-identical; the full-azimuth
+    form tells the two apart; a strided sample against the oracle."""
+    import torch
+    from mitsuba_customization_amd import host
+    wi, wo, u = batch64
+    dims = (64, 64, 128)
+    scale = (1.0 / 1500.0, 1.15 / 1500.0, 1.66 / 1500.0)
+    flip = torch.tensor([1.0, -1.0, 1.0], device="cuda")
+    with host.MerlHip(0) as g:
+        g.set_option(host.OPT_TABLE_PARAM, host.PARAM_STANDARD)
+        std = g.upload_table(tables("noise", 21, dims), scale)
+        g.set_option(host.OPT_TABLE_PARAM, host.PARAM_STANDARD_FULL)
+        full = g.upload_table(tables("ggx_std_full", 3, dims), scale)
+        one = g.eval_sample(wi, wo, u, material=std)
+        cuts = [0, 21_000_003, 21_000_004, N64]
+        parts = [g.eval_sample(wi[a:b], wo[a:b], u[a:b], material=std) for a, b in zip(cuts, cuts[1:])]
+        for k in range(5):
+            assert torch.equal(one[k], torch.cat([p[k] for p in parts])), f"output {k} depends on the launch tiling"
+        rgb = one[0]
+        mirrored = g.eval(wi * flip, wo * flip, material=std)
+        assert torch.equal(rgb.view(torch.int32), mirrored.view(torch.int32))
+        a = g.eval(wi[: 1 << 22], wo[: 1 << 22], material=full)
+        b = g.eval(wi[: 1 << 22] * flip, wo[: 1 << 22] * flip, material=full)
+        assert float(((a - b).abs() > 1e-3 * a.abs()).float().mean()) > 0.5
+        idx = _spot(N64)
+        ref = oracle.eval_sample_multi([oracle.OracleTable(tables("noise", 21, dims), scale, param=1)], wi[idx].cpu().numpy(), wo[idx].cpu().numpy(),
+                                       u[idx].cpu().numpy(), None)
+        got = [o[idx].cpu().numpy() for o in one]
+    assert _rel_ok(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    assert np.array_equal(got[3], ref[3]) and _rel_ok(got[4], ref[4])
+
+
 def test_256m_mixed_16_materials(gpu, oracle, tables):
     """BASELINE config 4: 16 MERL materials mixed in one 256M batch."""
     import torch
