@@ -407,14 +407,16 @@ int mrl_group_generate_tiles(mrl_group *g, uint64_t seed, uint64_t first_index, 
     return MRL_OK;
 }
 
-int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, int32_t single_id, size_t n_total, size_t chunk_units, int root,
-                                  float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
+// which: 0 the fused unit (five result arrays, 44 B per unit across the links), 1 eval only (rgb, 12 B per unit)
+static int sharded(mrl_group *g, int which, const mrl_tile_inputs *tiles, int32_t single_id, size_t n_total, size_t chunk_units, int root,
+                   float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
 {
+    const int n_arrays = which == 0 ? 5 : 1;
     if (!g) return MRL_ERR_INVALID;
     const int G = (int)g->members.size();
     if (!tiles || root < 0 || root >= G || chunk_units == 0) return gfail(g, MRL_ERR_INVALID, "bad argument");
     if (n_total == 0) return MRL_OK;
-    if (!out_rgb || !out_pdf || !out_wo || !out_pdf2 || !out_weight) return gfail(g, MRL_ERR_INVALID, "null array argument");
+    if (!out_rgb || (which == 0 && (!out_pdf || !out_wo || !out_pdf2 || !out_weight))) return gfail(g, MRL_ERR_INVALID, "null array argument");
     const size_t steps = mrl_chunk_steps(n_total, G, chunk_units);
     const size_t per = (n_total + (size_t)G - 1) / (size_t)G;
     const size_t cap = std::min(chunk_units, per);
@@ -424,7 +426,7 @@ int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, in
         size_t lo, hi;
         mrl_tile_bounds(n_total, G, r, &lo, &hi);
         m.timed = hi > lo;
-        if (hi > lo && (!tiles[r].wi || !tiles[r].wo || !tiles[r].u)) return gfail(g, MRL_ERR_INVALID, "null tile inputs on member " + std::to_string(r));
+        if (hi > lo && (!tiles[r].wi || !tiles[r].wo || (which == 0 && !tiles[r].u))) return gfail(g, MRL_ERR_INVALID, "null tile inputs on member " + std::to_string(r));
         if (r != root && hi > lo) { const int rc = ensure_buffers(g, m, cap); if (rc != MRL_OK) return rc; }
         if (m.timed) { MRL_GHIP(g, hipSetDevice(m.device)); MRL_GHIP(g, hipEventRecord(m.t0, m.compute)); }
     }
@@ -440,14 +442,16 @@ int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, in
             const size_t off = a - tlo, n = b - a;
             const mrl_tile_inputs &in = tiles[r];
             ChunkOut o;
-            if (r == root) o = { out_rgb + 3 * a, out_pdf + a, out_wo + 3 * a, out_pdf2 + a, out_weight + 3 * a };
+            if (r == root) o = { out_rgb + 3 * a, which == 0 ? out_pdf + a : nullptr, which == 0 ? out_wo + 3 * a : nullptr, which == 0 ? out_pdf2 + a : nullptr,
+                                 which == 0 ? out_weight + 3 * a : nullptr };
             else {
                 o = chunk_out(m.buf[s], m.buf_units);
                 if (m.sent_valid[s]) { MRL_GHIP(g, hipSetDevice(m.device)); MRL_GHIP(g, hipStreamWaitEvent(m.compute, m.sent[s], 0)); }
             }
-            const int rc = mrl_eval_sample_batch(m.ctx, in.wi + 3 * off, in.wo + 3 * off, in.u + 2 * off, in.mat ? in.mat + off : nullptr,
-                                                 single_id, n, o.rgb, o.pdf, o.wo, o.pdf2, o.weight);
-            if (rc != MRL_OK) return member_fail(g, r, rc, "mrl_eval_sample_batch");
+            const int rc = which == 0 ? mrl_eval_sample_batch(m.ctx, in.wi + 3 * off, in.wo + 3 * off, in.u + 2 * off, in.mat ? in.mat + off : nullptr,
+                                                              single_id, n, o.rgb, o.pdf, o.wo, o.pdf2, o.weight)
+                                      : mrl_eval_batch(m.ctx, in.wi + 3 * off, in.wo + 3 * off, in.mat ? in.mat + off : nullptr, single_id, n, o.rgb);
+            if (rc != MRL_OK) return member_fail(g, r, rc, which == 0 ? "mrl_eval_sample_batch" : "mrl_eval_batch");
             if (r != root) {
                 MRL_GHIP(g, hipSetDevice(m.device));
                 MRL_GHIP(g, hipEventRecord(m.done[s], m.compute));
@@ -470,9 +474,10 @@ int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, in
             const size_t n = b - a;
             const ChunkOut src = chunk_out(m.buf[s], m.buf_units);
             const float *from[5] = { src.rgb, src.pdf, src.wo, src.pdf2, src.weight };
-            float *to[5] = { out_rgb + 3 * a, out_pdf + a, out_wo + 3 * a, out_pdf2 + a, out_weight + 3 * a };
+            float *to[5] = { out_rgb + 3 * a, which == 0 ? out_pdf + a : nullptr, which == 0 ? out_wo + 3 * a : nullptr, which == 0 ? out_pdf2 + a : nullptr,
+                             which == 0 ? out_weight + 3 * a : nullptr };
             const size_t count[5] = { 3 * n, n, 3 * n, n, 3 * n };
-            for (int k = 0; k < 5 && posted == MRL_OK; ++k) {
+            for (int k = 0; k < n_arrays && posted == MRL_OK; ++k) {
                 if (rccl) {
                     ncclResult_t nr = g->rccl.Send(from[k], count[k], ncclFloat, root, m.comm, m.transfer);
                     if (nr == ncclSuccess) nr = g->rccl.Recv(to[k], count[k], ncclFloat, r, R.comm, R.transfer);
@@ -522,6 +527,17 @@ int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, in
         MRL_GHIP(g, hipEventRecord(m.t1, m.compute));
     }
     return MRL_OK;
+}
+
+int mrl_group_eval_sample_sharded(mrl_group *g, const mrl_tile_inputs *tiles, int32_t single_id, size_t n_total, size_t chunk_units, int root,
+                                  float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
+{
+    return sharded(g, 0, tiles, single_id, n_total, chunk_units, root, out_rgb, out_pdf, out_wo, out_pdf2, out_weight);
+}
+
+int mrl_group_eval_sharded(mrl_group *g, const mrl_tile_inputs *tiles, int32_t single_id, size_t n_total, size_t chunk_units, int root, float *out_rgb)
+{
+    return sharded(g, 1, tiles, single_id, n_total, chunk_units, root, out_rgb, nullptr, nullptr, nullptr, nullptr);
 }
 
 int mrl_group_eval_sample_batch(mrl_group *g, const float *wi, const float *wo, const float *u, const int32_t *mat, int32_t single_id, size_t n,

@@ -44,7 +44,7 @@ ABI_SYMBOLS = (
     "mrl_group_init", "mrl_group_destroy", "mrl_group_size", "mrl_group_transport", "mrl_group_last_error", "mrl_group_context",
     "mrl_group_set_option", "mrl_group_material_load_merl", "mrl_group_material_upload_f64", "mrl_group_material_upload_table",
     "mrl_group_material_ggx", "mrl_group_material_release", "mrl_tile_bounds", "mrl_chunk_bounds", "mrl_chunk_steps",
-    "mrl_group_generate_tiles", "mrl_group_eval_sample_sharded", "mrl_group_eval_sample_batch", "mrl_group_synchronize",
+    "mrl_group_generate_tiles", "mrl_group_eval_sample_sharded", "mrl_group_eval_sharded", "mrl_group_eval_sample_batch", "mrl_group_synchronize",
     "mrl_group_eval_batch", "mrl_group_pdf_batch", "mrl_group_eval_pdf_batch", "mrl_group_sample_batch",
     "mrl_group_last_timing",
 )
@@ -172,6 +172,7 @@ def load_library(path: Optional[str] = None):
     L.mrl_chunk_steps.argtypes = [C.c_size_t, C.c_int, C.c_size_t]; L.mrl_chunk_steps.restype = C.c_size_t
     L.mrl_group_generate_tiles.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, C.POINTER(TileInputs)]
     L.mrl_group_eval_sample_sharded.argtypes = [vp, C.POINTER(TileInputs), C.c_int32, C.c_size_t, C.c_size_t, C.c_int, fp, fp, fp, fp, fp]
+    L.mrl_group_eval_sharded.argtypes = [vp, C.POINTER(TileInputs), C.c_int32, C.c_size_t, C.c_size_t, C.c_int, fp]
     L.mrl_group_eval_sample_batch.argtypes = [vp, fp, fp, fp, vp, C.c_int32, C.c_size_t, fp, fp, fp, fp, fp]
     L.mrl_group_eval_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp]
     L.mrl_group_pdf_batch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, fp]
@@ -763,6 +764,12 @@ class MerlGroup:
             _addr(wo2, np.float32, 3, n_total, "out_wo"), _addr(pdf2, np.float32, None, n_total, "out_pdf2"),
             _addr(w, np.float32, 3, n_total, "out_weight")), "mrl_group_eval_sample_sharded")
         return out
+
+    def eval_sharded(self, tiles, n_total: int, chunk: int, out_rgb, root: int = 0, material: int = 0):
+        """eval only: one GPU tensor (n_total x 3) on the root member's device; 12 B per unit cross the links."""
+        self._check(self._lib.mrl_group_eval_sharded(self._g, tiles, material, n_total, chunk, root,
+                                                     _addr(out_rgb, np.float32, 3, n_total, "out_rgb")), "mrl_group_eval_sharded")
+        return out_rgb
 
     def eval_sample_host(self, wi, wo, u, mat=None, material: int = 0):
         """Host (numpy) arrays split over the members, staged concurrently; returns numpy outputs."""

@@ -68,6 +68,20 @@ def test_members_sharing_the_gpu_reproduce_the_single_device_run(tables, members
         for a, b in zip(out, ref):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
         assert len(grp.last_timing()) == members
+        # eval only: one result array through the same pipeline (alternating with the fused call on the same buffers)
+        rgb = torch.full((n, 3), -7.0, device="cuda")
+        grp.eval_sharded(tiles, n, chunk, rgb, root=root, material=ids[0])
+        grp.eval_sample_sharded(tiles, n, chunk, out, root=root, material=ids[0])
+        grp.eval_sharded(tiles, n, max(1, chunk // 2), rgb, root=root, material=ids[0])
+        grp.synchronize()
+        with host.MerlHip(0) as single:
+            sid = [single.upload_merl(t) for t in tabs]
+            wi, wo, u = single.generate_pairs(0x5EED, 0, n)
+            mat = single.generate_materials(0x5EED, 0, n, n_tables) if n_tables > 1 else None
+            want = single.eval(wi, wo, mat=mat, material=sid[0])
+            assert torch.equal(rgb.view(torch.int32), want.view(torch.int32))
+        for a, b in zip(out, ref):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
 def test_host_arrays_split_over_members(oracle, tables):
