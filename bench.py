@@ -99,6 +99,7 @@ def parse(argv=None):
                    help="control-plane backend; gloo only rehearses the multi-rank logic (ranks may then share one GPU: --share-gpu)")
     p.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     p.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the child ranks are killed")
+    p.add_argument("--no-scalar-calls", action="store_true", help="N=1: skip the separately reported one-unit call leg (lib/scalar_host)")
     p.add_argument("--no-native-group", action="store_true",
                    help="N>1: skip the separately reported run of the native C++ host (lib/group_host: one process, mrl_group over the N GPUs, RCCL gather)")
     p.add_argument("--native-units", type=int, default=8 << 20, help="N>1: units per device of the native C++ host's run")
@@ -189,6 +190,30 @@ def native_group_leg(n_gpus: int, share_gpu: bool, units: int, deadline: float) 
     out = json.loads(line[-1])
     out["cmd"] = " ".join(cmd)
     return out
+
+
+def scalar_calls_leg(deadline: float = 60.0) -> dict:
+    """What ONE-unit calls cost (the virtual BSDF::eval / sample / pdf of a stock per-ray integrator; mrl_scalar_*),
+    reported beside `value`: examples/scalar_host.cpp as a child process once this process has released the GPU — microseconds
+    per call from one thread and amortised over 16, every answer bit-compared with the batch call inside the program."""
+    import subprocess
+    exe = os.path.join(ROOT, "mitsuba_customization_amd", "lib", "scalar_host")
+    if not os.path.exists(exe):
+        return {"skipped": "lib/scalar_host is not built"}
+    cmd = [exe, "--threads", "16", "--calls", "5000"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=deadline)
+    except subprocess.TimeoutExpired:
+        return {"failed": f"lib/scalar_host did not finish within {deadline} s and was killed"}
+    except Exception as e:
+        return {"failed": repr(e)}
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"failed": f"exit code {r.returncode}", "stderr": r.stderr[-300:]}
+    d = json.loads(line[-1])
+    return {"us_per_call_one_thread": d["solo_us_per_call"], "us_per_eval_pdf_call_one_thread": d["solo_eval_pdf_us"],
+            "us_per_sample_call_one_thread": d["solo_sample_us"], "us_per_call_amortised_16_threads": d["all_threads_us_per_call_amortised"],
+            "answers_differing_from_the_batch_call": d["wrong"], "cmd": " ".join(cmd)}
 
 
 def cpu_baseline(ob, table, lookup: int, reps: int) -> dict:
@@ -520,6 +545,9 @@ def main():
         del wi, wo, u, out, mat
         torch.cuda.empty_cache()
         result["native_group"] = native_group_leg(world, args.share_gpu, args.native_units, args.native_deadline)
+    # ---- N=1: the per-ray plugin path (one-unit calls), beside `value`, never in it ----
+    if world == 1 and args.config == "merl64m" and not args.no_scalar_calls and not args.no_cpu_baseline:
+        result["scalar_calls"] = scalar_calls_leg()
     emit()
 
 
