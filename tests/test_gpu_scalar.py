@@ -140,3 +140,21 @@ def test_nothing_spins_after_the_calls_stop():
         assert time.perf_counter() - t0 < 0.5
         g.scalar_eval_sample((0.3, 0.1, 0.9), (-0.2, 0.4, 0.8), (0.3, 0.7), material=mid)
     # destroyed with an instance possibly still alive: mrl_destroy stops it
+
+
+def test_null_arguments_are_refused():
+    """Negative status codes, no crash: NULL context, NULL arrays, material ids beyond the 28 bits the mailbox carries."""
+    import ctypes as C
+    from mitsuba_customization_amd import host, synth
+    with host.MerlHip(0) as g:
+        mid = g.upload_table(synth.make_table("noise", 1, (4, 4, 4)), (1.0, 1.0, 1.0))
+        L, ctx = g._lib, g._ctx
+        v3 = (C.c_float * 3)(0.1, 0.2, 0.9); v2 = (C.c_float * 2)(0.3, 0.7); out = (C.c_float * 11)(); pdf = C.c_float()
+        assert L.mrl_scalar_eval_sample(None, mid, v3, v3, v2, out) == host.ERR_INVALID
+        assert L.mrl_scalar_eval_sample(ctx, mid, None, v3, v2, out) == host.ERR_INVALID
+        assert L.mrl_scalar_eval_sample(ctx, mid, v3, v3, v2, None) == host.ERR_INVALID
+        assert L.mrl_scalar_eval_pdf(ctx, mid, v3, v3, None, C.byref(pdf)) == host.ERR_INVALID
+        assert L.mrl_scalar_sample(ctx, mid, v3, None, v3, C.byref(pdf), v3) == host.ERR_INVALID
+        for bad in (-1, 1 << 28, (1 << 31) - 1):
+            assert L.mrl_scalar_eval_sample(ctx, bad, v3, v3, v2, out) == host.ERR_MATERIAL
+        assert L.mrl_scalar_eval_sample(ctx, mid, v3, v3, v2, out) == 0          # and the service still answers
