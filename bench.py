@@ -95,6 +95,9 @@ def parse(argv=None):
     p.add_argument("--gather-units", type=int, default=16 << 20, help="N>1: units per rank moved by the gather leg")
     p.add_argument("--gather-deadline", type=float, default=90.0, help="N>1: seconds after which the gather leg counts as failed")
     p.add_argument("--parity-sample", type=int, default=4096)
+    p.add_argument("--coherent", type=int, default=0,
+                   help="diagnostic, never the bench line: the inputs repeat with this period (units), so the table traffic is served by "
+                        "L2 the way a real render's coherent rays are and the launch shows its non-fabric floor (VALU + LDS + streams)")
     p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                    help="control-plane backend; gloo only rehearses the multi-rank logic (ranks may then share one GPU: --share-gpu)")
     p.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -316,6 +319,10 @@ def main():
     first = rank * n
     wi, wo, u = gpu.generate_pairs(SEED, first, n)          # untimed, in place on the device
     dev = wi.device
+    if args.coherent and args.coherent < n:
+        p_ = args.coherent
+        reps = (n + p_ - 1) // p_
+        wi, wo, u = (x[:p_].repeat(reps, 1)[:n].contiguous() for x in (wi, wo, u))
     mat = None
     if len(ids) > 1:
         mat = gpu.generate_materials(SEED, first, n, len(ids))
@@ -417,6 +424,7 @@ def main():
             "kernel_variant": variant,
             "table_layout": layout,
             "sharding": f"index tiles x{world}, tables replicated, no data-path collective",
+            **({"coherent_period": args.coherent, "not_the_bench_line": "inputs repeat: table traffic is L2-served"} if args.coherent else {}),
         },
         "roofline": roofline,
     }

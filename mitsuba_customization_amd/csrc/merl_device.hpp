@@ -125,22 +125,26 @@ __device__ __forceinline__ Rgbd lookup_nearest_t(const MaterialDev &m, const Coo
     return { (double)t.x, (double)t.y, (double)t.z };
 }
 
-// clamped axis: i0 in [0,n-1], f in [0,1]; i0+1 is always a valid (padded) index
+// Both splits take x in [-1, n] (every coordinate map of this file lands there: angles are atan2 results scaled by n / range,
+// minus the half-texel shift of the centre-node convention) or NaN, and stay inside the table for anything else.
+// clamped axis: i0 in [0,n-1], f in [0,1]; i0+1 is always a valid (padded) index.  (int)x truncates towards zero, which for
+// x > -1 is floor(x) clamped at 0 (v_cvt_i32_f64 saturates and maps NaN to 0): no floor, no lower clamp.
 __device__ __forceinline__ void split_clamped(double x, int n, int &i0, double &f)
 {
-    int i = clampi((int)floor(x), 0, n - 1);
-    double fr = x - (double)i;
-    f = fr < 0.0 ? 0.0 : (fr > 1.0 ? 1.0 : fr);
+    const int i = min((int)x, n - 1);
+    f = __builtin_fmin(__builtin_fmax(x - (double)i, 0.0), 1.0);
     i0 = i;
 }
-// periodic axis: i0 in [0,n-1]; i0+1 <= n hits the appended wrap texel
+// periodic axis: i0 in [0,n-1]; i0+1 <= n hits the appended wrap texel.  floor(x) is in [-1, n]: shifted by n it lies in
+// [n-1, 2n] and two unsigned min(j, j - n) steps bring it to [0, n-1] (j < n: j - n wraps around to a huge value and j wins).
 __device__ __forceinline__ void split_periodic(double x, int n, int &i0, double &f)
 {
-    double fl = floor(x);
-    int i = (int)fl;
+    const double fl = floor(x);
     f = x - fl;
-    i = i % n;
-    i0 = i < 0 ? i + n : i;
+    unsigned j = (unsigned)((int)fl + n);
+    j = min(j, j - (unsigned)n);
+    j = min(j, j - (unsigned)n);
+    i0 = (int)min(j, (unsigned)(n - 1));          // only reached by x outside [-1, n]: stay inside the table
 }
 
 // the azimuth axis: periodic, except for the mirrored standard form (0 and pi are its two ends)
@@ -226,17 +230,20 @@ __device__ __forceinline__ void square_to_cosine_hemisphere(int disk_map, float 
 #pragma clang fp contract(off)
     const float QUARTER_PI = 0.78539816339744830962f;
     float a = 2.0f * u0 - 1.0f, b = 2.0f * u1 - 1.0f;
-    if (a == 0.0f && b == 0.0f) {
-        x = 0.0f; y = 0.0f;
-    } else {
+    {
+        // one IEEE division for both branches of the map (num / den selected first); a == b == 0 divides 0 by 0 and is
+        // replaced below — the same values, instruction for instruction, as the two-branch form of the oracle
         float aa = a * a, bb = b * b;
         bool first = disk_map ? !(fabsf(a) < fabsf(b)) : (aa > bb);
         float r = first ? a : b;
-        float ratio = first ? (b / a) : (a / b);
+        float ratio = (first ? b : a) / r;
         float s, c;
         sincos_quarter_f32(QUARTER_PI * ratio, s, c);
         x = r * (first ? c : s);
         y = r * (first ? s : c);
+        const bool origin = (a == 0.0f) && (b == 0.0f);
+        x = origin ? 0.0f : x;
+        y = origin ? 0.0f : y;
     }
     float xx = x * x;
     float zz = 1.0f - __builtin_fmaf(y, y, xx);
@@ -406,6 +413,63 @@ __device__ __forceinline__ void table_sample_dir(const MaterialDev &m, int disk_
     x = (float)(2.0 * c * h.x - in.x); y = (float)(2.0 * c * h.y - in.y); z = (float)(2.0 * c * h.z - in.z);
 }
 
+// ---- tails shared by every kernel (generic and tuned), so that entry points agree bit for bit on the same lookup value ----
+namespace fast {
+// 1 / x: v_rcp_f64 seed + one Newton step (relative error ~1e-15)
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
+// NaN / inf directions: the floors and guards of this file would turn them into finite garbage; an f64 CPU evaluation
+// propagates NaN instead, so the cosine factor is poisoned when a component of either input is not finite.
+// wi_sum = wix + wiy + wiz is shared by the two lookups of a unit.
+__device__ __forceinline__ float cos_or_nan32(float wi_sum, float wox, float woy, float woz)
+{
+    const float t = wi_sum + (wox + woy + woz);                     // NaN or inf iff some component is
+    return (__builtin_fabsf(t) <= 3.0e38f) ? woz : __builtin_nanf("");
+}
+__device__ __forceinline__ double cos_or_nan(float wix, float wiy, float wiz, float wox, float woy, float woz)
+{
+    return (double)cos_or_nan32((wix + wiy + wiz), wox, woy, woz);
+}
+
+// a5 tail: rgb = f cos(theta_o); zero for a pair that fails the cosine guards (texels are finite by construction,
+// so the factor 0 is enough), NaN where an input component is not finite and the guards pass
+__device__ __forceinline__ void eval_tail(const Rgbd &v, float wi_sum, float wiz, float wox, float woy, float woz, float rgb[3])
+{
+    const bool valid = (wiz > 0.0f) && (woz > 0.0f);
+    const float c32 = cos_or_nan32(wi_sum, wox, woy, woz);
+    const double c = (double)(valid ? c32 : 0.0f);
+    rgb[0] = (float)(v.r * c); rgb[1] = (float)(v.g * c); rgb[2] = (float)(v.b * c);
+}
+// a6 tail: weight = eval(wi, wo') / pdf IN Float, as the plugin computes it: f = Float(f_d cos theta_o') first, then the
+// Float quotient f / pdf.  The three IEEE divisions share one reciprocal: q = double(f) * (1/pdf) with 1/pdf good to
+// ~3e-16 (two Newton steps) is within 5e-16 of the true quotient, and a quotient of two 24-bit floats is never closer
+// than 2^-49 = 1.8e-15 (relative) to a rounding boundary of Float, so Float(q) IS the correctly rounded f / pdf
+// (tests/test_gpu_fullsize.py checks weight == eval / pdf bit for bit on 64M units).  Zero when the sample is invalid
+// or its pdf is zero.
+__device__ __forceinline__ void sample_tail(const Rgbd &v, float wi_sum, float wiz, float sx, float sy, float sz, float p, bool table_sampling,
+                                            float wo[3], float &pdf, float weight[3])
+{
+    const bool valid = (wiz > 0.0f) && (!table_sampling || p > 0.0f);
+    const bool has = valid && (p > 0.0f);
+    const float c32 = cos_or_nan32(wi_sum, sx, sy, sz);
+    const double c = (double)(has ? c32 : 0.0f);
+    const double pd = (double)(has ? p : 1.0f);
+    double y = __builtin_amdgcn_rcp(pd);
+    y = __builtin_fma(y, __builtin_fma(-pd, y, 1.0), y);
+    y = __builtin_fma(y, __builtin_fma(-pd, y, 1.0), y);
+    wo[0] = valid ? sx : 0.0f; wo[1] = valid ? sy : 0.0f; wo[2] = valid ? sz : 0.0f;
+    pdf = valid ? p : 0.0f;
+    weight[0] = (float)((double)(float)(v.r * c) * y);
+    weight[1] = (float)((double)(float)(v.g * c) * y);
+    weight[2] = (float)((double)(float)(v.b * c) * y);
+}
+} // namespace fast
+
 // ---- a5 / a6 / a7 for one unit, any material kind ------------------------------------------
 // eval(): rgb = f * cos(theta_o), zero unless cos(theta_i) > 0 and cos(theta_o) > 0
 __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o,
@@ -420,8 +484,8 @@ __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o
         v = ggx_eval(m, in, out);
     } else {
         v = table_brdf(m, o, in, out);
-        double c = (double)woz;
-        v.r *= c; v.g *= c; v.b *= c;
+        fast::eval_tail(v, (wix + wiy + wiz), wiz, wox, woy, woz, rgb);
+        return;
     }
     rgb[0] = (float)v.r; rgb[1] = (float)v.g; rgb[2] = (float)v.b;
 }
@@ -459,12 +523,9 @@ __device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options 
         square_to_cosine_hemisphere(o.disk_map, u0, u1, x, y, z);
         p = z > 0.0f ? z * kInvPiF : 0.0f;
     }
-    wo[0] = x; wo[1] = y; wo[2] = z;
-    pdf = p;
-    if (!(p > 0.0f)) return;
-    float f[3];
-    unit_eval(m, o, wix, wiy, wiz, x, y, z, f);
-    weight[0] = (f[0] / p); weight[1] = (f[1] / p); weight[2] = (f[2] / p);
+    Vec3d in = normalized(wix, wiy, wiz), out = normalized(x, y, z);
+    const Rgbd v = table_brdf(m, o, in, out);
+    fast::sample_tail(v, (wix + wiy + wiz), wiz, x, y, z, p, o.sampling != 0, wo, pdf, weight);
 }
 
 // ---- synthetic inputs, bit-identical to the oracle's generator ---------------

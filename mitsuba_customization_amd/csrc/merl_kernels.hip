@@ -174,31 +174,39 @@ constexpr int kDmaBlock = MRL_DMA_BLOCK;
 
 __device__ __forceinline__ unsigned brick_swz(unsigned unit) { return (unit >> 1) & 7u; }
 
-// Source address of the 16-B piece this lane copies in step k (unit 8k + lane/8), gathered from the
-// owning lane by ds_bpermute.  All exchanges of a lookup are issued back to back, BEFORE the copies:
-// a copy needs its address, and interleaving them one by one exposes sixteen bpermute latencies per unit.
+// Source address of the 16-B piece this lane copies in step k (unit 8k + lane/8).  The 64 cell indices of the wave
+// change hands through a wave-private LDS page: lane L = 8k + g stores its index at dword g*8 + k, and lane-group g then
+// reads the eight indices it copies for (units g, 8 + g, ..., 56 + g) back as TWO ds_read_b128 of dwords g*8 .. g*8 + 7.
+// One ds_write_b32 + two ds_read_b128 per lookup instead of eight ds_bpermute_b32 (24 cycles each on the CU's one LDS
+// pipe, which this kernel keeps 60 % busy: tools/microbench/valu_issue.hip, profiles/r03_valu_issue.json).  Mixed batches
+// exchange the 64-bit brick address the same way (ds_write_b64, four ds_read_b128).  LDS operations of one wave execute
+// in order, so the reads see the writes; the wavefront fence keeps the compiler from moving them.
 template <bool MULTI>
 struct BrickSources {
     const float4 *src[8];
-    __device__ __forceinline__ BrickSources(const float4 *single_base, uint32_t idx, const float4 *lane_base, unsigned lane)
+    __device__ __forceinline__ BrickSources(const float4 *single_base, uint32_t idx, const float4 *lane_base, unsigned lane, uint32_t *page)
     {
-        const unsigned g = lane >> 3, piece_lane = lane & 7u;
-        uint32_t lo = 0, hi = 0, got_lo[8], got_hi[8];
+        const unsigned g = lane >> 3, k_own = lane >> 3, g_own = lane & 7u;
+        const unsigned piece_lane = lane & 7u;
         if constexpr (MULTI) {
-            const uint64_t addr = (uint64_t)(lane_base + (size_t)idx * 8);
-            lo = (uint32_t)addr; hi = (uint32_t)(addr >> 32);
-        }
+            uint64_t *page64 = (uint64_t *)page;
+            page64[g_own * 8u + k_own] = (uint64_t)(lane_base + (size_t)idx * 8);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const ulonglong2 *rd = (const ulonglong2 *)(page64 + g * 8u);
+            const ulonglong2 a0 = rd[0], a1 = rd[1], a2 = rd[2], a3 = rd[3];
+            const uint64_t got[8] = { a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y };
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int sel = (int)((8u * k + g) << 2);
-            got_lo[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)(MULTI ? lo : idx));
-            if constexpr (MULTI) got_hi[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)hi);
-        }
+            for (int k = 0; k < 8; ++k) src[k] = (const float4 *)got[k] + (piece_lane ^ brick_swz(8u * k + g));
+        } else {
+            page[g_own * 8u + k_own] = idx;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint4 *rd = (const uint4 *)(page + g * 8u);
+            const uint4 a0 = rd[0], a1 = rd[1];
+            const uint32_t got[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned piece = piece_lane ^ brick_swz(8u * k + g);
-            if constexpr (MULTI) src[k] = (const float4 *)(((uint64_t)got_hi[k] << 32) | got_lo[k]) + piece;
-            else src[k] = single_base + (size_t)got_lo[k] * 8 + piece;
+            for (int k = 0; k < 8; ++k) src[k] = single_base + ((size_t)got[k] * 8 + (piece_lane ^ brick_swz(8u * k + g)));
         }
     }
     __device__ __forceinline__ void copy_to(float4 *lds_slots) const
@@ -244,6 +252,7 @@ __device__ __forceinline__ Rgbd brick_interp(const float4 *lds_slots, unsigned l
 // One unit's registers while it travels through the DMA kernels.
 struct UnitIO {
     float wix, wiy, wiz, wox, woy, woz, u0, u1;
+    float wi_sum;                                             // wix + wiy + wiz (NaN / inf probe shared by the unit's lookups)
     float rgb[3], pdf, wo2[3], pdf2, w[3];
 };
 
@@ -254,7 +263,7 @@ struct UnitIO {
 // is the half/diff-only code (A/B on one box: the wave-uniform parameterisation branch costs the headline launch 0.5 %).
 template <int MODE, bool MULTI, bool GGX, bool STD>
 __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDev &m, bool is_table, UnitIO &io,
-                                            const fast::Vec3 &in, float4 *ldsA, float4 *ldsB, unsigned lane)
+                                            const fast::Vec3 &in, float4 *ldsA, float4 *ldsB, uint32_t *pageA, uint32_t *pageB, unsigned lane)
 {
     constexpr bool HAS_EVAL = mode_eval(MODE);
     constexpr bool HAS_SAMPLE = mode_sample(MODE);
@@ -286,7 +295,7 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
     }
     {
         // every address exchange of the unit first, then every copy
-        const BrickSources<MULTI> srcA(m.texels, cellA, lane_base, lane), srcB(m.texels, cellB, lane_base, lane);
+        const BrickSources<MULTI> srcA(m.texels, cellA, lane_base, lane, pageA), srcB(m.texels, cellB, lane_base, lane, pageB);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (HAS_EVAL) srcA.copy_to(ldsA);
         if constexpr (HAS_SAMPLE) srcB.copy_to(ldsB);
@@ -295,11 +304,10 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
 
     if constexpr (HAS_EVAL) {
         const Rgbd v = brick_interp(ldsA, lane, wA);
-        const bool valid = (io.wiz > 0.0f) && (io.woz > 0.0f);
-        const double c = fast::cos_or_nan(io.wix, io.wiy, io.wiz, io.wox, io.woy, io.woz);
         if (!GGX || is_table) {
-            io.rgb[0] = valid ? (float)(v.r * c) : 0.0f; io.rgb[1] = valid ? (float)(v.g * c) : 0.0f; io.rgb[2] = valid ? (float)(v.b * c) : 0.0f;
+            fast::eval_tail(v, io.wi_sum, io.wiz, io.wox, io.woy, io.woz, io.rgb);
             if constexpr (mode_pdf(MODE)) {
+                const bool valid = (io.wiz > 0.0f) && (io.woz > 0.0f);
                 io.pdf = valid ? io.woz * kInvPiF : 0.0f;
                 if (a.opts.sampling && valid) io.pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(io.wox, io.woy, io.woz), io.woz);
             }
@@ -307,17 +315,7 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
     }
     if constexpr (HAS_SAMPLE) {
         const Rgbd v = brick_interp(ldsB, lane, wB);
-        const float p = sp;
-        const bool valid = (io.wiz > 0.0f) && (!a.opts.sampling || p > 0.0f);
-        const bool has = valid && (p > 0.0f);
-        const double c = fast::cos_or_nan(io.wix, io.wiy, io.wiz, sx, sy, sz);
-        const float f0 = has ? (float)(v.r * c) : 0.0f, f1 = has ? (float)(v.g * c) : 0.0f, f2 = has ? (float)(v.b * c) : 0.0f;
-        const float ps = has ? p : 1.0f;
-        if (!GGX || is_table) {
-            io.wo2[0] = valid ? sx : 0.0f; io.wo2[1] = valid ? sy : 0.0f; io.wo2[2] = valid ? sz : 0.0f;
-            io.pdf2 = valid ? p : 0.0f;
-            io.w[0] = f0 / ps; io.w[1] = f1 / ps; io.w[2] = f2 / ps;
-        }
+        if (!GGX || is_table) fast::sample_tail(v, io.wi_sum, io.wiz, sx, sy, sz, sp, a.opts.sampling != 0, io.wo2, io.pdf2, io.w);
     }
     asm volatile("" ::: "memory");                            // LDS reads above stay ahead of the next step's DMA
 }
@@ -345,17 +343,19 @@ __device__ __forceinline__ void ggx_lane(const MaterialDev &m, UnitIO &io, const
     }
 }
 
+// `first` is wave-uniform (the tile's first unit; 0 for queue launches), `i` the lane's offset from it: the stores then take a
+// scalar base and a 32-bit lane offset
 template <int MODE, bool NT>
-__device__ __forceinline__ void store_unit(const BatchArgs &a, size_t i, const UnitIO &io)
+__device__ __forceinline__ void store_unit(const BatchArgs &a, size_t first, size_t i, const UnitIO &io)
 {
     constexpr bool HAS_EVAL = mode_eval(MODE);
     constexpr bool HAS_SAMPLE = mode_sample(MODE);
-    if constexpr (HAS_EVAL) store3s<NT>(a.out_rgb, i, io.rgb);
-    if constexpr (mode_pdf(MODE)) stf<NT>(a.out_pdf + i, io.pdf);
+    if constexpr (HAS_EVAL) store3s<NT>(a.out_rgb + 3 * first, i, io.rgb);
+    if constexpr (mode_pdf(MODE)) stf<NT>(a.out_pdf + first + i, io.pdf);
     if constexpr (HAS_SAMPLE) {
-        store3s<NT>(a.out_wo, i, io.wo2);
-        stf<NT>(a.out_pdf2 + i, io.pdf2);
-        store3s<NT>(a.out_weight, i, io.w);
+        store3s<NT>(a.out_wo + 3 * first, i, io.wo2);
+        stf<NT>(a.out_pdf2 + first + i, io.pdf2);
+        store3s<NT>(a.out_weight + 3 * first, i, io.w);
     }
 }
 
@@ -375,10 +375,13 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
     constexpr bool HAS_SAMPLE = mode_sample(MODE);
     constexpr int LOOKUPS = (HAS_EVAL ? 1 : 0) + (HAS_SAMPLE ? 1 : 0);
     __shared__ float4 lds[kDmaBlock / 64][LOOKUPS][512];      // 8 KB per wave and lookup
+    __shared__ uint32_t pages[kDmaBlock / 64][LOOKUPS][MULTI ? 128 : 64];   // address exchange (BrickSources)
 
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // the wave index in an SGPR: LDS bases (M0 of the copies) and the tile's stream addresses are then scalar work
+    const unsigned lane = threadIdx.x & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float4 *ldsA = lds[wave][0];
     float4 *ldsB = lds[wave][LOOKUPS - 1];
+    uint32_t *pageA = pages[wave][0], *pageB = pages[wave][LOOKUPS - 1];
     const size_t n_items = item_count<INDEXED>(a);
     // Block -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (blocks b and b + 8 share one; observed, used
     // for speed only).  a.block_map = 1: XCD x walks ITS contiguous eighth of the batch, so units that are neighbours in
@@ -395,15 +398,19 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
     for (; tile < tile_end; tile += tile_step) {
         const size_t base = tile * kDmaBlock + wave * 64u;
         if (base >= n_items) break;                           // a wave beyond the tail of the last tile (wave-uniform)
-        const size_t j_raw = base + lane;
-        const bool active = j_raw < n_items;
-        const size_t j = active ? j_raw : n_items - 1;        // tail lanes recompute the last unit, store nothing
-        const size_t i = INDEXED ? (size_t)a.idx[j] : j;
+        const bool active = base + lane < n_items;
+        // `first` + `i`: a wave-uniform first unit plus a per-lane offset.  Whole-array launches: the tile's base and the lane
+        // number (tail lanes recompute the last unit, store nothing) — stream addresses are then a scalar base and a 32-bit
+        // lane offset; queue launches: 0 and the queued unit index.
+        const size_t first = INDEXED ? (size_t)0 : base;
+        size_t i;
+        if constexpr (INDEXED) i = (size_t)a.idx[active ? base + lane : n_items - 1];
+        else i = (size_t)(active ? lane : (unsigned)(n_items - 1 - base));
 
         MaterialDev m;
         bool known = true;
         if constexpr (MULTI) {
-            int id = a.mat[i];
+            int id = (a.mat + first)[i];
             known = id >= 0 && id < a.n_materials;
             m = a.materials[known ? id : 0];
             known = known && kind_is_rgb_path(m.kind);
@@ -415,18 +422,19 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
 
         UnitIO io = {};
         io.woz = 1.0f;
-        load3s<NT>(a.wi, i, io.wix, io.wiy, io.wiz);
+        load3s<NT>(a.wi + 3 * first, i, io.wix, io.wiy, io.wiz);
         if (!known) io.wiz = 0.0f;
-        if constexpr (HAS_EVAL) load3s<NT>(a.wo, i, io.wox, io.woy, io.woz);
-        if constexpr (HAS_SAMPLE) { io.u0 = ldf<NT>(a.u + 2 * i); io.u1 = ldf<NT>(a.u + 2 * i + 1); }
+        io.wi_sum = io.wix + io.wiy + io.wiz;
+        if constexpr (HAS_EVAL) load3s<NT>(a.wo + 3 * first, i, io.wox, io.woy, io.woz);
+        if constexpr (HAS_SAMPLE) { const float *up = a.u + 2 * first; io.u0 = ldf<NT>(up + 2 * i); io.u1 = ldf<NT>(up + 2 * i + 1); }
         const fast::Vec3 in = fast::normalize_f32(io.wix, io.wiy, io.wiz);
 
         if (!GGX || __ballot(is_table) != 0ull)               // wave-uniform
-            table_lanes<MODE, MULTI, GGX, STD>(a, m, is_table, io, in, ldsA, ldsB, lane);
+            table_lanes<MODE, MULTI, GGX, STD>(a, m, is_table, io, in, ldsA, ldsB, pageA, pageB, lane);
         if constexpr (GGX) {
             if (!is_table) ggx_lane<MODE>(m, io, in);
         }
-        if (active) store_unit<MODE, NT>(a, i, io);
+        if (active) store_unit<MODE, NT>(a, first, i, io);
     }
 }
 

@@ -15,13 +15,6 @@
 namespace mrl {
 namespace fast {
 
-__device__ __forceinline__ double rcp_nr(double x)
-{
-    double y = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, y, 1.0);
-    return __builtin_fma(y, e, y);
-}
-
 // n / d for finite d != 0: v_rcp_f64 seed + one Newton step (relative error ~1e-15; the
 // coordinate budget is 1e-10, so no residual correction)
 __device__ __forceinline__ double div_fast(double n, double d)
@@ -51,12 +44,30 @@ __device__ __forceinline__ double sqrt_fast(double x)
     double r = __builtin_fma(-h, g, 0.5);
     return __builtin_fma(g, r, g);
 }
+// sqrt(x) for x > 0 known (a sum of squares of a direction that passed the cosine guards): no floor
+__device__ __forceinline__ double sqrt_pos(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    return __builtin_fma(g, r, g);
+}
+// 1/sqrt(x) for x > 0: seed + one Newton step, y (1 + e/2) with e = 1 - x y^2.  x == 0 gives NaN (0 * inf): callers pass
+// squared lengths of directions whose lanes are masked by the cosine guards when the length is zero.
+__device__ __forceinline__ double rsqrt_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(0.5 * y, e, y);
+}
 
 // atan2(a, b) for a >= 0, b >= 0 -> [0, pi/2].
 // With mn = min, mx = max:  atan(mn/mx) = pi/8 + atan(r),  r = (mn - c mx) / (mx + c mn),  c = tan(pi/8),
 // and |r| <= c for every mn/mx in [0,1] — a fixed rotation by pi/8, so no range select is needed.
 // atan(r) = r P(r^2), P of degree 8 (abs error 9.4e-15 on |r| <= c).  a > b mirrors about pi/4.
 // (a, b) = (0, 0) returns pi/8: phi_d is undefined there (degenerate h or retro-reflection).
+// FLOOR = false: (a, b) != (0, 0) is known (den > 0), the kTiny floor on the denominator is dropped.
+template <bool FLOOR = true>
 __device__ __forceinline__ double atan2_q1(double a, double b)
 {
     constexpr double C = 0.41421356237309503;            // tan(pi/8)
@@ -64,7 +75,8 @@ __device__ __forceinline__ double atan2_q1(double a, double b)
     constexpr double PI_3_8 = 1.17809724509617246442;
     const double mn = __builtin_fmin(a, b), mx = __builtin_fmax(a, b);
     const double num = __builtin_fma(-C, mx, mn);
-    const double den = __builtin_fmax(__builtin_fma(C, mn, mx), kTiny);
+    double den = __builtin_fma(C, mn, mx);
+    if constexpr (FLOOR) den = __builtin_fmax(den, kTiny);
     const double r = div_fast(num, den);
     const double z = r * r;
     double p = 0x1.f5ef263ad0056p-6;
@@ -85,18 +97,9 @@ struct Vec3 { double x, y, z; };
 
 __device__ __forceinline__ Vec3 normalize_f32(float x, float y, float z)
 {
-    double dx = x, dy = y, dz = z;
-    double s, rs;
-    sqrt_rsqrt(__builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz)), s, rs);
+    const double dx = x, dy = y, dz = z;
+    const double rs = rsqrt_pos(__builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz)));
     return { dx * rs, dy * rs, dz * rs };
-}
-
-// NaN / inf directions: the kTiny floors above would turn them into finite garbage; an f64 CPU
-// evaluation propagates NaN instead, so the cosine factor is poisoned when either input is not finite.
-__device__ __forceinline__ double cos_or_nan(float wix, float wiy, float wiz, float wox, float woy, float woz)
-{
-    const float t = (wix + wiy + wiz) + (wox + woy + woz);          // NaN or inf iff some component is
-    return (__builtin_fabsf(t) <= 3.0e38f) ? (double)woz : __builtin_nan("");
 }
 
 // a2 + a3 for unit in/out (see merl_device.hpp::half_diff_coords for the derivation)
@@ -107,9 +110,10 @@ __device__ __forceinline__ Coords coords(const Vec3 &in, const Vec3 &out, double
     const double rho2 = __builtin_fma(sx, sx, sy * sy);
     const double s2 = __builtin_fma(sz, sz, rho2);
     const double e2 = __builtin_fma(ex, ex, __builtin_fma(ey, ey, ez * ez));
-    const double rho = sqrt_fast(rho2), ns = sqrt_fast(s2), ne = sqrt_fast(e2);
-    const double th = atan2_q1(rho, sz);
-    const double td = atan2_q1(ne, ns);
+    // |s| > 0 for every pair that passes the cosine guards (s_z > 0); rho and |e| are zero for h == n / retro-reflection
+    const double rho = sqrt_fast(rho2), ns = sqrt_pos(s2), ne = sqrt_fast(e2);
+    const double th = atan2_q1<false>(rho, sz);
+    const double td = atan2_q1<false>(ne, ns);
     double py = __builtin_fma(ey, sx, -(ex * sy));
     double px = -ez * ns;
     const bool degenerate = rho2 == 0.0;                  // h == n: phi_h = atan2(0,0) = 0
@@ -178,12 +182,8 @@ __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o
                                           float wix, float wiy, float wiz, float wox, float woy, float woz, float rgb[3])
 {
     const Vec3 out = normalize_f32(wox, woy, woz);
-    Rgbd v = table_brdf<LOOKUP, LAYOUT>(m, o, in, out);
-    const double c = cos_or_nan(wix, wiy, wiz, wox, woy, woz);
-    const bool valid = (wiz > 0.0f) && (woz > 0.0f);
-    rgb[0] = valid ? (float)(v.r * c) : 0.0f;
-    rgb[1] = valid ? (float)(v.g * c) : 0.0f;
-    rgb[2] = valid ? (float)(v.b * c) : 0.0f;
+    const Rgbd v = table_brdf<LOOKUP, LAYOUT>(m, o, in, out);
+    eval_tail(v, (wix + wiy + wiz), wiz, wox, woy, woz, rgb);
 }
 
 // ---- table importance sampling, tuned forms of merl_device.hpp::table_pdf / table_sample_dir ----
@@ -238,16 +238,8 @@ __device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options 
         square_to_cosine_hemisphere(o.disk_map, u0, u1, x, y, z);
         p = z > 0.0f ? z * kInvPiF : 0.0f;
     }
-    const bool valid = (wiz > 0.0f) && (!o.sampling || p > 0.0f);
-    float f[3];
-    unit_eval<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, x, y, z, f);
-    const bool has = valid && (p > 0.0f);
-    const float ps = has ? p : 1.0f;
-    wo[0] = valid ? x : 0.0f; wo[1] = valid ? y : 0.0f; wo[2] = valid ? z : 0.0f;
-    pdf = valid ? p : 0.0f;
-    weight[0] = has ? f[0] / ps : 0.0f;
-    weight[1] = has ? f[1] / ps : 0.0f;
-    weight[2] = has ? f[2] / ps : 0.0f;
+    const Rgbd v = table_brdf<LOOKUP, LAYOUT>(m, o, in, normalize_f32(x, y, z));
+    sample_tail(v, (wix + wiy + wiz), wiz, x, y, z, p, o.sampling != 0, wo, pdf, weight);
 }
 
 } // namespace fast
