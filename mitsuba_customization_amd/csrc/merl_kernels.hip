@@ -256,6 +256,14 @@ struct UnitIO {
     float rgb[3], pdf, wo2[3], pdf2, w[3];
 };
 
+// The stream inputs of one tile as requested from memory (k_table_dma's one-tile-ahead pipeline)
+struct TileIn {
+    float wix, wiy, wiz, wox, woy, woz, u0, u1;
+    int id;                                                   // material id (mixed batches)
+    uint32_t active;                                          // 0: a lane beyond the end of the batch (computes, stores nothing)
+    size_t first, i;                                          // wave-uniform first unit + the lane's offset / queued unit index
+};                                                            // no padding: the struct lives in registers (SROA), never in memory
+
 // Table lanes of one wave: transform, cooperative brick copy, blend.  EVERY lane of the wave must call
 // it (the copy is wave-wide); lanes whose material is not a table pass is_table = false, take part with
 // a harmless source and keep their outputs untouched.
@@ -273,10 +281,16 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
     BrickWeights wA, wB;
     uint32_t cellA = 0, cellB = 0;
     float sx = 0.0f, sy = 0.0f, sz = 1.0f;
+    // Per lookup: transform -> address exchange -> the 8 copies.  The eval lookup's copies are in flight while the sample
+    // lookup is transformed (its L2 / fabric latency hides behind ~250 VALU instructions of this wave, not only behind the
+    // SIMD's other wave): on the bench's random inputs 1.5 % faster than exchanging and copying both lookups at the end.
     if constexpr (HAS_EVAL) {
         const fast::Vec3 out = fast::normalize_f32(io.wox, io.woy, io.woz);
         cellA = brick_cell<STD>(m, STD ? maps(in, out) : fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wA);
         if (GGX && !is_table) cellA = 0;
+        const BrickSources<MULTI> srcA(m.texels, cellA, lane_base, lane, pageA);
+        srcA.copy_to(ldsA);
+        __builtin_amdgcn_sched_barrier(0);
     }
     float sp = 0.0f;                                          // pdf of the sampled direction
     if constexpr (HAS_SAMPLE) {
@@ -292,15 +306,12 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
         const fast::Vec3 out = fast::normalize_f32(sx, sy, sz);
         cellB = brick_cell<STD>(m, STD ? maps(in, out) : fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wB);
         if (GGX && !is_table) cellB = 0;
+        const BrickSources<MULTI> srcB(m.texels, cellB, lane_base, lane, pageB);
+        srcB.copy_to(ldsB);
     }
-    {
-        // every address exchange of the unit first, then every copy
-        const BrickSources<MULTI> srcA(m.texels, cellA, lane_base, lane, pageA), srcB(m.texels, cellB, lane_base, lane, pageB);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (HAS_EVAL) srcA.copy_to(ldsA);
-        if constexpr (HAS_SAMPLE) srcB.copy_to(ldsB);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA has landed (own wave only: no barrier)
+    // No explicit wait: the compiler tracks the LDS-DMA copies per LDS array (the eval and the sample lookup have their
+    // own __shared__ arrays), so the blend of the eval lookup waits for ITS eight copies only (s_waitcnt vmcnt(8): the sample
+    // lookup's are still in flight) and the sample blend for the rest.  Own wave only: no barrier.
 
     if constexpr (HAS_EVAL) {
         const Rgbd v = brick_interp(ldsA, lane, wA);
@@ -317,7 +328,6 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
         const Rgbd v = brick_interp(ldsB, lane, wB);
         if (!GGX || is_table) fast::sample_tail(v, io.wi_sum, io.wiz, sx, sy, sz, sp, a.opts.sampling != 0, io.wo2, io.pdf2, io.w);
     }
-    asm volatile("" ::: "memory");                            // LDS reads above stay ahead of the next step's DMA
 }
 
 // One analytic (GGX) lane: tuned functions of merl_ggx_fast.hpp
@@ -374,13 +384,15 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
     constexpr bool HAS_EVAL = mode_eval(MODE);
     constexpr bool HAS_SAMPLE = mode_sample(MODE);
     constexpr int LOOKUPS = (HAS_EVAL ? 1 : 0) + (HAS_SAMPLE ? 1 : 0);
-    __shared__ float4 lds[kDmaBlock / 64][LOOKUPS][512];      // 8 KB per wave and lookup
+    // 8 KB per wave and lookup; one array per lookup, so that the compiler's LDS-DMA tracking tells them apart
+    __shared__ float4 lds_eval[HAS_EVAL ? kDmaBlock / 64 : 1][HAS_EVAL ? 512 : 1];
+    __shared__ float4 lds_sample[HAS_SAMPLE ? kDmaBlock / 64 : 1][HAS_SAMPLE ? 512 : 1];
     __shared__ uint32_t pages[kDmaBlock / 64][LOOKUPS][MULTI ? 128 : 64];   // address exchange (BrickSources)
 
     // the wave index in an SGPR: LDS bases (M0 of the copies) and the tile's stream addresses are then scalar work
     const unsigned lane = threadIdx.x & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float4 *ldsA = lds[wave][0];
-    float4 *ldsB = lds[wave][LOOKUPS - 1];
+    float4 *ldsA = lds_eval[HAS_EVAL ? wave : 0];
+    float4 *ldsB = lds_sample[HAS_SAMPLE ? wave : 0];
     uint32_t *pageA = pages[wave][0], *pageB = pages[wave][LOOKUPS - 1];
     const size_t n_items = item_count<INDEXED>(a);
     // Block -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (blocks b and b + 8 share one; observed, used
@@ -395,24 +407,46 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
         tile_end = (x + 1) * tiles / 8;
         tile_step = per_xcd;
     }
-    for (; tile < tile_end; tile += tile_step) {
-        const size_t base = tile * kDmaBlock + wave * 64u;
-        if (base >= n_items) break;                           // a wave beyond the tail of the last tile (wave-uniform)
-        const bool active = base + lane < n_items;
+    // The loop is software-pipelined by one tile: the stream inputs of tile t + 1 are requested before tile t is
+    // transformed, so their HBM latency (the longest single wait of an iteration) runs under a whole iteration of work.
+    auto tile_live = [&](size_t t) { return t < tile_end && t * kDmaBlock + wave * 64u < n_items; };      // wave-uniform
+    auto request = [&](size_t t) {
+        TileIn r;
+        const size_t base = t * kDmaBlock + wave * 64u;
+        r.active = base + lane < n_items ? 1u : 0u;
         // `first` + `i`: a wave-uniform first unit plus a per-lane offset.  Whole-array launches: the tile's base and the lane
         // number (tail lanes recompute the last unit, store nothing) — stream addresses are then a scalar base and a 32-bit
         // lane offset; queue launches: 0 and the queued unit index.
-        const size_t first = INDEXED ? (size_t)0 : base;
-        size_t i;
-        if constexpr (INDEXED) i = (size_t)a.idx[active ? base + lane : n_items - 1];
-        else i = (size_t)(active ? lane : (unsigned)(n_items - 1 - base));
+        r.first = INDEXED ? (size_t)0 : base;
+        if constexpr (INDEXED) r.i = (size_t)a.idx[r.active ? base + lane : n_items - 1];
+        else r.i = (size_t)(r.active ? lane : (unsigned)(n_items - 1 - base));
+        r.id = 0;
+        if constexpr (MULTI) r.id = (a.mat + r.first)[r.i];
+        r.wox = 0.0f; r.woy = 0.0f; r.woz = 1.0f; r.u0 = 0.0f; r.u1 = 0.0f;
+        load3s<NT>(a.wi + 3 * r.first, r.i, r.wix, r.wiy, r.wiz);
+        if constexpr (HAS_EVAL) load3s<NT>(a.wo + 3 * r.first, r.i, r.wox, r.woy, r.woz);
+        if constexpr (HAS_SAMPLE) { const float *up = a.u + 2 * r.first; r.u0 = ldf<NT>(up + 2 * r.i); r.u1 = ldf<NT>(up + 2 * r.i + 1); }
+        return r;
+    };
+    bool live = tile_live(tile);
+    TileIn cur = {};
+    if (live) cur = request(tile);
+    // The first tile's inputs have landed before the loop is entered (a real S_WAITCNT vmcnt(0)): the compiler's wait-count
+    // pass merges the states of both loop entries, and with loads pending on this one it would wait for everything —
+    // the copies just issued included — at the first use of any loop-carried input register.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    while (live) {
+        const size_t tile_next = tile + tile_step;
+        const bool live_next = tile_live(tile_next);
+        // requested unconditionally (a wave without a next tile asks for its current one again): a conditional request
+        // turns into register copies right behind the loads, i.e. into a wait for them
+        const TileIn nxt = request(live_next ? tile_next : tile);
 
         MaterialDev m;
         bool known = true;
         if constexpr (MULTI) {
-            int id = (a.mat + first)[i];
-            known = id >= 0 && id < a.n_materials;
-            m = a.materials[known ? id : 0];
+            known = cur.id >= 0 && cur.id < a.n_materials;
+            m = a.materials[known ? cur.id : 0];
             known = known && kind_is_rgb_path(m.kind);
             if (!known) m = a.safe;
         } else {
@@ -421,12 +455,9 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
         const bool is_table = !GGX || m.kind != KIND_GGX;
 
         UnitIO io = {};
-        io.woz = 1.0f;
-        load3s<NT>(a.wi + 3 * first, i, io.wix, io.wiy, io.wiz);
-        if (!known) io.wiz = 0.0f;
+        io.wix = cur.wix; io.wiy = cur.wiy; io.wiz = known ? cur.wiz : 0.0f;
+        io.wox = cur.wox; io.woy = cur.woy; io.woz = cur.woz; io.u0 = cur.u0; io.u1 = cur.u1;
         io.wi_sum = io.wix + io.wiy + io.wiz;
-        if constexpr (HAS_EVAL) load3s<NT>(a.wo + 3 * first, i, io.wox, io.woy, io.woz);
-        if constexpr (HAS_SAMPLE) { const float *up = a.u + 2 * first; io.u0 = ldf<NT>(up + 2 * i); io.u1 = ldf<NT>(up + 2 * i + 1); }
         const fast::Vec3 in = fast::normalize_f32(io.wix, io.wiy, io.wiz);
 
         if (!GGX || __ballot(is_table) != 0ull)               // wave-uniform
@@ -434,7 +465,8 @@ __global__ __launch_bounds__(kDmaBlock) void k_table_dma(BatchArgs a)
         if constexpr (GGX) {
             if (!is_table) ggx_lane<MODE>(m, io, in);
         }
-        if (active) store_unit<MODE, NT>(a, first, i, io);
+        if (cur.active) store_unit<MODE, NT>(a, cur.first, cur.i, io);
+        cur = nxt; tile = tile_next; live = live_next;
     }
 }
 
