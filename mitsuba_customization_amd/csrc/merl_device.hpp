@@ -110,27 +110,74 @@ __device__ __forceinline__ Coords standard_coords(const Vec3d &in, const Vec3d &
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 struct Rgbd { double r, g, b; };
+struct Rgbf { float r, g, b; };       // a looked-up BRDF value: Float, like the texels it is blended from
+
+// The 8 trilinear corner weights, formed in f64 from the f64 fractions (a fraction near 1 would lose its complement's
+// relative accuracy in Float) and rounded ONCE to Float; corner k = 4 a + 2 b + c along (axis 0, axis 1, azimuth).
+struct CornerWeights { float w[8]; };
+__device__ __forceinline__ CornerWeights corner_weights(double fh, double fd, double fp)
+{
+#pragma clang fp contract(off)
+    const double gh = 1.0 - fh, gd = 1.0 - fd, gp = 1.0 - fp;
+    const double a00 = gh * gd, a01 = gh * fd, a10 = fh * gd, a11 = fh * fd;
+    CornerWeights c;
+    c.w[0] = (float)(a00 * gp); c.w[1] = (float)(a00 * fp); c.w[2] = (float)(a01 * gp); c.w[3] = (float)(a01 * fp);
+    c.w[4] = (float)(a10 * gp); c.w[5] = (float)(a10 * fp); c.w[6] = (float)(a11 * gp); c.w[7] = (float)(a11 * fp);
+    return c;
+}
+
+// Blend of one 96-B brick (8 corners x RGB f32, corner-major: float 3 k + ch) in packed Float math.  The brick's 24
+// floats are 12 aligned register pairs that cycle through (r,g) (b,r) (g,b): three pair accumulators A, B, C take four
+// v_pk_fma_f32 each — 12 packed FMAs instead of 24 f64 FMAs and 24 f32 -> f64 converts — and r = A.x + B.y, g = A.y + C.x,
+// b = B.x + C.y.  Texels and weights are non-negative, so nothing cancels: the result is within 6 roundings
+// (3.6e-7 relative; measured worst 2.8e-7 incl. the oracle's own rounding) of the exact blend of the same texels.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ Rgbf blend_brick(const float4 &q0, const float4 &q1, const float4 &q2, const float4 &q3, const float4 &q4,
+                                            const float4 &q5, const CornerWeights &c)
+{
+    // contraction off: every operation below is exactly what is written (entry points must agree bit for bit, and a
+    // multiply left to the compiler's fusing would round differently from one inlining context to the next)
+#pragma clang fp contract(off)
+    const float *w = c.w;
+    v2f_t A = v2f_t{w[0], w[0]} * v2f_t{q0.x, q0.y};
+    v2f_t B = v2f_t{w[0], w[1]} * v2f_t{q0.z, q0.w};
+    v2f_t C = v2f_t{w[1], w[1]} * v2f_t{q1.x, q1.y};
+    A = __builtin_elementwise_fma(v2f_t{w[2], w[2]}, v2f_t{q1.z, q1.w}, A);
+    B = __builtin_elementwise_fma(v2f_t{w[2], w[3]}, v2f_t{q2.x, q2.y}, B);
+    C = __builtin_elementwise_fma(v2f_t{w[3], w[3]}, v2f_t{q2.z, q2.w}, C);
+    A = __builtin_elementwise_fma(v2f_t{w[4], w[4]}, v2f_t{q3.x, q3.y}, A);
+    B = __builtin_elementwise_fma(v2f_t{w[4], w[5]}, v2f_t{q3.z, q3.w}, B);
+    C = __builtin_elementwise_fma(v2f_t{w[5], w[5]}, v2f_t{q4.x, q4.y}, C);
+    A = __builtin_elementwise_fma(v2f_t{w[6], w[6]}, v2f_t{q4.z, q4.w}, A);
+    B = __builtin_elementwise_fma(v2f_t{w[6], w[7]}, v2f_t{q5.x, q5.y}, B);
+    C = __builtin_elementwise_fma(v2f_t{w[7], w[7]}, v2f_t{q5.z, q5.w}, C);
+    return { A.x + B.y, A.y + C.x, B.x + C.y };
+}
 
 template <int LAYOUT>
-__device__ __forceinline__ Rgbd lookup_nearest_t(const MaterialDev &m, const Coords &c)
+__device__ __forceinline__ Rgbf lookup_nearest_t(const MaterialDev &m, const Coords &c)
 {
     int ih = clampi((int)c.xh, 0, m.n_th - 1);
     int id = clampi((int)c.xd, 0, m.n_td - 1);
     int ip = clampi((int)c.xp, 0, m.n_pd - 1);
     if constexpr (LAYOUT == LAYOUT_BRICK) {
         const float4 t = m.texels[(((size_t)ih * m.n_td + id) * m.n_pd + ip) * 8];     // corner 0 = the texel itself
-        return { (double)t.x, (double)t.y, (double)t.z };
+        return { t.x, t.y, t.z };
     }
     float4 t = m.texels[(size_t)ih * m.row_th + (size_t)id * m.row_td + ip];
-    return { (double)t.x, (double)t.y, (double)t.z };
+    return { t.x, t.y, t.z };
 }
 
 // Both splits take x in [-1, n] (every coordinate map of this file lands there: angles are atan2 results scaled by n / range,
 // minus the half-texel shift of the centre-node convention) or NaN, and stay inside the table for anything else.
 // clamped axis: i0 in [0,n-1], f in [0,1]; i0+1 is always a valid (padded) index.  (int)x truncates towards zero, which for
 // x > -1 is floor(x) clamped at 0 (v_cvt_i32_f64 saturates and maps NaN to 0): no floor, no lower clamp.
+// (contraction off in everything between a continuous coordinate and its Float corner weights: fused with the multiply
+// that produced x in one inlining context and not in another, x - i differs by ~1e-14, and the weights' rounding to
+// Float turns that into a one-ulp difference between entry points for about one unit in a million)
 __device__ __forceinline__ void split_clamped(double x, int n, int &i0, double &f)
 {
+#pragma clang fp contract(off)
     const int i = min((int)x, n - 1);
     f = __builtin_fmin(__builtin_fmax(x - (double)i, 0.0), 1.0);
     i0 = i;
@@ -139,6 +186,7 @@ __device__ __forceinline__ void split_clamped(double x, int n, int &i0, double &
 // [n-1, 2n] and two unsigned min(j, j - n) steps bring it to [0, n-1] (j < n: j - n wraps around to a huge value and j wins).
 __device__ __forceinline__ void split_periodic(double x, int n, int &i0, double &f)
 {
+#pragma clang fp contract(off)
     const double fl = floor(x);
     f = x - fl;
     unsigned j = (unsigned)((int)fl + n);
@@ -158,52 +206,49 @@ __device__ __forceinline__ void split_phi(bool periodic, double x, int n, int &i
 }
 
 template <int LAYOUT>
-__device__ __forceinline__ Rgbd lookup_trilinear_t(const MaterialDev &m, const Coords &c, int node)
+__device__ __forceinline__ Rgbf lookup_trilinear_t(const MaterialDev &m, const Coords &c, int node)
 {
+#pragma clang fp contract(off)
     const double shift = node ? 0.5 : 0.0;
     int h0, d0, p0; double fh, fd, fp;
     split_clamped(c.xh - shift, m.n_th, h0, fh);
     split_clamped(c.xd - shift, m.n_td, d0, fd);
     split_phi(param_phi_periodic(m.param), c.xp - shift, m.n_pd, p0, fp);
+    if constexpr (LAYOUT == LAYOUT_BRICK) {
+        // one 128-B line holds the whole neighbourhood: 8 corners x RGB f32 = 96 B, six 16-B loads; the same blend as
+        // k_table_dma's (entry points agree bit for bit)
+        const float4 *q = m.texels + (((size_t)h0 * m.n_td + d0) * m.n_pd + p0) * 8;
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+        return blend_brick(q0, q1, q2, q3, q4, q5, corner_weights(fh, fd, fp));
+    }
     const double gh = 1.0 - fh, gd = 1.0 - fd, gp = 1.0 - fp;
     const double w000 = gh * gd * gp, w001 = gh * gd * fp, w010 = gh * fd * gp, w011 = gh * fd * fp;
     const double w100 = fh * gd * gp, w101 = fh * gd * fp, w110 = fh * fd * gp, w111 = fh * fd * fp;
-    if constexpr (LAYOUT == LAYOUT_BRICK) {
-        // one 128-B line holds the whole neighbourhood: 8 corners x RGB f32 = 96 B, six 16-B loads
-        const float4 *q = m.texels + (((size_t)h0 * m.n_td + d0) * m.n_pd + p0) * 8;
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
-        // corner k (k = 4a + 2b + c) channel ch = float[3k + ch]
-        Rgbd o;
-        o.r = w000 * q0.x + w001 * q0.w + w010 * q1.z + w011 * q2.y + w100 * q3.x + w101 * q3.w + w110 * q4.z + w111 * q5.y;
-        o.g = w000 * q0.y + w001 * q1.x + w010 * q1.w + w011 * q2.z + w100 * q3.y + w101 * q4.x + w110 * q4.w + w111 * q5.z;
-        o.b = w000 * q0.z + w001 * q1.y + w010 * q2.x + w011 * q2.w + w100 * q3.z + w101 * q4.y + w110 * q5.x + w111 * q5.w;
-        return o;
-    }
     const float4 *b = m.texels + ((size_t)h0 * m.row_th + (size_t)d0 * m.row_td + p0);
     // issue all eight 16-B gathers before any use
     const float4 t000 = b[0],                 t001 = b[1];
     const float4 t010 = b[m.row_td],          t011 = b[m.row_td + 1];
     const float4 t100 = b[m.row_th],          t101 = b[m.row_th + 1];
     const float4 t110 = b[m.row_th + m.row_td], t111 = b[m.row_th + m.row_td + 1];
-    Rgbd o;
-    o.r = w000 * t000.x + w001 * t001.x + w010 * t010.x + w011 * t011.x + w100 * t100.x + w101 * t101.x + w110 * t110.x + w111 * t111.x;
-    o.g = w000 * t000.y + w001 * t001.y + w010 * t010.y + w011 * t011.y + w100 * t100.y + w101 * t101.y + w110 * t110.y + w111 * t111.y;
-    o.b = w000 * t000.z + w001 * t001.z + w010 * t010.z + w011 * t011.z + w100 * t100.z + w101 * t101.z + w110 * t110.z + w111 * t111.z;
+    Rgbf o;        // rows layout: f64 accumulation, rounded to Float once
+    o.r = (float)(w000 * t000.x + w001 * t001.x + w010 * t010.x + w011 * t011.x + w100 * t100.x + w101 * t101.x + w110 * t110.x + w111 * t111.x);
+    o.g = (float)(w000 * t000.y + w001 * t001.y + w010 * t010.y + w011 * t011.y + w100 * t100.y + w101 * t101.y + w110 * t110.y + w111 * t111.y);
+    o.b = (float)(w000 * t000.z + w001 * t001.z + w010 * t010.z + w011 * t011.z + w100 * t100.z + w101 * t101.z + w110 * t110.z + w111 * t111.z);
     return o;
 }
 
 // runtime-layout wrappers (generic kernel)
-__device__ __forceinline__ Rgbd lookup_nearest(const MaterialDev &m, const Coords &c)
+__device__ __forceinline__ Rgbf lookup_nearest(const MaterialDev &m, const Coords &c)
 {
     return m.layout == LAYOUT_BRICK ? lookup_nearest_t<LAYOUT_BRICK>(m, c) : lookup_nearest_t<LAYOUT_ROWS>(m, c);
 }
-__device__ __forceinline__ Rgbd lookup_trilinear(const MaterialDev &m, const Coords &c, int node)
+__device__ __forceinline__ Rgbf lookup_trilinear(const MaterialDev &m, const Coords &c, int node)
 {
     return m.layout == LAYOUT_BRICK ? lookup_trilinear_t<LAYOUT_BRICK>(m, c, node) : lookup_trilinear_t<LAYOUT_ROWS>(m, c, node);
 }
 
 // BRDF value (no cosine) of a table material for unit in/out
-__device__ __forceinline__ Rgbd table_brdf(const MaterialDev &m, const Options &o, const Vec3d &in, const Vec3d &out)
+__device__ __forceinline__ Rgbf table_brdf(const MaterialDev &m, const Options &o, const Vec3d &in, const Vec3d &out)
 {
     Coords c = m.param == PARAM_HALF_DIFF ? half_diff_coords(in, out, m.n_th, m.n_td, m.n_pd)
                                           : standard_coords(in, out, m.param, m.n_th, m.n_td, m.n_pd);
@@ -436,37 +481,40 @@ __device__ __forceinline__ double cos_or_nan(float wix, float wiy, float wiz, fl
     return (double)cos_or_nan32((wix + wiy + wiz), wox, woy, woz);
 }
 
-// a5 tail: rgb = f cos(theta_o); zero for a pair that fails the cosine guards (texels are finite by construction,
-// so the factor 0 is enough), NaN where an input component is not finite and the guards pass
-__device__ __forceinline__ void eval_tail(const Rgbd &v, float wi_sum, float wiz, float wox, float woy, float woz, float rgb[3])
+// a5 tail: rgb = f cos(theta_o) in Float (the plugin's own arithmetic: Spectrum * Float); zero for a pair that fails the
+// cosine guards (texels are finite by construction, so the factor 0 is enough), NaN where an input component is not
+// finite and the guards pass
+__device__ __forceinline__ void eval_tail(const Rgbf &v, float wi_sum, float wiz, float wox, float woy, float woz, float rgb[3])
 {
+#pragma clang fp contract(off)
     const bool valid = (wiz > 0.0f) && (woz > 0.0f);
     const float c32 = cos_or_nan32(wi_sum, wox, woy, woz);
-    const double c = (double)(valid ? c32 : 0.0f);
-    rgb[0] = (float)(v.r * c); rgb[1] = (float)(v.g * c); rgb[2] = (float)(v.b * c);
+    const float c = valid ? c32 : 0.0f;
+    rgb[0] = v.r * c; rgb[1] = v.g * c; rgb[2] = v.b * c;
 }
-// a6 tail: weight = eval(wi, wo') / pdf IN Float, as the plugin computes it: f = Float(f_d cos theta_o') first, then the
+// a6 tail: weight = eval(wi, wo') / pdf IN Float, as the plugin computes it: f = f_d cos theta_o' first, then the
 // Float quotient f / pdf.  The three IEEE divisions share one reciprocal: q = double(f) * (1/pdf) with 1/pdf good to
 // ~3e-16 (two Newton steps) is within 5e-16 of the true quotient, and a quotient of two 24-bit floats is never closer
 // than 2^-49 = 1.8e-15 (relative) to a rounding boundary of Float, so Float(q) IS the correctly rounded f / pdf
 // (tests/test_gpu_fullsize.py checks weight == eval / pdf bit for bit on 64M units).  Zero when the sample is invalid
 // or its pdf is zero.
-__device__ __forceinline__ void sample_tail(const Rgbd &v, float wi_sum, float wiz, float sx, float sy, float sz, float p, bool table_sampling,
+__device__ __forceinline__ void sample_tail(const Rgbf &v, float wi_sum, float wiz, float sx, float sy, float sz, float p, bool table_sampling,
                                             float wo[3], float &pdf, float weight[3])
 {
+#pragma clang fp contract(off)
     const bool valid = (wiz > 0.0f) && (!table_sampling || p > 0.0f);
     const bool has = valid && (p > 0.0f);
     const float c32 = cos_or_nan32(wi_sum, sx, sy, sz);
-    const double c = (double)(has ? c32 : 0.0f);
+    const float c = has ? c32 : 0.0f;
     const double pd = (double)(has ? p : 1.0f);
     double y = __builtin_amdgcn_rcp(pd);
     y = __builtin_fma(y, __builtin_fma(-pd, y, 1.0), y);
     y = __builtin_fma(y, __builtin_fma(-pd, y, 1.0), y);
     wo[0] = valid ? sx : 0.0f; wo[1] = valid ? sy : 0.0f; wo[2] = valid ? sz : 0.0f;
     pdf = valid ? p : 0.0f;
-    weight[0] = (float)((double)(float)(v.r * c) * y);
-    weight[1] = (float)((double)(float)(v.g * c) * y);
-    weight[2] = (float)((double)(float)(v.b * c) * y);
+    weight[0] = (float)((double)(v.r * c) * y);
+    weight[1] = (float)((double)(v.g * c) * y);
+    weight[2] = (float)((double)(v.b * c) * y);
 }
 } // namespace fast
 
@@ -479,14 +527,11 @@ __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o
     rgb[0] = rgb[1] = rgb[2] = 0.0f;
     if (!(wiz > 0.0f) || !(woz > 0.0f)) return;
     Vec3d in = normalized(wix, wiy, wiz), out = normalized(wox, woy, woz);
-    Rgbd v;
-    if (m.kind == KIND_GGX) {
-        v = ggx_eval(m, in, out);
-    } else {
-        v = table_brdf(m, o, in, out);
-        fast::eval_tail(v, (wix + wiy + wiz), wiz, wox, woy, woz, rgb);
+    if (m.kind != KIND_GGX) {
+        fast::eval_tail(table_brdf(m, o, in, out), (wix + wiy + wiz), wiz, wox, woy, woz, rgb);
         return;
     }
+    const Rgbd v = ggx_eval(m, in, out);
     rgb[0] = (float)v.r; rgb[1] = (float)v.g; rgb[2] = (float)v.b;
 }
 
@@ -524,8 +569,7 @@ __device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options 
         p = z > 0.0f ? z * kInvPiF : 0.0f;
     }
     Vec3d in = normalized(wix, wiy, wiz), out = normalized(x, y, z);
-    const Rgbd v = table_brdf(m, o, in, out);
-    fast::sample_tail(v, (wix + wiy + wiz), wiz, x, y, z, p, o.sampling != 0, wo, pdf, weight);
+    fast::sample_tail(table_brdf(m, o, in, out), (wix + wiy + wiz), wiz, x, y, z, p, o.sampling != 0, wo, pdf, weight);
 }
 
 // ---- synthetic inputs, bit-identical to the oracle's generator ---------------

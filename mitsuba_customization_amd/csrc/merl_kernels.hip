@@ -171,6 +171,13 @@ __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
 #define MRL_DMA_BLOCK 256
 #endif
 constexpr int kDmaBlock = MRL_DMA_BLOCK;
+// blocks of the LDS-DMA kernel one CU holds: 8 KB of LDS per wave and lookup (+ the exchange pages) out of 160 KB
+constexpr int dma_blocks_per_cu(int mode)
+{
+    const int lookups = (mode == 3 /* eval + sample */) ? 2 : 1;
+    const int per_block = (kDmaBlock / 64) * lookups * (8192 + 512);
+    return (160 * 1024) / per_block;
+}
 
 __device__ __forceinline__ unsigned brick_swz(unsigned unit) { return (unit >> 1) & 7u; }
 
@@ -183,8 +190,10 @@ __device__ __forceinline__ unsigned brick_swz(unsigned unit) { return (unit >> 1
 // in order, so the reads see the writes; the wavefront fence keeps the compiler from moving them.
 template <bool MULTI>
 struct BrickSources {
-    const float4 *src[8];
-    __device__ __forceinline__ BrickSources(const float4 *single_base, uint32_t idx, const float4 *lane_base, unsigned lane, uint32_t *page)
+    const float4 *src[8];          // MULTI: the 16-B piece this lane copies in step k
+    uint32_t cell[8];              // single material: the cell index of step k's unit
+    uint32_t piece_bytes[2];       // ... and this lane's piece offset inside a brick, for even / odd k
+    __device__ __forceinline__ BrickSources(uint32_t idx, const float4 *lane_base, unsigned lane, uint32_t *page)
     {
         const unsigned g = lane >> 3, k_own = lane >> 3, g_own = lane & 7u;
         const unsigned piece_lane = lane & 7u;
@@ -204,17 +213,37 @@ struct BrickSources {
             __builtin_amdgcn_wave_barrier();
             const uint4 *rd = (const uint4 *)(page + g * 8u);
             const uint4 a0 = rd[0], a1 = rd[1];
-            const uint32_t got[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-#pragma unroll
-            for (int k = 0; k < 8; ++k) src[k] = single_base + ((size_t)got[k] * 8 + (piece_lane ^ brick_swz(8u * k + g)));
+            cell[0] = a0.x; cell[1] = a0.y; cell[2] = a0.z; cell[3] = a0.w; cell[4] = a1.x; cell[5] = a1.y; cell[6] = a1.z; cell[7] = a1.w;
+            // brick_swz(8k + g) = (4k + (g >> 1)) & 7: two values, by the parity of k
+            piece_bytes[0] = (piece_lane ^ brick_swz(g)) * 16u;
+            piece_bytes[1] = (piece_lane ^ brick_swz(8u + g)) * 16u;
         }
     }
-    __device__ __forceinline__ void copy_to(float4 *lds_slots) const
+    // offsets32: the table is smaller than 4 GB (wave-uniform).  The source address of a copy is then the table's base in
+    // SGPRs plus a 32-bit lane offset — ONE vector instruction per copy (cell << 7 | piece) and the scalar-base form of
+    // global_load_lds — where the general form spends three on 64-bit shifts and adds.
+    __device__ __forceinline__ void copy_to(float4 *lds_slots, const float4 *single_base, bool offsets32) const
     {
+        if constexpr (MULTI) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src[k],
-                                             (__attribute__((address_space(3))) void *)(lds_slots + k * 64), 16, 0, 0);
+            for (int k = 0; k < 8; ++k)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src[k],
+                                                 (__attribute__((address_space(3))) void *)(lds_slots + k * 64), 16, 0, 0);
+        } else if (offsets32) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t off = (cell[k] << 7) + piece_bytes[k & 1];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)single_base + off),
+                                                 (__attribute__((address_space(3))) void *)(lds_slots + k * 64), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint64_t off = ((uint64_t)cell[k] << 7) + piece_bytes[k & 1];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)single_base + off),
+                                                 (__attribute__((address_space(3))) void *)(lds_slots + k * 64), 16, 0, 0);
+            }
+        }
     }
 };
 
@@ -225,6 +254,7 @@ struct BrickWeights { double fh, fd, fp; };
 template <bool STD>
 __device__ __forceinline__ uint32_t brick_cell(const MaterialDev &m, const Coords &c, int node, BrickWeights &w)
 {
+#pragma clang fp contract(off)
     const double shift = node ? 0.5 : 0.0;
     int h0, d0, p0;
     split_clamped(c.xh - shift, m.n_th, h0, w.fh);
@@ -234,19 +264,12 @@ __device__ __forceinline__ uint32_t brick_cell(const MaterialDev &m, const Coord
     return (uint32_t)((h0 * m.n_td + d0) * m.n_pd + p0);
 }
 
-__device__ __forceinline__ Rgbd brick_interp(const float4 *lds_slots, unsigned lane, const BrickWeights &w)
+__device__ __forceinline__ Rgbf brick_interp(const float4 *lds_slots, unsigned lane, const BrickWeights &w)
 {
     const unsigned f = brick_swz(lane);
     const float4 *q = lds_slots + 8u * lane;
     const float4 q0 = q[0u ^ f], q1 = q[1u ^ f], q2 = q[2u ^ f], q3 = q[3u ^ f], q4 = q[4u ^ f], q5 = q[5u ^ f];
-    const double gh = 1.0 - w.fh, gd = 1.0 - w.fd, gp = 1.0 - w.fp;
-    const double w000 = gh * gd * gp, w001 = gh * gd * w.fp, w010 = gh * w.fd * gp, w011 = gh * w.fd * w.fp;
-    const double w100 = w.fh * gd * gp, w101 = w.fh * gd * w.fp, w110 = w.fh * w.fd * gp, w111 = w.fh * w.fd * w.fp;
-    Rgbd o;
-    o.r = w000 * q0.x + w001 * q0.w + w010 * q1.z + w011 * q2.y + w100 * q3.x + w101 * q3.w + w110 * q4.z + w111 * q5.y;
-    o.g = w000 * q0.y + w001 * q1.x + w010 * q1.w + w011 * q2.z + w100 * q3.y + w101 * q4.x + w110 * q4.w + w111 * q5.z;
-    o.b = w000 * q0.z + w001 * q1.y + w010 * q2.x + w011 * q2.w + w100 * q3.z + w101 * q4.y + w110 * q5.x + w111 * q5.w;
-    return o;
+    return blend_brick(q0, q1, q2, q3, q4, q5, corner_weights(w.fh, w.fd, w.fp));
 }
 
 // One unit's registers while it travels through the DMA kernels.
@@ -275,6 +298,8 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
 {
     constexpr bool HAS_EVAL = mode_eval(MODE);
     constexpr bool HAS_SAMPLE = mode_sample(MODE);
+    // single material: bricks below 4 GB take 32-bit source offsets (wave-uniform; loop-invariant)
+    const bool offsets32 = !MULTI && (size_t)m.n_th * m.n_td * m.n_pd <= ((size_t)1 << 25);
     // a valid 128-B source for lanes without a table: the material array itself, cell 0
     const float4 *lane_base = (GGX && !is_table) ? (const float4 *)a.materials : m.texels;
     const fast::TableMaps maps = STD ? fast::TableMaps(m) : fast::TableMaps(m.n_th, m.n_td, m.n_pd, PARAM_HALF_DIFF);   // STD = false never reads m.param
@@ -285,11 +310,11 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
     // lookup is transformed (its L2 / fabric latency hides behind ~250 VALU instructions of this wave, not only behind the
     // SIMD's other wave): on the bench's random inputs 1.5 % faster than exchanging and copying both lookups at the end.
     if constexpr (HAS_EVAL) {
-        const fast::Vec3 out = fast::normalize_f32(io.wox, io.woy, io.woz);
+        const fast::Dir out = fast::dir_f32(io.wox, io.woy, io.woz);
         cellA = brick_cell<STD>(m, STD ? maps(in, out) : fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wA);
         if (GGX && !is_table) cellA = 0;
-        const BrickSources<MULTI> srcA(m.texels, cellA, lane_base, lane, pageA);
-        srcA.copy_to(ldsA);
+        const BrickSources<MULTI> srcA(cellA, lane_base, lane, pageA);
+        srcA.copy_to(ldsA, m.texels, offsets32);
         __builtin_amdgcn_sched_barrier(0);
     }
     float sp = 0.0f;                                          // pdf of the sampled direction
@@ -303,18 +328,18 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
             square_to_cosine_hemisphere(a.opts.disk_map, io.u0, io.u1, sx, sy, sz);
             sp = sz > 0.0f ? sz * kInvPiF : 0.0f;
         }
-        const fast::Vec3 out = fast::normalize_f32(sx, sy, sz);
+        const fast::Dir out = fast::dir_f32(sx, sy, sz);
         cellB = brick_cell<STD>(m, STD ? maps(in, out) : fast::coords(in, out, maps.k_th, maps.k_td, maps.k_pd), a.opts.node, wB);
         if (GGX && !is_table) cellB = 0;
-        const BrickSources<MULTI> srcB(m.texels, cellB, lane_base, lane, pageB);
-        srcB.copy_to(ldsB);
+        const BrickSources<MULTI> srcB(cellB, lane_base, lane, pageB);
+        srcB.copy_to(ldsB, m.texels, offsets32);
     }
     // No explicit wait: the compiler tracks the LDS-DMA copies per LDS array (the eval and the sample lookup have their
     // own __shared__ arrays), so the blend of the eval lookup waits for ITS eight copies only (s_waitcnt vmcnt(8): the sample
     // lookup's are still in flight) and the sample blend for the rest.  Own wave only: no barrier.
 
     if constexpr (HAS_EVAL) {
-        const Rgbd v = brick_interp(ldsA, lane, wA);
+        const Rgbf v = brick_interp(ldsA, lane, wA);
         if (!GGX || is_table) {
             fast::eval_tail(v, io.wi_sum, io.wiz, io.wox, io.woy, io.woz, io.rgb);
             if constexpr (mode_pdf(MODE)) {
@@ -325,7 +350,7 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
         }
     }
     if constexpr (HAS_SAMPLE) {
-        const Rgbd v = brick_interp(ldsB, lane, wB);
+        const Rgbf v = brick_interp(ldsB, lane, wB);
         if (!GGX || is_table) fast::sample_tail(v, io.wi_sum, io.wiz, sx, sy, sz, sp, a.opts.sampling != 0, io.wo2, io.pdf2, io.w);
     }
 }
@@ -836,7 +861,7 @@ hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, 
         // variant 3: cooperative LDS-DMA brick fetch (brick layout + trilinear only; otherwise variant 2)
         if (tuned && variant >= 3 && layout == LAYOUT_BRICK && a.opts.lookup == 1) {
             // 64 KB (two lookups) or 32 KB (one) of LDS per 256-thread block: 2 or 4 blocks per CU
-            constexpr int per_cu = ((MODE == MODE_EVAL_SAMPLE) ? 2 : 4) * (256 / kDmaBlock);
+            constexpr int per_cu = dma_blocks_per_cu(MODE);
             size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;
             if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
             blocks = (blocks + 7) / 8 * 8;                    // whole rounds over the 8 XCDs (BatchArgs::block_map)
@@ -907,7 +932,7 @@ hipError_t launch_queue_mode(const BatchArgs &a, bool ggx_queue, int compute_uni
         if (ggx_queue) {
             hipLaunchKernelGGL((k_ggx<MODE, true, true, true>), dim3(grid_for(a.n, compute_units)), dim3(kBlock), 0, stream, a);
         } else {
-            constexpr int per_cu = ((MODE == MODE_EVAL_SAMPLE) ? 2 : 4) * (256 / kDmaBlock);
+            constexpr int per_cu = dma_blocks_per_cu(MODE);
             size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;
             if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
             const dim3 g((unsigned)blocks), b(kDmaBlock);
@@ -946,7 +971,7 @@ hipError_t launch_indexed_mode(const BatchArgs &a, bool multi, int layout, bool 
     }
     if constexpr (MODE != MODE_PDF) {
         if (layout == LAYOUT_BRICK && a.opts.lookup == 1) {
-            constexpr int per_cu = ((MODE == MODE_EVAL_SAMPLE) ? 2 : 4) * (256 / kDmaBlock);
+            constexpr int per_cu = dma_blocks_per_cu(MODE);
             size_t blocks = (a.n + kDmaBlock - 1) / kDmaBlock;
             if (blocks > (size_t)compute_units * per_cu) blocks = (size_t)compute_units * per_cu;
             blocks = (blocks + 7) / 8 * 8;

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
         uint32_t cellA = 0, cellB = 0;
         float sx = 0.0f, sy = 0.0f, sz = 1.0f, sp = 0.0f;
         if constexpr (HAS_EVAL)
-            cellA = nch_cell(n_th, n_td, n_pd, phi_periodic, maps(in, fast::normalize_f32(wox, woy, woz)), a.opts, wA);
+            cellA = nch_cell(n_th, n_td, n_pd, phi_periodic, maps(in, fast::dir_f32(wox, woy, woz)), a.opts, wA);
         if constexpr (HAS_SAMPLE) {
             if (a.opts.sampling && known) {                   // option is wave-uniform
                 fast::table_sample_dir(m, a.opts.disk_map, in, u0, u1, sx, sy, sz);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
                 square_to_cosine_hemisphere(a.opts.disk_map, u0, u1, sx, sy, sz);
                 sp = sz > 0.0f ? sz * kInvPiF : 0.0f;
             }
-            cellB = nch_cell(n_th, n_td, n_pd, phi_periodic, maps(in, fast::normalize_f32(sx, sy, sz)), a.opts, wB);
+            cellB = nch_cell(n_th, n_td, n_pd, phi_periodic, maps(in, fast::dir_f32(sx, sy, sz)), a.opts, wB);
         }
         const bool validA = (wiz > 0.0f) && (woz > 0.0f);
         const bool validB = (wiz > 0.0f) && (!a.opts.sampling || sp > 0.0f);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
 
         // one lookup: copy + blend every group into the staging rows (scaled by `factor`), then stream the span out
         // (guards are selects on the finished value: a non-finite direction may have poisoned the blend)
-        auto lookup = [&](const fast::Vec3 &out_dir, bool keep, double factor, float divide, float *dst) {
+        auto lookup = [&](const fast::Dir &out_dir, bool keep, double factor, float divide, float *dst) {
             NchWeights w;
             const uint32_t cell = nch_cell(n_th, n_td, n_pd, phi_periodic, maps(in, out_dir), a.opts, w);
             for (int g = 0; g < groups; ++g) {                // wave-uniform trip count
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
         if constexpr (HAS_EVAL) {
             const bool valid = (wiz > 0.0f) && (woz > 0.0f);
             const double c = fast::cos_or_nan(wix, wiy, wiz, wox, woy, woz);
-            lookup(fast::normalize_f32(wox, woy, woz), valid, c, 1.0f, a.out_rgb);
+            lookup(fast::dir_f32(wox, woy, woz), valid, c, 1.0f, a.out_rgb);
             if constexpr (mode_pdf(MODE)) {
                 float p = valid ? woz * kInvPiF : 0.0f;
                 if (a.opts.sampling && valid && known) p = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz);
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
             const bool valid = (wiz > 0.0f) && (!a.opts.sampling || sp > 0.0f);
             const bool has = valid && (sp > 0.0f);
             const double c = fast::cos_or_nan(wix, wiy, wiz, sx, sy, sz);
-            lookup(fast::normalize_f32(sx, sy, sz), has, c, has ? sp : 1.0f, a.out_weight);
+            lookup(fast::dir_f32(sx, sy, sz), has, c, has ? sp : 1.0f, a.out_weight);
             if (active) {
                 const float wo2[3] = { valid ? sx : 0.0f, valid ? sy : 0.0f, valid ? sz : 0.0f };
                 store3(a.out_wo, i, wo2);

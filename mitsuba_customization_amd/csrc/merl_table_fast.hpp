@@ -102,11 +102,30 @@ __device__ __forceinline__ Vec3 normalize_f32(float x, float y, float z)
     return { dx * rs, dy * rs, dz * rs };
 }
 
-// a2 + a3 for unit in/out (see merl_device.hpp::half_diff_coords for the derivation)
-__device__ __forceinline__ Coords coords(const Vec3 &in, const Vec3 &out, double k_th, double k_td, double k_pd)
+// An outgoing direction as the coordinate maps take it: the raw components and the reciprocal of their length.  The maps
+// fold the normalisation into the sum / difference with the (unit) incident direction — s = in + rs out, e = in - rs out
+// as six explicit FMAs.  Left to the compiler's contraction the same six FMAs come out, but WHICH multiply is fused
+// depends on the inlining context (basic-block boundaries), the coordinates then differ by an ulp (1e-14 texel) from one
+// entry point to the next, and the Float corner weights turn that into a one-ulp difference in about two results per
+// million: explicit here, and contraction is off in everything downstream of the coordinates.
+struct Dir { double x, y, z, rs; };
+__device__ __forceinline__ Dir dir_f32(float x, float y, float z)
 {
-    const double sx = in.x + out.x, sy = in.y + out.y, sz = in.z + out.z;
-    const double ex = in.x - out.x, ey = in.y - out.y, ez = in.z - out.z;
+    const double dx = x, dy = y, dz = z;
+    return { dx, dy, dz, rsqrt_pos(__builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz))) };
+}
+__device__ __forceinline__ Vec3 unit(const Dir &d)
+{
+#pragma clang fp contract(off)
+    return { d.x * d.rs, d.y * d.rs, d.z * d.rs };
+}
+
+// a2 + a3 for a unit incident and any outgoing direction (see merl_device.hpp::half_diff_coords for the derivation)
+__device__ __forceinline__ Coords coords(const Vec3 &in, const Dir &out, double k_th, double k_td, double k_pd)
+{
+#pragma clang fp contract(off)
+    const double sx = __builtin_fma(out.x, out.rs, in.x), sy = __builtin_fma(out.y, out.rs, in.y), sz = __builtin_fma(out.z, out.rs, in.z);
+    const double ex = __builtin_fma(-out.x, out.rs, in.x), ey = __builtin_fma(-out.y, out.rs, in.y), ez = __builtin_fma(-out.z, out.rs, in.z);
     const double rho2 = __builtin_fma(sx, sx, sy * sy);
     const double s2 = __builtin_fma(sz, sz, rho2);
     const double e2 = __builtin_fma(ex, ex, __builtin_fma(ey, ey, ez * ez));
@@ -131,8 +150,10 @@ __device__ __forceinline__ Coords coords(const Vec3 &in, const Vec3 &out, double
 // the standard parameterisations (merl_device.hpp::standard_coords): theta = atan2(|v_xy|, v_z) for both directions,
 // dphi = atan2(cross_z, dot_xy); all three axes linear.  k_0 = n_0 / (pi/2), k_1 = n_1 / (pi/2), k_2 = n_2 / pi (mirrored)
 // or n_2 / 2pi (full).  Directions below the horizon are discarded by the caller; |z| keeps atan2_q1 in its domain.
-__device__ __forceinline__ Coords coords_standard(const Vec3 &in, const Vec3 &out, bool full, double k_0, double k_1, double k_2)
+__device__ __forceinline__ Coords coords_standard(const Vec3 &in, const Dir &out_dir, bool full, double k_0, double k_1, double k_2)
 {
+#pragma clang fp contract(off)
+    const Vec3 out = unit(out_dir);
     const double ti = atan2_q1(sqrt_fast(__builtin_fma(in.x, in.x, in.y * in.y)), __builtin_fabs(in.z));
     const double to = atan2_q1(sqrt_fast(__builtin_fma(out.x, out.x, out.y * out.y)), __builtin_fabs(out.z));
     const double cr = __builtin_fma(in.x, out.y, -(in.y * out.x));
@@ -157,7 +178,7 @@ struct TableMaps {
         : k_th((double)n_th * (prm == PARAM_HALF_DIFF ? (double)n_th : 1.0) / kHalfPi), k_td((double)n_td / kHalfPi),
           k_pd((double)n_pd / (prm == PARAM_STANDARD_FULL ? 2.0 * kPi : kPi)), param(prm) {}
     // a2 + a3 under the material's parameterisation (wave-uniform branch for a single-material launch)
-    __device__ __forceinline__ Coords operator()(const Vec3 &in, const Vec3 &out) const
+    __device__ __forceinline__ Coords operator()(const Vec3 &in, const Dir &out) const
     {
         return param == PARAM_HALF_DIFF ? coords(in, out, k_th, k_td, k_pd)
                                         : coords_standard(in, out, param == PARAM_STANDARD_FULL, k_th, k_td, k_pd);
@@ -168,7 +189,7 @@ struct TableMaps {
 // sample lookup of a unit stay in ONE basic block: their gathers are then all in flight together
 // (a wave-uniform runtime branch here halves the memory-level parallelism and doubles the time).
 template <int LOOKUP, int LAYOUT>
-__device__ __forceinline__ Rgbd table_brdf(const MaterialDev &m, const Options &o, const Vec3 &in, const Vec3 &out)
+__device__ __forceinline__ Rgbf table_brdf(const MaterialDev &m, const Options &o, const Vec3 &in, const Dir &out)
 {
     const TableMaps k(m);
     const Coords c = k(in, out);
@@ -181,8 +202,7 @@ template <int LOOKUP, int LAYOUT>
 __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o, const Vec3 &in,
                                           float wix, float wiy, float wiz, float wox, float woy, float woz, float rgb[3])
 {
-    const Vec3 out = normalize_f32(wox, woy, woz);
-    const Rgbd v = table_brdf<LOOKUP, LAYOUT>(m, o, in, out);
+    const Rgbf v = table_brdf<LOOKUP, LAYOUT>(m, o, in, dir_f32(wox, woy, woz));
     eval_tail(v, (wix + wiy + wiz), wiz, wox, woy, woz, rgb);
 }
 
@@ -191,6 +211,7 @@ __device__ __forceinline__ void sincos_2pi(double u, double &s, double &c);     
 
 __device__ __forceinline__ double table_pdf(const MaterialDev &m, const Vec3 &in, const Vec3 &out, float woz)
 {
+#pragma clang fp contract(off)
     double hx = in.x + out.x, hy = in.y + out.y, hz = in.z + out.z;
     double hs, hrs;
     sqrt_rsqrt(__builtin_fma(hx, hx, __builtin_fma(hy, hy, hz * hz)), hs, hrs);
@@ -238,7 +259,7 @@ __device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options 
         square_to_cosine_hemisphere(o.disk_map, u0, u1, x, y, z);
         p = z > 0.0f ? z * kInvPiF : 0.0f;
     }
-    const Rgbd v = table_brdf<LOOKUP, LAYOUT>(m, o, in, normalize_f32(x, y, z));
+    const Rgbf v = table_brdf<LOOKUP, LAYOUT>(m, o, in, dir_f32(x, y, z));
     sample_tail(v, (wix + wiy + wiz), wiz, x, y, z, p, o.sampling != 0, wo, pdf, weight);
 }
 

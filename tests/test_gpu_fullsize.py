@@ -66,8 +66,9 @@ def test_64m_constant_table_known_answer(gpu, batch64, tables):
     rgb = gpu.eval(wi, wo, material=mid)
     for c, raw in enumerate((300.0, 200.0, 100.0)):
         want = (wo[:, 2].double() * (raw * synth.MERL_SCALE[c])).float()
-        # weights sum to 1 only up to rounding: allow 2 ulp
-        assert bool(((rgb[:, c] - want).abs() <= 2.5e-7 * want.abs()).all())
+        # the 8 Float corner weights sum to 1 only up to rounding and the packed-Float blend adds 5 more roundings
+        # (merl_device.hpp::blend_brick: bound 3.6e-7, + the cosine product's): 5e-7, half the 1e-6 parity bar
+        assert bool(((rgb[:, c] - want).abs() <= 5e-7 * want.abs()).all())
     pdf = gpu.pdf(wi, wo, material=mid)
     assert torch.equal(pdf, wo[:, 2] * torch.tensor(0.31830988618379067154, dtype=torch.float32, device="cuda"))
 

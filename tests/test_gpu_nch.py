@@ -151,7 +151,7 @@ def test_four_channel_table_agrees_with_rgb_path(tables):
         wi, wo, u = g.generate_pairs(0x5EED, 5, 100_000)
         r = g.eval_sample(wi, wo, u, material=a)
         f = g.eval_sample_nch(wi, wo, u, 4, material=b)
-        assert _close(f[0][:, :3].cpu().numpy(), r[0].cpu().numpy(), 2e-7) and _close(f[4][:, :3].cpu().numpy(), r[4].cpu().numpy(), 2e-7)
+        assert _close(f[0][:, :3].cpu().numpy(), r[0].cpu().numpy(), 5e-7) and _close(f[4][:, :3].cpu().numpy(), r[4].cpu().numpy(), 5e-7)     # the RGB path blends in packed Float (bound 3.6e-7), the n-channel path in f64
         assert torch.equal(f[2], r[2]) and torch.equal(f[1], r[1]) and torch.equal(f[3], r[3])
 
 

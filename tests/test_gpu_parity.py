@@ -401,7 +401,8 @@ def test_kernel_variants_and_layouts_match_oracle(gpu, oracle, tables, kind, see
     base = results[(0, 1, 0, 1)]
     for key, r in results.items():
         if key[1:3] == (1, 0):
-            assert_close(r, base, rel=2.5e-7, what=f"{key} vs rows/variant 1")
+            # rows blend in f64 and round once; bricks blend in packed Float (merl_device.hpp::blend_brick, bound 3.6e-7)
+            assert_close(r, base, rel=5e-7, what=f"{key} vs rows/variant 1")
 
 
 # ------------------------------------------------------------------ batches that mix material KINDS
