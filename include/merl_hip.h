@@ -187,6 +187,32 @@ int mrl_scalar_eval_sample(mrl_ctx *ctx, int32_t material, const float wi[3], co
 int mrl_scalar_eval_pdf(mrl_ctx *ctx, int32_t material, const float wi[3], const float wo[3], float out_rgb[3], float *out_pdf);
 int mrl_scalar_sample(mrl_ctx *ctx, int32_t material, const float wi[3], const float u[2], float out_wo[3], float *out_pdf, float out_weight[3]);
 
+/* ---- one-unit calls on the calling CPU thread (SURVEY.md §8b "what calls it (2)": scalar BSDF::eval / sample / pdf call
+ * the CPU core directly, no shim hop to the device).  Replaces, for the per-ray virtual calls of a stock integrator, what the
+ * reference's scalar plugin does in its eval()/sample()/pdf() bodies (reference sources absent: README.md:1 names the plugins).
+ * mrl_material_host_table takes a host image of a RESIDENT three-channel table — the device's own Float texel values, copied
+ * back from HBM once (24 MB for a MERL table), with the sampling marginal and a snapshot of the context's lookup options
+ * (MRL_OPT_LOOKUP / NODE / DISK_MAP / SAMPLING as they are at that moment) — and the mrl_host_* calls evaluate one unit on
+ * it with the kernels' own per-unit functions compiled for the host (one formulation, two targets; the two differ only in
+ * the hardware reciprocal seeds, i.e. by ~1e-15 before rounding: sampled directions and cosine pdfs are bit-identical to
+ * the batch calls', values and weights equal to 1 ulp of Float).  The image is immutable: the calls are lock-free, allocation-
+ * free and safe from any number of threads; it is reference-counted and outlives the material and the context it was taken
+ * from.  This is NOT a fallback for the batch / queue calls (they have none: no device, no context) — it is where ONE-unit
+ * calls belong: 0.2-0.4 us on a core against 4.8-6.7 us through the device's one-unit call service (mrl_scalar_*).
+ * Needs a host CPU with FMA + AVX2 (MRL_ERR_INVALID otherwise).  GGX and n-channel materials: MRL_ERR_MATERIAL. ---- */
+typedef struct mrl_host_table mrl_host_table;
+int mrl_material_host_table(mrl_ctx *ctx, int material, mrl_host_table **out);
+int mrl_host_table_retain(mrl_host_table *table);
+int mrl_host_table_release(mrl_host_table *table);
+/* dims, enum mrl_param, lookup mode, sampling strategy and host bytes of an image (any pointer may be NULL) */
+int mrl_host_table_info(const mrl_host_table *table, int dims[3], int *param, int *lookup, int *sampling, size_t *bytes);
+/* eval(wi, wo) -> rgb (cosine included) and, when out_pdf is not NULL, pdf(wi, wo): one lookup */
+int mrl_host_eval_pdf(const mrl_host_table *table, const float wi[3], const float wo[3], float out_rgb[3], float *out_pdf);
+/* sample(wi, u) -> wo', pdf', weight' = eval(wi, wo') / pdf' in Float */
+int mrl_host_sample(const mrl_host_table *table, const float wi[3], const float u[2], float out_wo[3], float *out_pdf, float out_weight[3]);
+/* the fused unit: out[11] = rgb[3] pdf wo'[3] pdf' weight'[3], as mrl_scalar_eval_sample lays it out */
+int mrl_host_eval_sample(const mrl_host_table *table, const float wi[3], const float wo[3], const float u[2], float out[11]);
+
 /* ---- n-channel tables: customized_measurement beyond RGB (monochrome, RGB + alpha, spectral bins; SURVEY.md §8f
  * item 3).  Same MERL parameterisation, same transform and trilinear blend; a texel has n_channels values, 1..32.
  * planar: n_channels planes in MERL order; scale: n_channels factors (NULL = all 1).  Bricks only (the table-layout

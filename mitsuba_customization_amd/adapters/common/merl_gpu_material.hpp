@@ -3,13 +3,15 @@
 // plumbing.  Host C++ only; everything that computes goes through the C ABI (include/merl_hip.h).
 //
 // Threading: the renderers call eval()/sample()/pdf() on a const BSDF from all render threads
-// (SURVEY.md §8b).  A scalar call goes to the library's one-unit call service (mrl_scalar_eval_sample):
-// the calling thread writes its request into a mailbox slot of its own in pinned memory and a resident
-// wave on the GPU — one lane per calling thread — answers it; no kernel launch, no stream synchronisation
-// and no lock shared between render threads on the call path.  A call still costs a PCIe round trip plus
-// the evaluation (~10 us alone, ~1.5 us amortised over 16 threads: INTEGRATION.md §2) against ~0.3 us for a
-// CPU plugin — scalar calls remain plumbing for existing integrators; the fast path is the batch /
-// wavefront entry points, which take whole arrays.
+// (SURVEY.md §8b).  Where a ONE-unit (scalar, virtual) call is evaluated is the plugin's `scalar` property:
+//   "cpu" (default)  on the calling render thread, over a host image of the resident table, with the kernels' own
+//                    per-unit functions compiled for the host (mrl_host_*; SURVEY.md §8b "what calls it (2)"): lock-free,
+//                    ~0.2-0.4 us per call — what the CPU plugin this replaces costs;
+//   "gpu"            through the library's one-unit call service (mrl_scalar_*): the thread writes its request into a
+//                    mailbox slot in pinned memory and a resident wave answers it — a PCIe round trip per call
+//                    (4.8-6.7 us alone, ~0.6 us amortised over 16 threads).
+// Either way the table is resident on the GPU and the batch / wavefront entry points — the fast path, whole arrays —
+// run there; without a gfx950 device the constructor throws.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -94,8 +96,17 @@ public:
             std::lock_guard<std::mutex> lk(mu);
             return ++n;
         }
+        // the host image for one-unit calls on the CPU: taken once per resident table, on the first instance that wants it
+        const mrl_host_table *host_table()
+        {
+            std::lock_guard<std::mutex> call(owner->m_mutex);
+            if (!host) check(owner->m_ctx, mrl_material_host_table(owner->m_ctx, id, &host), "mrl_material_host_table");
+            return host;
+        }
+        mrl_host_table *host = nullptr;
         ~Resident()
         {
+            if (host) mrl_host_table_release(host);
             std::lock_guard<std::mutex> call(owner->m_mutex);
             auto it = owner->m_resident.find(key);      // a newer upload of the same key may already sit there: keep it
             if (it != owner->m_resident.end() && it->second.expired()) owner->m_resident.erase(it);
@@ -228,6 +239,9 @@ public:
         return path.size() > 5 && path.compare(path.size() - 5, 5, ".bsdf") == 0;
     }
 
+    // scalar = "cpu": one-unit calls evaluate on the calling thread from now on (idempotent)
+    void use_cpu_scalar() { m_host = m_res->host_table(); }
+    bool cpu_scalar() const { return m_host != nullptr; }
     bool valid() const { return m_ctx && m_id >= 0; }
     int id() const { return m_id; }
     mrl_ctx *ctx() const { return m_ctx->raw(); }
@@ -252,7 +266,8 @@ public:
         Memo &m = memo();
         if (m.table != m_res->serial || std::memcmp(m.wi, wi, 12) != 0 || std::memcmp(m.wo, wo, 12) != 0) {
             m.table = 0;                                             // not valid while it is being refilled (an exception leaves it so)
-            m_ctx->scalar_eval_pdf(m_id, wi, wo, m.rgb, m.pdf);
+            if (m_host) check(nullptr, mrl_host_eval_pdf(m_host, wi, wo, m.rgb, &m.pdf), "mrl_host_eval_pdf");
+            else m_ctx->scalar_eval_pdf(m_id, wi, wo, m.rgb, m.pdf);
             std::memcpy(m.wi, wi, 12); std::memcpy(m.wo, wo, 12);
             m.table = m_res->serial;
         }
@@ -261,7 +276,8 @@ public:
     }
     void sample1(const float wi[3], const float u[2], float wo[3], float &pdf, float weight[3]) const
     {
-        m_ctx->scalar_sample(m_id, wi, u, wo, pdf, weight);
+        if (m_host) check(nullptr, mrl_host_sample(m_host, wi, u, wo, &pdf, weight), "mrl_host_sample");
+        else m_ctx->scalar_sample(m_id, wi, u, wo, pdf, weight);
     }
     // ---- batch / wavefront calls: host or device arrays, n units (see include/merl_hip.h) ----
     void eval_batch(const float *wi, const float *wo, size_t n, float *rgb) const
@@ -323,6 +339,7 @@ private:
     std::shared_ptr<Context> m_ctx;
     std::shared_ptr<Context::Resident> m_res;
     int m_id = -1;
+    const mrl_host_table *m_host = nullptr;            // owned by m_res; non-null = one-unit calls run on the CPU
 };
 
 inline int parse_lookup(const std::string &s)
@@ -343,6 +360,12 @@ inline int parse_parameterization(const std::string &s)
     if (s == "standard") return MRL_PARAM_STANDARD;
     if (s == "standard_full") return MRL_PARAM_STANDARD_FULL;
     throw Error(MRL_ERR_INVALID, "parameterization must be \"half_diff\", \"standard\" or \"standard_full\", got \"" + s + "\"");
+}
+inline bool parse_scalar_cpu(const std::string &s)
+{
+    if (s == "cpu") return true;
+    if (s == "gpu") return false;
+    throw Error(MRL_ERR_INVALID, "scalar must be \"cpu\" or \"gpu\", got \"" + s + "\"");
 }
 inline int parse_node(const std::string &s)
 {

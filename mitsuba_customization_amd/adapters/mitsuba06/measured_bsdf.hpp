@@ -8,7 +8,9 @@
 //        <float name="scaleR" value="1"/> ... </bsdf>
 // Optional: interpolation = "trilinear" (default) | "nearest";  node = "integer" (default) | "center";
 //           sampling = "cosine" (default, the upstream convention) | "table" (importance sampling off the table);
-//           device = GPU ordinal (default 0).
+//           scalar = "cpu" (default: the virtual per-ray eval / sample / pdf evaluate on the calling render thread, like
+//                    the CPU plugin this replaces) | "gpu" (through the device's one-unit call service);
+//           device = GPU ordinal (default 0).  Whole-array and wavefront calls (BatchedBSDF) always run on the GPU.
 #pragma once
 #ifdef MERL_USE_REAL_MITSUBA
 #include <mitsuba/render/bsdf.h>
@@ -27,8 +29,11 @@ class MeasuredBSDFBase : public BSDF, public BatchedBSDF {
 public:
     explicit MeasuredBSDFBase(const Properties &props) : BSDF(props)
     {
-        // scene-relative names resolve through the host's FileResolver, like every 0.6 plugin that reads a file
-        m_filename = Thread::getThread()->getFileResolver()->resolve(props.getString("filename")).string();
+        // scene-relative names resolve through the host's FileResolver, like every 0.6 plugin that reads a file; the name
+        // as the scene gave it is what serialize() sends to a network-render worker, whose own resolver finds ITS copy
+        m_scene_filename = props.getString("filename");
+        m_filename = Thread::getThread()->getFileResolver()->resolve(m_scene_filename).string();
+        m_cpu_scalar = merl_gpu::parse_scalar_cpu(props.getString("scalar", "cpu"));
         m_key.device = props.getInteger("device", 0);
         m_key.lookup = merl_gpu::parse_lookup(props.getString("interpolation", "trilinear"));
         m_key.node = merl_gpu::parse_node(props.getString("node", "integer"));
@@ -40,7 +45,9 @@ public:
     // worker reloads the table from the same path onto ITS GPU, so the path must resolve there too.
     MeasuredBSDFBase(Stream *stream, InstanceManager *manager) : BSDF(stream, manager)
     {
-        m_filename = Thread::getThread()->getFileResolver()->resolve(stream->readString()).string();
+        m_scene_filename = stream->readString();
+        m_filename = Thread::getThread()->getFileResolver()->resolve(m_scene_filename).string();
+        m_cpu_scalar = stream->readInt() != 0;
         m_key.device = stream->readInt();
         m_key.lookup = stream->readInt();
         m_key.node = stream->readInt();
@@ -53,7 +60,8 @@ public:
     void serialize(Stream *stream, InstanceManager *manager) const override
     {
         BSDF::serialize(stream, manager);
-        stream->writeString(m_filename);
+        stream->writeString(m_scene_filename);
+        stream->writeInt(m_cpu_scalar ? 1 : 0);
         stream->writeInt(m_key.device);
         stream->writeInt(m_key.lookup);
         stream->writeInt(m_key.node);
@@ -142,13 +150,18 @@ public:
     {
         std::ostringstream oss;
         oss << pluginName() << "[filename=\"" << m_filename << "\", device=" << m_key.device
-            << ", interpolation=" << (m_key.lookup ? "trilinear" : "nearest") << ", material=" << m_material.id() << "]";
+            << ", interpolation=" << (m_key.lookup ? "trilinear" : "nearest") << ", scalar=" << (m_material.cpu_scalar() ? "cpu" : "gpu")
+            << ", material=" << m_material.id() << "]";
         return oss.str();
     }
 
 protected:
     virtual const char *pluginName() const = 0;
-    std::string m_filename;
+    // after the subclass has loaded m_material
+    void finish_load() { if (m_cpu_scalar) m_material.use_cpu_scalar(); }
+    std::string m_filename;          // resolved on this host
+    std::string m_scene_filename;    // as the scene (or the master) named it
+    bool m_cpu_scalar = true;
     merl_gpu::ContextKey m_key;
     merl_gpu::Material m_material;
 };
@@ -159,10 +172,12 @@ public:
     explicit MerlBSDF(const Properties &props) : MeasuredBSDFBase(props)
     {
         m_material = merl_gpu::Material::load_merl(m_key, m_filename);
+        finish_load();
     }
     MerlBSDF(Stream *stream, InstanceManager *manager) : MeasuredBSDFBase(stream, manager)
     {
         m_material = merl_gpu::Material::load_merl(m_key, m_filename);
+        finish_load();
         configure();
     }
     MTS_DECLARE_CLASS()
@@ -180,6 +195,10 @@ public:
         // which three angles index the table: "half_diff" (MERL's, default), "standard" (theta_i, theta_o, |dphi|),
         // "standard_full" (theta_i, theta_o, dphi mod 2 pi) — include/merl_hip.h enum mrl_param
         m_param = merl_gpu::parse_parameterization(props.getString("parameterization", "half_diff"));
+        if (merl_gpu::Material::is_tensor_file(m_filename) &&
+            (props.hasProperty("scaleR") || props.hasProperty("scaleG") || props.hasProperty("scaleB")))
+            throw merl_gpu::Error(MRL_ERR_INVALID, m_scene_filename + ": a tensor_file table brings its own channel scales (field \"scale\"); "
+                                                   "scaleR / scaleG / scaleB do not apply to it");
         load();
     }
     CustomizedMeasurement(Stream *stream, InstanceManager *manager) : MeasuredBSDFBase(stream, manager)
@@ -205,6 +224,7 @@ private:
         // *.bsdf: the table sits in a tensor_file container and brings its own channel scales
         m_material = merl_gpu::Material::is_tensor_file(m_filename) ? merl_gpu::Material::load_tensor_table(m_key, m_filename, m_param)
                                                                     : merl_gpu::Material::load_table(m_key, m_filename, scale, m_param);
+        finish_load();
     }
     Float m_scale[3];
     int m_param = 0;

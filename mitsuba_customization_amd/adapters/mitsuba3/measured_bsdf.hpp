@@ -5,6 +5,8 @@
 // warp uses Mitsuba 3's branch-free concentric disk map).
 //
 //   <bsdf type="merl"> <string name="filename" value="gold-metallic-paint.binary"/> </bsdf>
+// scalar = "cpu" (default: the scalar-variant eval / sample / pdf evaluate on the calling thread, like the CPU plugin this
+// replaces) | "gpu" (through the device's one-unit call service).  BatchedBSDF calls always run on the GPU.
 #pragma once
 #ifdef MERL_USE_REAL_MITSUBA
 #include <mitsuba/render/bsdf.h>
@@ -48,6 +50,7 @@ public:
         m_key.node = merl_gpu::parse_node(props.string("node", "integer"));
         m_key.disk_map = 1;                       // Mitsuba 3's square_to_uniform_disk_concentric flavour
         m_key.sampling = merl_gpu::parse_sampling(props.string("sampling", "cosine"));
+        m_cpu_scalar = merl_gpu::parse_scalar_cpu(props.string("scalar", "cpu"));
         this->m_flags = BSDFFlags::GlossyReflection | BSDFFlags::FrontSide;
         this->m_components.push_back(this->m_flags);
     }
@@ -125,6 +128,7 @@ public:
         oss << plugin_class() << "[" << std::endl
             << "  filename = \"" << m_filename << "\"," << std::endl
             << "  interpolation = " << (m_key.lookup ? "trilinear" : "nearest") << "," << std::endl
+            << "  scalar = " << (m_material.cpu_scalar() ? "cpu" : "gpu") << "," << std::endl
             << "  device = " << m_key.device << std::endl
             << "]";
         return oss.str();
@@ -132,7 +136,9 @@ public:
 
 protected:
     virtual const char *plugin_class() const = 0;
+    void finish_load() { if (m_cpu_scalar) m_material.use_cpu_scalar(); }      // after the subclass has loaded m_material
     std::string m_filename;
+    bool m_cpu_scalar = true;
     merl_gpu::ContextKey m_key;
     merl_gpu::Material m_material;
 };
@@ -143,6 +149,7 @@ public:
     explicit MerlBSDF(const Properties &props) : MeasuredBSDFBase<Float, Spectrum>(props)
     {
         this->m_material = merl_gpu::Material::load_merl(this->m_key, this->m_filename);
+        this->finish_load();
     }
     MI_DECLARE_CLASS()
 protected:
@@ -163,6 +170,7 @@ public:
         this->m_material = merl_gpu::Material::is_tensor_file(this->m_filename)
                                ? merl_gpu::Material::load_tensor_table(this->m_key, this->m_filename, param)
                                : merl_gpu::Material::load_table(this->m_key, this->m_filename, scale, param);
+        this->finish_load();
     }
     MI_DECLARE_CLASS()
 protected:

@@ -62,6 +62,8 @@ int main(int argc, char **argv)
 
     if (argc > 10) props.setString("sampling", argv[10]);
     if (argc > 11) props.setString("parameterization", argv[11]);
+    // where the scalar virtual calls evaluate: MERL_DRIVER_SCALAR = cpu | gpu (unset: the plugin's default, cpu)
+    if (const char *sc = std::getenv("MERL_DRIVER_SCALAR")) props.setString("scalar", sc);
     BSDF *bsdf = nullptr;
     try {
         bsdf = static_cast<BSDF *>(create(props));
@@ -128,7 +130,7 @@ int main(int argc, char **argv)
         for (auto &th : pool) th.join();
         const double us_threads = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_threads).count() / (2.0 * m);
         std::cout << "scalar calls: " << us_single << " us/call from one thread, " << us_threads << " us/call amortised over " << T
-                  << " threads (one-unit call service)\n";
+                  << " threads (scalar=" << (std::getenv("MERL_DRIVER_SCALAR") ? std::getenv("MERL_DRIVER_SCALAR") : "cpu") << ")\n";
         for (unsigned t = 0; t < T; ++t) {
             size_t k = 0;
             for (size_t i = t; i < m; i += T, ++k) {

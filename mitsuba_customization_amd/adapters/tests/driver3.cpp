@@ -57,6 +57,8 @@ int main(int argc, char **argv)
 
     if (argc > 10) props.set_string("sampling", argv[10]);
     if (argc > 11) props.set_string("parameterization", argv[11]);
+    // where the scalar virtual calls evaluate: MERL_DRIVER_SCALAR = cpu | gpu (unset: the plugin's default, cpu)
+    if (const char *sc = std::getenv("MERL_DRIVER_SCALAR")) props.set_string("scalar", sc);
     ScalarBSDF *bsdf = nullptr;
     try {
         bsdf = static_cast<ScalarBSDF *>(create(props));

@@ -21,6 +21,7 @@
 
 #include "merl_kernels.hpp"
 #include "merl_scalar_host.hpp"
+#include "merl_host_table.hpp"
 
 namespace {
 
@@ -1241,6 +1242,67 @@ int mrl_material_count(const mrl_ctx *ctx)
     if (!ctx) return MRL_ERR_INVALID;
     MRL_GUARD(ctx);
     return (int)ctx->materials.size();
+}
+
+// The host image of a resident RGB table for one-unit calls on the CPU (merl_host_scalar.hip): the device's own Float texel
+// values, re-read from HBM into the rows layout — from a rows-layout table as it is, from bricks by taking corner 0 of
+// every cell (= the texel itself) and re-creating the padding rows — plus the sampling marginal and a snapshot of the
+// context's lookup options.  One D2H copy of the table (24 MB rows / 187 MB bricks for MERL): about 15 ms, once per image.
+int mrl_material_host_table(mrl_ctx *ctx, int id, mrl_host_table **out)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
+    if (!out) return fail(ctx, MRL_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
+    const MaterialHost &mh = ctx->materials[(size_t)id];
+    if (mh.dev.kind != mrl::KIND_MERL && mh.dev.kind != mrl::KIND_TABLE)
+        return fail(ctx, MRL_ERR_MATERIAL, "host images exist for three-channel table materials");
+    if (!__builtin_cpu_supports("fma") || !__builtin_cpu_supports("avx2"))
+        return fail(ctx, MRL_ERR_INVALID, "the host one-unit path needs a CPU with FMA and AVX2");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    const int n_th = mh.dev.n_th, n_td = mh.dev.n_td, n_pd = mh.dev.n_pd;
+    const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1, cells = (size_t)n_th * n_td * n_pd;
+    mrl_host_table *t = nullptr;
+    try {
+        t = new mrl_host_table;
+        t->rows.resize(H * D * P);
+        t->marginal.resize(3 * (size_t)n_th + 2);
+        std::vector<float4> bricks;
+        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hipError_t e = hipSuccess;
+        if (mh.dev.layout == mrl::LAYOUT_ROWS) {
+            e = hipMemcpy(t->rows.data(), mh.d_texels, t->rows.size() * sizeof(float4), hipMemcpyDeviceToHost);
+        } else {
+            bricks.resize(cells * 8);
+            e = hipMemcpy(bricks.data(), mh.d_texels, bricks.size() * sizeof(float4), hipMemcpyDeviceToHost);
+        }
+        if (e == hipSuccess) e = hipMemcpy(t->marginal.data(), mh.d_sampling, t->marginal.size() * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { (void)hipGetLastError(); delete t; return fail(ctx, MRL_ERR_HIP, std::string("host image: ") + hipGetErrorString(e)); }
+        if (mh.dev.layout != mrl::LAYOUT_ROWS) {
+            const bool periodic = mrl::param_phi_periodic(mh.dev.param);
+            for (size_t ih = 0; ih < H; ++ih)
+                for (size_t idd = 0; idd < D; ++idd)
+                    for (size_t ip = 0; ip < P; ++ip) {
+                        const size_t sh = ih < (size_t)n_th ? ih : n_th - 1, sd = idd < (size_t)n_td ? idd : n_td - 1;
+                        const size_t sp = ip == (size_t)n_pd ? (periodic ? 0 : n_pd - 1) : ip;
+                        const float4 q = bricks[((sh * n_td + sd) * n_pd + sp) * 8];        // corner 0: x y z = the cell's own texel
+                        t->rows[(ih * D + idd) * P + ip] = make_float4(q.x, q.y, q.z, 0.0f);
+                    }
+        }
+    } catch (const std::bad_alloc &) {
+        delete t;
+        return fail(ctx, MRL_ERR_OOM, "host image");
+    }
+    t->m = mh.dev;
+    t->m.texels = t->rows.data();
+    t->m.sampling = t->marginal.data();
+    t->m.layout = mrl::LAYOUT_ROWS;
+    t->m.row_td = (int)P;
+    t->m.row_th = (int)(D * P);
+    t->opts = ctx->opts;
+    *out = t;
+    return MRL_OK;
 }
 
 int mrl_material_info(const mrl_ctx *ctx, int id, int *kind, int dims[3])

@@ -15,7 +15,33 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Every per-unit function below is compiled for the device AND for the host: the host build is the product's own
+// one-unit path (merl_host_scalar.hip: the scalar virtual BSDF::eval / sample / pdf of a per-ray integrator evaluates
+// on the calling CPU thread, SURVEY.md §8b "what calls it (2)") — one formulation, two targets.  Only the hardware
+// reciprocal / reciprocal-square-root seeds differ (v_rcp_f64 / v_rsq_f64 on the device, an exact quotient on the
+// host); both are followed by the same Newton steps, so the two builds agree to ~1e-15 before the outputs are rounded.
+#define MRL_HD __host__ __device__ __forceinline__
+
 namespace mrl {
+
+MRL_HD double rcp_seed(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(x);
+#else
+    return 1.0 / x;
+#endif
+}
+MRL_HD double rsq_seed(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsq(x);
+#else
+    return 1.0 / __builtin_sqrt(x);
+#endif
+}
+MRL_HD int min_i(int a, int b) { return a < b ? a : b; }
+MRL_HD unsigned min_u(unsigned a, unsigned b) { return a < b ? a : b; }
 
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kHalfPi = 1.57079632679489661923;
@@ -59,17 +85,17 @@ struct Options {
 
 struct Vec3d { double x, y, z; };
 
-__device__ __forceinline__ Vec3d normalized(float x, float y, float z)
+MRL_HD Vec3d normalized(float x, float y, float z)
 {
     double dx = x, dy = y, dz = z;
-    double inv = rsqrt(dx * dx + dy * dy + dz * dz);
+    double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
     return { dx * inv, dy * inv, dz * inv };
 }
 
 // ---- a2 + a3: unit in/out -> continuous table coordinates ---------------------------------
 struct Coords { double xh, xd, xp; };
 
-__device__ __forceinline__ Coords half_diff_coords(const Vec3d &in, const Vec3d &out, int n_th, int n_td, int n_pd)
+MRL_HD Coords half_diff_coords(const Vec3d &in, const Vec3d &out, int n_th, int n_td, int n_pd)
 {
     const double sx = in.x + out.x, sy = in.y + out.y, sz = in.z + out.z;
     const double ex = in.x - out.x, ey = in.y - out.y, ez = in.z - out.z;
@@ -92,7 +118,7 @@ __device__ __forceinline__ Coords half_diff_coords(const Vec3d &in, const Vec3d 
 }
 
 // the standard parameterisations: polar angles of both directions and their azimuth difference, linear axes
-__device__ __forceinline__ Coords standard_coords(const Vec3d &in, const Vec3d &out, int param, int n_0, int n_1, int n_2)
+MRL_HD Coords standard_coords(const Vec3d &in, const Vec3d &out, int param, int n_0, int n_1, int n_2)
 {
     const double ti = atan2(sqrt(in.x * in.x + in.y * in.y), in.z);
     const double to = atan2(sqrt(out.x * out.x + out.y * out.y), out.z);
@@ -107,7 +133,7 @@ __device__ __forceinline__ Coords standard_coords(const Vec3d &in, const Vec3d &
 }
 
 // ---- a4: table fetch -------------------------------------------------------------------------
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+MRL_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 struct Rgbd { double r, g, b; };
 struct Rgbf { float r, g, b; };       // a looked-up BRDF value: Float, like the texels it is blended from
@@ -115,7 +141,7 @@ struct Rgbf { float r, g, b; };       // a looked-up BRDF value: Float, like the
 // The 8 trilinear corner weights, formed in f64 from the f64 fractions (a fraction near 1 would lose its complement's
 // relative accuracy in Float) and rounded ONCE to Float; corner k = 4 a + 2 b + c along (axis 0, axis 1, azimuth).
 struct CornerWeights { float w[8]; };
-__device__ __forceinline__ CornerWeights corner_weights(double fh, double fd, double fp)
+MRL_HD CornerWeights corner_weights(double fh, double fd, double fp)
 {
 #pragma clang fp contract(off)
     const double gh = 1.0 - fh, gd = 1.0 - fd, gp = 1.0 - fp;
@@ -132,7 +158,7 @@ __device__ __forceinline__ CornerWeights corner_weights(double fh, double fd, do
 // b = B.x + C.y.  Texels and weights are non-negative, so nothing cancels: the result is within 6 roundings
 // (3.6e-7 relative; measured worst 2.8e-7 incl. the oracle's own rounding) of the exact blend of the same texels.
 typedef float v2f_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ Rgbf blend_brick(const float4 &q0, const float4 &q1, const float4 &q2, const float4 &q3, const float4 &q4,
+MRL_HD Rgbf blend_brick(const float4 &q0, const float4 &q1, const float4 &q2, const float4 &q3, const float4 &q4,
                                             const float4 &q5, const CornerWeights &c)
 {
     // contraction off: every operation below is exactly what is written (entry points must agree bit for bit, and a
@@ -155,7 +181,7 @@ __device__ __forceinline__ Rgbf blend_brick(const float4 &q0, const float4 &q1, 
 }
 
 template <int LAYOUT>
-__device__ __forceinline__ Rgbf lookup_nearest_t(const MaterialDev &m, const Coords &c)
+MRL_HD Rgbf lookup_nearest_t(const MaterialDev &m, const Coords &c)
 {
     int ih = clampi((int)c.xh, 0, m.n_th - 1);
     int id = clampi((int)c.xd, 0, m.n_td - 1);
@@ -175,28 +201,28 @@ __device__ __forceinline__ Rgbf lookup_nearest_t(const MaterialDev &m, const Coo
 // (contraction off in everything between a continuous coordinate and its Float corner weights: fused with the multiply
 // that produced x in one inlining context and not in another, x - i differs by ~1e-14, and the weights' rounding to
 // Float turns that into a one-ulp difference between entry points for about one unit in a million)
-__device__ __forceinline__ void split_clamped(double x, int n, int &i0, double &f)
+MRL_HD void split_clamped(double x, int n, int &i0, double &f)
 {
 #pragma clang fp contract(off)
-    const int i = min((int)x, n - 1);
+    const int i = min_i((int)x, n - 1);
     f = __builtin_fmin(__builtin_fmax(x - (double)i, 0.0), 1.0);
     i0 = i;
 }
 // periodic axis: i0 in [0,n-1]; i0+1 <= n hits the appended wrap texel.  floor(x) is in [-1, n]: shifted by n it lies in
 // [n-1, 2n] and two unsigned min(j, j - n) steps bring it to [0, n-1] (j < n: j - n wraps around to a huge value and j wins).
-__device__ __forceinline__ void split_periodic(double x, int n, int &i0, double &f)
+MRL_HD void split_periodic(double x, int n, int &i0, double &f)
 {
 #pragma clang fp contract(off)
     const double fl = floor(x);
     f = x - fl;
     unsigned j = (unsigned)((int)fl + n);
-    j = min(j, j - (unsigned)n);
-    j = min(j, j - (unsigned)n);
-    i0 = (int)min(j, (unsigned)(n - 1));          // only reached by x outside [-1, n]: stay inside the table
+    j = min_u(j, j - (unsigned)n);
+    j = min_u(j, j - (unsigned)n);
+    i0 = (int)min_u(j, (unsigned)(n - 1));          // only reached by x outside [-1, n]: stay inside the table
 }
 
 // the azimuth axis: periodic, except for the mirrored standard form (0 and pi are its two ends)
-__device__ __forceinline__ void split_phi(bool periodic, double x, int n, int &i0, double &f)
+MRL_HD void split_phi(bool periodic, double x, int n, int &i0, double &f)
 {
     int ip, ic; double fp, fc;
     split_periodic(x, n, ip, fp);
@@ -206,7 +232,7 @@ __device__ __forceinline__ void split_phi(bool periodic, double x, int n, int &i
 }
 
 template <int LAYOUT>
-__device__ __forceinline__ Rgbf lookup_trilinear_t(const MaterialDev &m, const Coords &c, int node)
+MRL_HD Rgbf lookup_trilinear_t(const MaterialDev &m, const Coords &c, int node)
 {
 #pragma clang fp contract(off)
     const double shift = node ? 0.5 : 0.0;
@@ -221,34 +247,32 @@ __device__ __forceinline__ Rgbf lookup_trilinear_t(const MaterialDev &m, const C
         const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
         return blend_brick(q0, q1, q2, q3, q4, q5, corner_weights(fh, fd, fp));
     }
-    const double gh = 1.0 - fh, gd = 1.0 - fd, gp = 1.0 - fp;
-    const double w000 = gh * gd * gp, w001 = gh * gd * fp, w010 = gh * fd * gp, w011 = gh * fd * fp;
-    const double w100 = fh * gd * gp, w101 = fh * gd * fp, w110 = fh * fd * gp, w111 = fh * fd * fp;
     const float4 *b = m.texels + ((size_t)h0 * m.row_th + (size_t)d0 * m.row_td + p0);
     // issue all eight 16-B gathers before any use
     const float4 t000 = b[0],                 t001 = b[1];
     const float4 t010 = b[m.row_td],          t011 = b[m.row_td + 1];
     const float4 t100 = b[m.row_th],          t101 = b[m.row_th + 1];
     const float4 t110 = b[m.row_th + m.row_td], t111 = b[m.row_th + m.row_td + 1];
-    Rgbf o;        // rows layout: f64 accumulation, rounded to Float once
-    o.r = (float)(w000 * t000.x + w001 * t001.x + w010 * t010.x + w011 * t011.x + w100 * t100.x + w101 * t101.x + w110 * t110.x + w111 * t111.x);
-    o.g = (float)(w000 * t000.y + w001 * t001.y + w010 * t010.y + w011 * t011.y + w100 * t100.y + w101 * t101.y + w110 * t110.y + w111 * t111.y);
-    o.b = (float)(w000 * t000.z + w001 * t001.z + w010 * t010.z + w011 * t011.z + w100 * t100.z + w101 * t101.z + w110 * t110.z + w111 * t111.z);
-    return o;
+    // the eight texels in brick order (corner-major RGB) through the SAME blend: a rows-layout table, a brick table and the
+    // host image of either give the same bits for the same coordinates
+    return blend_brick(make_float4(t000.x, t000.y, t000.z, t001.x), make_float4(t001.y, t001.z, t010.x, t010.y),
+                       make_float4(t010.z, t011.x, t011.y, t011.z), make_float4(t100.x, t100.y, t100.z, t101.x),
+                       make_float4(t101.y, t101.z, t110.x, t110.y), make_float4(t110.z, t111.x, t111.y, t111.z),
+                       corner_weights(fh, fd, fp));
 }
 
 // runtime-layout wrappers (generic kernel)
-__device__ __forceinline__ Rgbf lookup_nearest(const MaterialDev &m, const Coords &c)
+MRL_HD Rgbf lookup_nearest(const MaterialDev &m, const Coords &c)
 {
     return m.layout == LAYOUT_BRICK ? lookup_nearest_t<LAYOUT_BRICK>(m, c) : lookup_nearest_t<LAYOUT_ROWS>(m, c);
 }
-__device__ __forceinline__ Rgbf lookup_trilinear(const MaterialDev &m, const Coords &c, int node)
+MRL_HD Rgbf lookup_trilinear(const MaterialDev &m, const Coords &c, int node)
 {
     return m.layout == LAYOUT_BRICK ? lookup_trilinear_t<LAYOUT_BRICK>(m, c, node) : lookup_trilinear_t<LAYOUT_ROWS>(m, c, node);
 }
 
 // BRDF value (no cosine) of a table material for unit in/out
-__device__ __forceinline__ Rgbf table_brdf(const MaterialDev &m, const Options &o, const Vec3d &in, const Vec3d &out)
+MRL_HD Rgbf table_brdf(const MaterialDev &m, const Options &o, const Vec3d &in, const Vec3d &out)
 {
     Coords c = m.param == PARAM_HALF_DIFF ? half_diff_coords(in, out, m.n_th, m.n_td, m.n_pd)
                                           : standard_coords(in, out, m.param, m.n_th, m.n_td, m.n_pd);
@@ -256,7 +280,7 @@ __device__ __forceinline__ Rgbf table_brdf(const MaterialDev &m, const Options &
 }
 
 // ---- a6: cosine-hemisphere sampling, pinned f32 sequence (bit-identical to oracle/merl_oracle.c) --
-__device__ __forceinline__ void sincos_quarter_f32(float t, float &s, float &c)
+MRL_HD void sincos_quarter_f32(float t, float &s, float &c)
 {
 #pragma clang fp contract(off)
     const float S0 = -0x1.555552p-3f, S1 = 0x1.110c28p-7f, S2 = -0x1.9ac98ep-13f;
@@ -270,7 +294,7 @@ __device__ __forceinline__ void sincos_quarter_f32(float t, float &s, float &c)
     c = __builtin_fmaf(qz, z, __builtin_fmaf(-0.5f, z, 1.0f));
 }
 
-__device__ __forceinline__ void square_to_cosine_hemisphere(int disk_map, float u0, float u1, float &x, float &y, float &z)
+MRL_HD void square_to_cosine_hemisphere(int disk_map, float u0, float u1, float &x, float &y, float &z)
 {
 #pragma clang fp contract(off)
     const float QUARTER_PI = 0.78539816339744830962f;
@@ -297,7 +321,7 @@ __device__ __forceinline__ void square_to_cosine_hemisphere(int disk_map, float 
 }
 
 // ---- a9: GGX rough conductor, f64, formula-for-formula the oracle's ---------
-__device__ __forceinline__ double ggx_D(double alpha, const Vec3d &m)
+MRL_HD double ggx_D(double alpha, const Vec3d &m)
 {
     if (m.z <= 0.0) return 0.0;
     double c2 = m.z * m.z;
@@ -306,7 +330,7 @@ __device__ __forceinline__ double ggx_D(double alpha, const Vec3d &m)
     double r = 1.0 / (kPi * alpha * alpha * root * root);
     return r * m.z < 1e-20 ? 0.0 : r;
 }
-__device__ __forceinline__ double ggx_G1(double alpha, const Vec3d &v, const Vec3d &m)
+MRL_HD double ggx_G1(double alpha, const Vec3d &v, const Vec3d &m)
 {
     double vm = v.x * m.x + v.y * m.y + v.z * m.z;
     if (vm * v.z <= 0.0) return 0.0;
@@ -315,8 +339,8 @@ __device__ __forceinline__ double ggx_G1(double alpha, const Vec3d &v, const Vec
     double tan2 = s2 / (v.z * v.z);
     return 2.0 / (1.0 + sqrt(1.0 + alpha * alpha * tan2));
 }
-__device__ __forceinline__ double safe_sqrt(double x) { return x > 0.0 ? sqrt(x) : 0.0; }
-__device__ __forceinline__ double fresnel_conductor(double c, double eta, double k)
+MRL_HD double safe_sqrt(double x) { return x > 0.0 ? sqrt(x) : 0.0; }
+MRL_HD double fresnel_conductor(double c, double eta, double k)
 {
     double c2 = c * c, s2 = 1.0 - c2, s4 = s2 * s2;
     double t1 = eta * eta - k * k - s2;
@@ -328,7 +352,7 @@ __device__ __forceinline__ double fresnel_conductor(double c, double eta, double
     double rp2 = rs2 * (term3 - term4) / (term3 + term4);
     return 0.5 * (rp2 + rs2);
 }
-__device__ __forceinline__ Vec3d unit_sum(const Vec3d &a, const Vec3d &b)
+MRL_HD Vec3d unit_sum(const Vec3d &a, const Vec3d &b)
 {
     double x = a.x + b.x, y = a.y + b.y, z = a.z + b.z;
     double len = sqrt(x * x + y * y + z * z);
@@ -336,7 +360,7 @@ __device__ __forceinline__ Vec3d unit_sum(const Vec3d &a, const Vec3d &b)
     return { x, y, z };
 }
 // eval with the cosine folded in: F D G / (4 cos ti)
-__device__ __forceinline__ Rgbd ggx_eval(const MaterialDev &g, const Vec3d &in, const Vec3d &out)
+MRL_HD Rgbd ggx_eval(const MaterialDev &g, const Vec3d &in, const Vec3d &out)
 {
     Vec3d m = unit_sum(in, out);
     Rgbd o = { 0.0, 0.0, 0.0 };
@@ -350,12 +374,12 @@ __device__ __forceinline__ Rgbd ggx_eval(const MaterialDev &g, const Vec3d &in, 
     o.b = fresnel_conductor(c, g.eta[2], g.k[2]) * model;
     return o;
 }
-__device__ __forceinline__ double ggx_pdf(const MaterialDev &g, const Vec3d &in, const Vec3d &out)
+MRL_HD double ggx_pdf(const MaterialDev &g, const Vec3d &in, const Vec3d &out)
 {
     Vec3d m = unit_sum(in, out);
     return ggx_D(g.alpha, m) * ggx_G1(g.alpha, in, m) / (4.0 * in.z);
 }
-__device__ __forceinline__ void ggx_sample_visible_11(double theta_i, double u1, double u2, double &slx, double &sly)
+MRL_HD void ggx_sample_visible_11(double theta_i, double u1, double u2, double &slx, double &sly)
 {
     if (theta_i < 1e-4) {
         double r = safe_sqrt(u1 / (1.0 - u1));
@@ -381,7 +405,7 @@ __device__ __forceinline__ void ggx_sample_visible_11(double theta_i, double u1,
     sly = S * z * sqrt(1.0 + slx * slx);
 }
 // returns false when the sample is rejected (all outputs zero)
-__device__ __forceinline__ bool ggx_sample(const MaterialDev &g, const Vec3d &in, float u0, float u1,
+MRL_HD bool ggx_sample(const MaterialDev &g, const Vec3d &in, float u0, float u1,
                                            float wo[3], float &pdf, float weight[3])
 {
     const double al = g.alpha;
@@ -417,7 +441,7 @@ __device__ __forceinline__ bool ggx_sample(const MaterialDev &g, const Vec3d &in
 // one-sample mixture: u0 < 1/2 -> cosine hemisphere with (2 u0, u1); else theta_h from the table's row
 // marginal (sin^2 theta_h is uniform inside a row bin), phi_h = 2 pi u1, wo = reflect(wi, h).
 // pdf(wi, wo) = 1/2 cos(theta_o)/pi + 1/2 c_i h.z / (4 wi.h)
-__device__ __forceinline__ int bin_of(const double *a, int n, double x)      // largest i in [0,n-1] with a[i] <= x
+MRL_HD int bin_of(const double *a, int n, double x)      // largest i in [0,n-1] with a[i] <= x
 {
     int lo = 0, hi = n;
     while (hi - lo > 1) {
@@ -427,10 +451,10 @@ __device__ __forceinline__ int bin_of(const double *a, int n, double x)      // 
     return lo;
 }
 
-__device__ __forceinline__ double table_pdf(const MaterialDev &m, const Vec3d &in, const Vec3d &out, float woz)
+MRL_HD double table_pdf(const MaterialDev &m, const Vec3d &in, const Vec3d &out, float woz)
 {
     Vec3d h = { in.x + out.x, in.y + out.y, in.z + out.z };
-    const double inv = rsqrt(h.x * h.x + h.y * h.y + h.z * h.z);
+    const double inv = 1.0 / sqrt(h.x * h.x + h.y * h.y + h.z * h.z);
     h.x *= inv; h.y *= inv; h.z *= inv;
     const int i = bin_of(m.sampling, m.n_th, h.x * h.x + h.y * h.y);
     const double ih = in.x * h.x + in.y * h.y + in.z * h.z;
@@ -439,7 +463,7 @@ __device__ __forceinline__ double table_pdf(const MaterialDev &m, const Vec3d &i
 }
 
 // direction of the mixture sample (Float); z <= 0 means "rejected"
-__device__ __forceinline__ void table_sample_dir(const MaterialDev &m, int disk_map, const Vec3d &in, float u0, float u1,
+MRL_HD void table_sample_dir(const MaterialDev &m, int disk_map, const Vec3d &in, float u0, float u1,
                                                  float &x, float &y, float &z)
 {
     if (u0 < 0.5f) {
@@ -461,9 +485,9 @@ __device__ __forceinline__ void table_sample_dir(const MaterialDev &m, int disk_
 // ---- tails shared by every kernel (generic and tuned), so that entry points agree bit for bit on the same lookup value ----
 namespace fast {
 // 1 / x: v_rcp_f64 seed + one Newton step (relative error ~1e-15)
-__device__ __forceinline__ double rcp_nr(double x)
+MRL_HD double rcp_nr(double x)
 {
-    double y = __builtin_amdgcn_rcp(x);
+    double y = rcp_seed(x);
     double e = __builtin_fma(-x, y, 1.0);
     return __builtin_fma(y, e, y);
 }
@@ -471,12 +495,12 @@ __device__ __forceinline__ double rcp_nr(double x)
 // NaN / inf directions: the floors and guards of this file would turn them into finite garbage; an f64 CPU evaluation
 // propagates NaN instead, so the cosine factor is poisoned when a component of either input is not finite.
 // wi_sum = wix + wiy + wiz is shared by the two lookups of a unit.
-__device__ __forceinline__ float cos_or_nan32(float wi_sum, float wox, float woy, float woz)
+MRL_HD float cos_or_nan32(float wi_sum, float wox, float woy, float woz)
 {
     const float t = wi_sum + (wox + woy + woz);                     // NaN or inf iff some component is
     return (__builtin_fabsf(t) <= 3.0e38f) ? woz : __builtin_nanf("");
 }
-__device__ __forceinline__ double cos_or_nan(float wix, float wiy, float wiz, float wox, float woy, float woz)
+MRL_HD double cos_or_nan(float wix, float wiy, float wiz, float wox, float woy, float woz)
 {
     return (double)cos_or_nan32((wix + wiy + wiz), wox, woy, woz);
 }
@@ -484,7 +508,7 @@ __device__ __forceinline__ double cos_or_nan(float wix, float wiy, float wiz, fl
 // a5 tail: rgb = f cos(theta_o) in Float (the plugin's own arithmetic: Spectrum * Float); zero for a pair that fails the
 // cosine guards (texels are finite by construction, so the factor 0 is enough), NaN where an input component is not
 // finite and the guards pass
-__device__ __forceinline__ void eval_tail(const Rgbf &v, float wi_sum, float wiz, float wox, float woy, float woz, float rgb[3])
+MRL_HD void eval_tail(const Rgbf &v, float wi_sum, float wiz, float wox, float woy, float woz, float rgb[3])
 {
 #pragma clang fp contract(off)
     const bool valid = (wiz > 0.0f) && (woz > 0.0f);
@@ -498,7 +522,7 @@ __device__ __forceinline__ void eval_tail(const Rgbf &v, float wi_sum, float wiz
 // than 2^-49 = 1.8e-15 (relative) to a rounding boundary of Float, so Float(q) IS the correctly rounded f / pdf
 // (tests/test_gpu_fullsize.py checks weight == eval / pdf bit for bit on 64M units).  Zero when the sample is invalid
 // or its pdf is zero.
-__device__ __forceinline__ void sample_tail(const Rgbf &v, float wi_sum, float wiz, float sx, float sy, float sz, float p, bool table_sampling,
+MRL_HD void sample_tail(const Rgbf &v, float wi_sum, float wiz, float sx, float sy, float sz, float p, bool table_sampling,
                                             float wo[3], float &pdf, float weight[3])
 {
 #pragma clang fp contract(off)
@@ -507,7 +531,7 @@ __device__ __forceinline__ void sample_tail(const Rgbf &v, float wi_sum, float w
     const float c32 = cos_or_nan32(wi_sum, sx, sy, sz);
     const float c = has ? c32 : 0.0f;
     const double pd = (double)(has ? p : 1.0f);
-    double y = __builtin_amdgcn_rcp(pd);
+    double y = rcp_seed(pd);
     y = __builtin_fma(y, __builtin_fma(-pd, y, 1.0), y);
     y = __builtin_fma(y, __builtin_fma(-pd, y, 1.0), y);
     wo[0] = valid ? sx : 0.0f; wo[1] = valid ? sy : 0.0f; wo[2] = valid ? sz : 0.0f;
@@ -520,7 +544,7 @@ __device__ __forceinline__ void sample_tail(const Rgbf &v, float wi_sum, float w
 
 // ---- a5 / a6 / a7 for one unit, any material kind ------------------------------------------
 // eval(): rgb = f * cos(theta_o), zero unless cos(theta_i) > 0 and cos(theta_o) > 0
-__device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o,
+MRL_HD void unit_eval(const MaterialDev &m, const Options &o,
                                           float wix, float wiy, float wiz, float wox, float woy, float woz,
                                           float rgb[3])
 {
@@ -535,7 +559,7 @@ __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o
     rgb[0] = (float)v.r; rgb[1] = (float)v.g; rgb[2] = (float)v.b;
 }
 
-__device__ __forceinline__ float unit_pdf(const MaterialDev &m, const Options &o, float wix, float wiy, float wiz, float wox, float woy, float woz)
+MRL_HD float unit_pdf(const MaterialDev &m, const Options &o, float wix, float wiy, float wiz, float wox, float woy, float woz)
 {
     if (!(wiz > 0.0f) || !(woz > 0.0f)) return 0.0f;
     if (m.kind == KIND_GGX) {
@@ -546,7 +570,7 @@ __device__ __forceinline__ float unit_pdf(const MaterialDev &m, const Options &o
     return woz * kInvPiF;
 }
 
-__device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options &o,
+MRL_HD void unit_sample(const MaterialDev &m, const Options &o,
                                             float wix, float wiy, float wiz, float u0, float u1,
                                             float wo[3], float &pdf, float weight[3])
 {
@@ -573,14 +597,14 @@ __device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options 
 }
 
 // ---- synthetic inputs, bit-identical to the oracle's generator ---------------
-__device__ __forceinline__ uint64_t mix64(uint64_t z)
+MRL_HD uint64_t mix64(uint64_t z)
 {
     z += 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-__device__ __forceinline__ void hemisphere_dir(uint64_t r, float &dx, float &dy, float &dz)
+MRL_HD void hemisphere_dir(uint64_t r, float &dx, float &dy, float &dz)
 {
 #pragma clang fp contract(off)
     const float TWO_NEG24 = 0x1p-24f, STEP = 0x1.921fb6p-22f;

@@ -87,7 +87,7 @@ __device__ __forceinline__ void ggx_eval_pdf(const GgxConsts &g, const Vec3 &in,
 }
 
 // sin / cos of 2 pi u for u in [0,1): only the (rare) normal-incidence branch of the sampler needs it
-__device__ __forceinline__ void sincos_2pi(double u, double &s, double &c)
+MRL_HD void sincos_2pi(double u, double &s, double &c)
 {   // declared in merl_table_fast.hpp
     // octant reduction: 2 pi u = q pi/2 + t, |t| <= pi/4
     const double x = 4.0 * u;

@@ -17,7 +17,7 @@ namespace fast {
 
 // n / d for finite d != 0: v_rcp_f64 seed + one Newton step (relative error ~1e-15; the
 // coordinate budget is 1e-10, so no residual correction)
-__device__ __forceinline__ double div_fast(double n, double d)
+MRL_HD double div_fast(double n, double d)
 {
     return n * rcp_nr(d);
 }
@@ -26,37 +26,37 @@ constexpr double kTiny = 1e-280;
 
 // sqrt(x) and 1/sqrt(x) for x >= 0: v_rsq_f64 seed + one coupled Newton step.  x is floored at
 // kTiny so that x == 0 needs no select (sqrt -> 1e-140 ~ 0).
-__device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs)
+MRL_HD void sqrt_rsqrt(double x, double &s, double &rs)
 {
     x = __builtin_fmax(x, kTiny);
-    double y = __builtin_amdgcn_rsq(x);
+    double y = rsq_seed(x);
     double g = x * y, h = 0.5 * y;
     double r = __builtin_fma(-h, g, 0.5);
     s = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
     rs = h + h;
 }
-__device__ __forceinline__ double sqrt_fast(double x)
+MRL_HD double sqrt_fast(double x)
 {
     x = __builtin_fmax(x, kTiny);
-    double y = __builtin_amdgcn_rsq(x);
+    double y = rsq_seed(x);
     double g = x * y, h = 0.5 * y;
     double r = __builtin_fma(-h, g, 0.5);
     return __builtin_fma(g, r, g);
 }
 // sqrt(x) for x > 0 known (a sum of squares of a direction that passed the cosine guards): no floor
-__device__ __forceinline__ double sqrt_pos(double x)
+MRL_HD double sqrt_pos(double x)
 {
-    double y = __builtin_amdgcn_rsq(x);
+    double y = rsq_seed(x);
     double g = x * y, h = 0.5 * y;
     double r = __builtin_fma(-h, g, 0.5);
     return __builtin_fma(g, r, g);
 }
 // 1/sqrt(x) for x > 0: seed + one Newton step, y (1 + e/2) with e = 1 - x y^2.  x == 0 gives NaN (0 * inf): callers pass
 // squared lengths of directions whose lanes are masked by the cosine guards when the length is zero.
-__device__ __forceinline__ double rsqrt_pos(double x)
+MRL_HD double rsqrt_pos(double x)
 {
-    const double y = __builtin_amdgcn_rsq(x);
+    const double y = rsq_seed(x);
     const double e = __builtin_fma(-(x * y), y, 1.0);
     return __builtin_fma(0.5 * y, e, y);
 }
@@ -68,7 +68,7 @@ __device__ __forceinline__ double rsqrt_pos(double x)
 // (a, b) = (0, 0) returns pi/8: phi_d is undefined there (degenerate h or retro-reflection).
 // FLOOR = false: (a, b) != (0, 0) is known (den > 0), the kTiny floor on the denominator is dropped.
 template <bool FLOOR = true>
-__device__ __forceinline__ double atan2_q1(double a, double b)
+MRL_HD double atan2_q1(double a, double b)
 {
     constexpr double C = 0.41421356237309503;            // tan(pi/8)
     constexpr double PI_8 = 0.39269908169872415481;
@@ -95,7 +95,7 @@ __device__ __forceinline__ double atan2_q1(double a, double b)
 
 struct Vec3 { double x, y, z; };
 
-__device__ __forceinline__ Vec3 normalize_f32(float x, float y, float z)
+MRL_HD Vec3 normalize_f32(float x, float y, float z)
 {
     const double dx = x, dy = y, dz = z;
     const double rs = rsqrt_pos(__builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz)));
@@ -109,19 +109,19 @@ __device__ __forceinline__ Vec3 normalize_f32(float x, float y, float z)
 // entry point to the next, and the Float corner weights turn that into a one-ulp difference in about two results per
 // million: explicit here, and contraction is off in everything downstream of the coordinates.
 struct Dir { double x, y, z, rs; };
-__device__ __forceinline__ Dir dir_f32(float x, float y, float z)
+MRL_HD Dir dir_f32(float x, float y, float z)
 {
     const double dx = x, dy = y, dz = z;
     return { dx, dy, dz, rsqrt_pos(__builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz))) };
 }
-__device__ __forceinline__ Vec3 unit(const Dir &d)
+MRL_HD Vec3 unit(const Dir &d)
 {
 #pragma clang fp contract(off)
     return { d.x * d.rs, d.y * d.rs, d.z * d.rs };
 }
 
 // a2 + a3 for a unit incident and any outgoing direction (see merl_device.hpp::half_diff_coords for the derivation)
-__device__ __forceinline__ Coords coords(const Vec3 &in, const Dir &out, double k_th, double k_td, double k_pd)
+MRL_HD Coords coords(const Vec3 &in, const Dir &out, double k_th, double k_td, double k_pd)
 {
 #pragma clang fp contract(off)
     const double sx = __builtin_fma(out.x, out.rs, in.x), sy = __builtin_fma(out.y, out.rs, in.y), sz = __builtin_fma(out.z, out.rs, in.z);
@@ -150,7 +150,7 @@ __device__ __forceinline__ Coords coords(const Vec3 &in, const Dir &out, double 
 // the standard parameterisations (merl_device.hpp::standard_coords): theta = atan2(|v_xy|, v_z) for both directions,
 // dphi = atan2(cross_z, dot_xy); all three axes linear.  k_0 = n_0 / (pi/2), k_1 = n_1 / (pi/2), k_2 = n_2 / pi (mirrored)
 // or n_2 / 2pi (full).  Directions below the horizon are discarded by the caller; |z| keeps atan2_q1 in its domain.
-__device__ __forceinline__ Coords coords_standard(const Vec3 &in, const Dir &out_dir, bool full, double k_0, double k_1, double k_2)
+MRL_HD Coords coords_standard(const Vec3 &in, const Dir &out_dir, bool full, double k_0, double k_1, double k_2)
 {
 #pragma clang fp contract(off)
     const Vec3 out = unit(out_dir);
@@ -171,14 +171,14 @@ __device__ __forceinline__ Coords coords_standard(const Vec3 &in, const Dir &out
 struct TableMaps {
     double k_th, k_td, k_pd;
     int param;
-    __device__ __forceinline__ explicit TableMaps(const MaterialDev &m)
+    MRL_HD explicit TableMaps(const MaterialDev &m)
         : k_th((double)m.n_th * (m.param == PARAM_HALF_DIFF ? (double)m.n_th : 1.0) / kHalfPi), k_td((double)m.n_td / kHalfPi),
           k_pd((double)m.n_pd / (m.param == PARAM_STANDARD_FULL ? 2.0 * kPi : kPi)), param(m.param) {}
-    __device__ __forceinline__ TableMaps(int n_th, int n_td, int n_pd, int prm)
+    MRL_HD TableMaps(int n_th, int n_td, int n_pd, int prm)
         : k_th((double)n_th * (prm == PARAM_HALF_DIFF ? (double)n_th : 1.0) / kHalfPi), k_td((double)n_td / kHalfPi),
           k_pd((double)n_pd / (prm == PARAM_STANDARD_FULL ? 2.0 * kPi : kPi)), param(prm) {}
     // a2 + a3 under the material's parameterisation (wave-uniform branch for a single-material launch)
-    __device__ __forceinline__ Coords operator()(const Vec3 &in, const Dir &out) const
+    MRL_HD Coords operator()(const Vec3 &in, const Dir &out) const
     {
         return param == PARAM_HALF_DIFF ? coords(in, out, k_th, k_td, k_pd)
                                         : coords_standard(in, out, param == PARAM_STANDARD_FULL, k_th, k_td, k_pd);
@@ -189,7 +189,7 @@ struct TableMaps {
 // sample lookup of a unit stay in ONE basic block: their gathers are then all in flight together
 // (a wave-uniform runtime branch here halves the memory-level parallelism and doubles the time).
 template <int LOOKUP, int LAYOUT>
-__device__ __forceinline__ Rgbf table_brdf(const MaterialDev &m, const Options &o, const Vec3 &in, const Dir &out)
+MRL_HD Rgbf table_brdf(const MaterialDev &m, const Options &o, const Vec3 &in, const Dir &out)
 {
     const TableMaps k(m);
     const Coords c = k(in, out);
@@ -199,7 +199,7 @@ __device__ __forceinline__ Rgbf table_brdf(const MaterialDev &m, const Options &
 
 // a5: eval (cosine included); valid == false gives zeros
 template <int LOOKUP, int LAYOUT>
-__device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o, const Vec3 &in,
+MRL_HD void unit_eval(const MaterialDev &m, const Options &o, const Vec3 &in,
                                           float wix, float wiy, float wiz, float wox, float woy, float woz, float rgb[3])
 {
     const Rgbf v = table_brdf<LOOKUP, LAYOUT>(m, o, in, dir_f32(wox, woy, woz));
@@ -207,9 +207,9 @@ __device__ __forceinline__ void unit_eval(const MaterialDev &m, const Options &o
 }
 
 // ---- table importance sampling, tuned forms of merl_device.hpp::table_pdf / table_sample_dir ----
-__device__ __forceinline__ void sincos_2pi(double u, double &s, double &c);      // merl_ggx_fast.hpp
+MRL_HD void sincos_2pi(double u, double &s, double &c);      // merl_ggx_fast.hpp
 
-__device__ __forceinline__ double table_pdf(const MaterialDev &m, const Vec3 &in, const Vec3 &out, float woz)
+MRL_HD double table_pdf(const MaterialDev &m, const Vec3 &in, const Vec3 &out, float woz)
 {
 #pragma clang fp contract(off)
     double hx = in.x + out.x, hy = in.y + out.y, hz = in.z + out.z;
@@ -222,7 +222,7 @@ __device__ __forceinline__ double table_pdf(const MaterialDev &m, const Vec3 &in
     return 0.5 * ((double)woz * 0.31830988618379067154) + 0.5 * ph;
 }
 
-__device__ __forceinline__ void table_sample_dir(const MaterialDev &m, int disk_map, const Vec3 &in, float u0, float u1,
+MRL_HD void table_sample_dir(const MaterialDev &m, int disk_map, const Vec3 &in, float u0, float u1,
                                                  float &x, float &y, float &z)
 {
     if (u0 < 0.5f) {
@@ -245,7 +245,7 @@ __device__ __forceinline__ void table_sample_dir(const MaterialDev &m, int disk_
 
 // a6: sample
 template <int LOOKUP, int LAYOUT>
-__device__ __forceinline__ void unit_sample(const MaterialDev &m, const Options &o, const Vec3 &in,
+MRL_HD void unit_sample(const MaterialDev &m, const Options &o, const Vec3 &in,
                                             float wix, float wiy, float wiz,
                                             float u0, float u1, float wo[3], float &pdf, float weight[3])
 {

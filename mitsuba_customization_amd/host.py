@@ -47,9 +47,45 @@ ABI_SYMBOLS = (
     "mrl_group_generate_tiles", "mrl_group_eval_sample_sharded", "mrl_group_eval_sharded", "mrl_group_eval_sample_batch", "mrl_group_synchronize",
     "mrl_group_eval_batch", "mrl_group_pdf_batch", "mrl_group_eval_pdf_batch", "mrl_group_sample_batch",
     "mrl_group_last_timing",
+    "mrl_material_host_table", "mrl_host_table_retain", "mrl_host_table_release", "mrl_host_table_info",
+    "mrl_host_eval_pdf", "mrl_host_sample", "mrl_host_eval_sample",
 )
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_PEER_COPY = 0, 1, 2
 ERR_COMM = -9
+
+
+class HostTable:
+    """mrl_host_table: immutable, reference-counted; outlives the context it was taken from."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+
+    def close(self):
+        if self._h:
+            self._lib.mrl_host_table_release(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def info(self):
+        dims = (C.c_int * 3)(); prm = C.c_int(); lk = C.c_int(); smp = C.c_int(); nbytes = C.c_size_t()
+        self._lib.mrl_host_table_info(self._h, dims, C.byref(prm), C.byref(lk), C.byref(smp), C.byref(nbytes))
+        return {"dims": tuple(dims), "param": prm.value, "lookup": lk.value, "sampling": smp.value, "bytes": nbytes.value}
+
+    def eval_sample(self, wi, wo, u) -> np.ndarray:
+        """ONE fused unit on this thread: rgb[3] pdf wo'[3] pdf' weight'[3]."""
+        a = (C.c_float * 3)(*[float(x) for x in wi]); b = (C.c_float * 3)(*[float(x) for x in wo]); c = (C.c_float * 2)(*[float(x) for x in u])
+        out = (C.c_float * 11)()
+        rc = self._lib.mrl_host_eval_sample(self._h, a, b, c, out)
+        if rc != 0:
+            raise MerlHipError(rc, "mrl_host_eval_sample")
+        return np.frombuffer(out, dtype=np.float32).copy()
 
 
 class TileInputs(C.Structure):
@@ -137,6 +173,13 @@ def load_library(path: Optional[str] = None):
     L.mrl_scalar_eval_pdf.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.mrl_scalar_sample.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.mrl_material_param.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+    L.mrl_material_host_table.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.mrl_host_table_retain.argtypes = [vp]
+    L.mrl_host_table_release.argtypes = [vp]
+    L.mrl_host_table_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    L.mrl_host_eval_pdf.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.mrl_host_sample.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.mrl_host_eval_sample.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.mrl_eval_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp]
     L.mrl_sample_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp, fp, fp]
     L.mrl_eval_pdf_batch_nch.argtypes = [vp, fp, fp, vp, C.c_int32, C.c_size_t, C.c_int, fp, fp]
@@ -337,6 +380,14 @@ class MerlHip:
         wo = (C.c_float * 3)(); pdf = C.c_float(); w = (C.c_float * 3)()
         self._check(self._lib.mrl_scalar_sample(self._ctx, int(material), a, c, wo, C.byref(pdf), w), "mrl_scalar_sample")
         return np.frombuffer(wo, dtype=np.float32).copy(), float(pdf.value), np.frombuffer(w, dtype=np.float32).copy()
+
+    # ---- one-unit calls on the calling CPU thread (mrl_host_*) ----
+    def host_table(self, material: int = 0) -> "HostTable":
+        """A host image of a resident three-channel table (mrl_material_host_table): one-unit calls on it run on the
+        calling CPU thread with the kernels' own per-unit functions compiled for the host."""
+        h = C.c_void_p()
+        self._check(self._lib.mrl_material_host_table(self._ctx, int(material), C.byref(h)), "mrl_material_host_table")
+        return HostTable(self._lib, h)
 
     # ---- n-channel tables ----
     def upload_table_nch(self, planar: np.ndarray, scale: Optional[Sequence[float]] = None) -> int:

@@ -401,8 +401,12 @@ def test_kernel_variants_and_layouts_match_oracle(gpu, oracle, tables, kind, see
     base = results[(0, 1, 0, 1)]
     for key, r in results.items():
         if key[1:3] == (1, 0):
-            # rows blend in f64 and round once; bricks blend in packed Float (merl_device.hpp::blend_brick, bound 3.6e-7)
-            assert_close(r, base, rel=5e-7, what=f"{key} vs rows/variant 1")
+            # rows and bricks hold the same Float texels and go through the same blend (merl_device.hpp::blend_brick): the
+            # tuned variants agree bit for bit across layouts; variant 0 computes its coordinates with libm (ocml)
+            if key[3] >= 1:
+                assert np.array_equal(r, base), f"{key} vs rows/variant 1"
+            else:
+                assert_close(r, base, rel=5e-7, what=f"{key} vs rows/variant 1")
 
 
 # ------------------------------------------------------------------ batches that mix material KINDS
