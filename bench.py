@@ -170,7 +170,11 @@ def self_launch(args) -> int:
 
 
 def native_group_leg(n_gpus: int, share_gpu: bool, units: int, deadline: float) -> dict:
-    """The native multi-device host path on the same GPUs, reported beside `value`: examples/group_host.cpp (plain C++
+    """Schema: compute_only_Meval_s (no inter-device traffic), rgb_gathered_Meval_s (eval alone, 12 B/unit to
+    the root), gathered_Meval_s (the fused unit, 44 B/unit to the root), root_ingress_GBps, transport ("rccl" | "peer_copy"),
+    fallback_from (null, or what failed before the run was repeated with device copies in a fresh process), selftest
+    (per-link GB/s of 1-64 MB payloads, bit-checked, before the pipeline), check_mismatches (must be 0).
+    The native multi-device host path on the same GPUs, reported beside `value`: examples/group_host.cpp (plain C++
     over mrl_group_*, no Python in it) runs as a CHILD process after this job's ranks have released their GPUs —
     replicated tables, tiles generated in place, sharded eval+sample with the chunk-pipelined result gather (RCCL
     point-to-point when the devices are distinct), checked inside the program against a single-device run."""
@@ -180,7 +184,7 @@ def native_group_leg(n_gpus: int, share_gpu: bool, units: int, deadline: float) 
         return {"skipped": "lib/group_host is not built"}
     devices = ",".join("0" if share_gpu else str(i) for i in range(n_gpus))
     cmd = [exe, "--devices", devices, "--units-per-device", str(units), "--chunk", str(max(1, units // 4)),
-           "--steps", "3", "--warmup", "1", "--check"]
+           "--steps", "3", "--warmup", "1", "--check", "--selftest"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=deadline)
     except subprocess.TimeoutExpired:
@@ -216,7 +220,11 @@ def scalar_calls_leg(deadline: float = 60.0) -> dict:
     d = json.loads(line[-1])
     return {"us_per_call_one_thread": d["solo_us_per_call"], "us_per_eval_pdf_call_one_thread": d["solo_eval_pdf_us"],
             "us_per_sample_call_one_thread": d["solo_sample_us"], "us_per_call_amortised_16_threads": d["all_threads_us_per_call_amortised"],
-            "answers_differing_from_the_batch_call": d["wrong"], "cmd": " ".join(cmd)}
+            "answers_differing_from_the_batch_call": d["wrong"],
+            # the plugins' default (scalar="cpu"): the same fused unit on the calling CPU thread (mrl_host_eval_sample)
+            "cpu_path_us_per_call": d.get("cpu_path_us_per_call"), "cpu_path_us_per_call_amortised_16_threads": d.get("cpu_path_us_per_call_amortised"),
+            "cpu_path_units_bit_identical_to_batch": d.get("cpu_path_units_bit_identical_to_batch"),
+            "cpu_path_worst_rel_diff_to_batch": d.get("cpu_path_worst_rel_diff_to_batch"), "cmd": " ".join(cmd)}
 
 
 def cpu_baseline(ob, table, lookup: int, reps: int) -> dict:

@@ -7,9 +7,20 @@
 //
 //   g++ -std=c++17 -O2 -I include examples/group_host.cpp -L mitsuba_customization_amd/lib -lmerl_hip -o group_host
 //   group_host --devices 0,1,2,3 [--transport auto|rccl|copy] [--units-per-device N] [--chunk C] [--tables T]
-//              [--steps K] [--warmup W] [--table file.binary] [--check] [--root R]
+//              [--steps K] [--warmup W] [--table file.binary] [--check] [--root R] [--selftest] [--no-fallback]
 //   (a device may repeat, e.g. --devices 0,0,0: rehearsal on a 1-GPU box, transport = device copies)
-// Prints ONE JSON line; exit code 0 only if every call succeeded and --check (when given) found no difference.
+// --selftest: before the pipeline, every peer -> root link on its own (mrl_group_link_test: 1 / 4 / 16 / 64 MB, timed and
+//   bit-checked, RCCL and device copies), reported per link.
+// With more than one device and a transport that may be RCCL, the work runs in a CHILD process (this program again,
+//   started before anything here touches the GPU); if that child fails — RCCL cannot initialise, a send errors, the
+//   process dies — a fresh child repeats the run with device copies, and the line it prints says what failed.  Exit code
+//   non-zero only if both fail (--no-fallback: no second attempt).
+// Prints ONE JSON line; three rates side by side: compute only, with the rgb-only gather (12 B per unit across the links)
+//   and with the full gather (44 B per unit); exit code 0 only if every call succeeded and --check found no difference.
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -73,13 +84,31 @@ double now_ms()
 
 } // namespace
 
+extern char **environ;
+
+// this program again, as a child process, with extra arguments; returns its exit code, or 128 + signal
+static int run_child(char **argv, const std::vector<std::string> &extra)
+{
+    std::vector<std::string> args;
+    for (char **a = argv; *a; ++a) args.push_back(*a);
+    for (const std::string &e : extra) args.push_back(e);
+    std::vector<char *> cargs;
+    for (std::string &a : args) cargs.push_back(&a[0]);
+    cargs.push_back(nullptr);
+    pid_t pid = 0;
+    if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, cargs.data(), environ) != 0) return 127;
+    int status = 0;
+    if (waitpid(pid, &status, 0) < 0) return 127;
+    return WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
+}
+
 int main(int argc, char **argv)
 {
     std::vector<int> devices = { 0 };
     int transport = MRL_TRANSPORT_AUTO, tables = 1, steps = 5, warmup = 2, root = 0;
     size_t units_per_device = (size_t)8 << 20, chunk = (size_t)2 << 20;
-    bool check = false;
-    std::string table_file;
+    bool check = false, selftest = false, child = false, fallback = true;
+    std::string table_file, fallback_from;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -104,10 +133,27 @@ int main(int argc, char **argv)
         else if (a == "--root") root = std::atoi(next());
         else if (a == "--table") table_file = next();
         else if (a == "--check") check = true;
+        else if (a == "--selftest") selftest = true;
+        else if (a == "--no-fallback") fallback = false;
+        else if (a == "--child") child = true;
+        else if (a == "--fallback-from") fallback_from = next();
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     const int G = (int)devices.size();
     if (G < 1 || tables < 1 || steps < 1 || root < 0 || root >= G || chunk < 1) { std::fprintf(stderr, "bad arguments\n"); return 2; }
+
+    // ---- parent: with an RCCL leg possible, the run happens in a child; a failed child is followed by a fresh one on copies.
+    //      Nothing before this point has touched the GPU (a process that has must not start another program). ----
+    if (!child && G > 1 && transport != MRL_TRANSPORT_PEER_COPY) {
+        const int rc = run_child(argv, { "--child" });
+        if (rc == 0 || !fallback) return rc;
+        std::fprintf(stderr, "group_host: the run with transport %s failed (%s %d); repeating it with device copies in a fresh process\n",
+                     transport == MRL_TRANSPORT_RCCL ? "rccl" : "auto", rc >= 128 ? "signal" : "exit code", rc >= 128 ? rc - 128 : rc);
+        const int rc2 = run_child(argv, { "--child", "--transport", "copy", "--fallback-from",
+                                          std::string(transport == MRL_TRANSPORT_RCCL ? "rccl" : "auto") + (rc >= 128 ? " signal " : " exit code ") +
+                                              std::to_string(rc >= 128 ? rc - 128 : rc) });
+        return rc2;
+    }
 
     mrl_group *group = nullptr;
     {
@@ -131,6 +177,37 @@ int main(int argc, char **argv)
     float *out = nullptr;                                        // rgb[3n] pdf[n] wo[3n] pdf2[n] weight[3n] on the root
     CCHECK(rctx, mrl_device_alloc(rctx, n_total * 11 * sizeof(float), (void **)&out));
     float *o_rgb = out, *o_pdf = out + 3 * n_total, *o_wo = out + 4 * n_total, *o_pdf2 = out + 7 * n_total, *o_w = out + 8 * n_total;
+
+    // ---- link selftest: every peer -> root link on its own, before the pipeline ----
+    std::string selftest_json = "null";
+    if (selftest && G > 1) {
+        selftest_json = "{";
+        const int modes[2] = { MRL_TRANSPORT_RCCL, MRL_TRANSPORT_PEER_COPY };
+        bool first_mode = true;
+        for (int mode : modes) {
+            if (mode == MRL_TRANSPORT_RCCL && used_transport != MRL_TRANSPORT_RCCL) continue;
+            selftest_json += std::string(first_mode ? "" : ", ") + "\"" + (mode == MRL_TRANSPORT_RCCL ? "rccl" : "peer_copy") + "\": [";
+            first_mode = false;
+            const size_t sizes[4] = { (size_t)1 << 20, (size_t)4 << 20, (size_t)16 << 20, (size_t)64 << 20 };
+            for (int k = 0; k < 4; ++k) {
+                std::vector<mrl_link_report> rep((size_t)G);
+                GCHECK(mrl_group_link_test(group, sizes[k], mode, root, rep.data()));       // wrong data or a failed call: exit non-zero
+                GCHECK(mrl_group_link_test(group, sizes[k], mode, root, rep.data()));       // second pass: timed warm
+                selftest_json += std::string(k ? ", " : "") + "{\"bytes\": " + std::to_string(sizes[k]) + ", \"GBps_per_peer\": [";
+                bool first_peer = true;
+                for (int r = 0; r < G; ++r) {
+                    if (r == root) continue;
+                    char num[32];
+                    std::snprintf(num, sizeof num, "%.2f", rep[(size_t)r].GBps);
+                    selftest_json += std::string(first_peer ? "" : ", ") + num;
+                    first_peer = false;
+                }
+                selftest_json += "], \"mismatches\": 0}";
+            }
+            selftest_json += "]";
+        }
+        selftest_json += "}";
+    }
 
     // ---- compute only: every member runs its tile into member-local arrays, nothing moves between devices ----
     std::vector<float *> local((size_t)G, nullptr);
@@ -170,6 +247,17 @@ int main(int argc, char **argv)
     std::vector<float> member_ms((size_t)G, 0.0f);
     GCHECK(mrl_group_last_timing(group, member_ms.data()));
 
+    // ---- the same with the rgb-only gather: eval alone, 12 B per unit across the links ----
+    auto sharded_rgb = [&]() -> int {
+        const int rc = mrl_group_eval_sharded(group, tiles.data(), ids[0], n_total, chunk, root, o_rgb);
+        return rc != MRL_OK ? rc : mrl_group_synchronize(group);
+    };
+    for (int w = 0; w < warmup; ++w) GCHECK(sharded_rgb());
+    t0 = now_ms();
+    for (int s = 0; s < steps; ++s) GCHECK(sharded_rgb());
+    const double rgb_gathered_ms = (now_ms() - t0) / steps;
+    GCHECK(sharded());                                           // the arrays --check compares are the fused call's
+
     // ---- check: the gathered arrays == one device evaluating the whole unit range, bit for bit ----
     long long mismatches = -1;
     if (check) {
@@ -208,11 +296,17 @@ int main(int argc, char **argv)
     std::printf("{\"what\": \"native C++ host, one process, mrl_group over %d device(s)\", \"devices\": [", G);
     for (int r = 0; r < G; ++r) std::printf("%s%d", r ? ", " : "", devices[(size_t)r]);
     std::printf("], \"transport\": \"%s\", \"units_per_device\": %zu, \"chunk_units\": %zu, \"tables_resident\": %d, \"steps\": %d, "
-                "\"compute_only_ms\": %.4f, \"compute_only_Meval_s\": %.1f, \"gathered_ms\": %.4f, \"gathered_Meval_s\": %.1f, "
-                "\"slowest_member_device_ms\": %.4f, \"bytes_into_root\": %.0f, \"root_ingress_GBps\": %.2f, \"check_mismatches\": %lld}\n",
+                "\"compute_only_ms\": %.4f, \"compute_only_Meval_s\": %.1f, \"rgb_gathered_ms\": %.4f, \"rgb_gathered_Meval_s\": %.1f, "
+                "\"gathered_ms\": %.4f, \"gathered_Meval_s\": %.1f, "
+                "\"slowest_member_device_ms\": %.4f, \"bytes_into_root\": %.0f, \"root_ingress_GBps\": %.2f, \"rgb_bytes_into_root\": %.0f, "
+                "\"rgb_root_ingress_GBps\": %.2f, \"check_mismatches\": %lld, \"fallback_from\": %s%s%s, \"selftest\": %s}\n",
                 used_transport == MRL_TRANSPORT_RCCL ? "rccl" : "peer_copy", units_per_device, chunk, tables, steps,
-                compute_ms, (double)n_total / compute_ms / 1e3, gathered_ms, (double)n_total / gathered_ms / 1e3, slowest,
-                bytes_into_root, gathered_ms > 0 ? bytes_into_root / gathered_ms / 1e6 : 0.0, mismatches);
+                compute_ms, (double)n_total / compute_ms / 1e3, rgb_gathered_ms, (double)n_total / rgb_gathered_ms / 1e3,
+                gathered_ms, (double)n_total / gathered_ms / 1e3, slowest,
+                bytes_into_root, gathered_ms > 0 ? bytes_into_root / gathered_ms / 1e6 : 0.0, bytes_into_root * 12.0 / 44.0,
+                rgb_gathered_ms > 0 ? bytes_into_root * 12.0 / 44.0 / rgb_gathered_ms / 1e6 : 0.0, mismatches,
+                fallback_from.empty() ? "" : "\"", fallback_from.empty() ? "null" : fallback_from.c_str(), fallback_from.empty() ? "" : "\"",
+                selftest_json.c_str());
     for (int r = 0; r < G; ++r) (void)mrl_device_free(ctxs[(size_t)r], local[(size_t)r]);
     (void)mrl_device_free(rctx, out);
     GCHECK(mrl_group_destroy(group));

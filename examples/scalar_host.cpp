@@ -7,6 +7,7 @@
 // thread alone (the latency of a call) and T threads together (what a render sees) —, (3) with --churn lets another
 // thread upload and release tables and flip an option meanwhile (the calls must keep returning the right numbers: the
 // service pauses around every change).  Prints one JSON line; exit code 0 = all answers right.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -132,12 +133,53 @@ int main(int argc, char **argv)
     const double all_s = std::chrono::duration<double>(Clock::now() - t0).count();
     stop.store(true);
     if (churner.joinable()) churner.join();
+    // 3. the same units on the CPU (mrl_host_*: what a plugin with scalar="cpu" calls): one thread, then all threads; answers
+    //    compared with the batch call — one Float ulp at most, and how many units are the same bits
+    double host_solo_us = 0.0, host_all_us = 0.0, host_same = 0.0, host_worst = 0.0;
+    {
+        mrl_host_table *ht = nullptr;
+        CHECK(mrl_material_host_table(ctx, tab, &ht));
+        std::atomic<long> same{ 0 }, units{ 0 };
+        std::vector<double> worst((size_t)threads, 0.0);
+        auto host_worker = [&](int t, long k0, long k1) {
+            for (long k = k0; k < k1; ++k) {
+                const size_t i = (size_t)t * (size_t)calls + (size_t)k;
+                if (mat[i] != tab) continue;
+                float o[11];
+                if (mrl_host_eval_sample(ht, &wi[3 * i], &wo[3 * i], &u[2 * i], o) != MRL_OK) { ++failed; continue; }
+                ++units;
+                if (!std::memcmp(o, &want[11 * i], sizeof o)) { ++same; continue; }
+                for (int c = 0; c < 11; ++c) {
+                    const double a = o[c], b = want[11 * i + c];
+                    if (a != b) worst[(size_t)t] = std::max(worst[(size_t)t], std::fabs(a - b) / std::max(std::fabs(b), 1e-30));
+                }
+            }
+        };
+        host_worker(0, 0, std::min<long>(calls, 200));
+        same = 0; units = 0;
+        t0 = Clock::now();
+        host_worker(0, 0, calls);
+        host_solo_us = std::chrono::duration<double, std::micro>(Clock::now() - t0).count() / (double)std::max<long>(units.load(), 1);
+        same = 0; units = 0;
+        t0 = Clock::now();
+        std::vector<std::thread> hp;
+        for (int t = 0; t < threads; ++t) hp.emplace_back(host_worker, t, 0L, calls);
+        for (auto &th : hp) th.join();
+        host_all_us = std::chrono::duration<double, std::micro>(Clock::now() - t0).count() / (double)std::max<long>(units.load(), 1);
+        host_same = (double)same.load() / (double)std::max<long>(units.load(), 1);
+        for (double w : worst) host_worst = std::max(host_worst, w);
+        if (host_worst > 1.3e-7) ++wrong;                        // more than one Float ulp from the batch call
+        mrl_host_table_release(ht);
+    }
     // an id the scalar path refuses
     float out[11];
     const int bad = mrl_scalar_eval_sample(ctx, 99, &wi[0], &wo[0], &u[0], out);
     std::printf("{\"threads\": %d, \"calls_per_thread\": %ld, \"solo_us_per_call\": %.3f, \"solo_eval_pdf_us\": %.3f, \"solo_sample_us\": %.3f, \"all_threads_Mcalls_per_s\": %.4f, "
-                "\"all_threads_us_per_call_amortised\": %.4f, \"wrong\": %ld, \"failed\": %ld, \"churn_rounds\": %ld, \"unknown_id_status\": %d}\n",
-                threads, calls, solo_us, half_us[0], half_us[1], (double)n / all_s / 1e6, all_s * 1e6 / (double)n, wrong.load(), failed.load(), churn_rounds, bad);
+                "\"all_threads_us_per_call_amortised\": %.4f, \"cpu_path_us_per_call\": %.4f, \"cpu_path_us_per_call_amortised\": %.4f, "
+                "\"cpu_path_units_bit_identical_to_batch\": %.6f, \"cpu_path_worst_rel_diff_to_batch\": %.3g, "
+                "\"wrong\": %ld, \"failed\": %ld, \"churn_rounds\": %ld, \"unknown_id_status\": %d}\n",
+                threads, calls, solo_us, half_us[0], half_us[1], (double)n / all_s / 1e6, all_s * 1e6 / (double)n, host_solo_us, host_all_us, host_same, host_worst,
+                wrong.load(), failed.load(), churn_rounds, bad);
     mrl_destroy(ctx);
     return (wrong.load() == 0 && failed.load() == 0 && bad == MRL_ERR_MATERIAL) ? 0 : 1;
 }

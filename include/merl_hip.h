@@ -366,6 +366,32 @@ void mrl_tile_bounds(size_t n_total, int world, int rank, size_t *lo, size_t *hi
 /* chunk `step` of member `rank`'s tile: units [*lo, *hi) in global numbering (empty once the tile is exhausted) */
 void mrl_chunk_bounds(size_t n_total, int world, int rank, size_t chunk_units, size_t step, size_t *lo, size_t *hi);
 size_t mrl_chunk_steps(size_t n_total, int world, size_t chunk_units);
+/* The schedule of one sharded call as data — pure arithmetic like the three functions above, no device: the operations
+ * mrl_group_eval_sample_sharded / mrl_group_eval_sharded issue, in issue order.  Per step: one COMPUTE per member that still has
+ * units (buffer -1: the root writes the caller's arrays; 0 / 1: a peer writes its chunk buffer, after the transfer of step
+ * after_transfer_of_step — the last reader of that buffer — has left it, -1: none in this call), then one TRANSFER per such
+ * peer out of that buffer to the root's arrays at [first, first + count).  Returns the number of operations (also when
+ * ops is NULL or max_ops is too small: call twice).  The library's own pipeline walks this list. */
+enum mrl_plan_kind { MRL_PLAN_COMPUTE = 0, MRL_PLAN_TRANSFER = 1 };
+typedef struct mrl_plan_op {
+    int kind;                       /* enum mrl_plan_kind */
+    int member;
+    int buffer;                     /* -1: the caller's arrays on the root; 0 / 1: the member's chunk buffer */
+    size_t step;
+    size_t first, count;            /* units [first, first + count) of the batch */
+    size_t tile_offset;             /* first - the member's tile start: where its inputs sit in mrl_tile_inputs */
+    long long after_transfer_of_step;
+} mrl_plan_op;
+size_t mrl_group_plan(size_t n_total, int world, size_t chunk_units, int root, mrl_plan_op *ops, size_t max_ops);
+/* One payload of `bytes` from every peer to the root, each link on its own, over the named transport (AUTO: the group's):
+ * timed with events, compared bit for bit on the host.  out: n_devices entries (the root's own entry stays ok = 1, 0 bytes/s).
+ * The first contact of a machine's links with this traffic should be this call, not the pipeline. */
+typedef struct mrl_link_report {
+    int peer, ok;
+    size_t bytes, mismatches;
+    float ms, GBps;
+} mrl_link_report;
+int mrl_group_link_test(mrl_group *g, size_t bytes, int transport, int root, mrl_link_report *out);
 /* Synthetic inputs generated in place on every member for its own tile (a pure function of the unit
  * index, so the union over members equals mrl_generate_pairs over [first_index, first_index + n_total)).
  * n_materials > 0 also fills mat with ids in [0, n_materials).  The buffers belong to the group and stay valid until

@@ -1005,7 +1005,18 @@ const char *mrl_strerror(int status)
     return "unknown status";
 }
 
-const char *mrl_last_error(const mrl_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+// The text is copied under the context's lock into a buffer of the CALLING thread: another thread's failing call reassigns
+// ctx->last_error at any time (render threads all report through here), so a pointer into it would dangle.
+const char *mrl_last_error(const mrl_ctx *ctx)
+{
+    if (!ctx) return "null context";
+    static thread_local std::string copy;
+    {
+        MRL_GUARD(ctx);
+        copy = ctx->last_error;
+    }
+    return copy.c_str();
+}
 
 int mrl_init(int device_id, mrl_ctx **out)
 {

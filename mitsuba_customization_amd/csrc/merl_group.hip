@@ -195,7 +195,13 @@ int replicated_material(mrl_group *g, const char *what, int *out_id, F &&call)
             return member_fail(g, (int)r, rc, what);
         }
         if (r == 0) first = id;
-        else if (id != first) return gfail(g, MRL_ERR_MATERIAL, "members disagree on the material id (a member context was used directly)");
+        else if (id != first) {
+            // undo what this call has placed — `first` on the members before r, `id` on member r — so that the tables do not
+            // stay resident and the members' id sequences are what they were
+            for (size_t q = 0; q < r; ++q) (void)mrl_material_release(g->members[q].ctx, first);
+            (void)mrl_material_release(g->members[r].ctx, id);
+            return gfail(g, MRL_ERR_MATERIAL, "members disagree on the material id (a member context was used directly)");
+        }
     }
     *out_id = first;
     return MRL_OK;
@@ -258,6 +264,39 @@ void mrl_chunk_bounds(size_t n_total, int world, int rank, size_t chunk_units, s
     }
     if (lo) *lo = a;
     if (hi) *hi = b;
+}
+
+// The schedule of one sharded call as a list of operations, in issue order — pure arithmetic, no device.  The call itself
+// (sharded() below) walks exactly this list, so that the buffer / offset / dependency bookkeeping of the pipeline can be
+// checked on a CPU against a stub transport (tests/test_group_cpu.py) and a multi-GPU run only has to validate the
+// transport itself.  Per step c: one COMPUTE per member with units left (the root into the caller's arrays, a peer
+// into its chunk buffer c % 2, after the transfer that last read that buffer — step c - 2 — has left it), then one
+// TRANSFER per such peer out of that buffer into the root's arrays at the chunk's global offset.
+size_t mrl_group_plan(size_t n_total, int world, size_t chunk_units, int root, mrl_plan_op *ops, size_t max_ops)
+{
+    if (world < 1 || root < 0 || root >= world || chunk_units == 0 || n_total == 0) return 0;
+    const size_t steps = mrl_chunk_steps(n_total, world, chunk_units);
+    size_t n_ops = 0;
+    auto emit = [&](const mrl_plan_op &op) { if (ops && n_ops < max_ops) ops[n_ops] = op; ++n_ops; };
+    for (size_t c = 0; c < steps; ++c) {
+        const int s = (int)(c & 1);
+        for (int pass = 0; pass < 2; ++pass)                  // every compute of the step, then its transfers
+            for (int r = 0; r < world; ++r) {
+                if (pass == 1 && r == root) continue;
+                size_t tlo, thi, a, b;
+                mrl_tile_bounds(n_total, world, r, &tlo, &thi);
+                mrl_chunk_bounds(n_total, world, r, chunk_units, c, &a, &b);
+                if (b <= a) continue;
+                mrl_plan_op op;
+                op.kind = pass == 0 ? MRL_PLAN_COMPUTE : MRL_PLAN_TRANSFER;
+                op.step = c; op.member = r;
+                op.buffer = r == root ? -1 : s;
+                op.first = a; op.count = b - a; op.tile_offset = a - tlo;
+                op.after_transfer_of_step = (pass == 0 && r != root && c >= 2) ? (long long)(c - 2) : -1;
+                emit(op);
+            }
+    }
+    return n_ops;
 }
 
 int mrl_group_init(int n_devices, const int *device_ids, int transport, mrl_group **out)
@@ -417,7 +456,6 @@ static int sharded(mrl_group *g, int which, const mrl_tile_inputs *tiles, int32_
     if (!tiles || root < 0 || root >= G || chunk_units == 0) return gfail(g, MRL_ERR_INVALID, "bad argument");
     if (n_total == 0) return MRL_OK;
     if (!out_rgb || (which == 0 && (!out_pdf || !out_wo || !out_pdf2 || !out_weight))) return gfail(g, MRL_ERR_INVALID, "null array argument");
-    const size_t steps = mrl_chunk_steps(n_total, G, chunk_units);
     const size_t per = (n_total + (size_t)G - 1) / (size_t)G;
     const size_t cap = std::min(chunk_units, per);
     Member &R = g->members[(size_t)root];
@@ -430,49 +468,51 @@ static int sharded(mrl_group *g, int which, const mrl_tile_inputs *tiles, int32_
         if (r != root && hi > lo) { const int rc = ensure_buffers(g, m, cap); if (rc != MRL_OK) return rc; }
         if (m.timed) { MRL_GHIP(g, hipSetDevice(m.device)); MRL_GHIP(g, hipEventRecord(m.t0, m.compute)); }
     }
-    for (size_t c = 0; c < steps; ++c) {
-        const int s = (int)(c & 1);
+    // the schedule: mrl_group_plan's operations in issue order (computes of a step, then its transfers).  sent_valid[]
+    // survives the call: the first two steps of the NEXT call wait for this call's last transfers out of the same buffers.
+    std::vector<mrl_plan_op> plan(mrl_group_plan(n_total, G, chunk_units, root, nullptr, 0));
+    (void)mrl_group_plan(n_total, G, chunk_units, root, plan.data(), plan.size());
+    const bool rccl = g->transport == MRL_TRANSPORT_RCCL;
+    size_t at = 0;
+    while (at < plan.size()) {
+        const size_t c = plan[at].step;
         // 1. every member's compute of chunk c
-        for (int r = 0; r < G; ++r) {
+        for (; at < plan.size() && plan[at].step == c && plan[at].kind == MRL_PLAN_COMPUTE; ++at) {
+            const mrl_plan_op &op = plan[at];
+            const int r = op.member;
             Member &m = g->members[(size_t)r];
-            size_t tlo, thi, a, b;
-            mrl_tile_bounds(n_total, G, r, &tlo, &thi);
-            mrl_chunk_bounds(n_total, G, r, chunk_units, c, &a, &b);
-            if (b <= a) continue;
-            const size_t off = a - tlo, n = b - a;
+            const size_t a = op.first, off = op.tile_offset, n = op.count;
             const mrl_tile_inputs &in = tiles[r];
             ChunkOut o;
-            if (r == root) o = { out_rgb + 3 * a, which == 0 ? out_pdf + a : nullptr, which == 0 ? out_wo + 3 * a : nullptr, which == 0 ? out_pdf2 + a : nullptr,
-                                 which == 0 ? out_weight + 3 * a : nullptr };
+            if (op.buffer < 0) o = { out_rgb + 3 * a, which == 0 ? out_pdf + a : nullptr, which == 0 ? out_wo + 3 * a : nullptr, which == 0 ? out_pdf2 + a : nullptr,
+                                     which == 0 ? out_weight + 3 * a : nullptr };
             else {
-                o = chunk_out(m.buf[s], m.buf_units);
-                if (m.sent_valid[s]) { MRL_GHIP(g, hipSetDevice(m.device)); MRL_GHIP(g, hipStreamWaitEvent(m.compute, m.sent[s], 0)); }
+                if (n > m.buf_units) return gfail(g, MRL_ERR_INVALID, "plan: a chunk exceeds the member's buffer");
+                o = chunk_out(m.buf[op.buffer], m.buf_units);
+                if (m.sent_valid[op.buffer]) { MRL_GHIP(g, hipSetDevice(m.device)); MRL_GHIP(g, hipStreamWaitEvent(m.compute, m.sent[op.buffer], 0)); }
             }
             const int rc = which == 0 ? mrl_eval_sample_batch(m.ctx, in.wi + 3 * off, in.wo + 3 * off, in.u + 2 * off, in.mat ? in.mat + off : nullptr,
                                                               single_id, n, o.rgb, o.pdf, o.wo, o.pdf2, o.weight)
                                       : mrl_eval_batch(m.ctx, in.wi + 3 * off, in.wo + 3 * off, in.mat ? in.mat + off : nullptr, single_id, n, o.rgb);
             if (rc != MRL_OK) return member_fail(g, r, rc, which == 0 ? "mrl_eval_sample_batch" : "mrl_eval_batch");
-            if (r != root) {
+            if (op.buffer >= 0) {
                 MRL_GHIP(g, hipSetDevice(m.device));
-                MRL_GHIP(g, hipEventRecord(m.done[s], m.compute));
-                MRL_GHIP(g, hipStreamWaitEvent(m.transfer, m.done[s], 0));
+                MRL_GHIP(g, hipEventRecord(m.done[op.buffer], m.compute));
+                MRL_GHIP(g, hipStreamWaitEvent(m.transfer, m.done[op.buffer], 0));
             }
         }
         // 2. the chunk's transfers to the root, behind the computes, on the transfer streams
-        if (G == 1) continue;
-        const bool rccl = g->transport == MRL_TRANSPORT_RCCL;
-        bool any = false;
+        const size_t first_transfer = at;
+        while (at < plan.size() && plan[at].step == c && plan[at].kind == MRL_PLAN_TRANSFER) ++at;
+        if (first_transfer == at) continue;
         if (rccl) MRL_GNCCL(g, g->rccl.GroupStart());
         int posted = MRL_OK;                                  // a failure inside the group must still close it
-        for (int r = 0; r < G && posted == MRL_OK; ++r) {
-            if (r == root) continue;
+        for (size_t t = first_transfer; t < at && posted == MRL_OK; ++t) {
+            const mrl_plan_op &op = plan[t];
+            const int r = op.member;
             Member &m = g->members[(size_t)r];
-            size_t a, b;
-            mrl_chunk_bounds(n_total, G, r, chunk_units, c, &a, &b);
-            if (b <= a) continue;
-            any = true;
-            const size_t n = b - a;
-            const ChunkOut src = chunk_out(m.buf[s], m.buf_units);
+            const size_t a = op.first, n = op.count;
+            const ChunkOut src = chunk_out(m.buf[op.buffer], m.buf_units);
             const float *from[5] = { src.rgb, src.pdf, src.wo, src.pdf2, src.weight };
             float *to[5] = { out_rgb + 3 * a, which == 0 ? out_pdf + a : nullptr, which == 0 ? out_wo + 3 * a : nullptr, which == 0 ? out_pdf2 + a : nullptr,
                              which == 0 ? out_weight + 3 * a : nullptr };
@@ -494,16 +534,11 @@ static int sharded(mrl_group *g, int which, const mrl_tile_inputs *tiles, int32_
             if (nr != ncclSuccess && posted == MRL_OK) posted = gfail(g, MRL_ERR_COMM, std::string("ncclGroupEnd: ") + g->rccl.GetErrorString(nr));
         }
         if (posted != MRL_OK) return posted;
-        if (!any) continue;
-        for (int r = 0; r < G; ++r) {
-            if (r == root) continue;
-            Member &m = g->members[(size_t)r];
-            size_t a, b;
-            mrl_chunk_bounds(n_total, G, r, chunk_units, c, &a, &b);
-            if (b <= a) continue;
+        for (size_t t = first_transfer; t < at; ++t) {
+            Member &m = g->members[(size_t)plan[t].member];
             MRL_GHIP(g, hipSetDevice(m.device));
-            MRL_GHIP(g, hipEventRecord(m.sent[s], m.transfer));
-            m.sent_valid[s] = true;
+            MRL_GHIP(g, hipEventRecord(m.sent[plan[t].buffer], m.transfer));
+            m.sent_valid[plan[t].buffer] = true;
         }
     }
     // 3. order the root's context stream after everything that writes the caller's arrays, and close the timers
@@ -592,6 +627,79 @@ int mrl_group_sample_batch(mrl_group *g, const float *wi, const float *u, const 
     return host_split(g, n, "mrl_sample_batch", [=](mrl_ctx *c, size_t lo, size_t hi) {
         return mrl_sample_batch(c, wi + 3 * lo, u + 2 * lo, mat ? mat + lo : nullptr, single_id, hi - lo, out_wo + 3 * lo, out_pdf + lo, out_weight + 3 * lo);
     });
+}
+
+// One payload from every peer to the root over the group's transport (or the one named), each link on its own: timed with
+// events on the transfer stream and compared bit for bit on the host.  What mrl_group_eval_sample_sharded's gather does,
+// reduced to the transport — run it BEFORE the pipeline on a machine whose links have never carried this traffic.
+int mrl_group_link_test(mrl_group *g, size_t bytes, int transport, int root, mrl_link_report *out)
+{
+    if (!g || !out) return MRL_ERR_INVALID;
+    const int G = (int)g->members.size();
+    if (root < 0 || root >= G || bytes < 4 || bytes > ((size_t)1 << 31)) return gfail(g, MRL_ERR_INVALID, "bad argument");
+    if (transport == MRL_TRANSPORT_AUTO) transport = g->transport;
+    if (transport == MRL_TRANSPORT_RCCL && g->transport != MRL_TRANSPORT_RCCL)
+        return gfail(g, MRL_ERR_COMM, "the group holds no RCCL communicators (it was initialised for device copies)");
+    const size_t n = bytes / sizeof(float);
+    Member &R = g->members[(size_t)root];
+    std::vector<float> h_src(n), h_dst(n);
+    for (int r = 0; r < G; ++r) {
+        out[r].peer = r; out[r].ok = 1; out[r].ms = 0.0f; out[r].GBps = 0.0f; out[r].bytes = bytes; out[r].mismatches = 0;
+        if (r == root) continue;
+        Member &m = g->members[(size_t)r];
+        float *src = nullptr, *dst = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        int status = MRL_OK;
+        auto hip = [&](hipError_t e, const char *what) {
+            if (e != hipSuccess && status == MRL_OK) { (void)hipGetLastError(); status = gfail(g, MRL_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+            return e == hipSuccess;
+        };
+        for (size_t i = 0; i < n; ++i) { const uint32_t v = (uint32_t)(i * 2654435761u) ^ (uint32_t)(r * 0x9E3779B9u); std::memcpy(&h_src[i], &v, 4); }
+        hip(hipSetDevice(m.device), "hipSetDevice") && hip(hipMalloc((void **)&src, n * sizeof(float)), "hipMalloc(src)") &&
+            hip(hipMemcpy(src, h_src.data(), n * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(src)") &&
+            hip(hipEventCreate(&e0), "hipEventCreate") && hip(hipEventCreate(&e1), "hipEventCreate");
+        if (status == MRL_OK) hip(hipSetDevice(R.device), "hipSetDevice") && hip(hipMalloc((void **)&dst, n * sizeof(float)), "hipMalloc(dst)") &&
+            hip(hipMemset(dst, 0, n * sizeof(float)), "hipMemset(dst)") && hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        if (status == MRL_OK) {
+            // timed on the stream that ends the transfer: the root's for RCCL (ncclRecv), the peer's for a device copy
+            hipStream_t timed = transport == MRL_TRANSPORT_RCCL ? R.transfer : m.transfer;
+            hip(hipSetDevice(transport == MRL_TRANSPORT_RCCL ? R.device : m.device), "hipSetDevice");
+            hip(hipEventRecord(e0, timed), "hipEventRecord");
+            if (transport == MRL_TRANSPORT_RCCL) {
+                ncclResult_t nr = g->rccl.GroupStart();
+                if (nr == ncclSuccess) nr = g->rccl.Send(src, n, ncclFloat, root, m.comm, m.transfer);
+                if (nr == ncclSuccess) nr = g->rccl.Recv(dst, n, ncclFloat, r, R.comm, R.transfer);
+                const ncclResult_t ne = g->rccl.GroupEnd();
+                if (nr == ncclSuccess) nr = ne;
+                if (nr != ncclSuccess) status = gfail(g, MRL_ERR_COMM, std::string("ncclSend/ncclRecv: ") + g->rccl.GetErrorString(nr));
+            } else {
+                hip(hipMemcpyPeerAsync(dst, R.device, src, m.device, n * sizeof(float), m.transfer), "hipMemcpyPeerAsync");
+            }
+            if (status == MRL_OK) {
+                hip(hipEventRecord(e1, timed), "hipEventRecord");
+                hip(hipSetDevice(m.device), "hipSetDevice") && hip(hipStreamSynchronize(m.transfer), "hipStreamSynchronize(peer)");
+                hip(hipSetDevice(R.device), "hipSetDevice") && hip(hipStreamSynchronize(R.transfer), "hipStreamSynchronize(root)");
+                float ms = 0.0f;
+                if (status == MRL_OK && hip(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime")) {
+                    out[r].ms = ms;
+                    out[r].GBps = ms > 0.0f ? (float)((double)bytes / (double)ms / 1e6) : 0.0f;
+                }
+                if (status == MRL_OK && hip(hipMemcpy(h_dst.data(), dst, n * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy(dst)")) {
+                    size_t bad = 0;
+                    for (size_t i = 0; i < n; ++i) bad += std::memcmp(&h_dst[i], &h_src[i], 4) != 0;
+                    out[r].mismatches = bad;
+                    if (bad) status = gfail(g, MRL_ERR_COMM, "link test: " + std::to_string(bad) + " of " + std::to_string(n) + " words from member " +
+                                                            std::to_string(r) + " arrived wrong");
+                }
+            }
+        }
+        if (src) { (void)hipSetDevice(m.device); (void)hipFree(src); }
+        if (dst) { (void)hipSetDevice(R.device); (void)hipFree(dst); }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (status != MRL_OK) { out[r].ok = 0; return status; }
+    }
+    return MRL_OK;
 }
 
 int mrl_group_synchronize(mrl_group *g)

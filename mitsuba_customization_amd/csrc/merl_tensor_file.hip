@@ -20,6 +20,7 @@
 #include "../../include/merl_hip.h"
 
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
@@ -228,7 +229,8 @@ int mrl_material_load_tensor_table(mrl_ctx *ctx, const char *path, const char *f
         else if (q.dtype == 3 || q.dtype == 4) { int16_t t; std::memcpy(&t, b, 2); v = q.dtype == 3 ? (long long)(uint16_t)t : (long long)t; }
         else if (q.dtype == 5 || q.dtype == 6) { int32_t t; std::memcpy(&t, b, 4); v = q.dtype == 5 ? (long long)(uint32_t)t : (long long)t; }
         else if (q.dtype == 7 || q.dtype == 8) { int64_t t; std::memcpy(&t, b, 8); v = (long long)t; }
-        else if (mrl_tensor_file_read_f64(f, pf, &dv, 1) == MRL_OK && dv == (double)(long long)dv) v = (long long)dv;
+        // a float field: range-check BEFORE converting (NaN, inf or |dv| >= 2^63 make the cast undefined behaviour)
+        else if (mrl_tensor_file_read_f64(f, pf, &dv, 1) == MRL_OK && dv >= 0.0 && dv <= 2.0 && dv == std::floor(dv)) v = (long long)dv;
         if (v < MRL_PARAM_HALF_DIFF || v > MRL_PARAM_STANDARD_FULL) { t_open_error = "field \"parameterization\" must hold one integer 0..2 (enum mrl_param)"; rc = MRL_ERR_FORMAT; }
         else param = (int)v;
     }

@@ -46,7 +46,7 @@ ABI_SYMBOLS = (
     "mrl_group_material_ggx", "mrl_group_material_release", "mrl_tile_bounds", "mrl_chunk_bounds", "mrl_chunk_steps",
     "mrl_group_generate_tiles", "mrl_group_eval_sample_sharded", "mrl_group_eval_sharded", "mrl_group_eval_sample_batch", "mrl_group_synchronize",
     "mrl_group_eval_batch", "mrl_group_pdf_batch", "mrl_group_eval_pdf_batch", "mrl_group_sample_batch",
-    "mrl_group_last_timing",
+    "mrl_group_last_timing", "mrl_group_plan", "mrl_group_link_test",
     "mrl_material_host_table", "mrl_host_table_retain", "mrl_host_table_release", "mrl_host_table_info",
     "mrl_host_eval_pdf", "mrl_host_sample", "mrl_host_eval_sample",
 )
@@ -743,8 +743,44 @@ def chunk_steps(n_total: int, world: int, chunk: int) -> int:
     return int(load_library().mrl_chunk_steps(n_total, world, chunk))
 
 
+class PlanOp(C.Structure):
+    """mrl_plan_op: one operation of a sharded call's schedule (include/merl_hip.h)."""
+    _fields_ = [("kind", C.c_int), ("member", C.c_int), ("buffer", C.c_int), ("step", C.c_size_t), ("first", C.c_size_t),
+                ("count", C.c_size_t), ("tile_offset", C.c_size_t), ("after_transfer_of_step", C.c_longlong)]
+
+
+PLAN_COMPUTE, PLAN_TRANSFER = 0, 1
+
+
+def group_plan(n_total: int, world: int, chunk: int, root: int):
+    """mrl_group_plan: the operations of one sharded call in issue order (pure arithmetic: needs no GPU)."""
+    L = load_library()
+    L.mrl_group_plan.restype = C.c_size_t
+    L.mrl_group_plan.argtypes = [C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.POINTER(PlanOp), C.c_size_t]
+    n = L.mrl_group_plan(n_total, world, chunk, root, None, 0)
+    ops = (PlanOp * max(n, 1))()
+    got = L.mrl_group_plan(n_total, world, chunk, root, ops, n)
+    assert got == n
+    return [ops[i] for i in range(n)]
+
+
+class LinkReport(C.Structure):
+    """mrl_link_report: one peer -> root link of mrl_group_link_test."""
+    _fields_ = [("peer", C.c_int), ("ok", C.c_int), ("bytes", C.c_size_t), ("mismatches", C.c_size_t), ("ms", C.c_float), ("GBps", C.c_float)]
+
+
 class MerlGroup:
     """mrl_group: one host process, several GPUs (a device id may repeat: rehearsal with device copies)."""
+
+    def link_test(self, nbytes: int, transport: int = TRANSPORT_AUTO, root: int = 0):
+        """mrl_group_link_test: one payload from every peer to the root, timed and bit-checked; list of dicts."""
+        n = int(self._lib.mrl_group_size(self._g))
+        rep = (LinkReport * n)()
+        self._lib.mrl_group_link_test.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(LinkReport)]
+        rc = self._lib.mrl_group_link_test(self._g, nbytes, transport, root, rep)
+        if rc != 0:
+            raise MerlHipError(rc, "mrl_group_link_test", (self._lib.mrl_group_last_error(self._g) or b"").decode())
+        return [{"peer": r.peer, "ok": bool(r.ok), "bytes": r.bytes, "mismatches": r.mismatches, "ms": r.ms, "GBps": r.GBps} for r in rep]
 
     def __init__(self, devices: Sequence[int], transport: int = TRANSPORT_AUTO):
         self._lib = load_library()

@@ -38,7 +38,8 @@ static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 
 
 static void put(std::vector<unsigned char> &b, const void *p, size_t n) { const unsigned char *c = (const unsigned char *)p; b.insert(b.end(), c, c + n); }
 
-static std::vector<unsigned char> good_file()
+// param_as_f64 != nullptr: the "parameterization" field is a float64 scalar holding *param_as_f64 (files may say so)
+static std::vector<unsigned char> good_file(const double *param_as_f64 = nullptr)
 {
     std::vector<unsigned char> b;
     put(b, "tensor_file", 12);
@@ -46,7 +47,7 @@ static std::vector<unsigned char> good_file()
     const uint32_t nf = 4; put(b, &nf, 4);
     struct F { const char *name; uint16_t ndim; uint8_t dtype; std::vector<uint64_t> shape; size_t bytes; };
     const F fs[4] = { { "table", 4, 10, { 2, 3, 2, 4 }, 2 * 3 * 2 * 4 * 4 }, { "scale", 1, 11, { 2 }, 16 }, { "description", 1, 1, { 9 }, 9 },
-                      { "parameterization", 0, 1, {}, 1 } };
+                      { "parameterization", 0, (uint8_t)(param_as_f64 ? 11 : 1), {}, (size_t)(param_as_f64 ? 8 : 1) } };
     size_t head = b.size();
     for (const F &f : fs) head += 2 + std::strlen(f.name) + 2 + 1 + 8 + 8 * f.ndim;
     uint64_t off = (head + 7) / 8 * 8;
@@ -60,6 +61,7 @@ static std::vector<unsigned char> good_file()
     }
     for (int i = 0; i < 4; ++i) {
         b.resize(offs[i], 0);
+        if (i == 3 && param_as_f64) { put(b, param_as_f64, 8); continue; }
         for (size_t k = 0; k < fs[i].bytes; ++k) b.push_back(i == 3 ? (unsigned char)1 : (unsigned char)(k * 7 + i));    // parameterization = 1
     }
     return b;
@@ -123,6 +125,18 @@ int main(int argc, char **argv)
         }
         const int rc = probe(path, b);
         if (rc == MRL_OK) ++opened; else ++refused;
+    }
+    // a float-typed "parameterization": only 0.0, 1.0, 2.0 are values of enum mrl_param; NaN, infinities and magnitudes
+    // beyond the integer range must be refused BEFORE any float -> integer conversion (-fsanitize=float-cast-overflow)
+    {
+        const double inf = 1.0 / 0.0, nan = inf - inf;
+        const double cases[] = { 0.0, 1.0, 2.0, 1.5, 3.0, -1.0, 1e300, -1e300, 9.3e18, inf, -inf, nan, 4.9e-324 };
+        for (double v : cases) {
+            const int before = g_param_uploads;
+            (void)probe(path, good_file(&v));
+            const bool accepted = g_param_uploads == before + 1, valid = v == 0.0 || v == 1.0 || v == 2.0;
+            if (accepted != valid) { std::fprintf(stderr, "parameterization = %g: %s\n", v, accepted ? "accepted" : "refused"); return 1; }
+        }
     }
     std::remove(path.c_str());
     std::printf("tensor fuzz ok: %d corrupted files opened consistently, %d refused, %d table uploads\n", opened, refused, g_uploads);

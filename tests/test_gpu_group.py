@@ -165,3 +165,46 @@ def test_native_cpp_host_program():
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["transport"] == "rccl" and out["check_mismatches"] == 0
+
+
+def test_link_test_and_rgb_only_gather_on_the_rehearsal_transport():
+    """mrl_group_link_test: every peer -> root link on its own, timed and bit-checked (device copies here: members share
+    GPU 0; the RCCL branch needs distinct devices and is refused on this group)."""
+    from mitsuba_customization_amd import host
+    with host.MerlGroup([0, 0, 0]) as grp:
+        assert grp.transport == host.TRANSPORT_PEER_COPY
+        for nbytes in (1 << 20, 16 << 20):
+            rep = grp.link_test(nbytes, root=1)
+            assert [r["peer"] for r in rep] == [0, 1, 2]
+            assert all(r["ok"] and r["mismatches"] == 0 for r in rep)
+            assert rep[1]["GBps"] == 0.0 and rep[0]["GBps"] > 1.0 and rep[2]["GBps"] > 1.0
+        with pytest.raises(host.MerlHipError) as e:
+            grp.link_test(1 << 20, transport=host.TRANSPORT_RCCL)
+        assert e.value.status == host.ERR_COMM
+        with pytest.raises(host.MerlHipError):
+            grp.link_test(2)
+
+
+def test_native_host_selftest_and_fallback_to_device_copies_in_a_fresh_process():
+    """group_host --selftest --transport rccl over members that share GPU 0: RCCL cannot serve a repeated device, the child
+    running that leg fails, and the parent repeats the run with device copies in a FRESH child — the branch a real
+    multi-GPU run takes when RCCL fails.  The line says what failed; three rates are reported side by side."""
+    exe = os.path.join(LIB, "group_host")
+    common = ["--devices", "0,0", "--units-per-device", str(1 << 20), "--chunk", str(400_000), "--steps", "2", "--warmup", "1", "--check", "--selftest"]
+    r = subprocess.run([exe] + common + ["--transport", "rccl"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "repeating it with device copies in a fresh process" in r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["transport"] == "peer_copy" and out["fallback_from"].startswith("rccl exit code") and out["check_mismatches"] == 0
+    assert out["compute_only_Meval_s"] > 0 and out["rgb_gathered_Meval_s"] > 0 and out["gathered_Meval_s"] > 0
+    links = out["selftest"]["peer_copy"]
+    assert [row["bytes"] for row in links] == [1 << 20, 4 << 20, 16 << 20, 64 << 20]
+    assert all(len(row["GBps_per_peer"]) == 1 and row["GBps_per_peer"][0] > 1.0 and row["mismatches"] == 0 for row in links)
+    # without the fallback the failure is the exit code
+    r = subprocess.run([exe] + common + ["--transport", "rccl", "--no-fallback"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "members" not in r.stdout
+    # AUTO picks device copies for a repeated device by itself: one child, no fallback
+    r = subprocess.run([exe] + common, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["fallback_from"] is None and out["transport"] == "peer_copy"

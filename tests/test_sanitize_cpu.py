@@ -47,7 +47,7 @@ def test_tensor_file_reader_is_clean_under_asan_ubsan(tmp_path):
     """The tensor_file container reader parses untrusted files: 6000 corrupted copies of a well-formed file under
     AddressSanitizer + UBSan (the reader is host C++ inside a .hip source: built here with g++)."""
     exe = str(tmp_path / "tensor_fuzz")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=undefined",
                            "-fno-omit-frame-pointer", "-o", exe, os.path.join(ROOT, "tests", "tensor_file_fuzz.cpp"),
                            "-x", "c++", os.path.join(ROOT, "mitsuba_customization_amd", "csrc", "merl_tensor_file.hip")])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
