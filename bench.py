@@ -89,6 +89,10 @@ def parse(argv=None):
     p.add_argument("--lookup", choices=["trilinear", "nearest"], default="trilinear")
     p.add_argument("--kernel", type=int, default=-1, help="kernel variant (MRL_OPT_KERNEL); -1 = library default")
     p.add_argument("--layout", type=int, default=-1, help="table layout (MRL_OPT_TABLE_LAYOUT); -1 = library default")
+    p.add_argument("--arena-mb", type=int, default=-1,
+                   help="MRL_OPT_TABLE_ARENA_MB: place the tables back to back in one device allocation of this size; -1 (default): 20 GB for "
+                        "--config resident100 (address translation bounds that launch; one arena removes the slow mode of its process-to-process "
+                        "spread: profiles/r03_arena_ab.txt), none otherwise; 0: one allocation per table")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-reps", type=int, default=5, help="repetitions of each CPU baseline leg (median is reported)")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the separately reported RCCL gather leg")
@@ -300,6 +304,10 @@ def main():
     elif args.lookup == "nearest":
         gpu.set_option(host.OPT_TABLE_LAYOUT, host.LAYOUT_ROWS)     # one texel per lookup: the compact layout wins
 
+    if args.arena_mb < 0:
+        args.arena_mb = 20480 if args.config == "resident100" else 0
+    if args.arena_mb:
+        gpu.set_option(host.OPT_TABLE_ARENA_MB, args.arena_mb)
     GGX = (0.1, (0.143, 0.375, 1.442), (3.983, 2.386, 1.603))      # BASELINE config 3: alpha 0.1, gold-like eta / k
     n_tables = {"merl64m": 1, "ggx64m": 0, "mixed16_256m": 16, "resident100": 100}[args.config]
     default_units = {"merl64m": 64 << 20, "ggx64m": 64 << 20, "mixed16_256m": 256 << 20, "resident100": 125_000_000}[args.config]
@@ -375,6 +383,7 @@ def main():
         kname = "k_table<eval_sample,nt>"
     traffic = measured_traffic(variant, layout, n, args.config)
     mem = gpu.memory_info()
+    lib_sources = host.build_info()                        # "sources <hash>": what the running library was built from
 
     roofline = {
         "bound": "hbm",
@@ -386,6 +395,10 @@ def main():
         # hits are counted in them, so this is an upper bound on HBM bytes (MI355X_MICROARCH.md, HBM section)
         "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
         "traffic_source": traffic["source"] if traffic else None,
+        # the counters are not re-collected in this run (PMC passes need rocprofv3 around the process): they come from
+        # profiles/traffic.json, which records the library sources they were measured on — stale when this library differs
+        "traffic_measured_on": traffic.get("library", "unrecorded (before round 3)") if traffic else None,
+        "traffic_stale": (traffic.get("library") != lib_sources) if traffic else None,
         "kernel": kname,
         "kernel_ms": round(kernel_ms, 4),
         "bytes_per_unit": b_unit,
@@ -431,6 +444,8 @@ def main():
             "lookup": args.lookup,
             "kernel_variant": variant,
             "table_layout": layout,
+            "library": lib_sources,
+            **({"table_arena_mb": args.arena_mb} if args.arena_mb else {}),
             "sharding": f"index tiles x{world}, tables replicated, no data-path collective",
             **({"coherent_period": args.coherent, "not_the_bench_line": "inputs repeat: table traffic is L2-served"} if args.coherent else {}),
         },

@@ -108,6 +108,11 @@ enum mrl_option {
     MRL_OPT_TABLE_PARAM = 10,  /* parameterisation of the customized_measurement tables uploaded FROM NOW ON (enum mrl_param below;
                                   recorded per material, so one context can hold tables of all three; MERL files are always
                                   half/diff).  Same kernels, same HBM layouts: only the three lookup angles differ. */
+    MRL_OPT_TABLE_ARENA_MB = 11, /* one device allocation of this many MiB that the RGB tables uploaded from now on are placed in back
+                                  to back (2 MiB aligned) while it has room, instead of one allocation per table; a table
+                                  that does not fit gets its own.  Released tables return their space when the arena
+                                  empties.  Settable while no table lives in it; 0 frees it.  Measured effect on the
+                                  100-table launch: DESIGN.md §6 (address translation bounds that launch). */
     MRL_OPT_MEMORY_LIMIT_MB = 7 /* budget for the context's resident material data (tables + sampling marginals), in MiB;
                                   0 (default) = no budget, the device's free memory is the limit.  An upload that would
                                   exceed the budget — or the device — fails with MRL_ERR_OOM and leaves the context as it
@@ -122,6 +127,9 @@ enum mrl_material_kind { MRL_KIND_MERL = 0, MRL_KIND_TABLE = 1, MRL_KIND_GGX = 2
 int mrl_init(int device_id, mrl_ctx **out);
 int mrl_destroy(mrl_ctx *ctx);
 const char *mrl_strerror(int status);
+/* "sources <12 hex digits>": a hash over the library's source files, fixed at build time.  Committed counter measurements
+ * (profiles/traffic.json) carry it; bench.py marks them stale when the library it runs reports another one. */
+const char *mrl_build_info(void);
 const char *mrl_last_error(const mrl_ctx *ctx);
 int mrl_set_option(mrl_ctx *ctx, int option, int value);
 int mrl_get_option(const mrl_ctx *ctx, int option, int *value);

@@ -37,6 +37,18 @@ def lib_sources():
     return srcs, deps
 
 
+def source_hash() -> str:
+    """12 hex digits over the library's sources (kernels, C ABI, header): the library reports it (mrl_build_info) and
+    committed counter measurements carry it, so that bench.py can tell when profiles/traffic.json was measured on other code."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in lib_sources()[1]:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
 def build_lib(force: bool = False, asm: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     srcs, deps = lib_sources()
@@ -49,7 +61,7 @@ def build_lib(force: bool = False, asm: bool = False) -> str:
             if force or _newer(LIB, deps):
                 tmp = f"{LIB}.{os.getpid()}.tmp"
                 try:
-                    subprocess.check_call([HIPCC] + HIP_FLAGS + ["-shared", "-o", tmp] + srcs, cwd=PKG)
+                    subprocess.check_call([HIPCC] + HIP_FLAGS + [f'-DMRL_SOURCE_HASH="{source_hash()}"', "-shared", "-o", tmp] + srcs, cwd=PKG)
                     os.replace(tmp, LIB)
                 finally:
                     if os.path.exists(tmp):

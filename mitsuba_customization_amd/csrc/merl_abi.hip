@@ -31,6 +31,7 @@ constexpr double kMerlScale[3] = { 1.0 / 1500.0, 1.15 / 1500.0, 1.66 / 1500.0 };
 struct MaterialHost {
     mrl::MaterialDev dev;
     float4 *d_texels = nullptr;
+    bool in_arena = false;           // d_texels is a slice of the context's table arena (MRL_OPT_TABLE_ARENA_MB): not freed on its own
     double *d_sampling = nullptr;
     size_t bytes = 0;                // device bytes this material holds (table + sampling marginal)
     bool released = false;           // tombstone left by mrl_material_release; the slot may be reused
@@ -203,6 +204,10 @@ struct mrl_ctx {
     size_t d_stage_bytes = 0;
     ScalarDevice scalar_dev;
     std::atomic<ScalarSvc *> scalar{ nullptr };      // created by the first mrl_scalar_eval_sample
+    // MRL_OPT_TABLE_ARENA_MB: one device allocation that RGB tables are placed in back to back (2 MiB aligned)
+    char *arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    int arena_live = 0;              // tables currently placed in it; the bump pointer rewinds when the last one leaves
     std::string last_error;
 };
 
@@ -361,6 +366,29 @@ int place_material(mrl_ctx *ctx, const MaterialHost &m, int *out_id)
     return MRL_OK;
 }
 
+// Table storage: a slice of the context's arena while it has room (back to back, 2 MiB aligned: one mapping with the
+// largest page fragments the driver grants, instead of one mapping per table), else an allocation of its own.
+hipError_t table_alloc(mrl_ctx *ctx, size_t bytes, float4 **out, bool *in_arena)
+{
+    const size_t align = (size_t)2 << 20;
+    const size_t at = (ctx->arena_used + align - 1) / align * align;
+    if (ctx->arena && at + bytes <= ctx->arena_bytes) {
+        *out = (float4 *)(ctx->arena + at);
+        ctx->arena_used = at + bytes;
+        ++ctx->arena_live;
+        *in_arena = true;
+        return hipSuccess;
+    }
+    *in_arena = false;
+    return hipMalloc((void **)out, bytes);
+}
+void table_free(mrl_ctx *ctx, float4 *p, bool in_arena)
+{
+    if (!p) return;
+    if (!in_arena) { (void)hipFree(p); return; }
+    if (--ctx->arena_live == 0) ctx->arena_used = 0;         // a bump allocator: space comes back when the arena empties
+}
+
 // planar f64 (file layout) -> padded, texel-interleaved RGBA f32 in HBM.
 // Row layout [n_th+1][n_td+1][n_pd+1]: the extra theta rows repeat the last row (clamp), the
 // extra phi texel repeats texel 0 (phi_d is periodic with period pi), so the kernel's "+1"
@@ -388,7 +416,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     // the file payload goes to the device as it is; a kernel scales, clamps and re-lays it out
     double *d_planar = nullptr;
     MRL_ALLOC(ctx, hipMalloc((void **)&d_planar, 3 * plane * sizeof(double)));
-    hipError_t e = hipMalloc((void **)&m.d_texels, out_texels * sizeof(float4));
+    hipError_t e = table_alloc(ctx, out_texels * sizeof(float4), &m.d_texels, &m.in_arena);
     const bool oom = e == hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMemcpyAsync(d_planar, planar, 3 * plane * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = mrl::launch_build_table(d_planar, dims, scale, layout, param, m.d_texels, ctx->compute_units, ctx->stream);
@@ -396,7 +424,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     (void)hipFree(d_planar);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        if (m.d_texels) (void)hipFree(m.d_texels);
+        table_free(ctx, m.d_texels, m.in_arena);
         return fail(ctx, oom ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
     }
     {
@@ -406,7 +434,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
         if (e == hipSuccess) e = hipMemcpy(m.d_sampling, sampling.data(), sampling.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            (void)hipFree(m.d_texels);
+            table_free(ctx, m.d_texels, m.in_arena);
             if (m.d_sampling) (void)hipFree(m.d_sampling);
             return fail(ctx, oom2 ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("sampling table upload: ") + hipGetErrorString(e));
         }
@@ -422,7 +450,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     m.dev.n_ch = 3;
     m.dev.param = param;
     rc = place_material(ctx, m, out_id);
-    if (rc != MRL_OK) { (void)hipFree(m.d_texels); (void)hipFree(m.d_sampling); return rc; }
+    if (rc != MRL_OK) { table_free(ctx, m.d_texels, m.in_arena); (void)hipFree(m.d_sampling); return rc; }
     return MRL_OK;
 }
 
@@ -1005,6 +1033,13 @@ const char *mrl_strerror(int status)
     return "unknown status";
 }
 
+#ifndef MRL_SOURCE_HASH
+#define MRL_SOURCE_HASH "unknown"
+#endif
+// which sources this library was built from (mitsuba_customization_amd/build.py::source_hash): committed counter
+// measurements carry the same string, so a reader can tell whether they describe THIS code
+const char *mrl_build_info(void) { return "sources " MRL_SOURCE_HASH; }
+
 // The text is copied under the context's lock into a buffer of the CALLING thread: another thread's failing call reassigns
 // ctx->last_error at any time (render threads all report through here), so a pointer into it would dangle.
 const char *mrl_last_error(const mrl_ctx *ctx)
@@ -1058,7 +1093,8 @@ int mrl_destroy(mrl_ctx *ctx)
         if (ctx->scalar_dev.b) (void)hipHostFree(ctx->scalar_dev.b);
     }
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &m : ctx->materials) { if (m.d_texels) (void)hipFree(m.d_texels); if (m.d_sampling) (void)hipFree(m.d_sampling); }
+    for (auto &m : ctx->materials) { if (m.d_texels && !m.in_arena) (void)hipFree(m.d_texels); if (m.d_sampling) (void)hipFree(m.d_sampling); }
+    if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     if (ctx->d_dummy) (void)hipFree(ctx->d_dummy);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
@@ -1088,6 +1124,20 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
         case MRL_OPT_SAMPLING: if (value < 0 || value > 1) break; ctx->opts.sampling = value; return MRL_OK;
         case MRL_OPT_KERNEL:   if (value < 0 || value > 4) break; ctx->kernel_variant = value; return MRL_OK;
         case MRL_OPT_MEMORY_LIMIT_MB: if (value < 0) break; ctx->memory_limit = (size_t)value << 20; return MRL_OK;
+        case MRL_OPT_TABLE_ARENA_MB: {
+            // (re)sized only while no table lives in it; 0 gives the memory back
+            if (value < 0) break;
+            if (ctx->arena_live) return fail(ctx, MRL_ERR_INVALID, "the table arena is in use: resize it before the first table is uploaded");
+            MRL_HIP(ctx, hipSetDevice(ctx->device));
+            if (ctx->arena) { MRL_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->arena); ctx->arena = nullptr; ctx->arena_bytes = 0; ctx->arena_used = 0; }
+            if (value > 0) {
+                const size_t bytes = (size_t)value << 20;
+                if (budget_check(ctx, bytes) != MRL_OK) return MRL_ERR_OOM;
+                MRL_ALLOC(ctx, hipMalloc((void **)&ctx->arena, bytes));
+                ctx->arena_bytes = bytes;
+            }
+            return MRL_OK;
+        }
         case MRL_OPT_HOST_THREADS: if (value < 0 || value > 64) break; ctx->host_threads = value; return MRL_OK;
         case MRL_OPT_BLOCK_MAP: if (value < 0 || value > 1) break; ctx->block_map = value; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: if (value < 1) break; ctx->host_chunk = (size_t)value; return MRL_OK;
@@ -1116,6 +1166,7 @@ int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
         case MRL_OPT_SAMPLING: *value = ctx->opts.sampling; return MRL_OK;
         case MRL_OPT_KERNEL: *value = ctx->kernel_variant; return MRL_OK;
         case MRL_OPT_MEMORY_LIMIT_MB: *value = (int)(ctx->memory_limit >> 20); return MRL_OK;
+        case MRL_OPT_TABLE_ARENA_MB: *value = (int)(ctx->arena_bytes >> 20); return MRL_OK;
         case MRL_OPT_HOST_THREADS: *value = ctx->host_threads; return MRL_OK;
         case MRL_OPT_BLOCK_MAP: *value = ctx->block_map; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: *value = (int)ctx->host_chunk; return MRL_OK;
@@ -1222,7 +1273,7 @@ int mrl_material_release(mrl_ctx *ctx, int id)
     m.released = true;
     rc = sync_material_array(ctx);                               // the device array must stop naming the table first
     if (rc != MRL_OK) { m = before; return rc; }
-    if (before.d_texels) (void)hipFree(before.d_texels);
+    table_free(ctx, before.d_texels, before.in_arena);
     if (before.d_sampling) (void)hipFree(before.d_sampling);
     m.d_texels = nullptr; m.d_sampling = nullptr;
     ctx->material_bytes -= before.bytes;

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("MRL_LIB_PATH") or os.path.join(_PKG, "lib", "libmerl_
 
 OPT_LOOKUP, OPT_NODE, OPT_DISK_MAP, OPT_KERNEL, OPT_HOST_CHUNK, OPT_TABLE_LAYOUT, OPT_SAMPLING, OPT_MEMORY_LIMIT_MB, OPT_HOST_THREADS, OPT_BLOCK_MAP = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_TABLE_PARAM = 10
+OPT_TABLE_ARENA_MB = 11
 PARAM_HALF_DIFF, PARAM_STANDARD, PARAM_STANDARD_FULL = 0, 1, 2          # enum mrl_param
 SAMPLING_COSINE, SAMPLING_TABLE = 0, 1
 LAYOUT_ROWS, LAYOUT_BRICK = 0, 1
@@ -27,7 +28,7 @@ ERR_INVALID, ERR_HIP, ERR_IO, ERR_FORMAT, ERR_OOM, ERR_MATERIAL, ERR_POINTER_MIX
 
 # every symbol include/merl_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
-    "mrl_init", "mrl_destroy", "mrl_strerror", "mrl_last_error", "mrl_set_option", "mrl_get_option",
+    "mrl_init", "mrl_destroy", "mrl_strerror", "mrl_build_info", "mrl_last_error", "mrl_set_option", "mrl_get_option",
     "mrl_set_stream", "mrl_reset_stream", "mrl_synchronize", "mrl_device_info",
     "mrl_material_load_merl", "mrl_material_upload_f64", "mrl_material_upload_table", "mrl_material_load_table",
     "mrl_scalar_eval_sample", "mrl_scalar_eval_pdf", "mrl_scalar_sample", "mrl_material_ggx", "mrl_material_count", "mrl_material_info", "mrl_material_release", "mrl_memory_info",
@@ -724,6 +725,13 @@ def read_tensor_file(path: str) -> dict:
         return out
     finally:
         L.mrl_tensor_file_close(f)
+
+
+def build_info() -> str:
+    """mrl_build_info: "sources <hash>" of the loaded library."""
+    L = load_library()
+    L.mrl_build_info.restype = C.c_char_p
+    return L.mrl_build_info().decode()
 
 
 def tile_bounds(n_total: int, world: int, rank: int):

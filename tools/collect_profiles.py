@@ -26,6 +26,7 @@ for d in dirs:
         wr = k["TCC_EA0_WRREQ_64B_sum"] * 64 + (k["TCC_EA0_WRREQ_sum"] - k["TCC_EA0_WRREQ_64B_sum"]) * 32
         rows.append({
             "config": cfg, "kernel_variant": 3, "table_layout": 1, "units": bench["config"]["units_per_gpu_per_step"],
+            "library": bench["config"].get("library", "unrecorded"),        # mrl_build_info() of the library the counters were taken on
             "hbm_bytes_per_launch": int(k["FETCH_SIZE"] * 1024 * 2 + k["WRITE_SIZE"] * 1024),
             "fetch_bytes": int(k["FETCH_SIZE"] * 1024 * 2), "write_bytes": int(k["WRITE_SIZE"] * 1024),
             "tcc_ea0_request_bytes": int(rd + wr), "tcc_ea0_rdreq": int(k["TCC_EA0_RDREQ_sum"]),
