@@ -90,7 +90,9 @@ enum mrl_option {
                                   Every variant passes the same parity tests; they differ in speed only.  Values
                                   outside 0..4 are rejected with MRL_ERR_INVALID. */
     MRL_OPT_HOST_CHUNK = 4,    /* units per staging chunk for host-pointer calls (the pipelined path uses at most 2^20) */
-    MRL_OPT_SAMPLING = 6,      /* sample()/pdf() strategy of table materials: 0 cosine hemisphere (default, the upstream
+    MRL_OPT_SAMPLING = 6,      /* (2 = the conditional table P(theta_h | theta_i) with the cosine lobe at weight 1/8: see
+                                  mrl_material_sampling2d)
+                                  sample()/pdf() strategy of table materials: 0 cosine hemisphere (default, the upstream
                                   convention), 1 table importance sampling: one-sample mixture of the cosine lobe and a
                                   half-vector lobe read off the table's theta_h rows */
     MRL_OPT_TABLE_LAYOUT = 5,  /* HBM layout of the context's tables, settable only while it holds no table:
@@ -155,7 +157,11 @@ int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float 
 /* number of material SLOTS (live + released); ids are slot indices */
 int mrl_material_count(const mrl_ctx *ctx);
 int mrl_material_info(const mrl_ctx *ctx, int id, int *kind, int dims[3]);
-int mrl_material_param(const mrl_ctx *ctx, int id, int *param);     /* enum mrl_param of a table material (GGX: MRL_ERR_MATERIAL) */
+int mrl_material_param(const mrl_ctx *ctx, int id, int *param);
+/* The conditional sampling table P(theta_h | theta_i) of an RGB table material (MRL_OPT_SAMPLING = 2), as the device built
+ * it at upload (a quadrature kernel through the resident table's own trilinear lookup + a prefix-scan kernel): n_ti incident
+ * bins uniform in cos(theta_i), each a row of n_th + 1 cdf values followed by n_th densities c.  out == NULL: sizes only. */
+int mrl_material_sampling2d(mrl_ctx *ctx, int id, int *n_ti, int *n_th, double *out, size_t max_doubles);     /* enum mrl_param of a table material (GGX: MRL_ERR_MATERIAL) */
 /* Frees a material's device memory (plugin destructor).  Waits for the context's stream first.  The slot becomes a
  * tombstone: batch and queue calls treat its id like an unknown id (every output zero), single_id calls and
  * mrl_material_info return MRL_ERR_MATERIAL.  A later upload may reuse the slot (lowest free slot first), exactly like

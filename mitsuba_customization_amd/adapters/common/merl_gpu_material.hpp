@@ -352,7 +352,8 @@ inline int parse_sampling(const std::string &s)
 {
     if (s == "cosine") return 0;
     if (s == "table") return 1;
-    throw Error(MRL_ERR_INVALID, "sampling must be \"cosine\" or \"table\", got \"" + s + "\"");
+    if (s == "table2d") return 2;          // the conditional table P(theta_h | theta_i): include/merl_hip.h, mrl_material_sampling2d
+    throw Error(MRL_ERR_INVALID, "sampling must be \"cosine\", \"table\" or \"table2d\", got \"" + s + "\"");
 }
 inline int parse_parameterization(const std::string &s)
 {

@@ -7,7 +7,8 @@
 //   <bsdf type="customized_measurement"> <string name="filename" value="mine.binary"/>
 //        <float name="scaleR" value="1"/> ... </bsdf>
 // Optional: interpolation = "trilinear" (default) | "nearest";  node = "integer" (default) | "center";
-//           sampling = "cosine" (default, the upstream convention) | "table" (importance sampling off the table);
+//           sampling = "cosine" (default, the upstream convention) | "table" (importance sampling off the table's row
+//                      marginal) | "table2d" (off its conditional rows P(theta_h | theta_i): a third less variance again);
 //           scalar = "cpu" (default: the virtual per-ray eval / sample / pdf evaluate on the calling render thread, like
 //                    the CPU plugin this replaces) | "gpu" (through the device's one-unit call service);
 //           device = GPU ordinal (default 0).  Whole-array and wavefront calls (BatchedBSDF) always run on the GPU.
@@ -53,7 +54,7 @@ public:
         m_key.node = stream->readInt();
         m_key.disk_map = 0;
         m_key.sampling = stream->readInt();
-        if (m_key.lookup < 0 || m_key.lookup > 1 || m_key.node < 0 || m_key.node > 1 || m_key.sampling < 0 || m_key.sampling > 1)
+        if (m_key.lookup < 0 || m_key.lookup > 1 || m_key.node < 0 || m_key.node > 1 || m_key.sampling < 0 || m_key.sampling > 2)
             throw merl_gpu::Error(MRL_ERR_INVALID, "corrupt serialised BSDF");
     }
 

@@ -33,6 +33,7 @@ struct MaterialHost {
     float4 *d_texels = nullptr;
     bool in_arena = false;           // d_texels is a slice of the context's table arena (MRL_OPT_TABLE_ARENA_MB): not freed on its own
     double *d_sampling = nullptr;
+    double *d_sampling2d = nullptr;  // P(theta_h | theta_i) rows (RGB tables), built on the device at upload
     size_t bytes = 0;                // device bytes this material holds (table + sampling marginal)
     bool released = false;           // tombstone left by mrl_material_release; the slot may be reused
 };
@@ -449,8 +450,28 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     m.dev.layout = layout;
     m.dev.n_ch = 3;
     m.dev.param = param;
+    {
+        // the conditional sampling table, from the table that has just become resident (quadrature + prefix scan on the device)
+        const int n_ti = mrl::kSamplingIncidentBins;
+        double *d_work = nullptr;
+        e = hipMalloc((void **)&m.d_sampling2d, (size_t)n_ti * (2 * (size_t)n_th + 1) * sizeof(double));
+        const bool oom3 = e == hipErrorOutOfMemory;
+        if (e == hipSuccess) e = hipMalloc((void **)&d_work, (size_t)n_ti * (size_t)n_th * sizeof(double));
+        if (e == hipSuccess) e = mrl::launch_build_sampling2d(m.dev, ctx->opts, n_ti, m.d_sampling2d, d_work, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (d_work) (void)hipFree(d_work);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            table_free(ctx, m.d_texels, m.in_arena); (void)hipFree(m.d_sampling);
+            if (m.d_sampling2d) (void)hipFree(m.d_sampling2d);
+            return fail(ctx, oom3 ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("conditional sampling table: ") + hipGetErrorString(e));
+        }
+        m.dev.sampling2d = m.d_sampling2d;
+        m.dev.n_ti = n_ti;
+        m.bytes += (size_t)n_ti * (2 * (size_t)n_th + 1) * sizeof(double);
+    }
     rc = place_material(ctx, m, out_id);
-    if (rc != MRL_OK) { table_free(ctx, m.d_texels, m.in_arena); (void)hipFree(m.d_sampling); return rc; }
+    if (rc != MRL_OK) { table_free(ctx, m.d_texels, m.in_arena); (void)hipFree(m.d_sampling); (void)hipFree(m.d_sampling2d); return rc; }
     return MRL_OK;
 }
 
@@ -1093,7 +1114,7 @@ int mrl_destroy(mrl_ctx *ctx)
         if (ctx->scalar_dev.b) (void)hipHostFree(ctx->scalar_dev.b);
     }
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &m : ctx->materials) { if (m.d_texels && !m.in_arena) (void)hipFree(m.d_texels); if (m.d_sampling) (void)hipFree(m.d_sampling); }
+    for (auto &m : ctx->materials) { if (m.d_texels && !m.in_arena) (void)hipFree(m.d_texels); if (m.d_sampling) (void)hipFree(m.d_sampling); if (m.d_sampling2d) (void)hipFree(m.d_sampling2d); }
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     if (ctx->d_dummy) (void)hipFree(ctx->d_dummy);
@@ -1121,7 +1142,7 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
         case MRL_OPT_LOOKUP:   if (value < 0 || value > 1) break; ctx->opts.lookup = value; return MRL_OK;
         case MRL_OPT_NODE:     if (value < 0 || value > 1) break; ctx->opts.node = value; return MRL_OK;
         case MRL_OPT_DISK_MAP: if (value < 0 || value > 1) break; ctx->opts.disk_map = value; return MRL_OK;
-        case MRL_OPT_SAMPLING: if (value < 0 || value > 1) break; ctx->opts.sampling = value; return MRL_OK;
+        case MRL_OPT_SAMPLING: if (value < 0 || value > 2) break; ctx->opts.sampling = value; return MRL_OK;
         case MRL_OPT_KERNEL:   if (value < 0 || value > 4) break; ctx->kernel_variant = value; return MRL_OK;
         case MRL_OPT_MEMORY_LIMIT_MB: if (value < 0) break; ctx->memory_limit = (size_t)value << 20; return MRL_OK;
         case MRL_OPT_TABLE_ARENA_MB: {
@@ -1275,7 +1296,8 @@ int mrl_material_release(mrl_ctx *ctx, int id)
     if (rc != MRL_OK) { m = before; return rc; }
     table_free(ctx, before.d_texels, before.in_arena);
     if (before.d_sampling) (void)hipFree(before.d_sampling);
-    m.d_texels = nullptr; m.d_sampling = nullptr;
+    if (before.d_sampling2d) (void)hipFree(before.d_sampling2d);
+    m.d_texels = nullptr; m.d_sampling = nullptr; m.d_sampling2d = nullptr;
     ctx->material_bytes -= before.bytes;
     m.bytes = 0;
     return MRL_OK;
@@ -1340,6 +1362,10 @@ int mrl_material_host_table(mrl_ctx *ctx, int id, mrl_host_table **out)
             e = hipMemcpy(bricks.data(), mh.d_texels, bricks.size() * sizeof(float4), hipMemcpyDeviceToHost);
         }
         if (e == hipSuccess) e = hipMemcpy(t->marginal.data(), mh.d_sampling, t->marginal.size() * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && mh.d_sampling2d) {
+            t->marginal2d.resize((size_t)mh.dev.n_ti * (2 * (size_t)n_th + 1));
+            e = hipMemcpy(t->marginal2d.data(), mh.d_sampling2d, t->marginal2d.size() * sizeof(double), hipMemcpyDeviceToHost);
+        }
         if (e != hipSuccess) { (void)hipGetLastError(); delete t; return fail(ctx, MRL_ERR_HIP, std::string("host image: ") + hipGetErrorString(e)); }
         if (mh.dev.layout != mrl::LAYOUT_ROWS) {
             const bool periodic = mrl::param_phi_periodic(mh.dev.param);
@@ -1359,11 +1385,30 @@ int mrl_material_host_table(mrl_ctx *ctx, int id, mrl_host_table **out)
     t->m = mh.dev;
     t->m.texels = t->rows.data();
     t->m.sampling = t->marginal.data();
+    t->m.sampling2d = t->marginal2d.empty() ? nullptr : t->marginal2d.data();
     t->m.layout = mrl::LAYOUT_ROWS;
     t->m.row_td = (int)P;
     t->m.row_th = (int)(D * P);
     t->opts = ctx->opts;
     *out = t;
+    return MRL_OK;
+}
+
+// the conditional sampling table of an RGB table material, as the device built it: n_ti rows of (n_th + 1 cdf | n_th c)
+int mrl_material_sampling2d(mrl_ctx *ctx, int id, int *n_ti, int *n_th, double *out, size_t max_doubles)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
+    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
+    const MaterialHost &mh = ctx->materials[(size_t)id];
+    if (!mh.d_sampling2d) return fail(ctx, MRL_ERR_MATERIAL, "the material has no conditional sampling table (RGB table materials do)");
+    const size_t need = (size_t)mh.dev.n_ti * (2 * (size_t)mh.dev.n_th + 1);
+    if (n_ti) *n_ti = mh.dev.n_ti;
+    if (n_th) *n_th = mh.dev.n_th;
+    if (!out) return MRL_OK;
+    if (max_doubles < need) return fail(ctx, MRL_ERR_INVALID, "buffer too small");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    MRL_HIP(ctx, hipMemcpy(out, mh.d_sampling2d, need * sizeof(double), hipMemcpyDeviceToHost));
     return MRL_OK;
 }
 

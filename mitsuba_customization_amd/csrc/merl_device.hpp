@@ -40,6 +40,20 @@ MRL_HD double rsq_seed(double x)
     return 1.0 / __builtin_sqrt(x);
 #endif
 }
+// double -> int, truncating.  The device's v_cvt_i32_f64 saturates and maps NaN to 0, and the index maps below lean on that
+// (garbage coordinates of masked lanes must still address the table); x86's cvttsd2si returns INT_MIN for both, so the host
+// build spells the same semantics out.
+MRL_HD int trunc_i(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)x;
+#else
+    if (!(x == x)) return 0;
+    if (x >= 2147483647.0) return 2147483647;
+    if (x <= -2147483648.0) return -2147483647 - 1;
+    return (int)x;
+#endif
+}
 MRL_HD int min_i(int a, int b) { return a < b ? a : b; }
 MRL_HD unsigned min_u(unsigned a, unsigned b) { return a < b ? a : b; }
 
@@ -71,6 +85,8 @@ struct MaterialDev {
     int layout;                  // LAYOUT_ROWS / LAYOUT_BRICK
     int n_ch;                    // channels: 3 for the RGB kinds; KIND_TABLE_NCH: 1..32 (bricks of ceil(n_ch/4) x 128 B, or 32 / 64 B for 1 / 2 channels)
     const double *sampling;      // table importance sampling: s[n_th+1] | cdf[n_th+1] | c[n_th]  (see table_pdf below)
+    const double *sampling2d;    // conditional rows P(theta_h | theta_i): [n_ti][ cdf[n_th+1] | c[n_th] ], nullptr = none (see SamplingRow)
+    int n_ti;                    // incident bins of sampling2d (uniform in cos theta_i)
     int param;                   // PARAM_*: the axes are (n_th, n_td, n_pd) whatever they mean
     double alpha;                // GGX
     double eta[3], k[3];
@@ -183,9 +199,9 @@ MRL_HD Rgbf blend_brick(const float4 &q0, const float4 &q1, const float4 &q2, co
 template <int LAYOUT>
 MRL_HD Rgbf lookup_nearest_t(const MaterialDev &m, const Coords &c)
 {
-    int ih = clampi((int)c.xh, 0, m.n_th - 1);
-    int id = clampi((int)c.xd, 0, m.n_td - 1);
-    int ip = clampi((int)c.xp, 0, m.n_pd - 1);
+    int ih = clampi(trunc_i(c.xh), 0, m.n_th - 1);
+    int id = clampi(trunc_i(c.xd), 0, m.n_td - 1);
+    int ip = clampi(trunc_i(c.xp), 0, m.n_pd - 1);
     if constexpr (LAYOUT == LAYOUT_BRICK) {
         const float4 t = m.texels[(((size_t)ih * m.n_td + id) * m.n_pd + ip) * 8];     // corner 0 = the texel itself
         return { t.x, t.y, t.z };
@@ -204,7 +220,10 @@ MRL_HD Rgbf lookup_nearest_t(const MaterialDev &m, const Coords &c)
 MRL_HD void split_clamped(double x, int n, int &i0, double &f)
 {
 #pragma clang fp contract(off)
-    const int i = min_i((int)x, n - 1);
+    int i = min_i(trunc_i(x), n - 1);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    i = i < 0 ? 0 : i;                         // x <= -1 only happens for masked garbage; the device's (x > -1) never needs it
+#endif
     f = __builtin_fmin(__builtin_fmax(x - (double)i, 0.0), 1.0);
     i0 = i;
 }
@@ -215,7 +234,7 @@ MRL_HD void split_periodic(double x, int n, int &i0, double &f)
 #pragma clang fp contract(off)
     const double fl = floor(x);
     f = x - fl;
-    unsigned j = (unsigned)((int)fl + n);
+    unsigned j = (unsigned)trunc_i(fl) + (unsigned)n;
     j = min_u(j, j - (unsigned)n);
     j = min_u(j, j - (unsigned)n);
     i0 = (int)min_u(j, (unsigned)(n - 1));          // only reached by x outside [-1, n]: stay inside the table
@@ -451,30 +470,52 @@ MRL_HD int bin_of(const double *a, int n, double x)      // largest i in [0,n-1]
     return lo;
 }
 
-MRL_HD double table_pdf(const MaterialDev &m, const Vec3d &in, const Vec3d &out, float woz)
+// The distribution one sample()/pdf() call uses (MRL_OPT_SAMPLING): 1 = the table's row marginal with the cosine lobe at
+// weight 1/2; 2 = the row of the incident direction's bin in the conditional table P(theta_h | theta_i) — it follows the
+// BRDF itself at that incidence, so the cosine lobe only keeps the estimator bounded: weight 1/8 (definition:
+// oracle/merl_oracle.h; measured on the GGX-shaped table: the weights' variance falls by a third against mode 1).
+// A material without a conditional table (n-channel tables) answers mode 2 with its marginal.
+struct SamplingRow {
+    const double *s, *cdf, *c;
+    int n;
+    float alpha;             // 1/2 or 1/8: u / alpha and u - alpha are exact in Float
+};
+MRL_HD SamplingRow sampling_row(const MaterialDev &m, int mode, double in_z)
 {
+    if (mode == 2 && m.sampling2d) {
+        int i = (int)(in_z * (double)m.n_ti);
+        i = i < 0 ? 0 : (i >= m.n_ti ? m.n_ti - 1 : i);
+        const double *row = m.sampling2d + (size_t)i * (size_t)(2 * m.n_th + 1);
+        return { m.sampling, row, row + (m.n_th + 1), m.n_th, 0.125f };
+    }
+    return { m.sampling, m.sampling + (m.n_th + 1), m.sampling + 2 * (m.n_th + 1), m.n_th, 0.5f };
+}
+
+MRL_HD double table_pdf(const MaterialDev &m, const Vec3d &in, const Vec3d &out, float woz, int mode)
+{
+    const SamplingRow r = sampling_row(m, mode, in.z);
     Vec3d h = { in.x + out.x, in.y + out.y, in.z + out.z };
     const double inv = 1.0 / sqrt(h.x * h.x + h.y * h.y + h.z * h.z);
     h.x *= inv; h.y *= inv; h.z *= inv;
-    const int i = bin_of(m.sampling, m.n_th, h.x * h.x + h.y * h.y);
+    const int i = bin_of(r.s, r.n, h.x * h.x + h.y * h.y);
     const double ih = in.x * h.x + in.y * h.y + in.z * h.z;
-    const double ph = m.sampling[2 * (m.n_th + 1) + i] * h.z / (4.0 * ih);
-    return 0.5 * ((double)woz * 0.31830988618379067154) + 0.5 * ph;
+    const double ph = r.c[i] * h.z / (4.0 * ih);
+    return (double)r.alpha * ((double)woz * 0.31830988618379067154) + (1.0 - (double)r.alpha) * ph;
 }
 
 // direction of the mixture sample (Float); z <= 0 means "rejected"
 MRL_HD void table_sample_dir(const MaterialDev &m, int disk_map, const Vec3d &in, float u0, float u1,
-                                                 float &x, float &y, float &z)
+                                                 float &x, float &y, float &z, int mode)
 {
-    if (u0 < 0.5f) {
-        square_to_cosine_hemisphere(disk_map, 2.0f * u0, u1, x, y, z);
+    const SamplingRow r = sampling_row(m, mode, in.z);
+    if (u0 < r.alpha) {
+        square_to_cosine_hemisphere(disk_map, u0 * (1.0f / r.alpha), u1, x, y, z);
         return;
     }
-    const double *s = m.sampling, *cdf = m.sampling + (m.n_th + 1);
-    const double t = (double)(2.0f * u0 - 1.0f);
-    const int i = bin_of(cdf, m.n_th, t);
-    const double xi = (t - cdf[i]) / (cdf[i + 1] - cdf[i]);
-    const double sin2 = s[i] + xi * (s[i + 1] - s[i]);
+    const double t = (double)(u0 - r.alpha) * (1.0 / (1.0 - (double)r.alpha));
+    const int i = bin_of(r.cdf, r.n, t);
+    const double xi = (t - r.cdf[i]) / (r.cdf[i + 1] - r.cdf[i]);
+    const double sin2 = r.s[i] + xi * (r.s[i + 1] - r.s[i]);
     const double ct = sqrt(1.0 - sin2 > 0.0 ? 1.0 - sin2 : 0.0), st = sqrt(sin2);
     const double phi = 2.0 * kPi * (double)u1;
     const Vec3d h = { st * cos(phi), st * sin(phi), ct };
@@ -566,7 +607,7 @@ MRL_HD float unit_pdf(const MaterialDev &m, const Options &o, float wix, float w
         Vec3d in = normalized(wix, wiy, wiz), out = normalized(wox, woy, woz);
         return (float)ggx_pdf(m, in, out);
     }
-    if (o.sampling) return (float)table_pdf(m, normalized(wix, wiy, wiz), normalized(wox, woy, woz), woz);
+    if (o.sampling) return (float)table_pdf(m, normalized(wix, wiy, wiz), normalized(wox, woy, woz), woz, o.sampling);
     return woz * kInvPiF;
 }
 
@@ -584,9 +625,9 @@ MRL_HD void unit_sample(const MaterialDev &m, const Options &o,
     float x, y, z, p;
     if (o.sampling) {
         const Vec3d in = normalized(wix, wiy, wiz);
-        table_sample_dir(m, o.disk_map, in, u0, u1, x, y, z);
+        table_sample_dir(m, o.disk_map, in, u0, u1, x, y, z, o.sampling);
         if (!(z > 0.0f)) return;                          // reflected below the horizon: rejected
-        p = (float)table_pdf(m, in, normalized(x, y, z), z);
+        p = (float)table_pdf(m, in, normalized(x, y, z), z, o.sampling);
         if (!(p > 0.0f)) return;
     } else {
         square_to_cosine_hemisphere(o.disk_map, u0, u1, x, y, z);

@@ -36,7 +36,7 @@ MRL_HOST_FAST inline void host_eval_pdf(const mrl_host_table *t, const float wi[
     mrl::fast::unit_eval<LOOKUP, mrl::LAYOUT_ROWS>(t->m, t->opts, in, wi[0], wi[1], wi[2], wo[0], wo[1], wo[2], rgb);
     if (pdf) {
         float p = (wi[2] > 0.0f && wo[2] > 0.0f) ? wo[2] * mrl::kInvPiF : 0.0f;
-        if (t->opts.sampling && p > 0.0f) p = (float)mrl::fast::table_pdf(t->m, in, mrl::fast::normalize_f32(wo[0], wo[1], wo[2]), wo[2]);
+        if (t->opts.sampling && p > 0.0f) p = (float)mrl::fast::table_pdf(t->m, in, mrl::fast::normalize_f32(wo[0], wo[1], wo[2]), wo[2], t->opts.sampling);
         *pdf = p;
     }
 }

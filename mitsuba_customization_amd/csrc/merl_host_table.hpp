@@ -13,4 +13,5 @@ struct mrl_host_table {
     mrl::Options opts;                  // lookup / node / disk map / sampling of the context when the image was taken
     std::vector<float4> rows;           // [(n_th+1)][(n_td+1)][(n_pd+1)] RGBA f32: the device's own texel values
     std::vector<double> marginal;       // s | cdf | c (table importance sampling)
+    std::vector<double> marginal2d;     // the conditional rows P(theta_h | theta_i), as the device built them
 };

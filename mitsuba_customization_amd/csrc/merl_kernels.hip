@@ -136,13 +136,13 @@ __global__ __launch_bounds__(kBlock) void k_table(BatchArgs a)
             if constexpr (MODE == MODE_PDF) {
                 pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
                 if (a.opts.sampling && pdf > 0.0f)
-                    pdf = (float)fast::table_pdf(m, fast::normalize_f32(wix, wiy, wiz), fast::normalize_f32(wox, woy, woz), woz);
+                    pdf = (float)fast::table_pdf(m, fast::normalize_f32(wix, wiy, wiz), fast::normalize_f32(wox, woy, woz), woz, a.opts.sampling);
             } else {
                 const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
                 if constexpr (mode_eval(MODE)) fast::unit_eval<LOOKUP, LAYOUT>(m, a.opts, in, wix, wiy, wiz, wox, woy, woz, rgb);
                 if constexpr (mode_pdf(MODE)) {
                     pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
-                    if (a.opts.sampling && pdf > 0.0f) pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz);
+                    if (a.opts.sampling && pdf > 0.0f) pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz, a.opts.sampling);
                 }
                 if constexpr (mode_sample(MODE)) fast::unit_sample<LOOKUP, LAYOUT>(m, a.opts, in, wix, wiy, wiz, u0, u1, wo2, pdf2, w);
             }
@@ -320,10 +320,10 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
     float sp = 0.0f;                                          // pdf of the sampled direction
     if constexpr (HAS_SAMPLE) {
         if (a.opts.sampling && (!GGX || is_table)) {          // option is wave-uniform
-            fast::table_sample_dir(m, a.opts.disk_map, in, io.u0, io.u1, sx, sy, sz);
+            fast::table_sample_dir(m, a.opts.disk_map, in, io.u0, io.u1, sx, sy, sz, a.opts.sampling);
             const bool up = sz > 0.0f;
             if (!up) { sx = 0.0f; sy = 0.0f; sz = 1.0f; }     // rejected: look up a harmless cell, report zeros
-            sp = up ? (float)fast::table_pdf(m, in, fast::normalize_f32(sx, sy, sz), sz) : 0.0f;
+            sp = up ? (float)fast::table_pdf(m, in, fast::normalize_f32(sx, sy, sz), sz, a.opts.sampling) : 0.0f;
         } else {
             square_to_cosine_hemisphere(a.opts.disk_map, io.u0, io.u1, sx, sy, sz);
             sp = sz > 0.0f ? sz * kInvPiF : 0.0f;
@@ -345,7 +345,7 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
             if constexpr (mode_pdf(MODE)) {
                 const bool valid = (io.wiz > 0.0f) && (io.woz > 0.0f);
                 io.pdf = valid ? io.woz * kInvPiF : 0.0f;
-                if (a.opts.sampling && valid) io.pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(io.wox, io.woy, io.woz), io.woz);
+                if (a.opts.sampling && valid) io.pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(io.wox, io.woy, io.woz), io.woz, a.opts.sampling);
             }
         }
     }
@@ -779,6 +779,79 @@ __global__ __launch_bounds__(kBlock) void k_build_rows(const double *planar, int
     }
 }
 
+// ---- the conditional sampling table P(theta_h | theta_i) (definition: oracle/merl_oracle.h, "survey form") -------------
+// Built on the device from the RESIDENT table, through the kernels' own lookup.  Pass 1, one wave per (incident bin i,
+// theta_h bin j): its 64 lanes are the K_s x K_p = 4 x 16 quadrature midpoints of the bin; lane -> BRDF mass at its
+// half vector -> wave sum (shuffle tree) -> W[i][j].  Pass 2, one block per incident bin: the row's total (block
+// reduction), the 1 % floor, then an exclusive prefix scan over the n_th bins (per-thread serial chunks, a
+// Hillis-Steele scan of the 256 partials in LDS) -> cdf, and c = mass / (Z pi ds).
+constexpr int kS2dKs = 4, kS2dKp = 16;
+
+template <int LAYOUT>
+__global__ __launch_bounds__(64) void k_sampling2d_mass(MaterialDev m, Options o, int n_ti, double *W)
+{
+    const int j = (int)blockIdx.x, i = (int)blockIdx.y, lane = (int)threadIdx.x;
+    const int n = m.n_th;
+    const double s0 = m.sampling[j], s1 = m.sampling[j + 1], ds = s1 - s0;
+    const double mu = ((double)i + 0.5) / (double)n_ti;
+    const int a = lane / kS2dKp, b = lane % kS2dKp;
+    const double s = s0 + ((double)a + 0.5) / kS2dKs * ds, phi = ((double)b + 0.5) / kS2dKp * kPi;
+    double v = 0.0;
+    if (m.param == PARAM_HALF_DIFF) {
+        const fast::Vec3 in = { sqrt(fmax(1.0 - mu * mu, 0.0)), 0.0, mu };
+        const double st = sqrt(s), ct = sqrt(fmax(1.0 - s, 0.0));
+        const double hx = st * cos(phi), hy = st * sin(phi);
+        const double c = in.x * hx + in.z * ct;
+        const fast::Dir out = { 2.0 * c * hx - in.x, 2.0 * c * hy, 2.0 * c * ct - in.z, 1.0 };
+        if (c > 0.0 && ct > 0.0 && out.z > 0.0) {
+            const fast::TableMaps maps(m);
+            const Rgbf f = lookup_trilinear_t<LAYOUT>(m, maps(in, out), o.node);
+            const double lum = 0.2126 * (double)f.r + 0.7152 * (double)f.g + 0.0722 * (double)f.b;
+            v = lum * out.z * 4.0 * c / (2.0 * ct);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) W[(size_t)i * n + j] = ds * v / (double)(kS2dKs * kS2dKp);
+}
+
+__global__ __launch_bounds__(kBlock) void k_sampling2d_scan(const double *s, int n, const double *W, double *rows)
+{
+    __shared__ double part[kBlock];
+    const int i = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const double *w = W + (size_t)i * n;
+    double *cdf = rows + (size_t)i * (2 * n + 1), *c = cdf + (n + 1);
+    const int per = (n + kBlock - 1) / kBlock, lo = tid * per, hi = min(lo + per, n);
+    // 1. the row's total -> the floor (1 % of the mass, uniform in s; a flat row when the table gives nothing)
+    double sum = 0.0;
+    for (int j = lo; j < hi; ++j) sum += w[j];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) { if (tid < off) part[tid] += part[tid + off]; __syncthreads(); }
+    const double total = part[0], span = s[n] - s[0];
+    __syncthreads();
+    auto mass = [&](int j) { const double ds = s[j + 1] - s[j]; return total > 0.0 ? w[j] + 0.01 * total * ds / span : ds / span; };
+    // 2. exclusive prefix scan of the floored masses
+    sum = 0.0;
+    for (int j = lo; j < hi; ++j) sum += mass(j);
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {              // Hillis-Steele inclusive scan of the partials
+        const double add = tid >= off ? part[tid - off] : 0.0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    const double Z = part[kBlock - 1];
+    double run = tid ? part[tid - 1] : 0.0;
+    for (int j = lo; j < hi; ++j) {
+        const double wj = mass(j);
+        cdf[j] = run / Z;
+        c[j] = wj / (Z * kPi * (s[j + 1] - s[j]));
+        run += wj;
+    }
+    if (tid == 0) cdf[n] = 1.0;
+}
+
 __global__ __launch_bounds__(kBlock) void k_generate_pairs(uint64_t seed, uint64_t first, size_t n,
                                                           float *wi, float *wo, float *u)
 {
@@ -1044,6 +1117,16 @@ hipError_t launch_build_table(const double *d_planar, const int dims[3], const d
     else
         hipLaunchKernelGGL(k_build_rows, dim3(grid_for((size_t)(dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1), compute_units)), dim3(kBlock), 0, stream,
                            d_planar, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), scale[0], scale[1], scale[2], d_out);
+    return hipGetLastError();
+}
+
+// d_rows: n_ti x (2 n_th + 1) doubles; d_work: n_ti x n_th doubles.  m: the material with texels and the row marginal resident.
+hipError_t launch_build_sampling2d(const MaterialDev &m, const Options &opts, int n_ti, double *d_rows, double *d_work, hipStream_t stream)
+{
+    const dim3 grid((unsigned)m.n_th, (unsigned)n_ti);
+    if (m.layout == LAYOUT_BRICK) hipLaunchKernelGGL((k_sampling2d_mass<LAYOUT_BRICK>), grid, dim3(64), 0, stream, m, opts, n_ti, d_work);
+    else                          hipLaunchKernelGGL((k_sampling2d_mass<LAYOUT_ROWS>), grid, dim3(64), 0, stream, m, opts, n_ti, d_work);
+    hipLaunchKernelGGL(k_sampling2d_scan, dim3((unsigned)n_ti), dim3(kBlock), 0, stream, m.sampling, m.n_th, (const double *)d_work, d_rows);
     return hipGetLastError();
 }
 

@@ -54,6 +54,10 @@ hipError_t launch_partition_materials(const int32_t *mat, size_t n, int K, uint3
 // a1: planar f64 table (device copy of the file payload) -> padded rows or bricks
 hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, int param, float4 *d_out,
                               int compute_units, hipStream_t stream);
+// the conditional sampling table P(theta_h | theta_i) of a resident RGB table (MRL_OPT_SAMPLING = 2): a quadrature kernel
+// and a prefix-scan kernel; d_rows: n_ti x (2 n_th + 1) doubles, d_work: n_ti x n_th doubles
+constexpr int kSamplingIncidentBins = 32;
+hipError_t launch_build_sampling2d(const MaterialDev &m, const Options &opts, int n_ti, double *d_rows, double *d_work, hipStream_t stream);
 // ---- n-channel tables (merl_nch.hip): a.out_rgb / a.out_weight hold n x n_ch values ----
 constexpr int kMaxChannels = 32;
 size_t nch_brick_float4s(int n_ch);                      // float4s per cell: 2 (1 ch), 4 (2 ch), 8 * ceil(n_ch / 4)

@@ -179,10 +179,10 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
             cellA = nch_cell(n_th, n_td, n_pd, phi_periodic, maps(in, fast::dir_f32(wox, woy, woz)), a.opts, wA);
         if constexpr (HAS_SAMPLE) {
             if (a.opts.sampling && known) {                   // option is wave-uniform
-                fast::table_sample_dir(m, a.opts.disk_map, in, u0, u1, sx, sy, sz);
+                fast::table_sample_dir(m, a.opts.disk_map, in, u0, u1, sx, sy, sz, a.opts.sampling);
                 const bool up = sz > 0.0f;
                 if (!up) { sx = 0.0f; sy = 0.0f; sz = 1.0f; }
-                sp = up ? (float)fast::table_pdf(m, in, fast::normalize_f32(sx, sy, sz), sz) : 0.0f;
+                sp = up ? (float)fast::table_pdf(m, in, fast::normalize_f32(sx, sy, sz), sz, a.opts.sampling) : 0.0f;
             } else {
                 square_to_cosine_hemisphere(a.opts.disk_map, u0, u1, sx, sy, sz);
                 sp = sz > 0.0f ? sz * kInvPiF : 0.0f;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
         if (active) {
             if constexpr (mode_pdf(MODE)) {
                 float p = validA ? woz * kInvPiF : 0.0f;
-                if (a.opts.sampling && validA && known) p = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz);
+                if (a.opts.sampling && validA && known) p = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz, a.opts.sampling);
                 a.out_pdf[i] = p;
             }
             if constexpr (HAS_SAMPLE) {
@@ -333,17 +333,17 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
             lookup(fast::dir_f32(wox, woy, woz), valid, c, 1.0f, a.out_rgb);
             if constexpr (mode_pdf(MODE)) {
                 float p = valid ? woz * kInvPiF : 0.0f;
-                if (a.opts.sampling && valid && known) p = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz);
+                if (a.opts.sampling && valid && known) p = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz, a.opts.sampling);
                 if (active) a.out_pdf[i] = p;
             }
         }
         if constexpr (HAS_SAMPLE) {
             float sx, sy, sz, sp;
             if (a.opts.sampling && known) {                   // option is wave-uniform
-                fast::table_sample_dir(m, a.opts.disk_map, in, u0, u1, sx, sy, sz);
+                fast::table_sample_dir(m, a.opts.disk_map, in, u0, u1, sx, sy, sz, a.opts.sampling);
                 const bool up = sz > 0.0f;
                 if (!up) { sx = 0.0f; sy = 0.0f; sz = 1.0f; }
-                sp = up ? (float)fast::table_pdf(m, in, fast::normalize_f32(sx, sy, sz), sz) : 0.0f;
+                sp = up ? (float)fast::table_pdf(m, in, fast::normalize_f32(sx, sy, sz), sz, a.opts.sampling) : 0.0f;
             } else {
                 square_to_cosine_hemisphere(a.opts.disk_map, u0, u1, sx, sy, sz);
                 sp = sz > 0.0f ? sz * kInvPiF : 0.0f;

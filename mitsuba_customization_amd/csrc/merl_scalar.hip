@@ -57,7 +57,7 @@ __device__ __forceinline__ void table_unit(const MaterialDev &m, const Options &
     if (want != kWantSampleOnly) {
         fast::unit_eval<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, wox, woy, woz, out);
         float pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
-        if (o.sampling && pdf > 0.0f) pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz);
+        if (o.sampling && pdf > 0.0f) pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz, o.sampling);
         out[3] = pdf;
     }
     if (want != kWantEvalOnly) fast::unit_sample<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, u0, u1, out + 4, out[7], out + 8);

@@ -209,32 +209,33 @@ MRL_HD void unit_eval(const MaterialDev &m, const Options &o, const Vec3 &in,
 // ---- table importance sampling, tuned forms of merl_device.hpp::table_pdf / table_sample_dir ----
 MRL_HD void sincos_2pi(double u, double &s, double &c);      // merl_ggx_fast.hpp
 
-MRL_HD double table_pdf(const MaterialDev &m, const Vec3 &in, const Vec3 &out, float woz)
+MRL_HD double table_pdf(const MaterialDev &m, const Vec3 &in, const Vec3 &out, float woz, int mode)
 {
 #pragma clang fp contract(off)
+    const SamplingRow r = sampling_row(m, mode, in.z);
     double hx = in.x + out.x, hy = in.y + out.y, hz = in.z + out.z;
     double hs, hrs;
     sqrt_rsqrt(__builtin_fma(hx, hx, __builtin_fma(hy, hy, hz * hz)), hs, hrs);
     hx *= hrs; hy *= hrs; hz *= hrs;
-    const int i = bin_of(m.sampling, m.n_th, __builtin_fma(hx, hx, hy * hy));
+    const int i = bin_of(r.s, r.n, __builtin_fma(hx, hx, hy * hy));
     const double ih = __builtin_fma(in.x, hx, __builtin_fma(in.y, hy, in.z * hz));
-    const double ph = m.sampling[2 * (m.n_th + 1) + i] * hz * 0.25 * rcp_nr(__builtin_fmax(ih, kTiny));
-    return 0.5 * ((double)woz * 0.31830988618379067154) + 0.5 * ph;
+    const double ph = r.c[i] * hz * 0.25 * rcp_nr(__builtin_fmax(ih, kTiny));
+    return (double)r.alpha * ((double)woz * 0.31830988618379067154) + (1.0 - (double)r.alpha) * ph;
 }
 
 MRL_HD void table_sample_dir(const MaterialDev &m, int disk_map, const Vec3 &in, float u0, float u1,
-                                                 float &x, float &y, float &z)
+                                                 float &x, float &y, float &z, int mode)
 {
-    if (u0 < 0.5f) {
-        square_to_cosine_hemisphere(disk_map, 2.0f * u0, u1, x, y, z);
+    const SamplingRow r = sampling_row(m, mode, in.z);
+    if (u0 < r.alpha) {
+        square_to_cosine_hemisphere(disk_map, u0 * (1.0f / r.alpha), u1, x, y, z);
         return;
     }
-    const double *s = m.sampling, *cdf = m.sampling + (m.n_th + 1);
-    const double t = (double)(2.0f * u0 - 1.0f);
-    const int i = bin_of(cdf, m.n_th, t);
-    const double c0 = cdf[i], s0 = s[i];
-    const double xi = (t - c0) * rcp_nr(cdf[i + 1] - c0);
-    const double sin2 = __builtin_fma(xi, s[i + 1] - s0, s0);
+    const double t = (double)(u0 - r.alpha) * (1.0 / (1.0 - (double)r.alpha));
+    const int i = bin_of(r.cdf, r.n, t);
+    const double c0 = r.cdf[i], s0 = r.s[i];
+    const double xi = (t - c0) * rcp_nr(r.cdf[i + 1] - c0);
+    const double sin2 = __builtin_fma(xi, r.s[i + 1] - s0, s0);
     const double ct = sqrt_fast(__builtin_fmax(1.0 - sin2, 0.0)), st = sqrt_fast(sin2);
     double sp, cp;
     sincos_2pi((double)u1, sp, cp);
@@ -251,10 +252,10 @@ MRL_HD void unit_sample(const MaterialDev &m, const Options &o, const Vec3 &in,
 {
     float x, y, z, p;
     if (o.sampling) {                                       // wave-uniform
-        table_sample_dir(m, o.disk_map, in, u0, u1, x, y, z);
+        table_sample_dir(m, o.disk_map, in, u0, u1, x, y, z, o.sampling);
         const bool up = z > 0.0f;
         if (!up) { x = 0.0f; y = 0.0f; z = 1.0f; }          // rejected: evaluate a harmless direction, report zeros
-        p = up ? (float)table_pdf(m, in, normalize_f32(x, y, z), z) : 0.0f;
+        p = up ? (float)table_pdf(m, in, normalize_f32(x, y, z), z, o.sampling) : 0.0f;
     } else {
         square_to_cosine_hemisphere(o.disk_map, u0, u1, x, y, z);
         p = z > 0.0f ? z * kInvPiF : 0.0f;

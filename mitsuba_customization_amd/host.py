@@ -19,7 +19,7 @@ OPT_LOOKUP, OPT_NODE, OPT_DISK_MAP, OPT_KERNEL, OPT_HOST_CHUNK, OPT_TABLE_LAYOUT
 OPT_TABLE_PARAM = 10
 OPT_TABLE_ARENA_MB = 11
 PARAM_HALF_DIFF, PARAM_STANDARD, PARAM_STANDARD_FULL = 0, 1, 2          # enum mrl_param
-SAMPLING_COSINE, SAMPLING_TABLE = 0, 1
+SAMPLING_COSINE, SAMPLING_TABLE, SAMPLING_TABLE_2D = 0, 1, 2
 LAYOUT_ROWS, LAYOUT_BRICK = 0, 1
 LOOKUP_NEAREST, LOOKUP_TRILINEAR = 0, 1
 KIND_MERL, KIND_TABLE, KIND_GGX = 0, 1, 2
@@ -48,7 +48,7 @@ ABI_SYMBOLS = (
     "mrl_group_generate_tiles", "mrl_group_eval_sample_sharded", "mrl_group_eval_sharded", "mrl_group_eval_sample_batch", "mrl_group_synchronize",
     "mrl_group_eval_batch", "mrl_group_pdf_batch", "mrl_group_eval_pdf_batch", "mrl_group_sample_batch",
     "mrl_group_last_timing", "mrl_group_plan", "mrl_group_link_test",
-    "mrl_material_host_table", "mrl_host_table_retain", "mrl_host_table_release", "mrl_host_table_info",
+    "mrl_material_sampling2d", "mrl_material_host_table", "mrl_host_table_retain", "mrl_host_table_release", "mrl_host_table_info",
     "mrl_host_eval_pdf", "mrl_host_sample", "mrl_host_eval_sample",
 )
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_PEER_COPY = 0, 1, 2
@@ -381,6 +381,15 @@ class MerlHip:
         wo = (C.c_float * 3)(); pdf = C.c_float(); w = (C.c_float * 3)()
         self._check(self._lib.mrl_scalar_sample(self._ctx, int(material), a, c, wo, C.byref(pdf), w), "mrl_scalar_sample")
         return np.frombuffer(wo, dtype=np.float32).copy(), float(pdf.value), np.frombuffer(w, dtype=np.float32).copy()
+
+    def material_sampling2d(self, material: int = 0) -> np.ndarray:
+        """The conditional sampling table P(theta_h | theta_i) as the device built it: [n_ti, 2 n_th + 1] doubles (cdf | c)."""
+        n_ti, n_th = C.c_int(), C.c_int()
+        self._lib.mrl_material_sampling2d.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+        self._check(self._lib.mrl_material_sampling2d(self._ctx, int(material), C.byref(n_ti), C.byref(n_th), None, 0), "mrl_material_sampling2d")
+        out = np.empty((n_ti.value, 2 * n_th.value + 1), np.float64)
+        self._check(self._lib.mrl_material_sampling2d(self._ctx, int(material), None, None, out.ctypes.data, out.size), "mrl_material_sampling2d")
+        return out
 
     # ---- one-unit calls on the calling CPU thread (mrl_host_*) ----
     def host_table(self, material: int = 0) -> "HostTable":

@@ -30,7 +30,11 @@ class Table(C.Structure):
 
 
 class Sampling(C.Structure):
-    _fields_ = [("n", C.c_int), ("s", C.POINTER(C.c_double)), ("cdf", C.POINTER(C.c_double)), ("c", C.POINTER(C.c_double))]
+    _fields_ = [("n", C.c_int), ("s", C.POINTER(C.c_double)), ("cdf", C.POINTER(C.c_double)), ("c", C.POINTER(C.c_double)), ("alpha", C.c_double)]
+
+
+class Sampling2d(C.Structure):
+    _fields_ = [("n_i", C.c_int), ("rows", C.POINTER(Sampling))]
 
 
 class TableNch(C.Structure):
@@ -86,6 +90,11 @@ def lib():
         L.orc_free_sampling.argtypes = [C.POINTER(Sampling)]
         L.orc_pdf_table_batch.argtypes = [C.POINTER(Sampling), fp, fp, C.c_size_t, fp]
         L.orc_sample_table_batch.argtypes = [C.POINTER(Table), C.POINTER(Opts), C.POINTER(Sampling), fp, fp, C.c_size_t, fp, fp, fp]
+        L.orc_build_sampling2d.argtypes = [C.POINTER(Table), C.POINTER(Opts), C.c_int, C.POINTER(Sampling2d)]
+        L.orc_sampling2d_from_arrays.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(Sampling2d)]
+        L.orc_free_sampling2d.argtypes = [C.POINTER(Sampling2d)]
+        L.orc_pdf_table2d_batch.argtypes = [C.POINTER(Sampling2d), fp, fp, C.c_size_t, fp]
+        L.orc_sample_table2d_batch.argtypes = [C.POINTER(Table), C.POINTER(Opts), C.POINTER(Sampling2d), fp, fp, C.c_size_t, fp, fp, fp]
         L.orc_build_sampling_nch.argtypes = [C.POINTER(TableNch), C.POINTER(Sampling)]
         L.orc_eval_sample_batch_nch.argtypes = [C.POINTER(TableNch), C.c_int, C.c_int, C.POINTER(Opts), C.POINTER(Sampling), fp, fp, fp,
                                                 C.POINTER(C.c_int32), C.c_size_t, fp, fp, fp, fp, fp]
@@ -174,6 +183,41 @@ class OracleTable:
         wo = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32); w = np.empty((n, 3), np.float32)
         lib().orc_sample_table_batch(C.byref(self.c), C.byref(opts), C.byref(self.sampling()), pwi, pu, n,
                                      wo.ctypes.data_as(fp), pdf.ctypes.data_as(fp), w.ctypes.data_as(fp))
+        return wo, pdf, w
+
+    # ---- P(theta_h | theta_i): the two-dimensional conditional sampler (merl_oracle.h) ----
+    def sampling2d(self, n_i=32, opts=None, flat=None):
+        """The oracle's own build, or — flat given: [n_i, 2 n_th + 1] doubles — a table built elsewhere (the device's)."""
+        opts = opts or make_opts()
+        sp = Sampling2d()
+        if flat is None:
+            assert lib().orc_build_sampling2d(C.byref(self.c), C.byref(opts), int(n_i), C.byref(sp)) == 0
+        else:
+            flat = np.ascontiguousarray(flat, dtype=np.float64)
+            s = np.ascontiguousarray(self.sampling_arrays()[0])
+            assert flat.shape == (n_i, 2 * self.c.n_th + 1)
+            assert lib().orc_sampling2d_from_arrays(int(n_i), self.c.n_th, _dp(s), _dp(flat), C.byref(sp)) == 0
+        return sp
+
+    def sampling2d_arrays(self, sp):
+        n = self.c.n_th
+        return np.stack([np.concatenate([np.ctypeslib.as_array(sp.rows[i].cdf, (n + 1,)), np.ctypeslib.as_array(sp.rows[i].c, (n,))])
+                         for i in range(sp.n_i)]).copy()
+
+    def pdf_table2d(self, sp, wi, wo):
+        wi, pwi = _f32(wi); wo, pwo = _f32(wo)
+        out = np.empty(wi.shape[0], np.float32)
+        lib().orc_pdf_table2d_batch(C.byref(sp), pwi, pwo, wi.shape[0], out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def sample_table2d(self, sp, wi, u, opts=None):
+        opts = opts or make_opts()
+        wi, pwi = _f32(wi); u, pu = _f32(u)
+        n = wi.shape[0]
+        fp = C.POINTER(C.c_float)
+        wo = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32); w = np.empty((n, 3), np.float32)
+        lib().orc_sample_table2d_batch(C.byref(self.c), C.byref(opts), C.byref(sp), pwi, pu, n,
+                                       wo.ctypes.data_as(fp), pdf.ctypes.data_as(fp), w.ctypes.data_as(fp))
         return wo, pdf, w
 
     def lookup(self, th, td, pd, opts=None):

@@ -369,6 +369,7 @@ int orc_build_sampling(const orc_table *t, orc_sampling *out)
         out->c[i] = D[i] / (M_PI * Z);
     }
     out->cdf[n] = 1.0;
+    out->alpha = 0.5;
     free(D);
     return 0;
 }
@@ -401,7 +402,7 @@ static double pdf_table_f64(const orc_sampling *sp, const float wi[3], const flo
     int i = bin_of(sp->s, sp->n, sin2);
     double ih = in[0] * h[0] + in[1] * h[1] + in[2] * h[2];
     double ph = sp->c[i] * h[2] / (4.0 * ih);
-    return 0.5 * ((double)wo[2] * (1.0 / M_PI)) + 0.5 * ph;
+    return sp->alpha * ((double)wo[2] * (1.0 / M_PI)) + (1.0 - sp->alpha) * ph;
 }
 
 float orc_pdf_table(const orc_sampling *sp, const float wi[3], const float wo[3])
@@ -415,11 +416,12 @@ void orc_sample_table(const orc_table *t, const orc_opts *o, const orc_sampling 
     wo[0] = wo[1] = wo[2] = 0.0f; *pdf = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
     if (!(wi[2] > 0.0f)) return;
     float d[3];
-    if (u[0] < 0.5f) {
-        const float uu[2] = { 2.0f * u[0], u[1] };
+    const float alpha = (float)sp->alpha;                     /* 1/2 or 1/8: u / alpha and u - alpha are exact in Float */
+    if (u[0] < alpha) {
+        const float uu[2] = { u[0] * (1.0f / alpha), u[1] };
         orc_square_to_cosine_hemisphere(o->disk_map, uu, d);
     } else {
-        double x = (double)(2.0f * u[0] - 1.0f);
+        double x = (double)(u[0] - alpha) * (1.0 / (1.0 - sp->alpha));
         int i = bin_of(sp->cdf, sp->n, x);
         double xi = (x - sp->cdf[i]) / (sp->cdf[i + 1] - sp->cdf[i]);
         double sin2 = sp->s[i] + xi * (sp->s[i + 1] - sp->s[i]);
@@ -449,6 +451,129 @@ void orc_sample_table_batch(const orc_table *t, const orc_opts *o, const orc_sam
                             size_t n, float *wo, float *pdf, float *weight)
 {
     for (size_t i = 0; i < n; ++i) orc_sample_table(t, o, sp, wi + 3 * i, u + 2 * i, wo + 3 * i, pdf + i, weight + 3 * i);
+}
+
+/* ---- §8f item 2, survey form: P(theta_h | theta_i) (definition: merl_oracle.h) ---- */
+static double brdf_mass_sample(const orc_table *t, const orc_opts *o, double mu, double s, double phi)
+{
+    /* lum f(wi, wo) cos(theta_o) 4 (wi.h) / (2 cos(theta_h)) for wi = (sqrt(1 - mu^2), 0, mu), h from (s, phi) */
+    const double in[3] = { sqrt(1.0 - mu * mu > 0.0 ? 1.0 - mu * mu : 0.0), 0.0, mu };
+    const double st = sqrt(s), ct = sqrt(1.0 - s > 0.0 ? 1.0 - s : 0.0);
+    const double h[3] = { st * cos(phi), st * sin(phi), ct };
+    const double c = in[0] * h[0] + in[1] * h[1] + in[2] * h[2];
+    if (!(c > 0.0) || !(ct > 0.0)) return 0.0;
+    double out[3] = { 2.0 * c * h[0] - in[0], 2.0 * c * h[1] - in[1], 2.0 * c * h[2] - in[2] };
+    if (!(out[2] > 0.0)) return 0.0;
+    double uin[3] = { in[0], in[1], in[2] }, a[3], rgb[3];
+    unit3(uin); unit3(out);
+    orc_table_angles(t, uin, out, a);
+    orc_lookup(t, o, a[0], a[1], a[2], rgb);
+    const double lum = 0.2126 * rgb[0] + 0.7152 * rgb[1] + 0.0722 * rgb[2];
+    return lum * out[2] * 4.0 * c / (2.0 * ct);
+}
+
+int orc_build_sampling2d(const orc_table *t, const orc_opts *o, int n_i, orc_sampling2d *out)
+{
+    const int n = t->n_th;
+    out->n_i = 0; out->rows = NULL;
+    if (n_i < 1 || n < 1) return -1;
+    out->rows = (orc_sampling *)calloc((size_t)n_i, sizeof(orc_sampling));
+    double *W = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!out->rows || !W) { free(W); free(out->rows); out->rows = NULL; return -4; }
+    out->n_i = n_i;
+    orc_opts lo = *o;
+    lo.lookup = 1;                                            /* the mass is measured with the interpolated table */
+    for (int i = 0; i < n_i; ++i) {
+        orc_sampling *r = &out->rows[i];
+        r->n = n;
+        r->s = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+        r->cdf = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+        r->c = (double *)malloc(sizeof(double) * (size_t)n);
+        if (!r->s || !r->cdf || !r->c) { free(W); orc_free_sampling2d(out); return -4; }
+        for (int j = 0; j <= n; ++j) {
+            const double q = (double)j / (double)n, sn = sin(q * q * (M_PI / 2.0));
+            r->s[j] = j == n ? 1.0 : sn * sn;
+        }
+        const double mu = ((double)i + 0.5) / (double)n_i;
+        double total = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double ds = r->s[j + 1] - r->s[j];
+            double acc = 0.0;
+            if (t->param == ORC_PARAM_HALF_DIFF)
+                for (int a = 0; a < ORC_S2D_KS; ++a)
+                    for (int b = 0; b < ORC_S2D_KP; ++b)
+                        acc += brdf_mass_sample(t, &lo, mu, r->s[j] + ((double)a + 0.5) / ORC_S2D_KS * ds, ((double)b + 0.5) / ORC_S2D_KP * M_PI);
+            W[j] = ds * acc / (double)(ORC_S2D_KS * ORC_S2D_KP);
+            total += W[j];
+        }
+        /* the floor: 1 % of the row's mass, uniform in s (a flat row when the table gives nothing, e.g. a standard parameterisation) */
+        const double span = r->s[n] - r->s[0];
+        double Z = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double ds = r->s[j + 1] - r->s[j];
+            W[j] = total > 0.0 ? W[j] + 0.01 * total * ds / span : ds / span;
+            Z += W[j];
+        }
+        double run = 0.0;
+        for (int j = 0; j < n; ++j) {
+            r->cdf[j] = run / Z;
+            run += W[j];
+            r->c[j] = W[j] / (Z * M_PI * (r->s[j + 1] - r->s[j]));
+        }
+        r->cdf[n] = 1.0;
+        r->alpha = 0.125;
+    }
+    free(W);
+    return 0;
+}
+
+int orc_sampling2d_from_arrays(int n_i, int n, const double *s, const double *flat, orc_sampling2d *out)
+{
+    out->n_i = 0; out->rows = NULL;
+    if (n_i < 1 || n < 1 || !s || !flat) return -1;
+    out->rows = (orc_sampling *)calloc((size_t)n_i, sizeof(orc_sampling));
+    if (!out->rows) return -4;
+    out->n_i = n_i;
+    for (int i = 0; i < n_i; ++i) {
+        orc_sampling *r = &out->rows[i];
+        r->n = n;
+        r->s = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+        r->cdf = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+        r->c = (double *)malloc(sizeof(double) * (size_t)n);
+        if (!r->s || !r->cdf || !r->c) { orc_free_sampling2d(out); return -4; }
+        memcpy(r->s, s, sizeof(double) * (size_t)(n + 1));
+        memcpy(r->cdf, flat + (size_t)i * (size_t)(2 * n + 1), sizeof(double) * (size_t)(n + 1));
+        memcpy(r->c, flat + (size_t)i * (size_t)(2 * n + 1) + (size_t)(n + 1), sizeof(double) * (size_t)n);
+        r->alpha = 0.125;
+    }
+    return 0;
+}
+
+void orc_free_sampling2d(orc_sampling2d *sp)
+{
+    if (sp->rows) for (int i = 0; i < sp->n_i; ++i) orc_free_sampling(&sp->rows[i]);
+    free(sp->rows);
+    sp->rows = NULL; sp->n_i = 0;
+}
+
+int orc_sampling2d_bin(const orc_sampling2d *sp, const float wi[3])
+{
+    double in[3] = { wi[0], wi[1], wi[2] };
+    unit3(in);
+    int i = (int)(in[2] * (double)sp->n_i);
+    return i < 0 ? 0 : (i >= sp->n_i ? sp->n_i - 1 : i);
+}
+
+void orc_pdf_table2d_batch(const orc_sampling2d *sp, const float *wi, const float *wo, size_t n, float *pdf)
+{
+    for (size_t k = 0; k < n; ++k) pdf[k] = orc_pdf_table(&sp->rows[orc_sampling2d_bin(sp, wi + 3 * k)], wi + 3 * k, wo + 3 * k);
+}
+
+void orc_sample_table2d_batch(const orc_table *t, const orc_opts *o, const orc_sampling2d *sp, const float *wi, const float *u,
+                              size_t n, float *wo, float *pdf, float *weight)
+{
+    for (size_t k = 0; k < n; ++k)
+        orc_sample_table(t, o, &sp->rows[orc_sampling2d_bin(sp, wi + 3 * k)], wi + 3 * k, u + 2 * k, wo + 3 * k, pdf + k, weight + 3 * k);
 }
 
 /* ---- batches ---- */
@@ -601,6 +726,7 @@ int orc_build_sampling_nch(const orc_table_nch *t, orc_sampling *out)
         out->c[i] = D[i] / (M_PI * Z);
     }
     out->cdf[n] = 1.0;
+    out->alpha = 0.5;
     free(D);
     return 0;
 }

@@ -120,6 +120,7 @@ typedef struct orc_sampling {
     double *s;        /* [n+1] sin^2(theta_i) */
     double *cdf;      /* [n+1] */
     double *c;        /* [n]   */
+    double alpha;     /* weight of the cosine lobe in the one-sample mixture: 1/2 (the row marginal), 1/8 (a row of the 2-D table) */
 } orc_sampling;
 int   orc_build_sampling(const orc_table *t, orc_sampling *out);
 void  orc_free_sampling(orc_sampling *sp);
@@ -129,6 +130,35 @@ void  orc_sample_table(const orc_table *t, const orc_opts *o, const orc_sampling
 void  orc_pdf_table_batch(const orc_sampling *sp, const float *wi, const float *wo, size_t n, float *pdf);
 void  orc_sample_table_batch(const orc_table *t, const orc_opts *o, const orc_sampling *sp, const float *wi, const float *u,
                              size_t n, float *wo, float *pdf, float *weight);
+
+/* ---- §8f item 2, survey form: conditional CDFs in two dimensions, P(theta_h | theta_i) --------------------------
+ * The 1-D lobe above knows how bright a theta_h row is on average; it does not know that the lobe a surface shows depends
+ * on the incident angle (Fresnel towards grazing, the 1 / (cos_i cos_o) of a microfacet shape, shadowed halves of the
+ * hemisphere).  Here the half-vector lobe is conditional on the incident direction: n_i bins of mu = cos(theta_i)
+ * (uniform in mu, bin i = [i / n_i, (i + 1) / n_i), centre mu_i), and per bin its own row distribution over the table's
+ * theta_h bins.  The mass of (i, j) is what the BRDF itself puts there, measured in half-vector space:
+ *     W_ij = ds_j * mean over K_s x K_p midpoints (s, phi) of  [ lum f(wi_i, wo) * cos(theta_o) * 4 (wi_i . h) / (2 cos(theta_h)) ]
+ * with wi_i = (sqrt(1 - mu_i^2), 0, mu_i), s = sin^2(theta_h) uniform in the bin, phi in (0, pi) (the table is symmetric
+ * in phi), h = (sqrt(s) cos phi, sqrt(s) sin phi, sqrt(1 - s)), wo = reflect(wi_i, h); samples with wi.h <= 0 or wo below
+ * the horizon contribute 0; f is the table's own trilinear lookup; + a floor of 1 % of the row's mass spread uniformly in s.
+ * A row is then exactly an orc_sampling (same s, its own cdf and c), and sample() / pdf() are the 1-D ones on the row of
+ * wi's bin — a valid density for every wi, piecewise constant in mu.  Because the row follows the BRDF itself (diffuse floor
+ * included) the cosine lobe only has to keep the estimator bounded: its mixture weight is alpha = 1/8 instead of 1/2
+ * (u1 < alpha -> cosine with (u1 / alpha, u2); else the row CDF with (u1 - alpha) / (1 - alpha)). */
+#define ORC_S2D_KS 4
+#define ORC_S2D_KP 16
+typedef struct orc_sampling2d {
+    int n_i;               /* incident bins */
+    orc_sampling *rows;    /* [n_i], rows[i].s all equal */
+} orc_sampling2d;
+int   orc_build_sampling2d(const orc_table *t, const orc_opts *o, int n_i, orc_sampling2d *out);
+/* a table built elsewhere (the device's prefix-scan build, downloaded): flat[n_i][(n+1) cdf | n c], s: [n+1] */
+int   orc_sampling2d_from_arrays(int n_i, int n, const double *s, const double *flat, orc_sampling2d *out);
+void  orc_free_sampling2d(orc_sampling2d *sp);
+int   orc_sampling2d_bin(const orc_sampling2d *sp, const float wi[3]);
+void  orc_pdf_table2d_batch(const orc_sampling2d *sp, const float *wi, const float *wo, size_t n, float *pdf);
+void  orc_sample_table2d_batch(const orc_table *t, const orc_opts *o, const orc_sampling2d *sp, const float *wi, const float *u,
+                               size_t n, float *wo, float *pdf, float *weight);
 
 /* ---- §8f item 3 ("next"): n-channel tables (customized_measurement beyond RGB) ---------------------------
  * Same parameterisation, transform, index maps and trilinear blend; a texel has n_ch values (planar: channel c at

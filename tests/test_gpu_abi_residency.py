@@ -17,20 +17,21 @@ def test_memory_info_counts_resident_tables(tables):
         assert g.memory_info()["table_bytes"] == 0
         a = g.upload_merl(tables("ggx_tab", 0))
         one = g.memory_info()
-        assert MERL_BRICK_BYTES <= one["table_bytes"] <= MERL_BRICK_BYTES + 4096      # + the sampling marginal (272 doubles)
+        assert MERL_BRICK_BYTES <= one["table_bytes"] <= MERL_BRICK_BYTES + 65536     # + the sampling marginal (272 doubles) + the conditional table (32 x 181 doubles)
         assert 0 < one["device_free"] < one["device_total"]
         g.ggx(0.1, (1, 1, 1), (2, 2, 2))
         assert g.memory_info()["table_bytes"] == one["table_bytes"]                    # analytic materials hold no table
         b = g.upload_table(tables("noise", 3, (8, 8, 16)))
-        assert g.memory_info()["table_bytes"] == one["table_bytes"] + 8 * 8 * 16 * 128 + (3 * 8 + 2) * 8
+        small = 8 * 8 * 16 * 128 + (3 * 8 + 2) * 8 + 32 * (2 * 8 + 1) * 8       # bricks + row marginal + 32 conditional rows of (2 n_th + 1) doubles
+        assert g.memory_info()["table_bytes"] == one["table_bytes"] + small
         g.release_material(a)
-        assert g.memory_info()["table_bytes"] == 8 * 8 * 16 * 128 + (3 * 8 + 2) * 8
+        assert g.memory_info()["table_bytes"] == small
         g.release_material(b)
         assert g.memory_info()["table_bytes"] == 0
     with host.MerlHip(0) as g:
         g.set_option(host.OPT_TABLE_LAYOUT, host.LAYOUT_ROWS)
         g.upload_merl(tables("ggx_tab", 0))
-        assert MERL_ROWS_BYTES <= g.memory_info()["table_bytes"] <= MERL_ROWS_BYTES + 4096
+        assert MERL_ROWS_BYTES <= g.memory_info()["table_bytes"] <= MERL_ROWS_BYTES + 65536
 
 
 def test_release_gives_memory_back_and_tombstones_render_zero(oracle, tables):
@@ -92,7 +93,7 @@ def test_upload_release_cycles_keep_free_memory_flat(tables):
             assert mid == 1
             g.release_material(mid)
             assert abs(g.memory_info()["device_free"] - base) <= (64 << 20)
-        assert g.memory_info()["table_bytes"] <= MERL_BRICK_BYTES + 4096
+        assert g.memory_info()["table_bytes"] <= MERL_BRICK_BYTES + 65536
 
 
 def test_memory_budget_and_oom(tables):
