@@ -76,6 +76,21 @@ def measured_traffic(variant: int, layout: int, units: int, config: str):
     return None
 
 
+def measured_valu():
+    """Executed VALU instructions per unit of the dominant kernel, from the committed SQ counter passes (profiles/valu.json)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "valu.json")))
+    except Exception:
+        return None
+
+
+# SURVEY.md §8d "Flops" row: the VALU reading.  256 CU x 4 SIMD x 2.4 GHz; a wave-instruction occupies its SIMD for 4 cycles at
+# the f64 / full-width rate (16 lanes per clock: 78.6 TFLOPS f64 FMA = 39.3 T lane-instructions/s) and for 2 at the plain-f32
+# rate (157.3 TFLOPS f32 FMA = 78.6 T lane-instructions/s) — tools/microbench/valu_issue.hip, profiles/r03_valu_issue.json.
+VALU_PEAK_T_LANE_INSTS_F64_RATE = 39.3
+VALU_PEAK_T_LANE_INSTS_F32_RATE = 78.6
+
+
 def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -410,6 +425,20 @@ def main():
                 "gather (192 B/unit algorithmic, 256 B/unit fetched as two 128-B lines) crosses the fabric too: with_gather "
                 "prices stream + gather bytes against the same peak",
     }
+    valu = measured_valu() if args.config == "merl64m" else None
+    if valu:
+        lane_insts = valu["valu_insts_per_unit"] * n / (kernel_ms * 1e-3) / 1e12
+        roofline["valu"] = {
+            "what": "SURVEY.md §8d 'Flops' row: executed VALU instructions per unit (one lane = one unit; SQ_INSTS_VALU per wave-iteration) x units/s, "
+                    "against the chip's vector issue rate — not the bound of this launch on random inputs (the fabric is), the bound on cache-served ones",
+            "valu_insts_per_unit": valu["valu_insts_per_unit"], "f64_arith_per_unit": valu["f64_fma_mul_add_per_unit"],
+            "f64_transcendental_per_unit": valu["f64_transcendental_per_unit"], "convert_per_unit": valu["convert_per_unit"],
+            "T_lane_insts_per_s": round(lane_insts, 2),
+            "frac_of_f64_rate_peak": round(lane_insts / VALU_PEAK_T_LANE_INSTS_F64_RATE, 4),
+            "frac_of_f32_rate_peak": round(lane_insts / VALU_PEAK_T_LANE_INSTS_F32_RATE, 4),
+            "peaks_T_lane_insts_per_s": {"f64_rate (78.6 TFLOPS f64 FMA / 2)": VALU_PEAK_T_LANE_INSTS_F64_RATE, "f32_rate (157.3 TFLOPS f32 FMA / 2)": VALU_PEAK_T_LANE_INSTS_F32_RATE},
+            "measured_on": valu.get("library"), "stale": valu.get("library") != lib_sources, "source": valu.get("source"),
+        }
     if traffic:
         gbps = traffic["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
         roofline["fabric_traffic"] = {
