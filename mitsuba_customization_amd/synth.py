@@ -256,3 +256,36 @@ def write_tensor_file(path: str, fields: dict) -> None:
         for a, off in zip(arrays, offsets):
             f.write(b"\0" * (off - f.tell()))
             f.write(a.astype(a.dtype.newbyteorder("<")).tobytes())
+
+
+# ------------------------------------------------------------------ synthetic RGL *.bsdf fields (the adaptive parameterisation)
+def make_rgl_fields(seed: int = 0, n_phi: int = 1, n_theta: int = 6, res: int = 12, res_ndf: int = 16, res_sigma: int = 8) -> dict:
+    """Fields of an RGL material-database file with the real names and shapes (what upstream Mitsuba 3's `measured` reads):
+    phi_i [n_phi], theta_i [n_theta], ndf [res_ndf, res_ndf], sigma [res_sigma, res_sigma], vndf / luminance
+    [n_phi, n_theta, res, res], rgb [n_phi, n_theta, 3, res, res], jacobian [1], description.  n_phi <= 2: isotropic.
+    No measured file exists offline: the tables are smooth, strictly positive synthetic functions (a lobe + seeded
+    low-frequency variation) — they exercise every code path of the model, they are not a material."""
+    rng = np.random.default_rng(seed)
+
+    def smooth(shape, lobe=2.0):
+        ny, nx = shape[-2:]
+        y, x = np.meshgrid((np.arange(ny) + 0.5) / ny, (np.arange(nx) + 0.5) / nx, indexing="ij")
+        out = np.empty(shape, np.float64)
+        lead = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+        flat = out.reshape(lead, ny, nx)
+        for k in range(lead):
+            a, b, c, d = rng.uniform(0.5, 3.0, 4)
+            px, py = rng.uniform(0.2, 0.8, 2)
+            flat[k] = 0.15 + np.exp(-lobe * a * (x - px) ** 2 - lobe * b * (y - py) ** 2) * (1.0 + 0.3 * np.sin(c * 6.0 * x) * np.cos(d * 5.0 * y))
+        return out.astype(np.float32)
+
+    theta_i = np.linspace(0.0, 0.5 * np.pi * 0.97, n_theta).astype(np.float32)
+    phi_i = (np.zeros(1) if n_phi == 1 else np.linspace(-np.pi, np.pi, n_phi)).astype(np.float32)
+    return {
+        "description": np.frombuffer(b"synthetic RGL-shaped fields (mitsuba_customization_amd.synth.make_rgl_fields)", np.uint8).copy(),
+        "phi_i": phi_i, "theta_i": theta_i,
+        "ndf": smooth((res_ndf, res_ndf), 4.0), "sigma": (0.4 + smooth((res_sigma, res_sigma), 1.0)).astype(np.float32),
+        "vndf": smooth((n_phi, n_theta, res, res), 3.0), "luminance": smooth((n_phi, n_theta, res, res), 1.0),
+        "rgb": (0.05 + 0.5 * smooth((n_phi, n_theta, 3, res, res), 1.5)).astype(np.float32),
+        "jacobian": np.array([1], np.uint8),
+    }

@@ -51,10 +51,9 @@ class Bsdf(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "merl_oracle.c")
-    hdr = os.path.join(_HERE, "merl_oracle.h")
+    srcs = [os.path.join(_HERE, f) for f in ("merl_oracle.c", "merl_oracle.h", "rgl_oracle.c", "rgl_oracle.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
     return _LIB_PATH
@@ -388,3 +387,109 @@ def bench_ggx(alpha, eta, k, n, n_threads, seed=0x5EED, with_sample=True):
     fn = lib().orc_bench_eval_sample if with_sample else lib().orc_bench_eval
     s = fn(C.byref(b), seed, 0, n, n_threads, C.byref(chk))
     return s, chk.value
+
+
+# ------------------------------------------------------------------ the RGL adaptive-parameterisation BSDF (rgl_oracle.c)
+class RglWarp(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("n_dim", C.c_int), ("n_par", C.c_int * 3), ("stride", C.c_int * 3), ("n_slices", C.c_int),
+                ("par", C.POINTER(C.c_float) * 3), ("data", C.POINTER(C.c_float)), ("marg", C.POINTER(C.c_float)), ("cond", C.POINTER(C.c_float)),
+                ("normalized", C.c_int)]
+
+
+class RglBsdf(C.Structure):
+    _fields_ = [("isotropic", C.c_int), ("jacobian", C.c_int), ("ndf", RglWarp), ("sigma", RglWarp), ("vndf", RglWarp), ("luminance", RglWarp), ("rgb", RglWarp)]
+
+
+def _rgl_lib():
+    L = lib()
+    if not getattr(L, "_rgl_ready", False):
+        fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        L.rgl_warp_init.argtypes = [C.POINTER(RglWarp), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(fp), fp, C.c_int, C.c_int]
+        L.rgl_warp_free.argtypes = [C.POINTER(RglWarp)]
+        L.rgl_warp_eval.argtypes = [C.POINTER(RglWarp), dp, dp]; L.rgl_warp_eval.restype = C.c_double
+        L.rgl_warp_sample.argtypes = [C.POINTER(RglWarp), dp, dp, dp, dp]
+        L.rgl_warp_invert.argtypes = [C.POINTER(RglWarp), dp, dp, dp, dp]
+        L.rgl_bsdf_init.argtypes = [C.POINTER(RglBsdf), C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, C.c_int]
+        L.rgl_bsdf_free.argtypes = [C.POINTER(RglBsdf)]
+        L.rgl_eval_pdf_batch.argtypes = [C.POINTER(RglBsdf), fp, fp, C.c_size_t, fp, fp]
+        L.rgl_sample_batch.argtypes = [C.POINTER(RglBsdf), fp, fp, C.c_size_t, fp, fp, fp]
+        L._rgl_ready = True
+    return L
+
+
+class OracleWarp:
+    """rgl_warp: data [n_slices..., ny, nx] float32, params: list of ascending float32 grids (one per leading axis)."""
+
+    def __init__(self, data, params=(), normalize=True, build_cdf=True):
+        L = _rgl_lib()
+        self.data = np.ascontiguousarray(data, np.float32)
+        self.params = [np.ascontiguousarray(p, np.float32) for p in params]
+        assert self.data.ndim == 2 + len(self.params)
+        ny, nx = self.data.shape[-2:]
+        n_par = (C.c_int * 3)(*[len(p) for p in self.params] + [0] * (3 - len(self.params)))
+        fp = C.POINTER(C.c_float)
+        par = (fp * 3)(*[p.ctypes.data_as(fp) for p in self.params] + [None] * (3 - len(self.params)))
+        self.c = RglWarp()
+        assert L.rgl_warp_init(C.byref(self.c), nx, ny, len(self.params), n_par, par, self.data.ctypes.data_as(fp), int(normalize), int(build_cdf)) == 0
+
+    def _p(self, params):
+        return (C.c_double * 3)(*list(params) + [0.0] * (3 - len(params)))
+
+    def eval(self, pos, params=()):
+        return _rgl_lib().rgl_warp_eval(C.byref(self.c), (C.c_double * 2)(*pos), self._p(params))
+
+    def sample(self, u, params=()):
+        pos = (C.c_double * 2)(); pdf = C.c_double()
+        _rgl_lib().rgl_warp_sample(C.byref(self.c), (C.c_double * 2)(*u), self._p(params), pos, C.byref(pdf))
+        return (pos[0], pos[1]), pdf.value
+
+    def invert(self, pos, params=()):
+        u = (C.c_double * 2)(); pdf = C.c_double()
+        _rgl_lib().rgl_warp_invert(C.byref(self.c), (C.c_double * 2)(*pos), self._p(params), u, C.byref(pdf))
+        return (u[0], u[1]), pdf.value
+
+    def __del__(self):
+        try:
+            _rgl_lib().rgl_warp_free(C.byref(self.c))
+        except Exception:
+            pass
+
+
+class OracleRgl:
+    """The BSDF over the fields of an RGL *.bsdf file (dict of arrays: phi_i, theta_i, ndf, sigma, vndf, luminance, rgb[, jacobian])."""
+
+    def __init__(self, fields):
+        L = _rgl_lib()
+        f32 = lambda k: np.ascontiguousarray(fields[k], np.float32)
+        self.f = {k: f32(k) for k in ("phi_i", "theta_i", "ndf", "sigma", "vndf", "luminance", "rgb")}
+        fp = C.POINTER(C.c_float)
+        p = lambda k: self.f[k].ctypes.data_as(fp)
+        vn = self.f["vndf"].shape
+        assert self.f["rgb"].shape == (vn[0], vn[1], 3, vn[2], vn[3]) and self.f["luminance"].shape == vn
+        jac = int(np.asarray(fields.get("jacobian", 1)).reshape(-1)[0])
+        self.c = RglBsdf()
+        rc = L.rgl_bsdf_init(C.byref(self.c), vn[0], vn[1], p("phi_i"), p("theta_i"), self.f["ndf"].shape[1], self.f["ndf"].shape[0], p("ndf"),
+                             self.f["sigma"].shape[1], self.f["sigma"].shape[0], p("sigma"), vn[3], vn[2], p("vndf"), p("luminance"), p("rgb"), jac)
+        assert rc == 0, rc
+
+    def eval_pdf(self, wi, wo):
+        wi, pwi = _f32(wi); wo, pwo = _f32(wo)
+        n = wi.shape[0]
+        fp = C.POINTER(C.c_float)
+        rgb = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32)
+        _rgl_lib().rgl_eval_pdf_batch(C.byref(self.c), pwi, pwo, n, rgb.ctypes.data_as(fp), pdf.ctypes.data_as(fp))
+        return rgb, pdf
+
+    def sample(self, wi, u):
+        wi, pwi = _f32(wi); u, pu = _f32(u)
+        n = wi.shape[0]
+        fp = C.POINTER(C.c_float)
+        wo = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32); w = np.empty((n, 3), np.float32)
+        _rgl_lib().rgl_sample_batch(C.byref(self.c), pwi, pu, n, wo.ctypes.data_as(fp), pdf.ctypes.data_as(fp), w.ctypes.data_as(fp))
+        return wo, pdf, w
+
+    def __del__(self):
+        try:
+            _rgl_lib().rgl_bsdf_free(C.byref(self.c))
+        except Exception:
+            pass

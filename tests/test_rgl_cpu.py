@@ -1,0 +1,116 @@
+"""The RGL adaptive-parameterisation BSDF (the "*.bsdf tensor format of upstream M3 `measured`") — the
+oracle's restatement (oracle/rgl_oracle.c) pinned by self-consistency on the CPU.  PARITY UNPINNED: no measured file, no upstream
+plugin and no reference vector exist in the container; what is checked is that the restated model is a consistent
+distribution machinery — the piecewise-bilinear warp's sample / invert / eval agree with each other and with closed forms, the
+BSDF's pdf is a density, sample() reports it, weight == eval / pdf."""
+import numpy as np
+import pytest
+
+from mitsuba_customization_amd import synth
+from oracle import binding as ob
+
+
+def test_constant_warp_is_the_identity():
+    w = ob.OracleWarp(np.ones((5, 7), np.float32))
+    for u in ((0.3, 0.8), (0.0, 0.0), (0.999, 0.001), (0.5, 0.5)):
+        pos, pdf = w.sample(u)
+        assert np.allclose(pos, u, atol=1e-7) and abs(pdf - 1) < 1e-6
+        assert np.allclose(w.invert(u)[0], u, atol=1e-7) and abs(w.eval(u) - 1) < 1e-6
+
+
+@pytest.mark.parametrize("params", [(), (0.3, 0.6)])
+def test_sample_and_invert_are_inverse_and_agree_with_eval(params):
+    rng = np.random.default_rng(3)
+    grids = [np.array([0.0, 0.5, 1.0], np.float32), np.array([0.0, 0.2, 0.7, 1.0], np.float32)][:len(params)]
+    shape = tuple(len(g) for g in grids) + (9, 13)
+    w = ob.OracleWarp((rng.random(shape) + 0.05).astype(np.float32), grids)
+    for u in rng.random((400, 2)):
+        pos, pdf = w.sample(u, params)
+        back, pdf2 = w.invert(pos, params)
+        assert np.allclose(back, u, atol=2e-9), (u, pos, back)
+        assert abs(pdf - pdf2) <= 1e-12 * pdf and abs(pdf - w.eval(pos, params)) <= 1e-12 * pdf
+        assert 0 <= pos[0] <= 1 and 0 <= pos[1] <= 1
+    # the density integrates to one at interpolated parameters: a bilinear patch integrates to the mean of its corners
+    ny, nx = 9, 13
+    tot = sum(0.25 * (w.eval((x / (nx - 1), y / (ny - 1)), params) + w.eval(((x + 1) / (nx - 1), y / (ny - 1)), params) +
+                      w.eval((x / (nx - 1), (y + 1) / (ny - 1)), params) + w.eval(((x + 1) / (nx - 1), (y + 1) / (ny - 1)), params))
+              for x in range(nx - 1) for y in range(ny - 1)) / ((nx - 1) * (ny - 1))
+    assert abs(tot - 1) < 2e-6
+
+
+def test_unnormalised_warp_is_bilinear_interpolation_of_the_data():
+    rng = np.random.default_rng(9)
+    d = rng.random((6, 5)).astype(np.float32)
+    w = ob.OracleWarp(d, normalize=False, build_cdf=False)
+    for x, y in rng.random((100, 2)):
+        px, py = x * 4, y * 5
+        i, j = min(int(px), 3), min(int(py), 4)
+        fx, fy = px - i, py - j
+        want = (1 - fy) * ((1 - fx) * d[j, i] + fx * d[j, i + 1]) + fy * ((1 - fx) * d[j + 1, i] + fx * d[j + 1, i + 1])
+        assert abs(w.eval((x, y)) - want) < 1e-12
+    # a parameter exactly on a grid node selects that slice (the rgb channel axis works that way)
+    s = rng.random((3, 4, 4)).astype(np.float32)
+    w3 = ob.OracleWarp(s, [np.array([0, 1, 2], np.float32)], normalize=False, build_cdf=False)
+    for c in range(3):
+        assert abs(w3.eval((0.0, 0.0), (float(c),)) - s[c, 0, 0]) < 1e-12
+
+
+@pytest.mark.parametrize("n_phi", [1, 5])
+def test_bsdf_pdf_is_a_density_and_sample_reports_it(n_phi):
+    B = ob.OracleRgl(synth.make_rgl_fields(4, n_phi=n_phi))
+    rng = np.random.default_rng(21)
+    for mu, az in ((0.95, 0.3), (0.6, -2.0), (0.25, 1.1)):
+        wi1 = np.array([np.sqrt(1 - mu * mu) * np.cos(az), np.sqrt(1 - mu * mu) * np.sin(az), mu], np.float32)
+        nz, nphi = 300, 360
+        z = (np.arange(nz) + 0.5) / nz
+        ph = (np.arange(nphi) + 0.5) / nphi * 2 * np.pi - np.pi
+        Z, P = np.meshgrid(z, ph, indexing="ij")
+        r = np.sqrt(1 - Z * Z)
+        wo = np.stack([r * np.cos(P), r * np.sin(P), Z], -1).reshape(-1, 3).astype(np.float32)
+        rgb, pdf = B.eval_pdf(np.tile(wi1, (wo.shape[0], 1)), wo)
+        assert (rgb >= 0).all() and np.isfinite(rgb).all() and (pdf >= 0).all()
+        u = rng.random((200000, 2)).astype(np.float32)
+        s_wo, s_pdf, s_w = B.sample(np.tile(wi1, (u.shape[0], 1)), u)
+        live = s_pdf > 0
+        # The pdf over directions has an integrable singularity at the mirror direction (the map u_m -> wo has Jacobian
+        # 2 pi^2 u sin(theta_m) 4 wi.m -> 0), which a quadrature over directions under-integrates; in the domain of the warp the
+        # same integral is smooth: the mass of u_m whose reflected direction is above the horizon == the accepted fraction.
+        import ctypes as C
+        L = ob._rgl_lib()
+        wi_d = wi1.astype(np.float64) / np.linalg.norm(wi1.astype(np.float64))
+        theta_i = 2 * np.arcsin(min(1.0, 0.5 * np.linalg.norm(wi_d - np.array([0, 0, 1.0]))))
+        phi_i = np.arctan2(wi_d[1], wi_d[0])
+        par = (C.c_double * 3)(phi_i, theta_i, 0.0)
+        G = 160
+        mass = 0.0
+        for a in range(G):
+            for b in range(G):
+                um = ((a + 0.5) / G, (b + 0.5) / G)
+                theta_m = um[0] ** 2 * np.pi / 2
+                phi_m = (2 * um[1] - 1) * np.pi + (phi_i if n_phi <= 2 else 0.0)
+                m = np.array([np.cos(phi_m) * np.sin(theta_m), np.sin(phi_m) * np.sin(theta_m), np.cos(theta_m)])
+                c = float(wi_d @ m)
+                if c <= 0 or (2 * c * m - wi_d)[2] <= 0:
+                    continue
+                smp = (C.c_double * 2)(); vp = C.c_double()
+                L.rgl_warp_invert(C.byref(B.c.vndf), (C.c_double * 2)(*um), par, smp, C.byref(vp))
+                mass += vp.value * L.rgl_warp_eval(C.byref(B.c.luminance), smp, par)
+        mass /= G * G
+        assert abs(mass - live.mean()) < 0.01, (mu, mass, live.mean())
+        # sample() reports pdf(wi, wo') and weight == eval / pdf, exactly
+        e_rgb, e_pdf = B.eval_pdf(np.tile(wi1, (int(live.sum()), 1)), s_wo[live])
+        assert np.array_equal(e_pdf, s_pdf[live]) and np.array_equal(s_w[live], (e_rgb / e_pdf[:, None]).astype(np.float32))
+        # the estimator's mean equals the quadrature of eval (f cos) over the hemisphere
+        albedo_q = rgb.astype(np.float64).mean(axis=0) * 2 * np.pi
+        albedo_s = s_w.astype(np.float64).mean(axis=0)
+        assert np.allclose(albedo_q, albedo_s, rtol=0.03), (albedo_q, albedo_s)
+
+
+def test_guards():
+    B = ob.OracleRgl(synth.make_rgl_fields(1))
+    wi = np.array([[0, 0, -1], [0.3, 0.1, 0.9]], np.float32)
+    wo = np.array([[0.1, 0.2, 0.9], [0.1, 0.2, -0.9]], np.float32)
+    rgb, pdf = B.eval_pdf(wi, wo)
+    assert not rgb.any() and not pdf.any()
+    s_wo, s_pdf, s_w = B.sample(wi[:1], np.array([[0.3, 0.4]], np.float32))
+    assert not s_wo.any() and not s_pdf.any() and not s_w.any()
