@@ -123,7 +123,8 @@ enum mrl_option {
 };
 
 enum mrl_material_kind { MRL_KIND_MERL = 0, MRL_KIND_TABLE = 1, MRL_KIND_GGX = 2, MRL_KIND_RELEASED = 3 /* tombstone, never reported */,
-                         MRL_KIND_TABLE_NCH = 4 /* n-channel table: evaluated by the *_nch entry points only */ };
+                         MRL_KIND_TABLE_NCH = 4 /* n-channel table: evaluated by the *_nch entry points only */,
+                         MRL_KIND_RGL = 5 /* adaptive-parameterisation measured BSDF (mrl_material_upload_rgl) */ };
 
 /* ---- context ---- */
 int mrl_init(int device_id, mrl_ctx **out);
@@ -154,6 +155,31 @@ int mrl_material_upload_table(mrl_ctx *ctx, const double *planar_rgb, const int 
  * file length) */
 int mrl_material_load_table(mrl_ctx *ctx, const char *path, const double scale[3], int *out_id);
 int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float k[3], int *out_id);
+/* The adaptive-parameterisation measured BSDF of the RGL material database's *.bsdf files (Dupuy & Jakob 2018; what upstream
+ * Mitsuba 3's stock `measured` plugin evaluates — its eval / sample / pdf are the interface this replaces; the reference
+ * snapshot holds neither that plugin nor a file: PARITY UNPINNED, restated from the published model, oracle/rgl_oracle.c).
+ * Arrays are the file's Float fields as they are, x (the last axis) fastest; res[] = { nodes along x, nodes along y }:
+ *     phi_i [n_phi], theta_i [n_theta]         incident-direction grids (strictly ascending; n_phi <= 2 means isotropic)
+ *     ndf [res_ndf[1]][res_ndf[0]], sigma [res_sigma[1]][res_sigma[0]]
+ *     vndf, luminance [n_phi][n_theta][res[1]][res[0]]          rgb [n_phi][n_theta][3][res[1]][res[0]]
+ * The library normalises vndf / luminance per slice and builds their running integrals once (host, f64), then keeps one
+ * image in HBM.  An RGL material is evaluated by SINGLE-material calls (mat == NULL; whole-array, host-array and queue entry
+ * points of the RGB family: eval, pdf, sample, eval_sample, eval_pdf): eval returns f * cos(theta_o); sample() draws from the
+ * file's own luminance / vndf warps whatever MRL_OPT_SAMPLING says, and reports eval / pdf AT the Float direction it returns.
+ * In a mixed batch (mat != NULL) its id renders zeros like an unknown id; one-unit mrl_scalar_* calls, host images and device
+ * groups do not take it (MRL_ERR_MATERIAL).  Spectral files (no "rgb" field) and anisotropic files whose phi_i covers only
+ * a symmetric part of the azimuth are rejected. */
+typedef struct mrl_rgl_fields {
+    int n_phi, n_theta;
+    const float *phi_i, *theta_i;
+    int res_ndf[2], res_sigma[2], res[2];
+    const float *ndf, *sigma, *vndf, *luminance, *rgb;
+    int jacobian;                    /* the file's "jacobian" flag: multiply the spectrum by ndf / (4 sigma) */
+} mrl_rgl_fields;
+int mrl_material_upload_rgl(mrl_ctx *ctx, const mrl_rgl_fields *fields, int *out_id);
+/* the same from a tensor_file container holding the fields under their RGL names (phi_i, theta_i, ndf, sigma, vndf,
+ * luminance, rgb, jacobian); why a file was refused: mrl_tensor_file_last_error(NULL) or mrl_last_error(ctx) */
+int mrl_material_load_rgl(mrl_ctx *ctx, const char *path, int *out_id);
 /* number of material SLOTS (live + released); ids are slot indices */
 int mrl_material_count(const mrl_ctx *ctx);
 int mrl_material_info(const mrl_ctx *ctx, int id, int *kind, int dims[3]);

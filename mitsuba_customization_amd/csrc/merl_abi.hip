@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "merl_kernels.hpp"
+#include "merl_rgl.hpp"
 #include "merl_scalar_host.hpp"
 #include "merl_host_table.hpp"
 
@@ -35,6 +36,7 @@ struct MaterialHost {
     double *d_sampling = nullptr;
     double *d_sampling2d = nullptr;  // P(theta_h | theta_i) rows (RGB tables), built on the device at upload
     size_t bytes = 0;                // device bytes this material holds (table + sampling marginal)
+    mrl::RglDev rgl{};               // KIND_RGL: the five functions' descriptor (pointers into d_texels)
     bool released = false;           // tombstone left by mrl_material_release; the slot may be reused
 };
 
@@ -597,6 +599,10 @@ int check_call(mrl_ctx *ctx, const BatchCall &c)
         return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
     if (!c.mat) {
         const mrl::MaterialDev &d = ctx->materials[(size_t)c.single_id].dev;
+        if (d.kind == mrl::KIND_RGL) {
+            if (c.n_ch > 0) return fail(ctx, MRL_ERR_MATERIAL, "an RGL material has three channels: use the RGB entry points");
+            return MRL_OK;
+        }
         if (c.n_ch == 0 && c.mode != 1 && !mrl::kind_is_rgb_path(d.kind))               // pdf is channel-free
             return fail(ctx, MRL_ERR_MATERIAL, "material has " + std::to_string(d.n_ch) + " channels: use the *_nch entry points");
         if (c.n_ch > 0 && c.mode != 1 && (d.kind != mrl::KIND_TABLE_NCH || d.n_ch != c.n_ch))
@@ -620,6 +626,10 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
 {
     const DeviceCall d = device_call(ctx, c);
     const mrl::BatchArgs &a = d.args;
+    if (!d.multi && a.single.kind == mrl::KIND_RGL) {         // adaptive-parameterisation material: its own kernel
+        MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, ctx->materials[(size_t)c.single_id].rgl, false, ctx->compute_units, ctx->stream));
+        return MRL_OK;
+    }
     if (c.n_ch > 0 && c.mode != 1) {                          // n-channel tables: their own kernels (pdf is channel-free)
         MRL_HIP(ctx, mrl::launch_batch_nch(c.mode, a, d.multi, c.n_ch, ctx->compute_units, ctx->stream));
         return MRL_OK;
@@ -794,6 +804,10 @@ int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uin
     if (call_pointer_kind(c, queue, queue_count) != 1) return fail(ctx, MRL_ERR_POINTER_MIX, "queue calls take device pointers only");
     DeviceCall d = device_call(ctx, c);
     d.args.idx = queue; d.args.idx_count = queue_count;
+    if (!d.multi && d.args.single.kind == mrl::KIND_RGL) {
+        MRL_HIP(ctx, mrl::launch_rgl(c.mode, d.args, ctx->materials[(size_t)c.single_id].rgl, true, ctx->compute_units, ctx->stream));
+        return MRL_OK;
+    }
     if (c.n_ch > 0 && c.mode != 1) {                          // n-channel tables: the same kernels walk the queue
         MRL_HIP(ctx, mrl::launch_batch_nch(c.mode, d.args, d.multi, c.n_ch, ctx->compute_units, ctx->stream));
         return MRL_OK;
@@ -1275,6 +1289,45 @@ int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float 
     m.dev.alpha = (double)alpha;
     for (int c = 0; c < 3; ++c) { m.dev.eta[c] = (double)eta[c]; m.dev.k[c] = (double)k[c]; }
     return place_material(ctx, m, out_id);
+}
+
+// The adaptive-parameterisation measured BSDF (RGL *.bsdf fields): the host normalises the two distributions and forms
+// their running integrals (f64, once), the image goes to HBM as one allocation.  PARITY UNPINNED (merl_rgl.hpp).
+int mrl_material_upload_rgl(mrl_ctx *ctx, const mrl_rgl_fields *f, int *out_id)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
+    if (!f || !out_id) return fail(ctx, MRL_ERR_INVALID, "null argument");
+    mrl::RglFields h;
+    h.n_phi = f->n_phi; h.n_theta = f->n_theta; h.phi_i = f->phi_i; h.theta_i = f->theta_i;
+    for (int k = 0; k < 2; ++k) { h.res_ndf[k] = f->res_ndf[k]; h.res_sigma[k] = f->res_sigma[k]; h.res[k] = f->res[k]; }
+    h.ndf = f->ndf; h.sigma = f->sigma; h.vndf = f->vndf; h.luminance = f->luminance; h.rgb = f->rgb;
+    h.jacobian = f->jacobian;
+    if (const char *why = mrl::rgl_check_fields(h)) return fail(ctx, MRL_ERR_INVALID, std::string("RGL fields: ") + why);
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<float> blob;
+    mrl::RglLayout layout;
+    try { layout = mrl::rgl_build_image(h, blob); } catch (const std::bad_alloc &) { return fail(ctx, MRL_ERR_OOM, "RGL image"); }
+    MaterialHost m;
+    m.bytes = blob.size() * sizeof(float);
+    int rc = budget_check(ctx, m.bytes);
+    if (rc != MRL_OK) return rc;
+    hipError_t e = hipMalloc((void **)&m.d_texels, m.bytes);
+    const bool oom = e == hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemcpy(m.d_texels, blob.data(), m.bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (m.d_texels) (void)hipFree(m.d_texels);
+        return fail(ctx, oom ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("RGL upload: ") + hipGetErrorString(e));
+    }
+    m.rgl = mrl::rgl_descriptor(h, layout, (const float *)m.d_texels);
+    std::memset(&m.dev, 0, sizeof m.dev);
+    m.dev.kind = mrl::KIND_RGL;
+    m.dev.n_ch = 3;
+    m.dev.n_th = h.n_phi; m.dev.n_td = h.n_theta; m.dev.n_pd = h.res[0];     // what mrl_material_info reports
+    rc = place_material(ctx, m, out_id);
+    if (rc != MRL_OK) { (void)hipFree(m.d_texels); return rc; }
+    return MRL_OK;
 }
 
 int mrl_material_release(mrl_ctx *ctx, int id)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <vector>
 
 #include "merl_device.hpp"
 
@@ -65,6 +66,21 @@ size_t nch_brick_float4s(int n_ch);                      // float4s per cell: 2 
 hipError_t launch_batch_nch(int mode, const BatchArgs &a, bool multi, int n_ch, int compute_units, hipStream_t stream);
 hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale, const int dims[3], int n_ch, int param, float4 *d_out,
                                   int compute_units, hipStream_t stream);
+// ---- the adaptive-parameterisation measured BSDF (merl_rgl.hip; RGL *.bsdf) ----
+struct RglDev;
+struct RglFields {                   // host arrays, as the file holds them (x fastest; res[] = { nx, ny })
+    int n_phi, n_theta;
+    const float *phi_i, *theta_i;
+    int res_ndf[2], res_sigma[2], res[2];
+    const float *ndf, *sigma, *vndf, *luminance, *rgb;
+    int jacobian;
+};
+struct RglLayout { size_t phi, theta, data[5], marg[5], cond[5]; };      // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
+const char *rgl_check_fields(const RglFields &f);                        // nullptr, or what is wrong
+RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob); // normalised tables + running integrals, host f64
+RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base);
+// a single-material launch; indexed: walk the queue a.idx / a.idx_count
+hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev &r, bool indexed, int compute_units, hipStream_t stream);
 // ---- one-unit calls (merl_scalar.hip): a bounded-lifetime service kernel answers requests posted in pinned host memory ----
 struct ScalarBoard;
 struct ScalarArgs {

@@ -1,0 +1,193 @@
+// merl_rgl.hip — the adaptive-parameterisation measured BSDF (RGL *.bsdf; upstream Mitsuba 3 `measured`) on gfx950:
+// the host-side image builder (normalisation + running integrals, f64, in the oracle's loop order) and the kernels.
+// PARITY UNPINNED (see merl_rgl.hpp).  SURVEY.md §8f item 3.
+//
+//   k_rgl<MODE, INDEXED>   one lane = one unit, grid-stride; the material's descriptor (five WarpDev) arrives by value in
+//                          SGPRs; every table read is a per-lane gather served by L1/L2 (a material is 0.2 - 20 MB).
+// What bounds it: dependent gathers (binary searches in the running integrals, ~40 (eval) to ~150 (sample) loads per unit
+// behind f64 arithmetic); measured rates: DESIGN.md §5c.
+#include "merl_kernels.hpp"
+#include "merl_rgl.hpp"
+
+#include <cmath>
+#include <vector>
+
+namespace mrl {
+
+namespace {
+
+constexpr int kRglBlock = 256;
+
+template <int MODE, bool INDEXED>
+__global__ __launch_bounds__(kRglBlock) void k_rgl(BatchArgs a, RglDev r)
+{
+    const size_t stride = (size_t)gridDim.x * kRglBlock;
+    size_t n_items = a.n;
+    if constexpr (INDEXED) { const size_t c = (size_t)*a.idx_count; n_items = c < a.n ? c : a.n; }
+    constexpr bool has_eval = MODE == 0 || MODE == 3 || MODE == 4, has_pdf = MODE == 1 || MODE == 3 || MODE == 4,
+                   has_sample = MODE == 2 || MODE == 3;
+    for (size_t j = (size_t)blockIdx.x * kRglBlock + threadIdx.x; j < n_items; j += stride) {
+        const size_t i = INDEXED ? (size_t)a.idx[j] : j;
+        const float wix = a.wi[3 * i], wiy = a.wi[3 * i + 1], wiz = a.wi[3 * i + 2];
+        if constexpr (has_eval || has_pdf) {
+            const float wox = a.wo[3 * i], woy = a.wo[3 * i + 1], woz = a.wo[3 * i + 2];
+            float rgb[3], pdf;
+            rgl::eval_pdf<has_eval, has_pdf>(r, wix, wiy, wiz, wox, woy, woz, rgb, pdf);
+            if constexpr (has_eval) { a.out_rgb[3 * i] = rgb[0]; a.out_rgb[3 * i + 1] = rgb[1]; a.out_rgb[3 * i + 2] = rgb[2]; }
+            if constexpr (has_pdf) a.out_pdf[i] = pdf;
+        }
+        if constexpr (has_sample) {
+            float wo2[3], pdf2, w[3];
+            rgl::sample(r, wix, wiy, wiz, a.u[2 * i], a.u[2 * i + 1], wo2, pdf2, w);
+            a.out_wo[3 * i] = wo2[0]; a.out_wo[3 * i + 1] = wo2[1]; a.out_wo[3 * i + 2] = wo2[2];
+            a.out_pdf2[i] = pdf2;
+            a.out_weight[3 * i] = w[0]; a.out_weight[3 * i + 1] = w[1]; a.out_weight[3 * i + 2] = w[2];
+        }
+    }
+}
+
+template <int MODE>
+hipError_t launch_mode(const BatchArgs &a, const RglDev &r, bool indexed, int compute_units, hipStream_t stream)
+{
+    size_t blocks = (a.n + kRglBlock - 1) / kRglBlock;
+    const size_t cap = (size_t)compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    const dim3 grid((unsigned)blocks), block(kRglBlock);
+    if (indexed) hipLaunchKernelGGL((k_rgl<MODE, true>), grid, block, 0, stream, a, r);
+    else hipLaunchKernelGGL((k_rgl<MODE, false>), grid, block, 0, stream, a, r);
+    return hipGetLastError();
+}
+
+bool all_finite(const float *p, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) if (!std::isfinite(p[i])) return false;
+    return true;
+}
+
+bool ascending(const float *p, int n)
+{
+    for (int i = 1; i < n; ++i) if (!(p[i] > p[i - 1])) return false;
+    return true;
+}
+
+// appends one function's tables to the image: data (normalised if asked), and for distributions the running integrals
+// cond (along x, per node row) and marg (over rows), all rounded to Float once from f64 sums.  Offsets in floats.
+struct WarpOffsets { size_t data = 0, marg = 0, cond = 0; };
+WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, int ny, size_t slices, bool distribution)
+{
+    const size_t per = (size_t)nx * ny;
+    WarpOffsets off;
+    off.data = blob.size();
+    blob.resize(blob.size() + per * slices);
+    if (distribution) {
+        off.marg = blob.size(); blob.resize(blob.size() + (size_t)(ny - 1) * slices);
+        off.cond = blob.size(); blob.resize(blob.size() + (size_t)ny * (size_t)(nx - 1) * slices);
+    }
+    std::vector<double> cond((size_t)ny * (size_t)(nx - 1)), marg((size_t)(ny - 1));
+    for (size_t s = 0; s < slices; ++s) {
+        const float *src = src_all + per * s;
+        double norm = 1.0;
+        if (distribution) {
+            for (int y = 0; y < ny; ++y) {
+                double sum = 0.0;
+                for (int x = 0; x < nx - 1; ++x) {
+                    sum += 0.5 * ((double)src[y * nx + x] + (double)src[y * nx + x + 1]);
+                    cond[(size_t)y * (size_t)(nx - 1) + (size_t)x] = sum;
+                }
+            }
+            double sum = 0.0;
+            for (int y = 0; y < ny - 1; ++y) {
+                sum += 0.5 * (cond[(size_t)y * (size_t)(nx - 1) + (size_t)(nx - 2)] + cond[(size_t)(y + 1) * (size_t)(nx - 1) + (size_t)(nx - 2)]);
+                marg[(size_t)y] = sum;
+            }
+            norm = sum > 0.0 ? 1.0 / sum : 1.0;
+            for (size_t k = 0; k < cond.size(); ++k) blob[off.cond + s * cond.size() + k] = (float)(cond[k] * norm);
+            for (size_t k = 0; k < marg.size(); ++k) blob[off.marg + s * marg.size() + k] = (float)(marg[k] * norm);
+        }
+        for (size_t k = 0; k < per; ++k) blob[off.data + per * s + k] = (float)((double)src[k] * norm);
+    }
+    return off;
+}
+
+} // namespace
+
+const char *rgl_check_fields(const RglFields &f)
+{
+    if (f.n_phi < 1 || f.n_theta < 1 || f.n_phi > 4096 || f.n_theta > 4096) return "phi_i / theta_i: 1..4096 nodes each";
+    for (int k = 0; k < 2; ++k)
+        if (f.res_ndf[k] < 2 || f.res_sigma[k] < 2 || f.res[k] < 2 || f.res_ndf[k] > 8192 || f.res_sigma[k] > 8192 || f.res[k] > 8192)
+            return "every table needs 2..8192 nodes per axis";
+    if (!f.phi_i || !f.theta_i || !f.ndf || !f.sigma || !f.vndf || !f.luminance || !f.rgb) return "null field";
+    const size_t slices = (size_t)f.n_phi * (size_t)f.n_theta, per = (size_t)f.res[0] * (size_t)f.res[1];
+    if (slices * per * 3 > ((size_t)1 << 28)) return "tables too large (more than 2^28 values)";
+    if (!all_finite(f.phi_i, (size_t)f.n_phi) || !all_finite(f.theta_i, (size_t)f.n_theta) || !ascending(f.phi_i, f.n_phi) || !ascending(f.theta_i, f.n_theta))
+        return "phi_i / theta_i must be finite and strictly ascending";
+    if (!all_finite(f.ndf, (size_t)f.res_ndf[0] * f.res_ndf[1]) || !all_finite(f.sigma, (size_t)f.res_sigma[0] * f.res_sigma[1]) ||
+        !all_finite(f.vndf, slices * per) || !all_finite(f.luminance, slices * per) || !all_finite(f.rgb, slices * per * 3))
+        return "non-finite table value";
+    for (size_t k = 0; k < slices * per; ++k)
+        if (f.vndf[k] < 0.0f || f.luminance[k] < 0.0f) return "vndf / luminance must be non-negative (they are densities)";
+    // an anisotropic file may cover only 1 / reduction of the azimuth and rely on the sample's symmetry: not built
+    if (f.n_phi > 2 && (double)f.phi_i[f.n_phi - 1] - (double)f.phi_i[0] < 1.5 * kPi)
+        return "anisotropic file with a symmetry-reduced phi_i range: not supported";
+    return nullptr;
+}
+
+RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob)
+{
+    blob.clear();
+    const size_t slices = (size_t)f.n_phi * (size_t)f.n_theta;
+    RglLayout l;
+    l.phi = 0; l.theta = (size_t)f.n_phi;
+    blob.insert(blob.end(), f.phi_i, f.phi_i + f.n_phi);
+    blob.insert(blob.end(), f.theta_i, f.theta_i + f.n_theta);
+    auto put = [&](int which, const float *src, const int res[2], size_t n, bool distribution) {
+        const WarpOffsets o = append_warp(blob, src, res[0], res[1], n, distribution);
+        l.data[which] = o.data; l.marg[which] = o.marg; l.cond[which] = o.cond;
+    };
+    put(0, f.ndf, f.res_ndf, 1, false);
+    put(1, f.sigma, f.res_sigma, 1, false);
+    put(2, f.vndf, f.res, slices, true);
+    put(3, f.luminance, f.res, slices, true);
+    put(4, f.rgb, f.res, slices * 3, false);
+    return l;
+}
+
+RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base)
+{
+    auto warp = [&](int which, const int res[2], int n_phi, int n_theta, int n_ch, bool distribution) {
+        WarpDev w;
+        w.data = base + l.data[which];
+        w.marg = distribution ? base + l.marg[which] : nullptr;
+        w.cond = distribution ? base + l.cond[which] : nullptr;
+        w.phi = base + l.phi; w.theta = base + l.theta;
+        w.nx = res[0]; w.ny = res[1]; w.n_phi = n_phi; w.n_theta = n_theta; w.n_ch = n_ch;
+        w.normalized = distribution ? 1 : 0;
+        return w;
+    };
+    RglDev r;
+    r.ndf = warp(0, f.res_ndf, 1, 1, 1, false);
+    r.sigma = warp(1, f.res_sigma, 1, 1, 1, false);
+    r.vndf = warp(2, f.res, f.n_phi, f.n_theta, 1, true);
+    r.luminance = warp(3, f.res, f.n_phi, f.n_theta, 1, true);
+    r.rgb = warp(4, f.res, f.n_phi, f.n_theta, 3, false);
+    r.isotropic = f.n_phi <= 2;
+    r.jacobian = f.jacobian ? 1 : 0;
+    return r;
+}
+
+hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev &r, bool indexed, int compute_units, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    switch (mode) {
+        case 0: return launch_mode<0>(a, r, indexed, compute_units, stream);
+        case 1: return launch_mode<1>(a, r, indexed, compute_units, stream);
+        case 2: return launch_mode<2>(a, r, indexed, compute_units, stream);
+        case 3: return launch_mode<3>(a, r, indexed, compute_units, stream);
+        case 4: return launch_mode<4>(a, r, indexed, compute_units, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+} // namespace mrl

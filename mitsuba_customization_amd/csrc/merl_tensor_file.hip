@@ -12,9 +12,9 @@
 //     payloads at their offsets, C order, little endian.
 // dtype: 1..8 integers (1-2: 1 byte, 3-4: 2 bytes, 5-6: 4 bytes, 7-8: 8 bytes; writers disagree on which of a pair is
 // the signed one, so integers are exposed by width only), 9 f16, 10 f32, 11 f64.
-// LOADER ONLY: the adaptive parameterisation the RGL *.bsdf fields describe (ndf / vndf / luminance warps) is a
-// different model from the MERL-parameterised tables this library evaluates and is not built.  What the loader feeds
-// the hot path is a customized_measurement table stored in this container: a float field of shape
+// Two consumers: mrl_material_load_rgl hands the RGL fields (phi_i, theta_i, ndf, sigma, vndf, luminance, rgb, jacobian) to
+// the adaptive-parameterisation material (merl_rgl.hip), and mrl_material_load_tensor_table feeds the table hot path
+// with a customized_measurement table stored in this container: a float field of shape
 // [channels, n_0, n_1, n_2] (default name "table"), optionally with a "scale" field [channels] and a "parameterization"
 // field (one integer, enum mrl_param: which three angles the axes are — half/diff by default).
 #include "../../include/merl_hip.h"
@@ -195,6 +195,7 @@ int mrl_material_load_tensor_table(mrl_ctx *ctx, const char *path, const char *f
     mrl_tensor_file *f = nullptr;
     int rc = mrl_tensor_file_open(path, &f);
     if (rc != MRL_OK) return rc;
+    t_open_error.clear();                                   // from here on a non-empty text is this call's own refusal
     const char *want = field ? field : "table";
     const int at = mrl_tensor_file_find(f, want);
     if (at < 0) { t_open_error = std::string("no field \"") + want + "\" in " + path; mrl_tensor_file_close(f); return MRL_ERR_FORMAT; }
@@ -239,6 +240,60 @@ int mrl_material_load_tensor_table(mrl_ctx *ctx, const char *path, const char *f
     rc = param >= 0 ? mrl_material_upload_table_param(ctx, data.data(), dims, n_ch, scale.data(), param, out_id)
                     : mrl_material_upload_table_nch(ctx, data.data(), dims, n_ch, scale.data(), out_id);
     if (rc == MRL_OK && out_channels) *out_channels = n_ch;
+    return rc;
+}
+
+int mrl_material_load_rgl(mrl_ctx *ctx, const char *path, int *out_id)
+{
+    if (!ctx || !path || !out_id) return MRL_ERR_INVALID;
+    mrl_tensor_file *f = nullptr;
+    int rc = mrl_tensor_file_open(path, &f);
+    if (rc != MRL_OK) return rc;
+    t_open_error.clear();                                   // from here on a non-empty text is this call's own refusal
+    auto refuse = [&](const std::string &why) { t_open_error = why + " (" + path + ")"; mrl_tensor_file_close(f); return (int)MRL_ERR_FORMAT; };
+    // a Float field of the given rank; returns nullptr (and the reason in `why`) otherwise
+    std::string why;
+    auto floats = [&](const char *name, size_t rank) -> const Field * {
+        const int at = mrl_tensor_file_find(f, name);
+        if (at < 0) { why = std::string("no field \"") + name + "\""; return nullptr; }
+        const Field &fd = f->fields[(size_t)at];
+        if (fd.dtype != 10 || fd.shape.size() != rank) { why = std::string("field \"") + name + "\" must be float32 of rank " + std::to_string(rank); return nullptr; }
+        if (fd.offset % 4 != 0) { why = std::string("field \"") + name + "\" is not 4-byte aligned"; return nullptr; }
+        for (uint64_t d : fd.shape) if (d < 1 || d > 8192) { why = std::string("field \"") + name + "\": every axis must have 1..8192 entries"; return nullptr; }
+        return &fd;
+    };
+    if (mrl_tensor_file_find(f, "rgb") < 0 && mrl_tensor_file_find(f, "spectra") >= 0)
+        return refuse("a spectral RGL file (\"spectra\" without \"rgb\"): only the *_rgb.bsdf variant is evaluated");
+    const Field *phi = floats("phi_i", 1);
+    const Field *theta = phi ? floats("theta_i", 1) : nullptr;
+    const Field *ndf = theta ? floats("ndf", 2) : nullptr;
+    const Field *sigma = ndf ? floats("sigma", 2) : nullptr;
+    const Field *vndf = sigma ? floats("vndf", 4) : nullptr;
+    const Field *lum = vndf ? floats("luminance", 4) : nullptr;
+    const Field *rgb = lum ? floats("rgb", 5) : nullptr;
+    if (!rgb) return refuse(why);
+    const uint64_t n_phi = phi->shape[0], n_theta = theta->shape[0];
+    if (vndf->shape[0] != n_phi || vndf->shape[1] != n_theta || lum->shape != vndf->shape || rgb->shape[0] != n_phi || rgb->shape[1] != n_theta ||
+        rgb->shape[2] != 3 || rgb->shape[3] != vndf->shape[2] || rgb->shape[4] != vndf->shape[3])
+        return refuse("vndf / luminance must be [n_phi, n_theta, res, res] and rgb [n_phi, n_theta, 3, res, res]");
+    int jacobian = 0;
+    const int jf = mrl_tensor_file_find(f, "jacobian");
+    if (jf >= 0) {
+        const Field &q = f->fields[(size_t)jf];
+        if (q.count != 1 || dtype_size(q.dtype) != 1) return refuse("field \"jacobian\" must hold one byte");
+        jacobian = f->bytes[q.offset] != 0;
+    }
+    auto data = [&](const Field *fd) { return (const float *)(const void *)(f->bytes.data() + fd->offset); };
+    mrl_rgl_fields r;
+    r.n_phi = (int)n_phi; r.n_theta = (int)n_theta;
+    r.phi_i = data(phi); r.theta_i = data(theta);
+    r.res_ndf[0] = (int)ndf->shape[1]; r.res_ndf[1] = (int)ndf->shape[0];
+    r.res_sigma[0] = (int)sigma->shape[1]; r.res_sigma[1] = (int)sigma->shape[0];
+    r.res[0] = (int)vndf->shape[3]; r.res[1] = (int)vndf->shape[2];
+    r.ndf = data(ndf); r.sigma = data(sigma); r.vndf = data(vndf); r.luminance = data(lum); r.rgb = data(rgb);
+    r.jacobian = jacobian;
+    rc = mrl_material_upload_rgl(ctx, &r, out_id);
+    mrl_tensor_file_close(f);
     return rc;
 }
 

@@ -24,6 +24,7 @@ LAYOUT_ROWS, LAYOUT_BRICK = 0, 1
 LOOKUP_NEAREST, LOOKUP_TRILINEAR = 0, 1
 KIND_MERL, KIND_TABLE, KIND_GGX = 0, 1, 2
 KIND_TABLE_NCH = 4
+KIND_RGL = 5
 ERR_INVALID, ERR_HIP, ERR_IO, ERR_FORMAT, ERR_OOM, ERR_MATERIAL, ERR_POINTER_MIX, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7, -8
 
 # every symbol include/merl_hip.h declares (tests check the library exports all of them)
@@ -42,6 +43,7 @@ ABI_SYMBOLS = (
     "mrl_eval_queue_nch", "mrl_sample_queue_nch", "mrl_eval_pdf_queue_nch", "mrl_eval_sample_queue_nch",
     "mrl_tensor_file_open", "mrl_tensor_file_close", "mrl_tensor_file_last_error", "mrl_tensor_file_field_count", "mrl_tensor_file_find",
     "mrl_tensor_file_field_info", "mrl_tensor_file_field_data", "mrl_tensor_file_read_f64", "mrl_material_load_tensor_table",
+    "mrl_material_upload_rgl", "mrl_material_load_rgl",
     "mrl_group_init", "mrl_group_destroy", "mrl_group_size", "mrl_group_transport", "mrl_group_last_error", "mrl_group_context",
     "mrl_group_set_option", "mrl_group_material_load_merl", "mrl_group_material_upload_f64", "mrl_group_material_upload_table",
     "mrl_group_material_ggx", "mrl_group_material_release", "mrl_tile_bounds", "mrl_chunk_bounds", "mrl_chunk_steps",
@@ -87,6 +89,14 @@ class HostTable:
         if rc != 0:
             raise MerlHipError(rc, "mrl_host_eval_sample")
         return np.frombuffer(out, dtype=np.float32).copy()
+
+
+class RglFields(C.Structure):
+    """struct mrl_rgl_fields"""
+    _fields_ = [("n_phi", C.c_int), ("n_theta", C.c_int), ("phi_i", C.POINTER(C.c_float)), ("theta_i", C.POINTER(C.c_float)),
+                ("res_ndf", C.c_int * 2), ("res_sigma", C.c_int * 2), ("res", C.c_int * 2),
+                ("ndf", C.POINTER(C.c_float)), ("sigma", C.POINTER(C.c_float)), ("vndf", C.POINTER(C.c_float)),
+                ("luminance", C.POINTER(C.c_float)), ("rgb", C.POINTER(C.c_float)), ("jacobian", C.c_int)]
 
 
 class TileInputs(C.Structure):
@@ -198,6 +208,8 @@ def load_library(path: Optional[str] = None):
     L.mrl_tensor_file_field_data.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]; L.mrl_tensor_file_field_data.restype = vp
     L.mrl_tensor_file_read_f64.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.mrl_material_load_tensor_table.argtypes = [vp, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mrl_material_upload_rgl.argtypes = [vp, C.POINTER(RglFields), C.POINTER(C.c_int)]
+    L.mrl_material_load_rgl.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     szp = C.POINTER(C.c_size_t)
     L.mrl_group_init.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.mrl_group_destroy.argtypes = [vp]
@@ -350,6 +362,33 @@ class MerlHip:
     def ggx(self, alpha: float, eta: Sequence[float], k: Sequence[float]) -> int:
         mid = C.c_int()
         self._check(self._lib.mrl_material_ggx(self._ctx, alpha, (C.c_float * 3)(*eta), (C.c_float * 3)(*k), C.byref(mid)), "mrl_material_ggx")
+        return mid.value
+
+    def upload_rgl(self, fields: dict) -> int:
+        """The adaptive-parameterisation measured BSDF from the fields of an RGL *.bsdf file (dict of arrays: phi_i, theta_i,
+        ndf, sigma, vndf, luminance, rgb[, jacobian]).  Single-material calls evaluate it (mrl_material_upload_rgl)."""
+        f32 = lambda k: np.ascontiguousarray(fields[k], np.float32)
+        a = {k: f32(k) for k in ("phi_i", "theta_i", "ndf", "sigma", "vndf", "luminance", "rgb")}
+        vn = a["vndf"].shape
+        if len(vn) != 4 or a["luminance"].shape != vn or a["rgb"].shape != (vn[0], vn[1], 3, vn[2], vn[3]) or a["ndf"].ndim != 2 or a["sigma"].ndim != 2 \
+                or a["phi_i"].shape != (vn[0],) or a["theta_i"].shape != (vn[1],):
+            raise ValueError("RGL fields: vndf / luminance [n_phi, n_theta, res, res], rgb [n_phi, n_theta, 3, res, res], ndf / sigma 2-D")
+        fp = C.POINTER(C.c_float)
+        p = lambda k: a[k].ctypes.data_as(fp)
+        r = RglFields(vn[0], vn[1], p("phi_i"), p("theta_i"), (C.c_int * 2)(a["ndf"].shape[1], a["ndf"].shape[0]),
+                      (C.c_int * 2)(a["sigma"].shape[1], a["sigma"].shape[0]), (C.c_int * 2)(vn[3], vn[2]),
+                      p("ndf"), p("sigma"), p("vndf"), p("luminance"), p("rgb"), int(np.asarray(fields.get("jacobian", 1)).reshape(-1)[0]))
+        mid = C.c_int()
+        self._check(self._lib.mrl_material_upload_rgl(self._ctx, C.byref(r), C.byref(mid)), "mrl_material_upload_rgl")
+        return mid.value
+
+    def load_rgl(self, path: str) -> int:
+        """An RGL *.bsdf file (tensor_file container with the RGL field names; the *_rgb variant)."""
+        mid = C.c_int()
+        rc = self._lib.mrl_material_load_rgl(self._ctx, path.encode(), C.byref(mid))
+        if rc != 0:
+            detail = self._lib.mrl_tensor_file_last_error(None).decode() or self._lib.mrl_last_error(self._ctx).decode()
+            raise MerlHipError(rc, "mrl_material_load_rgl", detail)
         return mid.value
 
     def material_count(self) -> int:

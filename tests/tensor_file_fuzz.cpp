@@ -33,6 +33,21 @@ extern "C" int mrl_material_upload_table_param(mrl_ctx *c, const double *planar,
     return mrl_material_upload_table_nch(c, planar, dims, n_channels, scale, out_id);
 }
 
+// the RGL loader's only context call: every array is read to the extent its shape claims
+static int g_rgl_uploads = 0;
+extern "C" int mrl_material_upload_rgl(mrl_ctx *, const mrl_rgl_fields *f, int *out_id)
+{
+    double sum = 0.0;
+    auto eat = [&](const float *p, size_t n) { for (size_t i = 0; i < n; ++i) sum += p[i]; };
+    const size_t slices = (size_t)f->n_phi * (size_t)f->n_theta, per = (size_t)f->res[0] * (size_t)f->res[1];
+    eat(f->phi_i, (size_t)f->n_phi); eat(f->theta_i, (size_t)f->n_theta);
+    eat(f->ndf, (size_t)f->res_ndf[0] * f->res_ndf[1]); eat(f->sigma, (size_t)f->res_sigma[0] * f->res_sigma[1]);
+    eat(f->vndf, slices * per); eat(f->luminance, slices * per); eat(f->rgb, slices * per * 3);
+    *out_id = sum == 12345.0 ? 1 : 0;
+    ++g_rgl_uploads;
+    return MRL_OK;
+}
+
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
 
@@ -63,6 +78,40 @@ static std::vector<unsigned char> good_file(const double *param_as_f64 = nullptr
         b.resize(offs[i], 0);
         if (i == 3 && param_as_f64) { put(b, param_as_f64, 8); continue; }
         for (size_t k = 0; k < fs[i].bytes; ++k) b.push_back(i == 3 ? (unsigned char)1 : (unsigned char)(k * 7 + i));    // parameterization = 1
+    }
+    return b;
+}
+
+// a well-formed file with the RGL field names: n_phi = 1, n_theta = 2, 3 x 2 warps, 2 x 2 ndf, 3 x 2 sigma
+static std::vector<unsigned char> good_rgl_file()
+{
+    std::vector<unsigned char> b;
+    put(b, "tensor_file", 12);
+    const uint8_t ver[2] = { 1, 0 }; put(b, ver, 2);
+    struct F { const char *name; uint8_t dtype; std::vector<uint64_t> shape; };
+    const std::vector<F> fs = { { "phi_i", 10, { 1 } }, { "theta_i", 10, { 2 } }, { "ndf", 10, { 2, 2 } }, { "sigma", 10, { 2, 3 } },
+                                { "vndf", 10, { 1, 2, 2, 3 } }, { "luminance", 10, { 1, 2, 2, 3 } }, { "rgb", 10, { 1, 2, 3, 2, 3 } },
+                                { "jacobian", 1, { 1 } } };
+    const uint32_t nf = (uint32_t)fs.size(); put(b, &nf, 4);
+    size_t head = b.size();
+    for (const F &f : fs) head += 2 + std::strlen(f.name) + 2 + 1 + 8 + 8 * f.shape.size();
+    uint64_t off = (head + 7) / 8 * 8;
+    std::vector<uint64_t> offs, sizes;
+    for (const F &f : fs) {
+        uint64_t n = f.dtype == 10 ? 4 : 1;
+        for (uint64_t e : f.shape) n *= e;
+        offs.push_back(off); sizes.push_back(n); off = (off + n + 7) / 8 * 8;
+    }
+    for (size_t i = 0; i < fs.size(); ++i) {
+        const F &f = fs[i];
+        const uint16_t nl = (uint16_t)std::strlen(f.name), nd = (uint16_t)f.shape.size(); put(b, &nl, 2); put(b, f.name, nl);
+        put(b, &nd, 2); put(b, &f.dtype, 1); put(b, &offs[i], 8);
+        for (uint64_t e : f.shape) put(b, &e, 8);
+    }
+    for (size_t i = 0; i < fs.size(); ++i) {
+        b.resize(offs[i], 0);
+        if (fs[i].dtype != 10) { b.push_back(1); continue; }
+        for (uint64_t k = 0; k < sizes[i] / 4; ++k) { const float v = 0.25f + 0.125f * (float)k + (float)i; put(b, &v, 4); }
     }
     return b;
 }
@@ -99,6 +148,7 @@ static int probe(const std::string &path, const std::vector<unsigned char> &byte
     mrl_tensor_file_close(t);
     int id = -1, ch = 0;
     (void)mrl_material_load_tensor_table((mrl_ctx *)0x1, path.c_str(), nullptr, &id, &ch);  // the fake context is never dereferenced
+    (void)mrl_material_load_rgl((mrl_ctx *)0x1, path.c_str(), &id);
     return rc;
 }
 
@@ -125,6 +175,22 @@ int main(int argc, char **argv)
         }
         const int rc = probe(path, b);
         if (rc == MRL_OK) ++opened; else ++refused;
+    }
+    // the RGL loader: a well-formed file is handed on once, corrupted copies never make the stub read past a payload
+    {
+        const std::vector<unsigned char> rgl = good_rgl_file();
+        if (probe(path, rgl) != MRL_OK || g_rgl_uploads != 1) { std::fprintf(stderr, "the well-formed RGL file was rejected: %s\n", mrl_tensor_file_last_error(nullptr)); return 1; }
+        for (int round = 0; round < 4000; ++round) {
+            std::vector<unsigned char> b = rgl;
+            const int kind = (int)(rnd() % 4);
+            if (kind == 0) { for (int k = 0, m = 1 + (int)(rnd() % 4); k < m; ++k) b[rnd() % 330] ^= (unsigned char)(1u << (rnd() % 8)); }
+            else if (kind == 1) b.resize(rnd() % b.size());
+            else if (kind == 2) { const uint64_t v = (rnd() % 2) ? ~0ull >> (rnd() % 40) : rnd() % 64; std::memcpy(&b[18 + rnd() % 300], &v, 8); }
+            else b[rnd() % b.size()] = (unsigned char)rnd();
+            const int rc = probe(path, b);
+            if (rc == MRL_OK) ++opened; else ++refused;
+        }
+        std::printf("rgl files handed on: %d\n", g_rgl_uploads);
     }
     // a float-typed "parameterization": only 0.0, 1.0, 2.0 are values of enum mrl_param; NaN, infinities and magnitudes
     // beyond the integer range must be refused BEFORE any float -> integer conversion (-fsanitize=float-cast-overflow)

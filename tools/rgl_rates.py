@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""What the adaptive-parameterisation (RGL) material costs: eval, pdf, sample and the fused eval+sample unit over 16M units,
+for a file of the database's isotropic shape (8 theta_i nodes, 32 x 32 warps, 128 x 128 ndf) and an anisotropic one.   python tools/rgl_rates.py > profiles/r03_rgl_rates.json"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from mitsuba_customization_amd import host, synth
+
+n = 16 << 20
+res = {"units": n, "library": host.build_info()}
+with host.MerlHip(0) as g:
+    g.use_torch_stream()
+    wi, wo, u = g.generate_pairs(0x5EED, 0, n)
+    for name, shape in (("isotropic_8x32x32", dict(n_phi=1, n_theta=8, res=32, res_ndf=128, res_sigma=64)),
+                        ("anisotropic_16x8x32x32", dict(n_phi=16, n_theta=8, res=32, res_ndf=128, res_sigma=64))):
+        mid = g.upload_rgl(synth.make_rgl_fields(seed=9, **shape))
+        row = {"image_bytes": g.memory_info()["table_bytes"]}
+        for what, call in (("eval", lambda: g.eval(wi, wo, material=mid)), ("pdf", lambda: g.pdf(wi, wo, material=mid)),
+                           ("sample", lambda: g.sample(wi, u, material=mid)), ("eval_sample", lambda: g.eval_sample(wi, wo, u, material=mid))):
+            for _ in range(2):
+                out = call()
+            torch.cuda.synchronize()
+            g.timer_start()
+            for _ in range(5):
+                out = call()
+            ms = g.timer_stop() / 5
+            row[what] = {"ms": round(ms, 3), "G_units_per_s": round(n / ms / 1e6, 3)}
+        res[name] = row
+        g.release_material(mid)
+print(json.dumps(res, indent=1))
