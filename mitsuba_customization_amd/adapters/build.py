@@ -3,6 +3,7 @@ goes through libmerl_hip.so).  Outputs under mitsuba_customization_amd/lib/:
 
     plugins06/merl.so, plugins06/customized_measurement.so     Mitsuba 0.6 plugins (CreateInstance / GetDescription)
     plugins3/merl.so,  plugins3/customized_measurement.so      Mitsuba 3 plugins (plugin_name / plugin_descr / ...)
+    plugins3/measured.so                                       Mitsuba 3's stock RGL plugin name over the library's RGL material
     driver06, driver3                                          stand-ins for the hosts' plugin managers (tests)
 
 Against a real Mitsuba tree: add -DMERL_USE_REAL_MITSUBA and the tree's include dirs instead of mirror/.
@@ -37,7 +38,7 @@ def build_all(force: bool = False):
         os.makedirs(out_dir, exist_ok=True)
         inc = ["-I", os.path.join(src_dir, "mirror")]
         deps = common + glob.glob(os.path.join(src_dir, "*.hpp")) + [os.path.join(src_dir, "mirror", "mitsuba", mirror_hdr)]
-        for name in ("merl", "customized_measurement"):
+        for name in ("merl", "customized_measurement") + (("measured",) if host == "mitsuba3" else ()):
             src = os.path.join(src_dir, name + ".cpp")
             out = os.path.join(out_dir, name + ".so")
             if force or _stale(out, deps + [src]):

@@ -234,6 +234,21 @@ public:
                                 }, "mrl_material_load_tensor_table");
         return Material(ctx, res);
     }
+    // the adaptive-parameterisation measured BSDF of an RGL *.bsdf file (what upstream Mitsuba 3's `measured` evaluates)
+    static Material load_rgl(const ContextKey &key, const std::string &path)
+    {
+        auto ctx = Context::get(key);
+        auto res = ctx->acquire("rgl|" + canonical_path(path),
+                                [&](mrl_ctx *c, int *id) {
+                                    const int rc = mrl_material_load_rgl(c, path.c_str(), id);
+                                    if (rc != MRL_OK && rc != MRL_ERR_HIP && rc != MRL_ERR_OOM) {
+                                        const char *why = mrl_tensor_file_last_error(nullptr);
+                                        if (why && *why) throw Error(rc, std::string("mrl_material_load_rgl: ") + why);
+                                    }
+                                    return rc;
+                                }, "mrl_material_load_rgl");
+        return Material(ctx, res);
+    }
     static bool is_tensor_file(const std::string &path)
     {
         return path.size() > 5 && path.compare(path.size() - 5, 5, ".bsdf") == 0;

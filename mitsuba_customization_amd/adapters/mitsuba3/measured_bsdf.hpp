@@ -177,4 +177,24 @@ protected:
     const char *plugin_class() const override { return "CustomizedMeasurement"; }
 };
 
+// <bsdf type="measured"> <string name="filename" value="cc_nothern_aurora_rgb.bsdf"/> </bsdf>
+// Upstream Mitsuba 3's stock plugin for the RGL material database (adaptive parameterisation, Dupuy & Jakob 2018), over the
+// library's RGL material (include/merl_hip.h, mrl_material_load_rgl).  PARITY UNPINNED: neither that plugin's source nor a
+// database file is in the reference snapshot; the model is restated from its published description.  Scalar calls run on
+// the calling thread (the per-unit functions compiled for the host); BatchedBSDF calls on the GPU.
+template <typename Float, typename Spectrum>
+class Measured final : public MeasuredBSDFBase<Float, Spectrum> {
+public:
+    explicit Measured(const Properties &props) : MeasuredBSDFBase<Float, Spectrum>(props)
+    {
+        if (!this->m_cpu_scalar)
+            throw merl_gpu::Error(MRL_ERR_INVALID, "measured: scalar = \"gpu\" is not available (the one-unit call service evaluates table and GGX materials)");
+        this->m_material = merl_gpu::Material::load_rgl(this->m_key, this->m_filename);
+        this->finish_load();
+    }
+    MI_DECLARE_CLASS()
+protected:
+    const char *plugin_class() const override { return "Measured"; }
+};
+
 NAMESPACE_END(mitsuba)

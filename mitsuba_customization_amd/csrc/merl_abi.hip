@@ -1393,11 +1393,35 @@ int mrl_material_host_table(mrl_ctx *ctx, int id, mrl_host_table **out)
     *out = nullptr;
     if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
     const MaterialHost &mh = ctx->materials[(size_t)id];
-    if (mh.dev.kind != mrl::KIND_MERL && mh.dev.kind != mrl::KIND_TABLE)
-        return fail(ctx, MRL_ERR_MATERIAL, "host images exist for three-channel table materials");
+    if (mh.dev.kind != mrl::KIND_MERL && mh.dev.kind != mrl::KIND_TABLE && mh.dev.kind != mrl::KIND_RGL)
+        return fail(ctx, MRL_ERR_MATERIAL, "host images exist for three-channel table materials and RGL materials");
     if (!__builtin_cpu_supports("fma") || !__builtin_cpu_supports("avx2"))
         return fail(ctx, MRL_ERR_INVALID, "the host one-unit path needs a CPU with FMA and AVX2");
     MRL_HIP(ctx, hipSetDevice(ctx->device));
+    if (mh.dev.kind == mrl::KIND_RGL) {                       // the image is position independent: copy it, move the descriptor's pointers
+        MRL_HIP(ctx, hipSetDevice(ctx->device));
+        mrl_host_table *t = nullptr;
+        try {
+            t = new mrl_host_table;
+            t->rgl_image.resize(mh.bytes / sizeof(float));
+        } catch (const std::bad_alloc &) { delete t; return fail(ctx, MRL_ERR_OOM, "host image"); }
+        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const hipError_t e = hipMemcpy(t->rgl_image.data(), mh.d_texels, mh.bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { (void)hipGetLastError(); delete t; return fail(ctx, MRL_ERR_HIP, std::string("host image: ") + hipGetErrorString(e)); }
+        t->rgl = mh.rgl;
+        const float *from = (const float *)mh.d_texels, *to = t->rgl_image.data();
+        mrl::WarpDev *all[5] = { &t->rgl.ndf, &t->rgl.sigma, &t->rgl.vndf, &t->rgl.luminance, &t->rgl.rgb };
+        for (mrl::WarpDev *w : all) {
+            w->data = to + (w->data - from);
+            if (w->marg) w->marg = to + (w->marg - from);
+            if (w->cond) w->cond = to + (w->cond - from);
+            w->phi = to + (w->phi - from); w->theta = to + (w->theta - from);
+        }
+        t->m = mh.dev;
+        t->opts = ctx->opts;
+        *out = t;
+        return MRL_OK;
+    }
     const int n_th = mh.dev.n_th, n_td = mh.dev.n_td, n_pd = mh.dev.n_pd;
     const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1, cells = (size_t)n_th * n_td * n_pd;
     mrl_host_table *t = nullptr;

@@ -48,6 +48,15 @@ MRL_HOST_FAST inline void host_sample(const mrl_host_table *t, const float wi[3]
     mrl::fast::unit_sample<LOOKUP, mrl::LAYOUT_ROWS>(t->m, t->opts, in, wi[0], wi[1], wi[2], u[0], u[1], wo, *pdf, weight);
 }
 
+// the adaptive-parameterisation material: the kernels' per-unit functions (merl_rgl.hpp) over the host copy of the image
+MRL_HOST_FAST inline void host_rgl_eval_pdf(const mrl_host_table *t, const float wi[3], const float wo[3], float rgb[3], float *pdf)
+{
+    float p;
+    if (pdf) mrl::rgl::eval_pdf<true, true>(t->rgl, wi[0], wi[1], wi[2], wo[0], wo[1], wo[2], rgb, p);
+    else mrl::rgl::eval_pdf<true, false>(t->rgl, wi[0], wi[1], wi[2], wo[0], wo[1], wo[2], rgb, p);
+    if (pdf) *pdf = p;
+}
+
 } // namespace
 
 extern "C" {
@@ -55,6 +64,7 @@ extern "C" {
 MRL_HOST_FAST int mrl_host_eval_pdf(const mrl_host_table *t, const float wi[3], const float wo[3], float out_rgb[3], float *out_pdf)
 {
     if (!t || !wi || !wo || !out_rgb) return MRL_ERR_INVALID;
+    if (t->m.kind == mrl::KIND_RGL) { host_rgl_eval_pdf(t, wi, wo, out_rgb, out_pdf); return MRL_OK; }
     if (t->opts.lookup) host_eval_pdf<1>(t, wi, wo, out_rgb, out_pdf);
     else host_eval_pdf<0>(t, wi, wo, out_rgb, out_pdf);
     return MRL_OK;
@@ -63,6 +73,7 @@ MRL_HOST_FAST int mrl_host_eval_pdf(const mrl_host_table *t, const float wi[3], 
 MRL_HOST_FAST int mrl_host_sample(const mrl_host_table *t, const float wi[3], const float u[2], float out_wo[3], float *out_pdf, float out_weight[3])
 {
     if (!t || !wi || !u || !out_wo || !out_pdf || !out_weight) return MRL_ERR_INVALID;
+    if (t->m.kind == mrl::KIND_RGL) { mrl::rgl::sample(t->rgl, wi[0], wi[1], wi[2], u[0], u[1], out_wo, *out_pdf, out_weight); return MRL_OK; }
     if (t->opts.lookup) host_sample<1>(t, wi, u, out_wo, out_pdf, out_weight);
     else host_sample<0>(t, wi, u, out_wo, out_pdf, out_weight);
     return MRL_OK;
@@ -71,6 +82,11 @@ MRL_HOST_FAST int mrl_host_sample(const mrl_host_table *t, const float wi[3], co
 MRL_HOST_FAST int mrl_host_eval_sample(const mrl_host_table *t, const float wi[3], const float wo[3], const float u[2], float out[11])
 {
     if (!t || !wi || !wo || !u || !out) return MRL_ERR_INVALID;
+    if (t->m.kind == mrl::KIND_RGL) {
+        host_rgl_eval_pdf(t, wi, wo, out, out + 3);
+        mrl::rgl::sample(t->rgl, wi[0], wi[1], wi[2], u[0], u[1], out + 4, out[7], out + 8);
+        return MRL_OK;
+    }
     if (t->opts.lookup) { host_eval_pdf<1>(t, wi, wo, out, out + 3); host_sample<1>(t, wi, u, out + 4, out + 7, out + 8); }
     else { host_eval_pdf<0>(t, wi, wo, out, out + 3); host_sample<0>(t, wi, u, out + 4, out + 7, out + 8); }
     return MRL_OK;
@@ -97,7 +113,7 @@ int mrl_host_table_info(const mrl_host_table *t, int dims[3], int *param, int *l
     if (param) *param = t->m.param;
     if (lookup) *lookup = t->opts.lookup;
     if (sampling) *sampling = t->opts.sampling;
-    if (bytes) *bytes = t->rows.size() * sizeof(float4) + t->marginal.size() * sizeof(double);
+    if (bytes) *bytes = t->rows.size() * sizeof(float4) + t->marginal.size() * sizeof(double) + t->rgl_image.size() * sizeof(float);
     return MRL_OK;
 }
 

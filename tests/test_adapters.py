@@ -46,6 +46,9 @@ def test_plugins_export_host_entry_points(built):
             assert hasattr(so3, sym)
         so3.plugin_name.restype = C.c_char_p
         assert so3.plugin_name() in (b"MerlBSDF", b"CustomizedMeasurement")
+    so3 = C.CDLL(os.path.join(built, "plugins3", "measured.so"))
+    so3.plugin_name.restype = C.c_char_p
+    assert so3.plugin_name() == b"Measured" and hasattr(so3, "plugin_create_scalar_rgb")
 
 
 def test_plugin_constructor_fails_loudly_without_gpu(built, merl_file):
@@ -315,3 +318,52 @@ def test_scalar_calls_on_the_cpu_match_oracle(built, merl_file, oracle, tables, 
         single = float(found.group(1))
         print(f"CPU scalar plugin call: {single:.3f} us per virtual call from one thread, {float(found.group(2)):.3f} us amortised over 16")
         assert single < 0.5, "a scalar virtual call on the CPU path should cost what the CPU plugin it replaces costs"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_phi", [1, 5])
+def test_mitsuba3_measured_plugin_evaluates_an_rgl_file(built, tmp_path, n_phi):
+    """<bsdf type="measured"> over a synthetic file with the RGL field names (PARITY UNPINNED: no database file and no upstream
+    source offline; the checker is oracle/rgl_oracle.c).  Scalar virtual calls run on the CPU (the per-unit functions compiled
+    for the host), BatchedBSDF calls on the GPU; both against the oracle at 1e-6, and against each other."""
+    from oracle.binding import OracleRgl, generate_pairs
+    fields = synth.make_rgl_fields(seed=11, n_phi=n_phi, n_theta=5, res=10)
+    tfile = str(tmp_path / "synthetic_rgb.bsdf")
+    synth.write_tensor_file(tfile, fields)
+    n, m = 6000, 400
+    wi, wo, u = generate_pairs(0x5EED, 4711, n)
+    wi[3, 2] = -wi[3, 2]; wo[5, 2] = -wo[5, 2]
+    pairs, out = str(tmp_path / "pairs.bin"), str(tmp_path / "out.bin")
+    _write_pairs(pairs, wi, wo, u)
+    drv, plug = os.path.join(built, "driver3"), os.path.join(built, "plugins3", "measured.so")
+    r = subprocess.run([drv, plug, tfile, pairs, out, str(m)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "plugin: Measured" in r.stdout and "scalar = cpu" in r.stdout
+    scalar, batch = _read_out(out, m, n)
+    orc = OracleRgl(fields)
+    rgb, pdf = orc.eval_pdf(wi, wo)
+
+    def close(a, b, what):
+        b = np.asarray(b, np.float64)
+        err = np.abs(a.astype(np.float64) - b) / (np.abs(b) + 0.1 * max(float(np.abs(b).max()), 1e-30))
+        assert float(err.max()) < 1e-6, (what, float(err.max()))
+
+    for got, name in ((batch, "batch"), (scalar, "scalar")):
+        k = got.shape[0]
+        close(got[:, 0:3], rgb[:k], name + " eval"); close(got[:, 3], pdf[:k], name + " pdf")
+        live = got[:, 7] > 0
+        assert live.mean() > 0.5
+        c_rgb, c_pdf = orc.eval_pdf(wi[:k][live], got[live, 4:7])            # the oracle AT the direction the plugin returned
+        close(got[live, 7], c_pdf, name + " sample pdf"); close(got[live, 8:11], c_rgb / c_pdf[:, None], name + " weight")
+    assert float(np.abs(batch[3]).max()) == 0.0 and float(np.abs(batch[5, 0:4]).max()) == 0.0     # below the horizon
+    # the CPU one-unit path and the GPU batch path: the same functions on two targets
+    close(scalar[:, 0:4], batch[:m, 0:4], "scalar vs batch")
+    assert float(np.abs(scalar[:, 4:7] - batch[:m, 4:7]).max()) < 5e-7
+    same = np.mean(scalar.view(np.int32) == batch[:m].view(np.int32))
+    assert same > 0.95, same
+    # scalar = "gpu" is refused by name; a table container is not an RGL file
+    r = subprocess.run([drv, plug, tfile, pairs, out, str(m)], capture_output=True, text=True, timeout=120, env=GPU_SCALAR)
+    assert r.returncode == 5 and "scalar" in r.stderr
+    table = os.path.join(os.path.dirname(__file__), "golden", "tensor_table_c5.bsdf")
+    r = subprocess.run([drv, plug, table, pairs, out, str(m)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 5 and "phi_i" in r.stderr

@@ -91,12 +91,18 @@ def test_host_arrays_queues_and_mixed_batches():
         mixed = g.eval(wi_t, wo_t, mat=mat)
         alone = g.eval(wi_t, wo_t, material=ggx)
         assert float(mixed[1::2].abs().max()) == 0.0 and torch.equal(mixed[0::2], alone[0::2])
-        # one-unit calls and host images do not take it
+        # the device's one-unit call service does not take it ...
         with pytest.raises(host.MerlHipError) as e:
             g.scalar_eval_sample(wi_t[0].cpu().numpy(), wo_t[0].cpu().numpy(), u_t[0].cpu().numpy(), material=mid)
         assert e.value.status == host.ERR_MATERIAL
-        with pytest.raises(host.MerlHipError):
-            g.host_table(mid)
+        # ... one-unit calls run on the CPU over a host image: the kernels' own per-unit functions compiled for the host
+        with g.host_table(mid) as h:
+            assert h.info()["bytes"] == g.memory_info()["table_bytes"]
+            wi_h, wo_h, u_h = wi_t.cpu().numpy(), wo_t.cpu().numpy(), u_t.cpu().numpy()
+            one = np.stack([h.eval_sample(wi_h[i], wo_h[i], u_h[i]) for i in range(512)])
+        want = np.concatenate([dev[0][:512], dev[1][:512, None], dev[2][:512], dev[3][:512, None], dev[4][:512]], axis=1)
+        assert np.allclose(one, want, rtol=1e-6, atol=1e-7 * float(np.abs(want).max()))
+        assert np.mean(one.view(np.int32) == want.view(np.int32)) > 0.95
         # release gives the memory back and the slot is reusable
         used = g.memory_info()["table_bytes"]
         assert used > 0
