@@ -1409,13 +1409,13 @@ int mrl_material_host_table(mrl_ctx *ctx, int id, mrl_host_table **out)
         const hipError_t e = hipMemcpy(t->rgl_image.data(), mh.d_texels, mh.bytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { (void)hipGetLastError(); delete t; return fail(ctx, MRL_ERR_HIP, std::string("host image: ") + hipGetErrorString(e)); }
         t->rgl = mh.rgl;
-        const float *from = (const float *)mh.d_texels, *to = t->rgl_image.data();
+        const char *from = (const char *)mh.d_texels, *to = (const char *)t->rgl_image.data();
         mrl::WarpDev *all[5] = { &t->rgl.ndf, &t->rgl.sigma, &t->rgl.vndf, &t->rgl.luminance, &t->rgl.rgb };
         for (mrl::WarpDev *w : all) {
-            w->data = to + (w->data - from);
-            if (w->marg) w->marg = to + (w->marg - from);
-            if (w->cond) w->cond = to + (w->cond - from);
-            w->phi = to + (w->phi - from); w->theta = to + (w->theta - from);
+            w->cells = (const float4 *)(to + ((const char *)w->cells - from));
+            if (w->cond) w->cond = (const float2 *)(to + ((const char *)w->cond - from));
+            if (w->rows) w->rows = (const float4 *)(to + ((const char *)w->rows - from));
+            w->phi = (const float *)(to + ((const char *)w->phi - from)); w->theta = (const float *)(to + ((const char *)w->theta - from));
         }
         t->m = mh.dev;
         t->opts = ctx->opts;

@@ -75,7 +75,7 @@ struct RglFields {                   // host arrays, as the file holds them (x f
     const float *ndf, *sigma, *vndf, *luminance, *rgb;
     int jacobian;
 };
-struct RglLayout { size_t phi, theta, data[5], marg[5], cond[5]; };      // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
+struct RglLayout { size_t phi, theta, cells[5], cond[5], rows[5]; };     // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
 const char *rgl_check_fields(const RglFields &f);                        // nullptr, or what is wrong
 RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob); // normalised tables + running integrals, host f64
 RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base);

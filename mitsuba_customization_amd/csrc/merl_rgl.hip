@@ -3,9 +3,10 @@
 // PARITY UNPINNED (see merl_rgl.hpp).  SURVEY.md §8f item 3.
 //
 //   k_rgl<MODE, INDEXED>   one lane = one unit, grid-stride; the material's descriptor (five WarpDev) arrives by value in
-//                          SGPRs; every table read is a per-lane gather served by L1/L2 (a material is 0.2 - 20 MB).
-// What bounds it: dependent gathers (binary searches in the running integrals, ~40 (eval) to ~150 (sample) loads per unit
-// behind f64 arithmetic); measured rates: DESIGN.md §5c.
+//                          SGPRs; every table read is a per-lane gather served by L1/L2 (a material is 0.5 - 50 MB).
+// What bounds it: the number of scattered lane-addresses the CU's texture addresser resolves (93 % of wave cycles wait on
+// memory, VALU is under 10 % busy: profiles/r03_rgl_pmc.json) — hence the image's cell bricks (one 16-B load per cell and
+// slice where the file's node-major layout needs four); measured rates: DESIGN.md §5c.
 #include "merl_kernels.hpp"
 #include "merl_rgl.hpp"
 
@@ -71,42 +72,63 @@ bool ascending(const float *p, int n)
     return true;
 }
 
-// appends one function's tables to the image: data (normalised if asked), and for distributions the running integrals
-// cond (along x, per node row) and marg (over rows), all rounded to Float once from f64 sums.  Offsets in floats.
-struct WarpOffsets { size_t data = 0, marg = 0, cond = 0; };
-WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, int ny, size_t slices, bool distribution)
+// appends one function's tables to the image (offsets in floats, each a multiple of 4 so that the vectors are 16-B aligned):
+// the corner bricks (normalised if a distribution) and, for distributions, the running integrals `cond` (along x, node rows
+// row / row + 1 side by side) and `rows` (marginal cdf before / after the cell row, totals of its two node rows) — all rounded
+// to Float once from f64 sums, in the oracle's loop order.  src: [slices][n_ch][ny][nx].
+struct WarpOffsets { size_t cells = 0, cond = 0, rows = 0; };
+WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, int ny, size_t slices, int n_ch, bool distribution)
 {
-    const size_t per = (size_t)nx * ny;
+    const size_t per = (size_t)nx * ny, cells = (size_t)(nx - 1) * (size_t)(ny - 1);
+    auto grow = [&](size_t floats) { const size_t at = (blob.size() + 3) / 4 * 4; blob.resize(at + floats, 0.0f); return at; };
     WarpOffsets off;
-    off.data = blob.size();
-    blob.resize(blob.size() + per * slices);
+    off.cells = grow(cells * 4 * (size_t)n_ch * slices);
     if (distribution) {
-        off.marg = blob.size(); blob.resize(blob.size() + (size_t)(ny - 1) * slices);
-        off.cond = blob.size(); blob.resize(blob.size() + (size_t)ny * (size_t)(nx - 1) * slices);
+        off.cond = grow(cells * 2 * slices);
+        off.rows = grow((size_t)(ny - 1) * 4 * slices);
     }
     std::vector<double> cond((size_t)ny * (size_t)(nx - 1)), marg((size_t)(ny - 1));
-    for (size_t s = 0; s < slices; ++s) {
-        const float *src = src_all + per * s;
-        double norm = 1.0;
-        if (distribution) {
-            for (int y = 0; y < ny; ++y) {
-                double sum = 0.0;
-                for (int x = 0; x < nx - 1; ++x) {
-                    sum += 0.5 * ((double)src[y * nx + x] + (double)src[y * nx + x + 1]);
-                    cond[(size_t)y * (size_t)(nx - 1) + (size_t)x] = sum;
+    std::vector<float> node(per), condf(cond.size()), margf(marg.size());
+    for (size_t s = 0; s < slices; ++s)
+        for (int ch = 0; ch < n_ch; ++ch) {
+            const float *src = src_all + per * (s * (size_t)n_ch + (size_t)ch);
+            double norm = 1.0;
+            if (distribution) {
+                for (int y = 0; y < ny; ++y) {
+                    double sum = 0.0;
+                    for (int x = 0; x < nx - 1; ++x) {
+                        sum += 0.5 * ((double)src[y * nx + x] + (double)src[y * nx + x + 1]);
+                        cond[(size_t)y * (size_t)(nx - 1) + (size_t)x] = sum;
+                    }
                 }
+                double sum = 0.0;
+                for (int y = 0; y < ny - 1; ++y) {
+                    sum += 0.5 * (cond[(size_t)y * (size_t)(nx - 1) + (size_t)(nx - 2)] + cond[(size_t)(y + 1) * (size_t)(nx - 1) + (size_t)(nx - 2)]);
+                    marg[(size_t)y] = sum;
+                }
+                norm = sum > 0.0 ? 1.0 / sum : 1.0;
+                for (size_t k = 0; k < cond.size(); ++k) condf[k] = (float)(cond[k] * norm);
+                for (size_t k = 0; k < marg.size(); ++k) margf[k] = (float)(marg[k] * norm);
             }
-            double sum = 0.0;
-            for (int y = 0; y < ny - 1; ++y) {
-                sum += 0.5 * (cond[(size_t)y * (size_t)(nx - 1) + (size_t)(nx - 2)] + cond[(size_t)(y + 1) * (size_t)(nx - 1) + (size_t)(nx - 2)]);
-                marg[(size_t)y] = sum;
-            }
-            norm = sum > 0.0 ? 1.0 / sum : 1.0;
-            for (size_t k = 0; k < cond.size(); ++k) blob[off.cond + s * cond.size() + k] = (float)(cond[k] * norm);
-            for (size_t k = 0; k < marg.size(); ++k) blob[off.marg + s * marg.size() + k] = (float)(marg[k] * norm);
+            for (size_t k = 0; k < per; ++k) node[k] = (float)((double)src[k] * norm);
+            for (int y = 0; y < ny - 1; ++y)
+                for (int x = 0; x < nx - 1; ++x) {
+                    const size_t cell = (size_t)y * (size_t)(nx - 1) + (size_t)x;
+                    float *q = &blob[off.cells + ((s * cells + cell) * (size_t)n_ch + (size_t)ch) * 4];
+                    q[0] = node[(size_t)y * nx + x]; q[1] = node[(size_t)y * nx + x + 1];
+                    q[2] = node[(size_t)(y + 1) * nx + x]; q[3] = node[(size_t)(y + 1) * nx + x + 1];
+                    if (distribution) {
+                        float *c = &blob[off.cond + (s * cells + cell) * 2];
+                        c[0] = condf[(size_t)y * (size_t)(nx - 1) + (size_t)x]; c[1] = condf[(size_t)(y + 1) * (size_t)(nx - 1) + (size_t)x];
+                    }
+                }
+            if (distribution)
+                for (int y = 0; y < ny - 1; ++y) {
+                    float *r = &blob[off.rows + (s * (size_t)(ny - 1) + (size_t)y) * 4];
+                    r[0] = y > 0 ? margf[(size_t)y - 1] : 0.0f; r[1] = margf[(size_t)y];
+                    r[2] = condf[(size_t)y * (size_t)(nx - 1) + (size_t)(nx - 2)]; r[3] = condf[(size_t)(y + 1) * (size_t)(nx - 1) + (size_t)(nx - 2)];
+                }
         }
-        for (size_t k = 0; k < per; ++k) blob[off.data + per * s + k] = (float)((double)src[k] * norm);
-    }
     return off;
 }
 
@@ -142,25 +164,26 @@ RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob)
     l.phi = 0; l.theta = (size_t)f.n_phi;
     blob.insert(blob.end(), f.phi_i, f.phi_i + f.n_phi);
     blob.insert(blob.end(), f.theta_i, f.theta_i + f.n_theta);
-    auto put = [&](int which, const float *src, const int res[2], size_t n, bool distribution) {
-        const WarpOffsets o = append_warp(blob, src, res[0], res[1], n, distribution);
-        l.data[which] = o.data; l.marg[which] = o.marg; l.cond[which] = o.cond;
+    auto put = [&](int which, const float *src, const int res[2], size_t n, int n_ch, bool distribution) {
+        const WarpOffsets o = append_warp(blob, src, res[0], res[1], n, n_ch, distribution);
+        l.cells[which] = o.cells; l.cond[which] = o.cond; l.rows[which] = o.rows;
     };
-    put(0, f.ndf, f.res_ndf, 1, false);
-    put(1, f.sigma, f.res_sigma, 1, false);
-    put(2, f.vndf, f.res, slices, true);
-    put(3, f.luminance, f.res, slices, true);
-    put(4, f.rgb, f.res, slices * 3, false);
+    put(0, f.ndf, f.res_ndf, 1, 1, false);
+    put(1, f.sigma, f.res_sigma, 1, 1, false);
+    put(2, f.vndf, f.res, slices, 1, true);
+    put(3, f.luminance, f.res, slices, 1, true);
+    put(4, f.rgb, f.res, slices, 3, false);
     return l;
 }
 
+// base: 16-B aligned
 RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base)
 {
     auto warp = [&](int which, const int res[2], int n_phi, int n_theta, int n_ch, bool distribution) {
         WarpDev w;
-        w.data = base + l.data[which];
-        w.marg = distribution ? base + l.marg[which] : nullptr;
-        w.cond = distribution ? base + l.cond[which] : nullptr;
+        w.cells = (const float4 *)(base + l.cells[which]);
+        w.cond = distribution ? (const float2 *)(base + l.cond[which]) : nullptr;
+        w.rows = distribution ? (const float4 *)(base + l.rows[which]) : nullptr;
         w.phi = base + l.phi; w.theta = base + l.theta;
         w.nx = res[0]; w.ny = res[1]; w.n_phi = n_phi; w.n_theta = n_theta; w.n_ch = n_ch;
         w.normalized = distribution ? 1 : 0;

@@ -15,18 +15,26 @@
 // pdf(wi, wo):   vndf.pdf(u_m) * luminance(s) / (max(2 pi^2 u_m.x sin theta_m, 1e-6) * 4 (wi . m))
 // sample(wi, u): s = luminance.sample(u), u_m = vndf.sample(s), wo = reflect(wi, m(u_m)); what is reported is eval / pdf
 //                AT the Float direction that is returned (so pdf(wi, sample.wo) == sample.pdf and weight == eval / pdf).
-// Math in f64 on Float tables, one lane per unit; every table read is a plain gather (tables are a few hundred KB to a
-// few MB per material: cache resident), so this path is latency / VALU bound, not HBM bound.
+// Math in f64 on Float tables with the table path's own building blocks (v_rcp / v_rsq seeds + one Newton step, the
+// pi/8-rotated atan polynomial, Taylor sin / cos: relative error ~1e-15 each) in place of ocml's correctly rounded
+// division, sqrt, asin, atan2, sin and cos (735 VALU instructions per eval, 93 VGPRs; the outputs are rounded to Float
+// anyway).  One lane per unit; every table read is a per-lane gather from an image of 1 - 50 MB (L2 resident), and the
+// gathers are what bounds the kernel (the texture addresser is 80 % busy, see WarpDev) — not VALU, not HBM.
 #pragma once
 #include "merl_device.hpp"
+#include "merl_table_fast.hpp"     // rcp_nr / div_fast / sqrt_fast / rsqrt_pos / atan2_q1: the table path's f64 building blocks
+#include "merl_ggx_fast.hpp"       // sincos_2pi
 
 namespace mrl {
 
-// one piecewise-bilinear function; slices are row-major in (phi, theta, channel), a slice is [ny][nx] nodes, x fastest
+// One piecewise-bilinear function.  Slices are row-major in (phi, theta); a slice is (ny - 1) x (nx - 1) cells, x fastest.
+// Everything a lookup needs about a cell sits in ONE aligned vector per table, so that a lane issues one load where the
+// node-major file layout needs four (the kernel is bound by the number of scattered lane-addresses the CU's texture
+// addresser resolves, not by VALU or bytes: DESIGN.md §5c, profiles/r03_rgl_pmc.json):
 struct WarpDev {
-    const float *data;      // [slices][ny][nx]        (divided by the slice's integral when normalised)
-    const float *marg;      // [slices][ny - 1]        running integral over rows         (distributions only)
-    const float *cond;      // [slices][ny][nx - 1]    running integral along a node row  (distributions only)
+    const float4 *cells;    // [slices][cell][n_ch]  the cell's four corner values (v00, v10, v01, v11), normalised if a distribution
+    const float2 *cond;     // [slices][cell]        running integrals along x, up to node col + 1, of node rows (row, row + 1)
+    const float4 *rows;     // [slices][ny - 1]      (marginal cdf before the row, after the row, total of node row `row`, of `row + 1`)
     const float *phi, *theta;   // ascending parameter grids (unused when the count is 1)
     int nx, ny, n_phi, n_theta, n_ch;
     int normalized;
@@ -43,7 +51,7 @@ namespace rgl {
 // the four parameter slices around (phi_i, theta_i) and their weights, phi fastest (the order the oracle sums in); `mask`
 // says which entries exist (a grid of one node has no upper neighbour) — uniform over a launch, so fetch()'s tests are
 // scalar branches and the arrays stay in registers
-struct Slices { int s[4]; double w[4]; int mask; };
+struct Slices { unsigned s[4]; double w[4]; int mask; };
 
 MRL_HD void bracket(const float *grid, int n, double p, int &i, double &t)
 {
@@ -52,7 +60,7 @@ MRL_HD void bracket(const float *grid, int n, double p, int &i, double &t)
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((double)grid[mid] <= p) lo = mid; else hi = mid; }
     i = lo;
     const double p0 = grid[lo], p1 = grid[lo + 1];
-    t = (p - p0) / (p1 - p0);
+    t = fast::div_fast(p - p0, p1 - p0);
     t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
 }
 
@@ -64,10 +72,10 @@ MRL_HD Slices find_slices(const WarpDev &w, double phi_i, double theta_i)
     if (w.n_theta > 1) bracket(w.theta, w.n_theta, theta_i, it, tt);
     const int ip1 = w.n_phi > 1 ? ip + 1 : ip, it1 = w.n_theta > 1 ? it + 1 : it;
     Slices out;
-    out.s[0] = ip * w.n_theta + it;  out.w[0] = (1.0 - tp) * (1.0 - tt);
-    out.s[1] = ip1 * w.n_theta + it; out.w[1] = tp * (1.0 - tt);
-    out.s[2] = ip * w.n_theta + it1; out.w[2] = (1.0 - tp) * tt;
-    out.s[3] = ip1 * w.n_theta + it1; out.w[3] = tp * tt;
+    out.s[0] = (unsigned)(ip * w.n_theta + it);  out.w[0] = (1.0 - tp) * (1.0 - tt);
+    out.s[1] = (unsigned)(ip1 * w.n_theta + it); out.w[1] = tp * (1.0 - tt);
+    out.s[2] = (unsigned)(ip * w.n_theta + it1); out.w[2] = (1.0 - tp) * tt;
+    out.s[3] = (unsigned)(ip1 * w.n_theta + it1); out.w[3] = tp * tt;
     out.mask = 1 | (w.n_phi > 1 ? 2 : 0) | (w.n_theta > 1 ? 4 : 0) | (w.n_phi > 1 && w.n_theta > 1 ? 8 : 0);
     return out;
 }
@@ -75,17 +83,44 @@ MRL_HD Slices find_slices(const WarpDev &w, double phi_i, double theta_i)
 MRL_HD Slices single_slice()
 {
     Slices out;
-    for (int k = 0; k < 4; ++k) { out.s[k] = 0; out.w[k] = 0.0; }
+    for (int k = 0; k < 4; ++k) { out.s[k] = 0u; out.w[k] = 0.0; }
     out.w[0] = 1.0; out.mask = 1;
     return out;
 }
 
-MRL_HD double fetch(const Slices &s, const float *base, int per_slice, int index)
+// weighted sums over the parameter slices, component by component in slice order (what the oracle's scalar loop does);
+// 32-bit offsets: a function's tables hold at most 2^28 values (rgl_check_fields)
+struct D4 { double x, y, z, w; };
+struct D2 { double x, y; };
+MRL_HD D4 fetch4(const Slices &s, const float4 *base, int per_slice, int index, int stride = 1, int offset = 0)
+{
+    D4 v = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if ((s.mask >> k) & 1) {
+            const float4 q = base[(s.s[k] * (unsigned)per_slice + (unsigned)index) * (unsigned)stride + (unsigned)offset];
+            v.x += s.w[k] * (double)q.x; v.y += s.w[k] * (double)q.y; v.z += s.w[k] * (double)q.z; v.w += s.w[k] * (double)q.w;
+        }
+    return v;
+}
+MRL_HD D2 fetch2(const Slices &s, const float2 *base, int per_slice, int index)
+{
+    D2 v = { 0.0, 0.0 };
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if ((s.mask >> k) & 1) {
+            const float2 q = base[s.s[k] * (unsigned)per_slice + (unsigned)index];
+            v.x += s.w[k] * (double)q.x; v.y += s.w[k] * (double)q.y;
+        }
+    return v;
+}
+// the marginal cdf after row `index` alone (the row search)
+MRL_HD double fetch_marg(const Slices &s, const float4 *rows, int per_slice, int index)
 {
     double v = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if ((s.mask >> k) & 1) v += s.w[k] * (double)base[(size_t)s.s[k] * (size_t)per_slice + (size_t)index];
+        if ((s.mask >> k) & 1) v += s.w[k] * (double)rows[s.s[k] * (unsigned)per_slice + (unsigned)index].y;
     return v;
 }
 
@@ -95,19 +130,17 @@ MRL_HD int clamp_cell(double p, int last)
     return i < 0 ? 0 : (i > last ? last : i);
 }
 
-MRL_HD double warp_eval(const WarpDev &w, const Slices &s, double x_in, double y_in)
+MRL_HD double warp_eval(const WarpDev &w, const Slices &s, double x_in, double y_in, int channel = 0)
 {
     const double px = x_in * (double)(w.nx - 1), py = y_in * (double)(w.ny - 1);
     const int ox = clamp_cell(px, w.nx - 2), oy = clamp_cell(py, w.ny - 2);
     const double fx = px - (double)ox, fy = py - (double)oy;
-    const int per = w.nx * w.ny, idx = oy * w.nx + ox;
-    const double v00 = fetch(s, w.data, per, idx), v10 = fetch(s, w.data, per, idx + 1);
-    const double v01 = fetch(s, w.data, per, idx + w.nx), v11 = fetch(s, w.data, per, idx + w.nx + 1);
-    const double v = (1.0 - fy) * ((1.0 - fx) * v00 + fx * v10) + fy * ((1.0 - fx) * v01 + fx * v11);
+    const D4 q = fetch4(s, w.cells, (w.nx - 1) * (w.ny - 1), oy * (w.nx - 1) + ox, w.n_ch, channel);
+    const double v = (1.0 - fy) * ((1.0 - fx) * q.x + fx * q.y) + fy * ((1.0 - fx) * q.z + fx * q.w);
     return w.normalized ? v * (double)(w.nx - 1) * (double)(w.ny - 1) : v;
 }
 
-MRL_HD double safe_sqrt(double x) { return x > 0.0 ? sqrt(x) : 0.0; }
+MRL_HD double safe_sqrt(double x) { return x > 0.0 ? fast::sqrt_fast(x) : 0.0; }
 MRL_HD double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 
 // position in [0, 1] at which a density running linearly from c0 to c1 has accumulated the mass u
@@ -116,39 +149,40 @@ MRL_HD double invert_linear(double c0, double c1, double u)
     const bool is_const = fabs(c0 - c1) < 1e-4 * (c0 + c1);
     const double num = is_const ? 2.0 * u : c0 - safe_sqrt(c0 * c0 - 2.0 * u * (c0 - c1));
     const double den = is_const ? c0 + c1 : c0 - c1;
-    return den != 0.0 ? num / den : 0.0;
+    return den != 0.0 ? fast::div_fast(num, den) : 0.0;
 }
 
 // uniform sample -> position; returns the density there
 MRL_HD double warp_sample(const WarpDev &w, const Slices &s, double ux, double uy, double &x_out, double &y_out)
 {
     const int nx = w.nx, ny = w.ny;
-    const int per_m = ny - 1, per_c = ny * (nx - 1), per_d = nx * ny;
+    const int per_r = ny - 1, per_c = (ny - 1) * (nx - 1);
     ux = clamp01(ux); uy = clamp01(uy);
     int lo = 0, hi = ny - 2;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (fetch(s, w.marg, per_m, mid) < uy) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (fetch_marg(s, w.rows, per_r, mid) < uy) lo = mid + 1; else hi = mid; }
     const int row = lo;
-    if (row > 0) uy -= fetch(s, w.marg, per_m, row - 1);
-    const double r0 = fetch(s, w.cond, per_c, row * (nx - 1) + (nx - 2));
-    const double r1 = fetch(s, w.cond, per_c, (row + 1) * (nx - 1) + (nx - 2));
+    const D4 rw = fetch4(s, w.rows, per_r, row);                // (cdf before the row, after it, r0, r1)
+    if (row > 0) uy -= rw.x;
+    const double r0 = rw.z, r1 = rw.w;
     const double y = clamp01(invert_linear(r0, r1, uy));
     ux *= (1.0 - y) * r0 + y * r1;
     lo = 0; hi = nx - 2;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        const double c = (1.0 - y) * fetch(s, w.cond, per_c, row * (nx - 1) + mid) + y * fetch(s, w.cond, per_c, (row + 1) * (nx - 1) + mid);
+        const D2 p = fetch2(s, w.cond, per_c, row * (nx - 1) + mid);
+        const double c = (1.0 - y) * p.x + y * p.y;
         if (c < ux) lo = mid + 1; else hi = mid;
     }
     const int col = lo;
-    if (col > 0)
-        ux -= (1.0 - y) * fetch(s, w.cond, per_c, row * (nx - 1) + col - 1) + y * fetch(s, w.cond, per_c, (row + 1) * (nx - 1) + col - 1);
-    const int idx = row * nx + col;
-    const double v00 = fetch(s, w.data, per_d, idx), v10 = fetch(s, w.data, per_d, idx + 1);
-    const double v01 = fetch(s, w.data, per_d, idx + nx), v11 = fetch(s, w.data, per_d, idx + nx + 1);
-    const double c0 = (1.0 - y) * v00 + y * v01, c1 = (1.0 - y) * v10 + y * v11;
+    if (col > 0) {
+        const D2 p = fetch2(s, w.cond, per_c, row * (nx - 1) + col - 1);
+        ux -= (1.0 - y) * p.x + y * p.y;
+    }
+    const D4 q = fetch4(s, w.cells, per_c, row * (nx - 1) + col);
+    const double c0 = (1.0 - y) * q.x + y * q.z, c1 = (1.0 - y) * q.y + y * q.w;
     const double x = clamp01(invert_linear(c0, c1, ux));
-    x_out = ((double)col + x) / (double)(nx - 1);
-    y_out = ((double)row + y) / (double)(ny - 1);
+    x_out = fast::div_fast((double)col + x, (double)(nx - 1));
+    y_out = fast::div_fast((double)row + y, (double)(ny - 1));
     return ((1.0 - x) * c0 + x * c1) * (double)(nx - 1) * (double)(ny - 1);
 }
 
@@ -156,45 +190,55 @@ MRL_HD double warp_sample(const WarpDev &w, const Slices &s, double ux, double u
 MRL_HD double warp_invert(const WarpDev &w, const Slices &s, double x_in, double y_in, double &ux_out, double &uy_out)
 {
     const int nx = w.nx, ny = w.ny;
-    const int per_m = ny - 1, per_c = ny * (nx - 1), per_d = nx * ny;
+    const int per_r = ny - 1, per_c = (ny - 1) * (nx - 1);
     const double px = x_in * (double)(nx - 1), py = y_in * (double)(ny - 1);
     const int col = clamp_cell(px, nx - 2), row = clamp_cell(py, ny - 2);
     const double x = px - (double)col, y = py - (double)row;
-    const int idx = row * nx + col;
-    const double v00 = fetch(s, w.data, per_d, idx), v10 = fetch(s, w.data, per_d, idx + 1);
-    const double v01 = fetch(s, w.data, per_d, idx + nx), v11 = fetch(s, w.data, per_d, idx + nx + 1);
-    const double c0 = (1.0 - y) * v00 + y * v01, c1 = (1.0 - y) * v10 + y * v11;
+    const D4 q = fetch4(s, w.cells, per_c, row * (nx - 1) + col);
+    const double c0 = (1.0 - y) * q.x + y * q.z, c1 = (1.0 - y) * q.y + y * q.w;
     const double pdf = ((1.0 - x) * c0 + x * c1) * (double)(nx - 1) * (double)(ny - 1);
     double sx = x * (c0 + 0.5 * x * (c1 - c0));
-    if (col > 0)
-        sx += (1.0 - y) * fetch(s, w.cond, per_c, row * (nx - 1) + col - 1) + y * fetch(s, w.cond, per_c, (row + 1) * (nx - 1) + col - 1);
-    const double r0 = fetch(s, w.cond, per_c, row * (nx - 1) + (nx - 2));
-    const double r1 = fetch(s, w.cond, per_c, (row + 1) * (nx - 1) + (nx - 2));
+    if (col > 0) {
+        const D2 p = fetch2(s, w.cond, per_c, row * (nx - 1) + col - 1);
+        sx += (1.0 - y) * p.x + y * p.y;
+    }
+    const D4 rw = fetch4(s, w.rows, per_r, row);
+    const double r0 = rw.z, r1 = rw.w;
     const double tot = (1.0 - y) * r0 + y * r1;
-    ux_out = tot > 0.0 ? sx / tot : 0.0;
+    ux_out = tot > 0.0 ? fast::div_fast(sx, tot) : 0.0;
     double sy = y * (r0 + 0.5 * y * (r1 - r0));
-    if (row > 0) sy += fetch(s, w.marg, per_m, row - 1);
+    if (row > 0) sy += rw.x;
     uy_out = sy;
     return pdf;
 }
 
-// 2 asin(|d - z| / 2): acos(d.z) without its cancellation near the pole
-MRL_HD double elevation(const Vec3d &d)
+// polar angle of a unit direction of the upper hemisphere (d.z > 0): atan2(|d_xy|, d_z), well conditioned at the pole
+MRL_HD double elevation(const Vec3d &d) { return fast::atan2_q1<false>(fast::sqrt_fast(d.x * d.x + d.y * d.y), d.z); }
+// atan2(y, x) over the full circle, IEEE signs (atan2(+-0, -x) = +-pi, atan2(+-0, +-0) = +-0 or +-pi)
+MRL_HD double azimuth(double y, double x)
 {
-    const double dz = d.z - 1.0;
-    const double h = 0.5 * sqrt(d.x * d.x + d.y * d.y + dz * dz);
-    return 2.0 * asin(h > 1.0 ? 1.0 : h);
+    const bool neg_x = __builtin_signbit(x), neg_y = __builtin_signbit(y);
+    const double t = (x == 0.0 && y == 0.0) ? 0.0 : fast::atan2_q1<false>(__builtin_fabs(y), __builtin_fabs(x));
+    const double r = neg_x ? kPi - t : t;
+    return neg_y ? -r : r;
 }
-MRL_HD double theta2u(double t) { return sqrt(t * (2.0 / kPi)); }
+MRL_HD double theta2u(double t) { return fast::sqrt_fast(t * (2.0 / kPi)); }
 MRL_HD double phi2u(double p) { return (p + kPi) * (0.5 / kPi); }
-MRL_HD double u2theta(double u) { return u * u * (kPi / 2.0); }
-MRL_HD double u2phi(double u) { return (2.0 * u - 1.0) * kPi; }
 
+// (contraction off: wi * rs + wo * rs must cancel exactly for a mirror pair — fused into fma(wi, rs, round(wo * rs)) it leaves
+// the product's rounding error, and the half vector of the specular direction gets an arbitrary azimuth)
 MRL_HD bool unit3(Vec3d &v)
 {
-    const double n = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
-    if (!(n > 0.0)) return false;
-    v.x /= n; v.y /= n; v.z /= n;
+#pragma clang fp contract(off)
+    const double n2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (!(n2 > 0.0)) return false;
+    // two Newton steps: for a near-mirror pair the half vector's transverse part is the DIFFERENCE of the two
+    // normalisations (|m_xy| ~ 1e-10 for inputs that differ by a few Float ulps), so the reciprocal norm must be good to
+    // an f64 ulp or the half vector's azimuth is noise
+    double y = fast::rsqrt_pos(n2);
+    const double e = __builtin_fma(-(n2 * y), y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    v.x *= y; v.y *= y; v.z *= y;
     return true;
 }
 
@@ -206,10 +250,14 @@ MRL_HD void eval_pdf(const RglDev &b, float wix, float wiy, float wiz, float wox
     if (!(wiz > 0.0f) || !(woz > 0.0f)) return;
     Vec3d wi = { (double)wix, (double)wiy, (double)wiz }, wo = { (double)wox, (double)woy, (double)woz };
     if (!unit3(wi) || !unit3(wo)) return;
-    Vec3d m = { wi.x + wo.x, wi.y + wo.y, wi.z + wo.z };
+    Vec3d m;
+    {
+#pragma clang fp contract(off)
+        m.x = wi.x + wo.x; m.y = wi.y + wo.y; m.z = wi.z + wo.z;
+    }
     if (!unit3(m)) return;
-    const double theta_i = elevation(wi), phi_i = atan2(wi.y, wi.x);
-    const double theta_m = elevation(m), phi_m = atan2(m.y, m.x);
+    const double theta_i = elevation(wi), phi_i = azimuth(wi.y, wi.x);
+    const double theta_m = elevation(m), phi_m = azimuth(m.y, m.x);
     const double u_wi_x = theta2u(theta_i), u_wi_y = phi2u(phi_i);
     const double u_m_x = theta2u(theta_m);
     double u_m_y = phi2u(b.isotropic ? phi_m - phi_i : phi_m);
@@ -221,21 +269,19 @@ MRL_HD void eval_pdf(const RglDev &b, float wix, float wiy, float wiz, float wox
         double scale = 1.0;
         if (b.jacobian) {
             const Slices one = single_slice();
-            scale = warp_eval(b.ndf, one, u_m_x, u_m_y) / (4.0 * warp_eval(b.sigma, one, u_wi_x, u_wi_y));
+            scale = fast::div_fast(warp_eval(b.ndf, one, u_m_x, u_m_y), 4.0 * warp_eval(b.sigma, one, u_wi_x, u_wi_y));
         }
         for (int c = 0; c < 3; ++c) {
-            Slices sc = sv;
-            for (int k = 0; k < 4; ++k) sc.s[k] = sv.s[k] * 3 + c;
-            double v = warp_eval(b.rgb, sc, sx, sy);
+            double v = warp_eval(b.rgb, sv, sx, sy, c);
             v = v < 0.0 ? 0.0 : v;
             rgb[c] = (float)(v * scale);
         }
     }
     if constexpr (WANT_PDF) {
         const double lum_pdf = warp_eval(b.luminance, sv, sx, sy);
-        const double sin_theta_m = sqrt(m.x * m.x + m.y * m.y);
+        const double sin_theta_m = fast::sqrt_fast(m.x * m.x + m.y * m.y);
         const double jac = fmax(2.0 * kPi * kPi * u_m_x * sin_theta_m, 1e-6) * 4.0 * (wi.x * m.x + wi.y * m.y + wi.z * m.z);
-        pdf = (float)(vndf_pdf * lum_pdf / jac);
+        pdf = (float)fast::div_fast(vndf_pdf * lum_pdf, jac);
     }
 }
 
@@ -245,16 +291,25 @@ MRL_HD void sample(const RglDev &b, float wix, float wiy, float wiz, float u0, f
     if (!(wiz > 0.0f)) return;
     Vec3d wi = { (double)wix, (double)wiy, (double)wiz };
     if (!unit3(wi)) return;
-    const double theta_i = elevation(wi), phi_i = atan2(wi.y, wi.x);
+    const double theta_i = elevation(wi), phi_i = azimuth(wi.y, wi.x);
     const Slices sv = find_slices(b.vndf, phi_i, theta_i);
     double sx, sy, umx, umy;
     (void)warp_sample(b.luminance, sv, (double)u1, (double)u0, sx, sy);
     (void)warp_sample(b.vndf, sv, sx, sy, umx, umy);
-    double phi_m = u2phi(umy);
-    const double theta_m = u2theta(umx);
-    if (b.isotropic) phi_m += phi_i;
-    const double st = sin(theta_m), ct = cos(theta_m);
-    const Vec3d m = { cos(phi_m) * st, sin(phi_m) * st, ct };
+    // m = (theta_m, phi_m) with theta_m = umx^2 pi/2 and phi_m = (2 umy - 1) pi [+ phi_i]: sin / cos of 2 pi (umx^2 / 4) and
+    // of 2 pi umy - pi; the isotropic offset is a rotation by wi's own azimuth (cos, sin = wi_xy / |wi_xy|), no second sincos
+    double st, ct, sp, cp;
+    fast::sincos_2pi(0.25 * umx * umx, st, ct);
+    fast::sincos_2pi(umy, sp, cp);
+    sp = -sp; cp = -cp;
+    if (b.isotropic) {
+        const double rho2 = wi.x * wi.x + wi.y * wi.y;
+        const double rr = rho2 > 0.0 ? fast::rsqrt_pos(rho2) : 0.0;
+        const double ci = rho2 > 0.0 ? wi.x * rr : (__builtin_signbit(wi.x) ? -1.0 : 1.0), si = wi.y * rr;
+        const double c2 = cp * ci - sp * si, s2 = sp * ci + cp * si;
+        cp = c2; sp = s2;
+    }
+    const Vec3d m = { cp * st, sp * st, ct };
     const double c = wi.x * m.x + wi.y * m.y + wi.z * m.z;
     const float wof[3] = { (float)(2.0 * c * m.x - wi.x), (float)(2.0 * c * m.y - wi.y), (float)(2.0 * c * m.z - wi.z) };
     if (!(wof[2] > 0.0f) || !(c > 0.0)) return;

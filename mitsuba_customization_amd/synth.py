@@ -264,7 +264,8 @@ def make_rgl_fields(seed: int = 0, n_phi: int = 1, n_theta: int = 6, res: int = 
     phi_i [n_phi], theta_i [n_theta], ndf [res_ndf, res_ndf], sigma [res_sigma, res_sigma], vndf / luminance
     [n_phi, n_theta, res, res], rgb [n_phi, n_theta, 3, res, res], jacobian [1], description.  n_phi <= 2: isotropic.
     No measured file exists offline: the tables are smooth, strictly positive synthetic functions (a lobe + seeded
-    low-frequency variation) — they exercise every code path of the model, they are not a material."""
+    low-frequency variation), periodic in every azimuth axis as a measurement is — they exercise every code path of the
+    model, they are not a material."""
     rng = np.random.default_rng(seed)
 
     def smooth(shape, lobe=2.0):
@@ -281,11 +282,22 @@ def make_rgl_fields(seed: int = 0, n_phi: int = 1, n_theta: int = 6, res: int = 
 
     theta_i = np.linspace(0.0, 0.5 * np.pi * 0.97, n_theta).astype(np.float32)
     phi_i = (np.zeros(1) if n_phi == 1 else np.linspace(-np.pi, np.pi, n_phi)).astype(np.float32)
+
+    def closed(a, slices_too=True):
+        # the y axis of every warp is an azimuth (u = (phi + pi) / 2 pi): the rows at u = 0 and u = 1 are the same direction,
+        # and so are the phi_i = -pi and phi_i = +pi slices of an anisotropic file — a measured file is periodic there
+        a[..., -1, :] = a[..., 0, :]
+        if slices_too and n_phi > 1:
+            a[-1] = a[0]
+        return a
+
+    ndf = closed(smooth((res_ndf, res_ndf), 4.0), False)
+    sigma = closed((0.4 + smooth((res_sigma, res_sigma), 1.0)).astype(np.float32), False)
+    vndf, luminance = closed(smooth((n_phi, n_theta, res, res), 3.0)), closed(smooth((n_phi, n_theta, res, res), 1.0))
+    rgb = closed((0.05 + 0.5 * smooth((n_phi, n_theta, 3, res, res), 1.5)).astype(np.float32))
     return {
         "description": np.frombuffer(b"synthetic RGL-shaped fields (mitsuba_customization_amd.synth.make_rgl_fields)", np.uint8).copy(),
         "phi_i": phi_i, "theta_i": theta_i,
-        "ndf": smooth((res_ndf, res_ndf), 4.0), "sigma": (0.4 + smooth((res_sigma, res_sigma), 1.0)).astype(np.float32),
-        "vndf": smooth((n_phi, n_theta, res, res), 3.0), "luminance": smooth((n_phi, n_theta, res, res), 1.0),
-        "rgb": (0.05 + 0.5 * smooth((n_phi, n_theta, 3, res, res), 1.5)).astype(np.float32),
+        "ndf": ndf, "sigma": sigma, "vndf": vndf, "luminance": luminance, "rgb": rgb,
         "jacobian": np.array([1], np.uint8),
     }

@@ -114,3 +114,54 @@ def test_guards():
     assert not rgb.any() and not pdf.any()
     s_wo, s_pdf, s_w = B.sample(wi[:1], np.array([[0.3, 0.4]], np.float32))
     assert not s_wo.any() and not s_pdf.any() and not s_w.any()
+
+
+@pytest.mark.skipif(__import__("shutil").which("hipcc") is None, reason="hipcc missing")
+@pytest.mark.parametrize("case", [dict(seed=1, n_phi=1, n_theta=6, res=12, res_ndf=16, res_sigma=8),
+                                  dict(seed=2, n_phi=5, n_theta=4, res=9, res_ndf=8, res_sigma=6),
+                                  dict(seed=3, n_phi=1, n_theta=1, res=2, res_ndf=2, res_sigma=2)],
+                         ids=lambda c: f"phi{c['n_phi']}_theta{c['n_theta']}_res{c['res']}")
+def test_product_per_unit_functions_on_the_host_match_the_oracle(case, tmp_path_factory):
+    """The product's RGL code — image builder (cell bricks, running integrals) and per-unit eval / pdf / sample, the SAME
+    functions the kernel runs (__host__ __device__) — compiled for the host (tests/rgl_host_harness.hip) against the
+    independent restatement in oracle/rgl_oracle.c.  The product uses reciprocal / rsqrt-seeded Newton steps, an atan
+    polynomial and Taylor sin / cos where the oracle calls libm: 1e-6 relative."""
+    import os
+    import subprocess
+    from oracle.binding import OracleRgl, generate_pairs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    build = tmp_path_factory.getbasetemp() / "rgl_host_harness"
+    if not build.exists():
+        subprocess.check_call(["hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-mavx2", "-mfma", "-w", "-o", str(build),
+                               os.path.join(root, "tests", "rgl_host_harness.hip")])
+    tmp = tmp_path_factory.mktemp("rgl_host")
+    f = synth.make_rgl_fields(**case)
+    with open(tmp / "f.bin", "wb") as o:
+        np.array([case["n_phi"], case["n_theta"], case["res"], case["res_ndf"], case["res_sigma"], 1], np.int32).tofile(o)
+        for k in ("phi_i", "theta_i", "ndf", "sigma", "vndf", "luminance", "rgb"):
+            f[k].astype(np.float32).tofile(o)
+    n = 30000
+    wi, wo, u = generate_pairs(7 + case["seed"], 0, n)
+    wi[:50] = wi[50:100]; wo[:50] = wi[:50] * np.array([-1, -1, 1], np.float32)          # exact mirror pairs: m == n
+    wo[100:150] = wi[100:150] * np.array([-1, -1, 1], np.float32) * np.float32(1 + 3e-7)   # ... and pairs a few ulps off
+    with open(tmp / "p.bin", "wb") as o:
+        np.array([n], np.uint64).tofile(o); wi.tofile(o); wo.tofile(o); u.tofile(o)
+    r = subprocess.run([str(build), str(tmp / "f.bin"), str(tmp / "p.bin"), str(tmp / "o.bin")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = np.fromfile(tmp / "o.bin", np.float32).reshape(n, 11)
+    orc = OracleRgl(f)
+
+    def close(a, b, what):
+        b = np.asarray(b, np.float64)
+        err = np.abs(a.astype(np.float64) - b) / (np.abs(b) + 0.1 * max(float(np.abs(b).max()), 1e-30))
+        assert float(err.max()) < 1e-6, (what, float(err.max()), int(err.argmax()))
+
+    rgb, pdf = orc.eval_pdf(wi, wo)
+    close(out[:, 0:3], rgb, "eval"); close(out[:, 3], pdf, "pdf")
+    o_wo, o_pdf, _ = orc.sample(wi, u)
+    live = out[:, 7] > 0
+    assert live.mean() > 0.5 and np.count_nonzero(live != (o_pdf > 0)) <= 2
+    both = live & (o_pdf > 0)
+    assert float(np.abs(out[both, 4:7] - o_wo[both]).max()) < 5e-7
+    c_rgb, c_pdf = orc.eval_pdf(wi[live], out[live, 4:7])
+    close(out[live, 7], c_pdf, "sample pdf"); close(out[live, 8:11], c_rgb / c_pdf[:, None], "sample weight")
