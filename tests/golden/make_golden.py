@@ -47,8 +47,29 @@ def standard_param_cases():
                             param=param, lookup=lookup, node=node, disk_map=0, wi=wi, wo=wo, u=u, rgb=rgb, pdf=pdf, wo2=wo2, pdf2=pdf2, weight=w)
 
 
+def rgl_cases():
+    """SURVEY.md §8f item 3, the RGL adaptive parameterisation (upstream Mitsuba 3 `measured`): a synthetic file with the real
+    field names in the real container (the file IS the fixture's input) + what oracle/rgl_oracle.c says about it."""
+    for name, shape, first in (("rgl_isotropic", dict(seed=21, n_phi=1, n_theta=4, res=8, res_ndf=8, res_sigma=6), 140_000),
+                               ("rgl_anisotropic", dict(seed=22, n_phi=5, n_theta=3, res=6, res_ndf=6, res_sigma=4), 150_000)):
+        fields = synth.make_rgl_fields(**shape)
+        synth.write_tensor_file(os.path.join(HERE, name + "_rgb.bsdf"), fields)
+        B = ob.OracleRgl(fields)
+        wi, wo, u = ob.generate_pairs(0x5EED, first, N)
+        s = np.float32(np.sqrt(0.5))
+        wi[:5] = [[0, 0, 1], [s, 0, s], [0.6, 0, 0.8], [0.6, 0, -0.8], [0, 0.6, 0.8]]        # normal incidence, mirror, retro,
+        wo[:5] = [[0.6, 0, 0.8], [-s, 0, s], [0.6, 0, 0.8], [0.6, 0, 0.8], [0, 0, 1]]         # below the horizon, normal exitance
+        rgb, pdf = B.eval_pdf(wi, wo)
+        wo2, pdf2, w = B.sample(wi, u)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), table_kind="rgl", table_seed=shape["seed"], bsdf_file=name + "_rgb.bsdf",
+                            wi=wi, wo=wo, u=u, rgb=rgb, pdf=pdf, wo2=wo2, pdf2=pdf2, weight=w)
+
+
 def main():
-    if "--standard-param-only" in sys.argv:            # the older fixtures stay byte-identical in git
+    if "--rgl-only" in sys.argv:                       # the older fixtures stay byte-identical in git
+        return rgl_cases()
+    rgl_cases()
+    if "--standard-param-only" in sys.argv:
         return standard_param_cases()
     standard_param_cases()
     for name, kind, seed, lookup, node, disk, first in CASES:

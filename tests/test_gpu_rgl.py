@@ -147,3 +147,27 @@ def test_load_from_a_tensor_file_and_refusals(tmp_path):
         with pytest.raises(host.MerlHipError) as e:
             g.upload_rgl(aniso)
         assert "symmetry" in str(e.value)
+
+
+@pytest.mark.parametrize("name", ["rgl_isotropic", "rgl_anisotropic"])
+def test_rgl_golden_fixtures(name):
+    """tests/golden/<name>_rgb.bsdf (a synthetic file with the RGL field names, written by make_golden.py) through
+    mrl_material_load_rgl against the committed outputs of oracle/rgl_oracle.c: eval / pdf at 1e-6; a sampled direction may differ from
+    the fixture's by a Float ulp (which moves its pdf and weight by more than 1e-6 near the specular peak), so pdf / weight are
+    held against the fixture only where the direction is bit-identical."""
+    import os
+    from mitsuba_customization_amd import host
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(here, name + ".npz"))
+    import torch
+    with host.MerlHip(0) as g:
+        mid = g.load_rgl(os.path.join(here, str(z["bsdf_file"])))
+        wi, wo, u = (torch.from_numpy(z[k]).cuda() for k in ("wi", "wo", "u"))
+        rgb, pdf, wo2, pdf2, w = (t.cpu().numpy() for t in g.eval_sample(wi, wo, u, material=mid))
+    _close(rgb, z["rgb"], "eval"); _close(pdf, z["pdf"], "pdf")
+    assert float(np.abs(rgb[3]).max()) == 0.0 and pdf[3] == 0.0                          # wi below the horizon
+    assert np.count_nonzero((pdf2 > 0) != (z["pdf2"] > 0)) <= 1
+    assert float(np.abs(wo2 - z["wo2"])[(pdf2 > 0) & (z["pdf2"] > 0)].max()) < 5e-7
+    same = (wo2.view(np.int32) == z["wo2"].view(np.int32)).all(axis=1) & (pdf2 > 0)
+    assert same.mean() > 0.6
+    _close(pdf2[same], z["pdf2"][same], "sample pdf"); _close(w[same], z["weight"][same], "sample weight")
