@@ -163,11 +163,13 @@ int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float 
  *     ndf [res_ndf[1]][res_ndf[0]], sigma [res_sigma[1]][res_sigma[0]]
  *     vndf, luminance [n_phi][n_theta][res[1]][res[0]]          rgb [n_phi][n_theta][3][res[1]][res[0]]
  * The library normalises vndf / luminance per slice and builds their running integrals once (host, f64), then keeps one
- * image in HBM.  An RGL material is evaluated by SINGLE-material calls (mat == NULL; whole-array, host-array and queue entry
- * points of the RGB family: eval, pdf, sample, eval_sample, eval_pdf): eval returns f * cos(theta_o); sample() draws from the
- * file's own luminance / vndf warps whatever MRL_OPT_SAMPLING says, and reports eval / pdf AT the Float direction it returns.
- * In a mixed batch (mat != NULL) its id renders zeros like an unknown id; one-unit mrl_scalar_* calls, host images and device
- * groups do not take it (MRL_ERR_MATERIAL).  Spectral files (no "rgb" field) and anisotropic files whose phi_i covers only
+ * image in HBM.  Every entry point of the RGB family evaluates it (eval, pdf, sample, eval_sample, eval_pdf; whole-array, host-array
+ * and queue calls; single_id or inside a batch with material ids next to tables and analytic materials — its units are then
+ * evaluated by a second launch of the same call, through a descriptor kept behind the image): eval returns f * cos(theta_o);
+ * sample() draws from the file's own luminance / vndf warps whatever MRL_OPT_SAMPLING says, and reports eval / pdf AT the Float
+ * direction it returns.  The n-channel entry points render its id as zeros; one-unit mrl_scalar_* calls and device groups do not
+ * take it (MRL_ERR_MATERIAL); mrl_material_host_table does (one-unit calls on the CPU).  Spectral files (no "rgb" field) and
+ * anisotropic files whose phi_i covers only
  * a symmetric part of the azimuth are rejected. */
 typedef struct mrl_rgl_fields {
     int n_phi, n_theta;

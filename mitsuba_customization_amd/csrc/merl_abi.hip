@@ -555,7 +555,7 @@ int ensure_queues(mrl_ctx *ctx, size_t units)
 // kernel arguments of a call whose pointers are all device-accessible
 struct DeviceCall {
     mrl::BatchArgs args;
-    bool multi, has_ggx, has_table;
+    bool multi, has_ggx, has_table, has_rgl;
 };
 
 DeviceCall device_call(const mrl_ctx *ctx, const BatchCall &c)
@@ -572,10 +572,11 @@ DeviceCall device_call(const mrl_ctx *ctx, const BatchCall &c)
     a.block_map = ctx->block_map;
     d.multi = c.mat != nullptr;
     if (!d.multi) a.single = ctx->materials[(size_t)c.single_id].dev;
-    d.has_ggx = d.has_table = false;
+    d.has_ggx = d.has_table = d.has_rgl = false;
     a.any_standard = 0;
     for (const auto &m : ctx->materials) {
         if (m.released) continue;
+        d.has_rgl = d.has_rgl || m.dev.kind == mrl::KIND_RGL;
         if (d.multi && m.dev.kind != mrl::KIND_GGX && m.dev.param != mrl::PARAM_HALF_DIFF) a.any_standard = 1;
         d.has_ggx = d.has_ggx || m.dev.kind == mrl::KIND_GGX;
         d.has_table = d.has_table || m.dev.kind == mrl::KIND_MERL || m.dev.kind == mrl::KIND_TABLE ||
@@ -627,7 +628,7 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
     const DeviceCall d = device_call(ctx, c);
     const mrl::BatchArgs &a = d.args;
     if (!d.multi && a.single.kind == mrl::KIND_RGL) {         // adaptive-parameterisation material: its own kernel
-        MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, ctx->materials[(size_t)c.single_id].rgl, false, ctx->compute_units, ctx->stream));
+        MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, &ctx->materials[(size_t)c.single_id].rgl, false, ctx->compute_units, ctx->stream));
         return MRL_OK;
     }
     if (c.n_ch > 0 && c.mode != 1) {                          // n-channel tables: their own kernels (pdf is channel-free)
@@ -653,9 +654,12 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
         MRL_HIP(ctx, mrl::launch_batch_queue(c.mode, qa, false, ctx->compute_units, ctx->stream));
         qa.idx = q_ggx; qa.idx_count = totals + 1;
         MRL_HIP(ctx, mrl::launch_batch_queue(c.mode, qa, true, ctx->compute_units, ctx->stream));
+        if (d.has_rgl) MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, nullptr, false, ctx->compute_units, ctx->stream));
         return MRL_OK;
     }
     MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->kernel_variant, ctx->table_layout, has_ggx, has_table, ctx->compute_units, ctx->stream));
+    // the context holds RGL materials: their units (zeros so far) are evaluated by a second launch on the same stream
+    if (multi && d.has_rgl) MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, nullptr, false, ctx->compute_units, ctx->stream));
     return MRL_OK;
 }
 
@@ -805,7 +809,7 @@ int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uin
     DeviceCall d = device_call(ctx, c);
     d.args.idx = queue; d.args.idx_count = queue_count;
     if (!d.multi && d.args.single.kind == mrl::KIND_RGL) {
-        MRL_HIP(ctx, mrl::launch_rgl(c.mode, d.args, ctx->materials[(size_t)c.single_id].rgl, true, ctx->compute_units, ctx->stream));
+        MRL_HIP(ctx, mrl::launch_rgl(c.mode, d.args, &ctx->materials[(size_t)c.single_id].rgl, true, ctx->compute_units, ctx->stream));
         return MRL_OK;
     }
     if (c.n_ch > 0 && c.mode != 1) {                          // n-channel tables: the same kernels walk the queue
@@ -813,6 +817,7 @@ int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uin
         return MRL_OK;
     }
     MRL_HIP(ctx, mrl::launch_batch_indexed(c.mode, d.args, d.multi, ctx->table_layout, d.has_ggx, d.has_table, ctx->compute_units, ctx->stream));
+    if (d.multi && d.has_rgl) MRL_HIP(ctx, mrl::launch_rgl(c.mode, d.args, nullptr, true, ctx->compute_units, ctx->stream));
     return MRL_OK;
 }
 
@@ -1309,20 +1314,25 @@ int mrl_material_upload_rgl(mrl_ctx *ctx, const mrl_rgl_fields *f, int *out_id)
     mrl::RglLayout layout;
     try { layout = mrl::rgl_build_image(h, blob); } catch (const std::bad_alloc &) { return fail(ctx, MRL_ERR_OOM, "RGL image"); }
     MaterialHost m;
-    m.bytes = blob.size() * sizeof(float);
+    const size_t image_bytes = (blob.size() * sizeof(float) + 255) / 256 * 256;          // the descriptor sits behind the image
+    m.bytes = image_bytes + sizeof(mrl::RglDev);
     int rc = budget_check(ctx, m.bytes);
     if (rc != MRL_OK) return rc;
     hipError_t e = hipMalloc((void **)&m.d_texels, m.bytes);
     const bool oom = e == hipErrorOutOfMemory;
-    if (e == hipSuccess) e = hipMemcpy(m.d_texels, blob.data(), m.bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m.d_texels, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        m.rgl = mrl::rgl_descriptor(h, layout, (const float *)m.d_texels);
+        e = hipMemcpy((char *)m.d_texels + image_bytes, &m.rgl, sizeof m.rgl, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (m.d_texels) (void)hipFree(m.d_texels);
         return fail(ctx, oom ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("RGL upload: ") + hipGetErrorString(e));
     }
-    m.rgl = mrl::rgl_descriptor(h, layout, (const float *)m.d_texels);
     std::memset(&m.dev, 0, sizeof m.dev);
     m.dev.kind = mrl::KIND_RGL;
+    m.dev.rgl = (const char *)m.d_texels + image_bytes;
     m.dev.n_ch = 3;
     m.dev.n_th = h.n_phi; m.dev.n_td = h.n_theta; m.dev.n_pd = h.res[0];     // what mrl_material_info reports
     rc = place_material(ctx, m, out_id);

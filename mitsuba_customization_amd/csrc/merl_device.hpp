@@ -64,7 +64,7 @@ constexpr float kInvPiF = 0.31830988618379067154f;
 enum Kind : int { KIND_MERL = 0, KIND_TABLE = 1, KIND_GGX = 2,
                   KIND_RELEASED = 3,     // tombstone of mrl_material_release: a valid 1x1x1 zero table, treated like an unknown id
                   KIND_TABLE_NCH = 4,    // n-channel table (merl_nch.hip): only the *_nch entry points evaluate it
-                  KIND_RGL = 5 };        // adaptive-parameterisation measured BSDF (merl_rgl.hip): single-material calls only
+                  KIND_RGL = 5 };        // adaptive-parameterisation measured BSDF (merl_rgl.hip): its own kernel, also behind mixed batches
 // the RGB kernels evaluate kinds 0..2; anything above renders as an unknown id (every output zero)
 __host__ __device__ constexpr bool kind_is_rgb_path(int kind) { return kind >= KIND_MERL && kind <= KIND_GGX; }
 enum Layout : int { LAYOUT_ROWS = 0, LAYOUT_BRICK = 1 };
@@ -89,6 +89,7 @@ struct MaterialDev {
     const double *sampling2d;    // conditional rows P(theta_h | theta_i): [n_ti][ cdf[n_th+1] | c[n_th] ], nullptr = none (see SamplingRow)
     int n_ti;                    // incident bins of sampling2d (uniform in cos theta_i)
     int param;                   // PARAM_*: the axes are (n_th, n_td, n_pd) whatever they mean
+    const void *rgl;             // KIND_RGL: the material's RglDev (merl_rgl.hpp), stored behind its image in device memory
     double alpha;                // GGX
     double eta[3], k[3];
 };

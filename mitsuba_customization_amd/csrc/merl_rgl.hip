@@ -2,7 +2,7 @@
 // the host-side image builder (normalisation + running integrals, f64, in the oracle's loop order) and the kernels.
 // PARITY UNPINNED (see merl_rgl.hpp).  SURVEY.md §8f item 3.
 //
-//   k_rgl<MODE, INDEXED>   one lane = one unit, grid-stride; the material's descriptor (five WarpDev) arrives by value in
+//   k_rgl<MODE, INDEXED, MULTI>   one lane = one unit, grid-stride; the material's descriptor (five WarpDev) arrives by value in
 //                          SGPRs; every table read is a per-lane gather served by L1/L2 (a material is 0.5 - 50 MB).
 // What bounds it: the number of scattered lane-addresses the CU's texture addresser resolves (93 % of wave cycles wait on
 // memory, VALU is under 10 % busy: profiles/r03_rgl_pmc.json) — hence the image's cell bricks (one 16-B load per cell and
@@ -19,44 +19,67 @@ namespace {
 
 constexpr int kRglBlock = 256;
 
-template <int MODE, bool INDEXED>
+// MULTI: a batch with a material id per unit — the lanes whose id names an RGL material evaluate it through the descriptor
+// stored behind that material's image (read on demand: a few more cache-resident loads per lookup) and overwrite the zeros
+// the table / GGX kernel of the same call left there; every other lane skips.  Launched after that kernel, on the same stream.
+template <int MODE>
+__device__ __forceinline__ void rgl_unit(const BatchArgs &a, const RglDev &r, size_t i)
+{
+    constexpr bool has_eval = MODE == 0 || MODE == 3 || MODE == 4, has_pdf = MODE == 1 || MODE == 3 || MODE == 4,
+                   has_sample = MODE == 2 || MODE == 3;
+    const float wix = a.wi[3 * i], wiy = a.wi[3 * i + 1], wiz = a.wi[3 * i + 2];
+    if constexpr (has_eval || has_pdf) {
+        const float wox = a.wo[3 * i], woy = a.wo[3 * i + 1], woz = a.wo[3 * i + 2];
+        float rgb[3], pdf;
+        rgl::eval_pdf<has_eval, has_pdf>(r, wix, wiy, wiz, wox, woy, woz, rgb, pdf);
+        if constexpr (has_eval) { a.out_rgb[3 * i] = rgb[0]; a.out_rgb[3 * i + 1] = rgb[1]; a.out_rgb[3 * i + 2] = rgb[2]; }
+        if constexpr (has_pdf) a.out_pdf[i] = pdf;
+    }
+    if constexpr (has_sample) {
+        float wo2[3], pdf2, w[3];
+        rgl::sample(r, wix, wiy, wiz, a.u[2 * i], a.u[2 * i + 1], wo2, pdf2, w);
+        a.out_wo[3 * i] = wo2[0]; a.out_wo[3 * i + 1] = wo2[1]; a.out_wo[3 * i + 2] = wo2[2];
+        a.out_pdf2[i] = pdf2;
+        a.out_weight[3 * i] = w[0]; a.out_weight[3 * i + 1] = w[1]; a.out_weight[3 * i + 2] = w[2];
+    }
+}
+
+template <int MODE, bool INDEXED, bool MULTI>
 __global__ __launch_bounds__(kRglBlock) void k_rgl(BatchArgs a, RglDev r)
 {
     const size_t stride = (size_t)gridDim.x * kRglBlock;
     size_t n_items = a.n;
     if constexpr (INDEXED) { const size_t c = (size_t)*a.idx_count; n_items = c < a.n ? c : a.n; }
-    constexpr bool has_eval = MODE == 0 || MODE == 3 || MODE == 4, has_pdf = MODE == 1 || MODE == 3 || MODE == 4,
-                   has_sample = MODE == 2 || MODE == 3;
     for (size_t j = (size_t)blockIdx.x * kRglBlock + threadIdx.x; j < n_items; j += stride) {
         const size_t i = INDEXED ? (size_t)a.idx[j] : j;
-        const float wix = a.wi[3 * i], wiy = a.wi[3 * i + 1], wiz = a.wi[3 * i + 2];
-        if constexpr (has_eval || has_pdf) {
-            const float wox = a.wo[3 * i], woy = a.wo[3 * i + 1], woz = a.wo[3 * i + 2];
-            float rgb[3], pdf;
-            rgl::eval_pdf<has_eval, has_pdf>(r, wix, wiy, wiz, wox, woy, woz, rgb, pdf);
-            if constexpr (has_eval) { a.out_rgb[3 * i] = rgb[0]; a.out_rgb[3 * i + 1] = rgb[1]; a.out_rgb[3 * i + 2] = rgb[2]; }
-            if constexpr (has_pdf) a.out_pdf[i] = pdf;
-        }
-        if constexpr (has_sample) {
-            float wo2[3], pdf2, w[3];
-            rgl::sample(r, wix, wiy, wiz, a.u[2 * i], a.u[2 * i + 1], wo2, pdf2, w);
-            a.out_wo[3 * i] = wo2[0]; a.out_wo[3 * i + 1] = wo2[1]; a.out_wo[3 * i + 2] = wo2[2];
-            a.out_pdf2[i] = pdf2;
-            a.out_weight[3 * i] = w[0]; a.out_weight[3 * i + 1] = w[1]; a.out_weight[3 * i + 2] = w[2];
+        if constexpr (MULTI) {
+            const int id = a.mat[i];
+            if (id < 0 || id >= a.n_materials) continue;
+            const MaterialDev &m = a.materials[id];
+            if (m.kind != KIND_RGL) continue;
+            rgl_unit<MODE>(a, *(const RglDev *)m.rgl, i);
+        } else {
+            rgl_unit<MODE>(a, r, i);
         }
     }
 }
 
 template <int MODE>
-hipError_t launch_mode(const BatchArgs &a, const RglDev &r, bool indexed, int compute_units, hipStream_t stream)
+hipError_t launch_mode(const BatchArgs &a, const RglDev *r, bool indexed, int compute_units, hipStream_t stream)
 {
     size_t blocks = (a.n + kRglBlock - 1) / kRglBlock;
     const size_t cap = (size_t)compute_units * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     const dim3 grid((unsigned)blocks), block(kRglBlock);
-    if (indexed) hipLaunchKernelGGL((k_rgl<MODE, true>), grid, block, 0, stream, a, r);
-    else hipLaunchKernelGGL((k_rgl<MODE, false>), grid, block, 0, stream, a, r);
+    if (!r) {                                                   // a batch with material ids: descriptors come from the material array
+        const RglDev none{};
+        if (indexed) hipLaunchKernelGGL((k_rgl<MODE, true, true>), grid, block, 0, stream, a, none);
+        else hipLaunchKernelGGL((k_rgl<MODE, false, true>), grid, block, 0, stream, a, none);
+    } else {
+        if (indexed) hipLaunchKernelGGL((k_rgl<MODE, true, false>), grid, block, 0, stream, a, *r);
+        else hipLaunchKernelGGL((k_rgl<MODE, false, false>), grid, block, 0, stream, a, *r);
+    }
     return hipGetLastError();
 }
 
@@ -200,7 +223,7 @@ RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base)
     return r;
 }
 
-hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev &r, bool indexed, int compute_units, hipStream_t stream)
+hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev *r, bool indexed, int compute_units, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     switch (mode) {

@@ -86,11 +86,40 @@ def test_host_arrays_queues_and_mixed_batches():
         cnt = torch.tensor([q.numel()], device=wi_t.device, dtype=torch.int32)
         outq = g.eval_sample_queue(wi_t, wo_t, u_t, q, cnt, material=mid)
         assert torch.equal(outq[0][0::2].cpu(), torch.from_numpy(dev[0][0::2]))
-        # in a mixed batch the id renders zeros (like an unknown id); the analytic material next to it is untouched
-        mat = torch.where(torch.arange(n, device=wi_t.device) % 2 == 0, ggx, mid).to(torch.int32)
-        mixed = g.eval(wi_t, wo_t, mat=mat)
-        alone = g.eval(wi_t, wo_t, material=ggx)
-        assert float(mixed[1::2].abs().max()) == 0.0 and torch.equal(mixed[0::2], alone[0::2])
+        # mixed batches: tables, an analytic material and two RGL materials side by side, every unit the bits of its material's own call
+        from mitsuba_customization_amd import synth as sy
+        tab = g.upload_table(sy.make_table("noise", 3, (8, 8, 16)), (1.0, 1.0, 1.0))
+        mid2 = g.upload_rgl(sy.make_rgl_fields(seed=8, n_phi=5, n_theta=3, res=6))
+        ids = torch.tensor([ggx, mid, tab, mid2, 99, -1], device=wi_t.device, dtype=torch.int32)
+        mat = ids[torch.arange(n, device=wi_t.device) % ids.numel()]
+        alone = {int(k): g.eval_sample(wi_t, wo_t, u_t, material=int(k)) for k in (ggx, mid, tab, mid2)}
+        for variant in (0, 1, 2, 3, 4):
+            g.set_option(host.OPT_KERNEL, variant)
+            mixed = g.eval_sample(wi_t, wo_t, u_t, mat=mat)
+            for slot, k in enumerate(ids.tolist()):
+                for got, want in zip(mixed, alone.get(k, [None] * 5)):
+                    if want is None:
+                        assert float(got[slot::6].abs().max()) == 0.0                      # unknown ids: zeros
+                    else:
+                        assert torch.equal(got[slot::6].view(torch.int32), want[slot::6].view(torch.int32)), (variant, k)
+        g.set_option(host.OPT_KERNEL, 3)
+        for call, single in ((lambda **kw: (g.eval(wi_t, wo_t, **kw),), 0), (lambda **kw: (g.pdf(wi_t, wo_t, **kw),), 1),
+                             (lambda **kw: g.sample(wi_t, u_t, **kw), 2), (lambda **kw: g.eval_pdf(wi_t, wo_t, **kw), 4)):
+            mixed = call(mat=mat)
+            for slot, k in ((1, mid), (3, mid2), (0, ggx)):
+                for got, want in zip(mixed, call(material=int(k))):
+                    assert torch.equal(got[slot::6].view(torch.int32), want[slot::6].view(torch.int32)), (single, k)
+        # a queue over a mixed batch, and host arrays
+        qm = torch.arange(1, n, 3, device=wi_t.device, dtype=torch.int32)
+        cm = torch.tensor([qm.numel()], device=wi_t.device, dtype=torch.int32)
+        full = g.eval_sample(wi_t, wo_t, u_t, mat=mat)
+        outm = g.eval_sample_queue(wi_t, wo_t, u_t, qm, cm, mat=mat)
+        for got, want in zip(outm, full):
+            assert torch.equal(got[1::3].view(torch.int32), want[1::3].view(torch.int32)) and float(got[0::3].abs().max()) == 0.0
+        hm = g.eval_sample(wi_t.cpu().numpy(), wo_t.cpu().numpy(), u_t.cpu().numpy(), mat=mat.cpu().numpy())
+        for got, want in zip(hm, full):
+            assert np.array_equal(np.asarray(got).view(np.int32), want.cpu().numpy().view(np.int32))
+        g.release_material(tab); g.release_material(mid2)
         # the device's one-unit call service does not take it ...
         with pytest.raises(host.MerlHipError) as e:
             g.scalar_eval_sample(wi_t[0].cpu().numpy(), wo_t[0].cpu().numpy(), u_t[0].cpu().numpy(), material=mid)

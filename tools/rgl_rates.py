@@ -31,4 +31,23 @@ with host.MerlHip(0) as g:
             row[what] = {"ms": round(ms, 3), "G_units_per_s": round(n / ms / 1e6, 3)}
         res[name] = row
         g.release_material(mid)
+    # a batch with material ids: a MERL-sized table, an analytic material and two RGL files, one quarter of the units each
+    tab = g.upload_merl(synth.make_table("ggx_tab", 0))
+    ggx = g.ggx(0.1, (0.143, 0.375, 1.442), (3.983, 2.386, 1.603))
+    r1 = g.upload_rgl(synth.make_rgl_fields(seed=9, n_phi=1, n_theta=8, res=32, res_ndf=128, res_sigma=64))
+    r2 = g.upload_rgl(synth.make_rgl_fields(seed=10, n_phi=1, n_theta=8, res=32, res_ndf=128, res_sigma=64))
+    ids = torch.tensor([tab, ggx, r1, r2], device="cuda", dtype=torch.int32)
+    mat = ids[torch.randint(0, 4, (n,), device="cuda")]
+    row = {}
+    for what, call in (("eval_sample_mixed", lambda: g.eval_sample(wi, wo, u, mat=mat)),
+                       ("eval_sample_table_and_ggx_only", lambda: g.eval_sample(wi, wo, u, mat=ids[:2][torch.randint(0, 2, (n,), device="cuda")]))):
+        for _ in range(2):
+            out = call()
+        torch.cuda.synchronize()
+        g.timer_start()
+        for _ in range(5):
+            out = call()
+        ms = g.timer_stop() / 5
+        row[what] = {"ms": round(ms, 3), "G_units_per_s": round(n / ms / 1e6, 3)}
+    res["mixed_batch_table_ggx_2rgl"] = row
 print(json.dumps(res, indent=1))
