@@ -109,3 +109,21 @@ def eval_standard(planar, wi, wo, full=False, trilinear=True, center=False, scal
     v = lookup(planar, x0, x1, x2, trilinear, center, scale, phi_clamped=not full) * wo[:, 2:3].astype(np.float64)
     ok = (wi[:, 2] > 0) & (wo[:, 2] > 0)
     return np.where(ok[:, None], v, 0.0)
+
+
+def square_to_cosine_hemisphere(u, mitsuba3=False):
+    """Independent formulation of the cosine-hemisphere warp (Shirley & Chiu's concentric map in its textbook form: radius
+    and angle, then libm sin / cos in f64) — what a Mitsuba built against libm computes, up to its own Float rounding.  The
+    oracle and the kernels instead share a hand-pinned f32 polynomial (oracle/merl_oracle.c sincos_quarter_f32), so this is
+    the evidence that the shared code is the right function, not just the same one."""
+    u = np.asarray(u, np.float32)
+    a = (np.float32(2) * u[:, 0] - np.float32(1)).astype(np.float64)
+    b = (np.float32(2) * u[:, 1] - np.float32(1)).astype(np.float64)
+    first = ~(np.abs(a) < np.abs(b)) if mitsuba3 else (a * a > b * b)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.where(first, a, b)
+        phi = np.where(first, (np.pi / 4) * (b / a), (np.pi / 2) - (np.pi / 4) * (a / b))
+    zero = (a == 0) & (b == 0)
+    x = np.where(zero, 0.0, r * np.cos(phi)); y = np.where(zero, 0.0, r * np.sin(phi))
+    z = np.sqrt(np.maximum(1.0 - x * x - y * y, 0.0))
+    return np.stack([x, y, z], axis=1)
