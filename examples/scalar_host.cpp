@@ -1,7 +1,7 @@
 // scalar_host.cpp — a C++ host that makes ONE-unit calls from many threads, the way the render threads of a stock per-ray
 // integrator call a BSDF plugin:  mrl_scalar_eval_sample(ctx, material, wi, wo, u, out[11]).
 //
-//   scalar_host [--threads T] [--calls K] [--table file.binary] [--churn]
+//   scalar_host [--threads T] [--calls K] [--table file.binary] [--rgl file_rgb.bsdf] [--churn]
 //
 // It (1) checks every answer bit for bit against mrl_eval_sample_batch on the same inputs, (2) times the calls — one
 // thread alone (the latency of a call) and T threads together (what a render sees) —, (3) with --churn lets another
@@ -38,13 +38,14 @@ static void hemi(uint64_t &s, float v[3])
 
 int main(int argc, char **argv)
 {
-    int threads = 16; long calls = 20000; bool churn = false; const char *table = nullptr;
+    int threads = 16; long calls = 20000; bool churn = false; const char *table = nullptr, *rgl_file = nullptr;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--calls") && i + 1 < argc) calls = std::atol(argv[++i]);
         else if (!std::strcmp(argv[i], "--table") && i + 1 < argc) table = argv[++i];
+        else if (!std::strcmp(argv[i], "--rgl") && i + 1 < argc) rgl_file = argv[++i];
         else if (!std::strcmp(argv[i], "--churn")) churn = true;
-        else { std::fprintf(stderr, "usage: scalar_host [--threads T] [--calls K] [--table file.binary] [--churn]\n"); return 64; }
+        else { std::fprintf(stderr, "usage: scalar_host [--threads T] [--calls K] [--table file.binary] [--rgl file_rgb.bsdf] [--churn]\n"); return 64; }
     }
     mrl_ctx *ctx = nullptr;
     { const int rc = mrl_init(0, &ctx); if (rc != MRL_OK) { std::fprintf(stderr, "mrl_init: %s\n", mrl_strerror(rc)); return 2; } }
@@ -171,15 +172,66 @@ int main(int argc, char **argv)
         if (host_worst > 1.3e-7) ++wrong;                        // more than one Float ulp from the batch call
         mrl_host_table_release(ht);
     }
+    // 4. --rgl: an RGL adaptive-parameterisation material (upstream Mitsuba 3 `measured`): one-unit calls on the CPU over its host
+    //    image against the GPU batch call on the same units — the same functions on two targets, 1e-6 relative at most
+    double rgl_solo_us = 0.0, rgl_all_us = 0.0, rgl_same = 0.0, rgl_worst = 0.0;
+    if (rgl_file) {
+        int rid = -1;
+        if (mrl_material_load_rgl(ctx, rgl_file, &rid) != MRL_OK) {
+            std::fprintf(stderr, "mrl_material_load_rgl: %s %s\n", mrl_tensor_file_last_error(nullptr), mrl_last_error(ctx));
+            return 3;
+        }
+        std::vector<float> rgb(3 * n), pdf(n), wo2(3 * n), pdf2(n), w(3 * n), ref(11 * n);
+        CHECK(mrl_eval_sample_batch(ctx, wi.data(), wo.data(), u.data(), nullptr, rid, n, rgb.data(), pdf.data(), wo2.data(), pdf2.data(), w.data()));
+        CHECK(mrl_synchronize(ctx));
+        for (size_t i = 0; i < n; ++i) {
+            float *o = &ref[11 * i];
+            std::memcpy(o, &rgb[3 * i], 12); o[3] = pdf[i]; std::memcpy(o + 4, &wo2[3 * i], 12); o[7] = pdf2[i]; std::memcpy(o + 8, &w[3 * i], 12);
+        }
+        mrl_host_table *ht = nullptr;
+        CHECK(mrl_material_host_table(ctx, rid, &ht));
+        std::atomic<long> same{ 0 };
+        std::vector<double> worst((size_t)threads, 0.0);
+        auto rgl_worker = [&](int t, long k0, long k1) {
+            for (long k = k0; k < k1; ++k) {
+                const size_t i = (size_t)t * (size_t)calls + (size_t)k;
+                float o[11];
+                if (mrl_host_eval_sample(ht, &wi[3 * i], &wo[3 * i], &u[2 * i], o) != MRL_OK) { ++failed; continue; }
+                if (!std::memcmp(o, &ref[11 * i], sizeof o)) { ++same; continue; }
+                // a sampled direction one ulp away moves its pdf / weight: compare eval and pdf, which are functions of the inputs alone
+                for (int c = 0; c < 4; ++c) {
+                    const double a = o[c], b = ref[11 * i + c];
+                    if (a != b) worst[(size_t)t] = std::max(worst[(size_t)t], std::fabs(a - b) / std::max(std::fabs(b), 1e-30));
+                }
+            }
+        };
+        rgl_worker(0, 0, std::min<long>(calls, 200));
+        same = 0;
+        t0 = Clock::now();
+        rgl_worker(0, 0, calls);
+        rgl_solo_us = std::chrono::duration<double, std::micro>(Clock::now() - t0).count() / (double)calls;
+        same = 0;
+        t0 = Clock::now();
+        std::vector<std::thread> hp;
+        for (int t = 0; t < threads; ++t) hp.emplace_back(rgl_worker, t, 0L, calls);
+        for (auto &th : hp) th.join();
+        rgl_all_us = std::chrono::duration<double, std::micro>(Clock::now() - t0).count() / (double)n;
+        rgl_same = (double)same.load() / (double)n;
+        for (double x : worst) rgl_worst = std::max(rgl_worst, x);
+        if (rgl_worst > 1e-6) ++wrong;
+        mrl_host_table_release(ht);
+        CHECK(mrl_material_release(ctx, rid));
+    }
     // an id the scalar path refuses
     float out[11];
     const int bad = mrl_scalar_eval_sample(ctx, 99, &wi[0], &wo[0], &u[0], out);
     std::printf("{\"threads\": %d, \"calls_per_thread\": %ld, \"solo_us_per_call\": %.3f, \"solo_eval_pdf_us\": %.3f, \"solo_sample_us\": %.3f, \"all_threads_Mcalls_per_s\": %.4f, "
                 "\"all_threads_us_per_call_amortised\": %.4f, \"cpu_path_us_per_call\": %.4f, \"cpu_path_us_per_call_amortised\": %.4f, "
                 "\"cpu_path_units_bit_identical_to_batch\": %.6f, \"cpu_path_worst_rel_diff_to_batch\": %.3g, "
-                "\"wrong\": %ld, \"failed\": %ld, \"churn_rounds\": %ld, \"unknown_id_status\": %d}\n",
+                "\"rgl_cpu_path_us_per_call\": %.4f, \"rgl_cpu_path_us_per_call_amortised\": %.4f, \"rgl_units_bit_identical_to_batch\": %.6f, "
+                "\"rgl_worst_rel_diff_to_batch\": %.3g, \"wrong\": %ld, \"failed\": %ld, \"churn_rounds\": %ld, \"unknown_id_status\": %d}\n",
                 threads, calls, solo_us, half_us[0], half_us[1], (double)n / all_s / 1e6, all_s * 1e6 / (double)n, host_solo_us, host_all_us, host_same, host_worst,
-                wrong.load(), failed.load(), churn_rounds, bad);
+                rgl_solo_us, rgl_all_us, rgl_same, rgl_worst, wrong.load(), failed.load(), churn_rounds, bad);
     mrl_destroy(ctx);
     return (wrong.load() == 0 && failed.load() == 0 && bad == MRL_ERR_MATERIAL) ? 0 : 1;
 }

@@ -126,6 +126,20 @@ def test_cpp_host_many_threads_with_churn():
     assert d["solo_us_per_call"] < 60.0                                      # a launch + synchronize per call costs 16-19 us; this path ~10
 
 
+def test_cpp_host_rgl_one_unit_calls_on_the_cpu(tmp_path):
+    """scalar_host --rgl: an RGL material's one-unit calls on the CPU (host image, the kernels' per-unit functions compiled for the
+    host) from 8 threads against the GPU batch call on the same units: eval / pdf within 1e-6, most units bit-identical."""
+    from mitsuba_customization_amd import synth
+    path = str(tmp_path / "synthetic_rgb.bsdf")
+    synth.write_tensor_file(path, synth.make_rgl_fields(seed=12, n_phi=1, n_theta=8, res=32, res_ndf=64, res_sigma=32))
+    r = subprocess.run([os.path.join(LIB, "scalar_host"), "--threads", "8", "--calls", "4000", "--rgl", path], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["wrong"] == 0 and d["failed"] == 0
+    assert d["rgl_units_bit_identical_to_batch"] > 0.9 and d["rgl_worst_rel_diff_to_batch"] < 1e-6
+    assert 0 < d["rgl_cpu_path_us_per_call"] < 20.0
+
+
 def test_nothing_spins_after_the_calls_stop():
     """Instances have a bounded lifetime: a device-wide synchronisation returns promptly once calls have stopped, and a
     context can be destroyed right after a burst of calls."""
