@@ -159,7 +159,9 @@ int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float 
  * Mitsuba 3's stock `measured` plugin evaluates — its eval / sample / pdf are the interface this replaces; the reference
  * snapshot holds neither that plugin nor a file: PARITY UNPINNED, restated from the published model, oracle/rgl_oracle.c).
  * Arrays are the file's Float fields as they are, x (the last axis) fastest; res[] = { nodes along x, nodes along y }:
- *     phi_i [n_phi], theta_i [n_theta]         incident-direction grids (strictly ascending; n_phi <= 2 means isotropic)
+ *     phi_i [n_phi], theta_i [n_theta]         incident-direction grids (strictly ascending; n_phi <= 2 means isotropic; an anisotropic
+ *                                              file spans the whole azimuth, or [-pi, 0] / [-pi, -pi/2] for a sample with a point
+ *                                              symmetry / two mirror planes: pairs are mapped into the stored part by the signs of wi)
  *     ndf [res_ndf[1]][res_ndf[0]], sigma [res_sigma[1]][res_sigma[0]]
  *     vndf, luminance [n_phi][n_theta][res[1]][res[0]]          rgb [n_phi][n_theta][3][res[1]][res[0]]
  * The library normalises vndf / luminance per slice and builds their running integrals once (host, f64), then keeps one
@@ -168,9 +170,8 @@ int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float 
  * evaluated by a second launch of the same call, through a descriptor kept behind the image): eval returns f * cos(theta_o);
  * sample() draws from the file's own luminance / vndf warps whatever MRL_OPT_SAMPLING says, and reports eval / pdf AT the Float
  * direction it returns.  The n-channel entry points render its id as zeros; one-unit mrl_scalar_* calls and device groups do not
- * take it (MRL_ERR_MATERIAL); mrl_material_host_table does (one-unit calls on the CPU).  Spectral files (no "rgb" field) and
- * anisotropic files whose phi_i covers only
- * a symmetric part of the azimuth are rejected. */
+ * take it (MRL_ERR_MATERIAL); mrl_material_host_table does (one-unit calls on the CPU).  Spectral files (no "rgb" field) are
+ * rejected. */
 typedef struct mrl_rgl_fields {
     int n_phi, n_theta;
     const float *phi_i, *theta_i;

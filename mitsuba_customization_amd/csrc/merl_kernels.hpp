@@ -76,6 +76,7 @@ struct RglFields {                   // host arrays, as the file holds them (x f
     int jacobian;
 };
 struct RglLayout { size_t phi, theta, cells[5], cond[5], rows[5]; };     // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
+int rgl_reduction(const RglFields &f);                                   // 1, 2, 4: the part of the azimuth an anisotropic file stores
 const char *rgl_check_fields(const RglFields &f);                        // nullptr, or what is wrong
 RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob); // normalised tables + running integrals, host f64
 RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base);

@@ -157,6 +157,14 @@ WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, 
 
 } // namespace
 
+// 2 pi / (span of phi_i), rounded: which part of the azimuth an anisotropic file stores
+int rgl_reduction(const RglFields &f)
+{
+    if (f.n_phi <= 2) return 1;
+    const double span = (double)f.phi_i[f.n_phi - 1] - (double)f.phi_i[0];
+    return span > 0.0 ? (int)std::floor(2.0 * kPi / span + 0.5) : 0;
+}
+
 const char *rgl_check_fields(const RglFields &f)
 {
     if (f.n_phi < 1 || f.n_theta < 1 || f.n_phi > 4096 || f.n_theta > 4096) return "phi_i / theta_i: 1..4096 nodes each";
@@ -173,9 +181,11 @@ const char *rgl_check_fields(const RglFields &f)
         return "non-finite table value";
     for (size_t k = 0; k < slices * per; ++k)
         if (f.vndf[k] < 0.0f || f.luminance[k] < 0.0f) return "vndf / luminance must be non-negative (they are densities)";
-    // an anisotropic file may cover only 1 / reduction of the azimuth and rely on the sample's symmetry: not built
-    if (f.n_phi > 2 && (double)f.phi_i[f.n_phi - 1] - (double)f.phi_i[0] < 1.5 * kPi)
-        return "anisotropic file with a symmetry-reduced phi_i range: not supported";
+    // an anisotropic file covers the whole azimuth, or the half / quarter a sample with a point symmetry / two mirror planes needs
+    if (f.n_phi > 2) {
+        const int reduction = rgl_reduction(f);
+        if (reduction != 1 && reduction != 2 && reduction != 4) return "anisotropic file: phi_i must span the whole azimuth, a half or a quarter of it";
+    }
     return nullptr;
 }
 
@@ -220,6 +230,7 @@ RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base)
     r.rgb = warp(4, f.res, f.n_phi, f.n_theta, 3, false);
     r.isotropic = f.n_phi <= 2;
     r.jacobian = f.jacobian ? 1 : 0;
+    r.reduction = rgl_reduction(f);
     return r;
 }
 

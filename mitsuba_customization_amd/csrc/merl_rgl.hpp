@@ -44,6 +44,7 @@ struct RglDev {
     WarpDev ndf, sigma, vndf, luminance, rgb;
     int isotropic;          // n_phi <= 2: phi_m is measured relative to phi_i
     int jacobian;           // the file's flag: multiply the spectrum by ndf / (4 sigma)
+    int reduction;          // anisotropic: 2 pi / (span of phi_i) — 1 the whole azimuth, 2 [-pi, 0] (point symmetry), 4 [-pi, -pi/2] (+ two mirror planes)
 };
 
 namespace rgl {
@@ -242,13 +243,26 @@ MRL_HD bool unit3(Vec3d &v)
     return true;
 }
 
+// Symmetry-reduced files: both directions of a pair go into the stored part of the azimuth with the signs of wi — x and y negated
+// together when wi.y is not negative (2), x when wi.x and y when wi.y is not negative (4); by the sign BIT (+0 is positive).
+// Returns the two factors so that sample() can take the direction it draws back out.
+MRL_HD void reduce_signs(int reduction, float wix, float wiy, float &sx, float &sy)
+{
+    sx = sy = 1.0f;
+    if (reduction < 2) return;
+    sy = __builtin_signbit(wiy) ? 1.0f : -1.0f;
+    sx = reduction == 4 ? (__builtin_signbit(wix) ? 1.0f : -1.0f) : sy;
+}
+
 // eval (f cos theta_o, RGB) and / or pdf of one unit; every output zero outside the upper hemisphere
 template <bool WANT_RGB, bool WANT_PDF>
 MRL_HD void eval_pdf(const RglDev &b, float wix, float wiy, float wiz, float wox, float woy, float woz, float rgb[3], float &pdf)
 {
     rgb[0] = rgb[1] = rgb[2] = 0.0f; pdf = 0.0f;
     if (!(wiz > 0.0f) || !(woz > 0.0f)) return;
-    Vec3d wi = { (double)wix, (double)wiy, (double)wiz }, wo = { (double)wox, (double)woy, (double)woz };
+    float fx, fy;
+    reduce_signs(b.reduction, wix, wiy, fx, fy);
+    Vec3d wi = { (double)(wix * fx), (double)(wiy * fy), (double)wiz }, wo = { (double)(wox * fx), (double)(woy * fy), (double)woz };
     if (!unit3(wi) || !unit3(wo)) return;
     Vec3d m;
     {
@@ -289,7 +303,9 @@ MRL_HD void sample(const RglDev &b, float wix, float wiy, float wiz, float u0, f
 {
     wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
     if (!(wiz > 0.0f)) return;
-    Vec3d wi = { (double)wix, (double)wiy, (double)wiz };
+    float fx, fy;
+    reduce_signs(b.reduction, wix, wiy, fx, fy);
+    Vec3d wi = { (double)(wix * fx), (double)(wiy * fy), (double)wiz };
     if (!unit3(wi)) return;
     const double theta_i = elevation(wi), phi_i = azimuth(wi.y, wi.x);
     const Slices sv = find_slices(b.vndf, phi_i, theta_i);
@@ -311,7 +327,8 @@ MRL_HD void sample(const RglDev &b, float wix, float wiy, float wiz, float u0, f
     }
     const Vec3d m = { cp * st, sp * st, ct };
     const double c = wi.x * m.x + wi.y * m.y + wi.z * m.z;
-    const float wof[3] = { (float)(2.0 * c * m.x - wi.x), (float)(2.0 * c * m.y - wi.y), (float)(2.0 * c * m.z - wi.z) };
+    // (the direction drawn in the stored part of the azimuth goes back through the same sign flips)
+    const float wof[3] = { (float)((2.0 * c * m.x - wi.x) * (double)fx), (float)((2.0 * c * m.y - wi.y) * (double)fy), (float)(2.0 * c * m.z - wi.z) };
     if (!(wof[2] > 0.0f) || !(c > 0.0)) return;
     float f[3], p;
     eval_pdf<true, true>(b, wix, wiy, wiz, wof[0], wof[1], wof[2], f, p);

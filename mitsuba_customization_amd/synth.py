@@ -259,10 +259,11 @@ def write_tensor_file(path: str, fields: dict) -> None:
 
 
 # ------------------------------------------------------------------ synthetic RGL *.bsdf fields (the adaptive parameterisation)
-def make_rgl_fields(seed: int = 0, n_phi: int = 1, n_theta: int = 6, res: int = 12, res_ndf: int = 16, res_sigma: int = 8) -> dict:
+def make_rgl_fields(seed: int = 0, n_phi: int = 1, n_theta: int = 6, res: int = 12, res_ndf: int = 16, res_sigma: int = 8, reduction: int = 1) -> dict:
     """Fields of an RGL material-database file with the real names and shapes (what upstream Mitsuba 3's `measured` reads):
     phi_i [n_phi], theta_i [n_theta], ndf [res_ndf, res_ndf], sigma [res_sigma, res_sigma], vndf / luminance
     [n_phi, n_theta, res, res], rgb [n_phi, n_theta, 3, res, res], jacobian [1], description.  n_phi <= 2: isotropic.
+    reduction = 2 / 4 (anisotropic only): phi_i covers [-pi, 0] / [-pi, -pi/2], as for a sample with a point symmetry / two mirror planes.
     No measured file exists offline: the tables are smooth, strictly positive synthetic functions (a lobe + seeded
     low-frequency variation), periodic in every azimuth axis as a measurement is — they exercise every code path of the
     model, they are not a material."""
@@ -281,13 +282,13 @@ def make_rgl_fields(seed: int = 0, n_phi: int = 1, n_theta: int = 6, res: int = 
         return out.astype(np.float32)
 
     theta_i = np.linspace(0.0, 0.5 * np.pi * 0.97, n_theta).astype(np.float32)
-    phi_i = (np.zeros(1) if n_phi == 1 else np.linspace(-np.pi, np.pi, n_phi)).astype(np.float32)
+    phi_i = (np.zeros(1) if n_phi == 1 else np.linspace(-np.pi, -np.pi + 2 * np.pi / reduction, n_phi)).astype(np.float32)
 
     def closed(a, slices_too=True):
         # the y axis of every warp is an azimuth (u = (phi + pi) / 2 pi): the rows at u = 0 and u = 1 are the same direction,
         # and so are the phi_i = -pi and phi_i = +pi slices of an anisotropic file — a measured file is periodic there
         a[..., -1, :] = a[..., 0, :]
-        if slices_too and n_phi > 1:
+        if slices_too and n_phi > 1 and reduction == 1:
             a[-1] = a[0]
         return a
 

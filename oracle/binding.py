@@ -397,7 +397,7 @@ class RglWarp(C.Structure):
 
 
 class RglBsdf(C.Structure):
-    _fields_ = [("isotropic", C.c_int), ("jacobian", C.c_int), ("ndf", RglWarp), ("sigma", RglWarp), ("vndf", RglWarp), ("luminance", RglWarp), ("rgb", RglWarp)]
+    _fields_ = [("isotropic", C.c_int), ("jacobian", C.c_int), ("reduction", C.c_int), ("ndf", RglWarp), ("sigma", RglWarp), ("vndf", RglWarp), ("luminance", RglWarp), ("rgb", RglWarp)]
 
 
 def _rgl_lib():

@@ -242,12 +242,29 @@ static void spectrum(const rgl_bsdf *b, const double sample[2], double phi_i, do
     }
 }
 
+/* Symmetry-reduced anisotropic files hold phi_i in [-pi, 0] (reduction 2: the sample looks the same turned by 180 degrees) or in
+ * [-pi, -pi/2] (reduction 4: it also has two mirror planes).  Both directions of a pair are mapped into the stored part with the
+ * signs of wi: x and y are negated together when wi.y is not negative (2), resp. x when wi.x and y when wi.y is not negative (4)
+ * — "not negative" by the sign BIT, +0 counts as positive.  flip[] receives the two factors (+-1) so that sample() can map the
+ * direction it draws back. */
+static void reduce_pair(const rgl_bsdf *b, double wi[3], double wo[3], double flip[2])
+{
+    flip[0] = flip[1] = 1.0;
+    if (b->reduction < 2) return;
+    const double sy = signbit(wi[1]) ? 1.0 : -1.0;
+    const double sx = b->reduction == 4 ? (signbit(wi[0]) ? 1.0 : -1.0) : sy;
+    flip[0] = sx; flip[1] = sy;
+    wi[0] *= sx; wi[1] *= sy; wo[0] *= sx; wo[1] *= sy;
+}
+
 void rgl_eval_pdf(const rgl_bsdf *b, const float wi_f[3], const float wo_f[3], float rgb[3], float *pdf_out)
 {
     rgb[0] = rgb[1] = rgb[2] = 0.0f;
     if (pdf_out) *pdf_out = 0.0f;
     if (!(wi_f[2] > 0.0f) || !(wo_f[2] > 0.0f)) return;
     double wi[3] = { wi_f[0], wi_f[1], wi_f[2] }, wo[3] = { wo_f[0], wo_f[1], wo_f[2] };
+    double flip[2];
+    reduce_pair(b, wi, wo, flip);
     if (!unit3(wi) || !unit3(wo)) return;
     double m[3] = { wi[0] + wo[0], wi[1] + wo[1], wi[2] + wo[2] };
     if (!unit3(m)) return;
@@ -279,6 +296,8 @@ void rgl_sample(const rgl_bsdf *b, const float wi_f[3], const float u[2], float 
     wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; *pdf_out = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
     if (!(wi_f[2] > 0.0f)) return;
     double wi[3] = { wi_f[0], wi_f[1], wi_f[2] };
+    double unused[3] = { 0.0, 0.0, 1.0 }, flip[2];
+    reduce_pair(b, wi, unused, flip);
     if (!unit3(wi)) return;
     const double theta_i = elevation(wi), phi_i = atan2(wi[1], wi[0]);
     const double params[2] = { phi_i, theta_i };
@@ -293,7 +312,8 @@ void rgl_sample(const rgl_bsdf *b, const float wi_f[3], const float u[2], float 
     const double st = sin(theta_m), ct = cos(theta_m);
     const double m[3] = { cos(phi_m) * st, sin(phi_m) * st, ct };
     const double c = wi[0] * m[0] + wi[1] * m[1] + wi[2] * m[2];
-    const double wo[3] = { 2.0 * c * m[0] - wi[0], 2.0 * c * m[1] - wi[1], 2.0 * c * m[2] - wi[2] };
+    /* the direction drawn in the stored part of the azimuth goes back through the same sign flips */
+    const double wo[3] = { (2.0 * c * m[0] - wi[0]) * flip[0], (2.0 * c * m[1] - wi[1]) * flip[1], 2.0 * c * m[2] - wi[2] };
     const float wof[3] = { (float)wo[0], (float)wo[1], (float)wo[2] };
     if (!(wof[2] > 0.0f) || !(c > 0.0)) return;
     /* report what eval / pdf say AT the Float direction returned, so that pdf(wi, sample.wo) == sample.pdf and weight == eval / pdf */
@@ -322,6 +342,12 @@ int rgl_bsdf_init(rgl_bsdf *b, int n_phi, int n_theta, const float *phi_i, const
     memset(b, 0, sizeof *b);
     b->isotropic = n_phi <= 2;
     b->jacobian = jacobian;
+    b->reduction = 1;
+    if (!b->isotropic) {
+        const double span = (double)phi_i[n_phi - 1] - (double)phi_i[0];
+        b->reduction = span > 0.0 ? (int)floor(2.0 * M_PI / span + 0.5) : 0;
+        if (b->reduction != 1 && b->reduction != 2 && b->reduction != 4) return -1;
+    }
     const int np2[2] = { n_phi, n_theta };
     const float *par2[2] = { phi_i, theta_i };
     const float chan[3] = { 0.f, 1.f, 2.f };

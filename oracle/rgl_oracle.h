@@ -24,6 +24,7 @@ void   rgl_warp_invert(const rgl_warp *w, const double pos[2], const double *par
 
 typedef struct rgl_bsdf {
     int isotropic, jacobian;
+    int reduction;              /* anisotropic files: 2 pi / (span of phi_i), rounded: 1 full azimuth, 2 half (point symmetry), 4 quarter */
     rgl_warp ndf, sigma, vndf, luminance, rgb;
 } rgl_bsdf;
 

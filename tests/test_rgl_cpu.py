@@ -55,9 +55,9 @@ def test_unnormalised_warp_is_bilinear_interpolation_of_the_data():
         assert abs(w3.eval((0.0, 0.0), (float(c),)) - s[c, 0, 0]) < 1e-12
 
 
-@pytest.mark.parametrize("n_phi", [1, 5])
-def test_bsdf_pdf_is_a_density_and_sample_reports_it(n_phi):
-    B = ob.OracleRgl(synth.make_rgl_fields(4, n_phi=n_phi))
+@pytest.mark.parametrize("n_phi,reduction", [(1, 1), (5, 1), (4, 2), (3, 4)])
+def test_bsdf_pdf_is_a_density_and_sample_reports_it(n_phi, reduction):
+    B = ob.OracleRgl(synth.make_rgl_fields(4, n_phi=n_phi, reduction=reduction))
     rng = np.random.default_rng(21)
     for mu, az in ((0.95, 0.3), (0.6, -2.0), (0.25, 1.1)):
         wi1 = np.array([np.sqrt(1 - mu * mu) * np.cos(az), np.sqrt(1 - mu * mu) * np.sin(az), mu], np.float32)
@@ -78,6 +78,10 @@ def test_bsdf_pdf_is_a_density_and_sample_reports_it(n_phi):
         import ctypes as C
         L = ob._rgl_lib()
         wi_d = wi1.astype(np.float64) / np.linalg.norm(wi1.astype(np.float64))
+        if reduction >= 2:                                          # into the stored part of the azimuth (the mass is the same there)
+            sy = 1.0 if np.signbit(wi_d[1]) else -1.0
+            sx = (1.0 if np.signbit(wi_d[0]) else -1.0) if reduction == 4 else sy
+            wi_d = wi_d * np.array([sx, sy, 1.0])
         theta_i = 2 * np.arcsin(min(1.0, 0.5 * np.linalg.norm(wi_d - np.array([0, 0, 1.0]))))
         phi_i = np.arctan2(wi_d[1], wi_d[0])
         par = (C.c_double * 3)(phi_i, theta_i, 0.0)
@@ -119,8 +123,10 @@ def test_guards():
 @pytest.mark.skipif(__import__("shutil").which("hipcc") is None, reason="hipcc missing")
 @pytest.mark.parametrize("case", [dict(seed=1, n_phi=1, n_theta=6, res=12, res_ndf=16, res_sigma=8),
                                   dict(seed=2, n_phi=5, n_theta=4, res=9, res_ndf=8, res_sigma=6),
-                                  dict(seed=3, n_phi=1, n_theta=1, res=2, res_ndf=2, res_sigma=2)],
-                         ids=lambda c: f"phi{c['n_phi']}_theta{c['n_theta']}_res{c['res']}")
+                                  dict(seed=3, n_phi=1, n_theta=1, res=2, res_ndf=2, res_sigma=2),
+                                  dict(seed=4, n_phi=4, n_theta=3, res=7, res_ndf=8, res_sigma=6, reduction=2),
+                                  dict(seed=5, n_phi=3, n_theta=3, res=6, res_ndf=6, res_sigma=4, reduction=4)],
+                         ids=lambda c: f"phi{c['n_phi']}_theta{c['n_theta']}_res{c['res']}_red{c.get('reduction', 1)}")
 def test_product_per_unit_functions_on_the_host_match_the_oracle(case, tmp_path_factory):
     """The product's RGL code — image builder (cell bricks, running integrals) and per-unit eval / pdf / sample, the SAME
     functions the kernel runs (__host__ __device__) — compiled for the host (tests/rgl_host_harness.hip) against the
@@ -165,3 +171,31 @@ def test_product_per_unit_functions_on_the_host_match_the_oracle(case, tmp_path_
     assert float(np.abs(out[both, 4:7] - o_wo[both]).max()) < 5e-7
     c_rgb, c_pdf = orc.eval_pdf(wi[live], out[live, 4:7])
     close(out[live, 7], c_pdf, "sample pdf"); close(out[live, 8:11], c_rgb / c_pdf[:, None], "sample weight")
+
+
+@pytest.mark.parametrize("reduction", [2, 4])
+def test_symmetry_reduced_files_are_equivariant(reduction):
+    """A file that stores phi_i in [-pi, 0] (reduction 2: point symmetry) or [-pi, -pi/2] (reduction 4: two mirror planes) answers for
+    the whole azimuth: eval / pdf are invariant under the sample's symmetry operations and sample() is equivariant (the direction
+    drawn for S wi is S applied to the direction drawn for wi) — which is what pins the map back out of the stored part."""
+    B = ob.OracleRgl(synth.make_rgl_fields(6, n_phi=4, n_theta=4, res=8, reduction=reduction))
+    assert B.c.reduction == reduction
+    wi, wo, u = ob.generate_pairs(77, 0, 4000)
+    ops = [np.array([-1, -1, 1], np.float32)] + ([np.array([-1, 1, 1], np.float32), np.array([1, -1, 1], np.float32)] if reduction == 4 else [])
+    rgb, pdf = B.eval_pdf(wi, wo)
+    s_wo, s_pdf, s_w = B.sample(wi, u)
+    assert (pdf > 0).mean() > 0.9 and (s_pdf > 0).mean() > 0.5
+    for S in ops:
+        r2, p2 = B.eval_pdf(wi * S, wo * S)
+        assert np.array_equal(r2, rgb) and np.array_equal(p2, pdf)
+        w2, q2, v2 = B.sample(wi * S, u)
+        assert np.array_equal(w2, s_wo * S) and np.array_equal(q2, s_pdf) and np.array_equal(v2, s_w)
+    # and the stored part is really what is read: wi inside it is not touched
+    inside = (wi[:, 1] < 0) & ((wi[:, 0] < 0) | (reduction == 2))
+    B1 = ob.OracleRgl(dict(synth.make_rgl_fields(6, n_phi=4, n_theta=4, res=8, reduction=reduction)))
+    assert inside.any() and np.array_equal(B1.eval_pdf(wi[inside], wo[inside])[0], rgb[inside])
+    # a span that is no integer fraction of the circle is refused
+    bad = synth.make_rgl_fields(6, n_phi=4, n_theta=4, res=8, reduction=2)
+    bad["phi_i"] = np.linspace(-np.pi, -1.0, 4).astype(np.float32)
+    with pytest.raises(AssertionError):
+        ob.OracleRgl(bad)
