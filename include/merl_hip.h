@@ -169,8 +169,8 @@ int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float 
  * and queue calls; single_id or inside a batch with material ids next to tables and analytic materials — its units are then
  * evaluated by a second launch of the same call, through a descriptor kept behind the image): eval returns f * cos(theta_o);
  * sample() draws from the file's own luminance / vndf warps whatever MRL_OPT_SAMPLING says, and reports eval / pdf AT the Float
- * direction it returns.  The n-channel entry points render its id as zeros; one-unit mrl_scalar_* calls and device groups do not
- * take it (MRL_ERR_MATERIAL); mrl_material_host_table does (one-unit calls on the CPU).  Spectral files (no "rgb" field) are
+ * direction it returns.  The n-channel entry points render its id as zeros; one-unit mrl_scalar_* calls do not take it
+ * (MRL_ERR_MATERIAL); mrl_material_host_table does (one-unit calls on the CPU); device groups replicate it like a table.  Spectral files (no "rgb" field) are
  * rejected. */
 typedef struct mrl_rgl_fields {
     int n_phi, n_theta;
@@ -403,6 +403,8 @@ int mrl_group_material_load_merl(mrl_group *g, const char *path, int *out_id);
 int mrl_group_material_upload_f64(mrl_group *g, const double *planar_rgb, int *out_id);
 int mrl_group_material_upload_table(mrl_group *g, const double *planar_rgb, const int dims[3], const double scale[3], int *out_id);
 int mrl_group_material_ggx(mrl_group *g, float alpha, const float eta[3], const float k[3], int *out_id);
+int mrl_group_material_upload_rgl(mrl_group *g, const mrl_rgl_fields *fields, int *out_id);      /* one image per member, like a table */
+int mrl_group_material_load_rgl(mrl_group *g, const char *path, int *out_id);
 int mrl_group_material_release(mrl_group *g, int id);
 /* tile / chunk arithmetic (pure functions; usable without a device) */
 void mrl_tile_bounds(size_t n_total, int world, int rank, size_t *lo, size_t *hi);

@@ -46,7 +46,7 @@ ABI_SYMBOLS = (
     "mrl_material_upload_rgl", "mrl_material_load_rgl",
     "mrl_group_init", "mrl_group_destroy", "mrl_group_size", "mrl_group_transport", "mrl_group_last_error", "mrl_group_context",
     "mrl_group_set_option", "mrl_group_material_load_merl", "mrl_group_material_upload_f64", "mrl_group_material_upload_table",
-    "mrl_group_material_ggx", "mrl_group_material_release", "mrl_tile_bounds", "mrl_chunk_bounds", "mrl_chunk_steps",
+    "mrl_group_material_ggx", "mrl_group_material_upload_rgl", "mrl_group_material_load_rgl", "mrl_group_material_release", "mrl_tile_bounds", "mrl_chunk_bounds", "mrl_chunk_steps",
     "mrl_group_generate_tiles", "mrl_group_eval_sample_sharded", "mrl_group_eval_sharded", "mrl_group_eval_sample_batch", "mrl_group_synchronize",
     "mrl_group_eval_batch", "mrl_group_pdf_batch", "mrl_group_eval_pdf_batch", "mrl_group_sample_batch",
     "mrl_group_last_timing", "mrl_group_plan", "mrl_group_link_test",
@@ -97,6 +97,21 @@ class RglFields(C.Structure):
                 ("res_ndf", C.c_int * 2), ("res_sigma", C.c_int * 2), ("res", C.c_int * 2),
                 ("ndf", C.POINTER(C.c_float)), ("sigma", C.POINTER(C.c_float)), ("vndf", C.POINTER(C.c_float)),
                 ("luminance", C.POINTER(C.c_float)), ("rgb", C.POINTER(C.c_float)), ("jacobian", C.c_int)]
+
+
+def rgl_fields_struct(fields: dict):
+    """(struct mrl_rgl_fields, the arrays it points into) from a dict of RGL field arrays."""
+    a = {k: np.ascontiguousarray(fields[k], np.float32) for k in ("phi_i", "theta_i", "ndf", "sigma", "vndf", "luminance", "rgb")}
+    vn = a["vndf"].shape
+    if len(vn) != 4 or a["luminance"].shape != vn or a["rgb"].shape != (vn[0], vn[1], 3, vn[2], vn[3]) or a["ndf"].ndim != 2 or a["sigma"].ndim != 2 \
+            or a["phi_i"].shape != (vn[0],) or a["theta_i"].shape != (vn[1],):
+        raise ValueError("RGL fields: vndf / luminance [n_phi, n_theta, res, res], rgb [n_phi, n_theta, 3, res, res], ndf / sigma 2-D")
+    fp = C.POINTER(C.c_float)
+    p = lambda k: a[k].ctypes.data_as(fp)
+    r = RglFields(vn[0], vn[1], p("phi_i"), p("theta_i"), (C.c_int * 2)(a["ndf"].shape[1], a["ndf"].shape[0]),
+                  (C.c_int * 2)(a["sigma"].shape[1], a["sigma"].shape[0]), (C.c_int * 2)(vn[3], vn[2]),
+                  p("ndf"), p("sigma"), p("vndf"), p("luminance"), p("rgb"), int(np.asarray(fields.get("jacobian", 1)).reshape(-1)[0]))
+    return r, a
 
 
 class TileInputs(C.Structure):
@@ -222,6 +237,8 @@ def load_library(path: Optional[str] = None):
     L.mrl_group_material_upload_f64.argtypes = [vp, vp, C.POINTER(C.c_int)]
     L.mrl_group_material_upload_table.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.mrl_group_material_ggx.argtypes = [vp, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.mrl_group_material_upload_rgl.argtypes = [vp, C.POINTER(RglFields), C.POINTER(C.c_int)]
+    L.mrl_group_material_load_rgl.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     L.mrl_group_material_release.argtypes = [vp, C.c_int]
     L.mrl_tile_bounds.argtypes = [C.c_size_t, C.c_int, C.c_int, szp, szp]; L.mrl_tile_bounds.restype = None
     L.mrl_chunk_bounds.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t, szp, szp]; L.mrl_chunk_bounds.restype = None
@@ -367,17 +384,7 @@ class MerlHip:
     def upload_rgl(self, fields: dict) -> int:
         """The adaptive-parameterisation measured BSDF from the fields of an RGL *.bsdf file (dict of arrays: phi_i, theta_i,
         ndf, sigma, vndf, luminance, rgb[, jacobian]).  Single-material calls evaluate it (mrl_material_upload_rgl)."""
-        f32 = lambda k: np.ascontiguousarray(fields[k], np.float32)
-        a = {k: f32(k) for k in ("phi_i", "theta_i", "ndf", "sigma", "vndf", "luminance", "rgb")}
-        vn = a["vndf"].shape
-        if len(vn) != 4 or a["luminance"].shape != vn or a["rgb"].shape != (vn[0], vn[1], 3, vn[2], vn[3]) or a["ndf"].ndim != 2 or a["sigma"].ndim != 2 \
-                or a["phi_i"].shape != (vn[0],) or a["theta_i"].shape != (vn[1],):
-            raise ValueError("RGL fields: vndf / luminance [n_phi, n_theta, res, res], rgb [n_phi, n_theta, 3, res, res], ndf / sigma 2-D")
-        fp = C.POINTER(C.c_float)
-        p = lambda k: a[k].ctypes.data_as(fp)
-        r = RglFields(vn[0], vn[1], p("phi_i"), p("theta_i"), (C.c_int * 2)(a["ndf"].shape[1], a["ndf"].shape[0]),
-                      (C.c_int * 2)(a["sigma"].shape[1], a["sigma"].shape[0]), (C.c_int * 2)(vn[3], vn[2]),
-                      p("ndf"), p("sigma"), p("vndf"), p("luminance"), p("rgb"), int(np.asarray(fields.get("jacobian", 1)).reshape(-1)[0]))
+        r, keep = rgl_fields_struct(fields)
         mid = C.c_int()
         self._check(self._lib.mrl_material_upload_rgl(self._ctx, C.byref(r), C.byref(mid)), "mrl_material_upload_rgl")
         return mid.value
@@ -877,6 +884,12 @@ class MerlGroup:
         p = np.ascontiguousarray(planar, dtype=np.float64)
         mid = C.c_int()
         self._check(self._lib.mrl_group_material_upload_f64(self._g, p.ctypes.data, C.byref(mid)), "mrl_group_material_upload_f64")
+        return mid.value
+
+    def upload_rgl(self, fields: dict) -> int:
+        r, keep = rgl_fields_struct(fields)
+        mid = C.c_int()
+        self._check(self._lib.mrl_group_material_upload_rgl(self._g, C.byref(r), C.byref(mid)), "mrl_group_material_upload_rgl")
         return mid.value
 
     def upload_table(self, planar: np.ndarray, scale: Sequence[float] = (1.0, 1.0, 1.0)) -> int:

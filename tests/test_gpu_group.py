@@ -84,6 +84,31 @@ def test_members_sharing_the_gpu_reproduce_the_single_device_run(tables, members
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
+def test_an_rgl_material_is_replicated_and_sharded_like_a_table():
+    """The adaptive-parameterisation material through the device-group pipeline (three members sharing GPU 0, root 1, uneven
+    chunks): bit-identical to the single-device call."""
+    import torch
+    from mitsuba_customization_amd import host, synth
+    fields = synth.make_rgl_fields(seed=13, n_phi=1, n_theta=5, res=10)
+    n = 120_007
+    with host.MerlHip(0) as g:
+        mid = g.upload_rgl(fields)
+        wi, wo, u = g.generate_pairs(0x5EED, 0, n)
+        ref = [t.clone() for t in g.eval_sample(wi, wo, u, material=mid)]
+    with host.MerlGroup([0, 0, 0]) as grp:
+        ggx = grp.ggx(0.2, (1.5, 1.5, 1.5), (3.0, 3.0, 3.0))
+        mid = grp.upload_rgl(fields)
+        assert (ggx, mid) == (0, 1)
+        tiles = grp.generate_tiles(0x5EED, 0, n)
+        out = _outs(n, torch.device("cuda", 0))
+        grp.eval_sample_sharded(tiles, n, 17_000, out, root=1, material=mid)
+        grp.synchronize()
+        for a, b in zip(out, ref):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        grp.release_material(mid)
+        assert grp.upload_rgl(fields) == mid
+
+
 def test_host_arrays_split_over_members(oracle, tables):
     from mitsuba_customization_amd import host
     n = 200_003
