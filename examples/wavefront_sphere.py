@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--sphere-merl", default=None)
     ap.add_argument("--ground-merl", default=None)
+    ap.add_argument("--sphere-rgl", default=None, help="an RGL *_rgb.bsdf file (or \"synthetic\") for the sphere: the queue call evaluates "
+                                                        "the adaptive-parameterisation material next to the ground's table")
     ap.add_argument("--sampling", choices=["cosine", "table"], default="cosine")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -31,7 +33,11 @@ def main():
 
     with host.MerlHip(0) as gpu:
         gpu.set_option(host.OPT_SAMPLING, 1 if args.sampling == "table" else 0)
-        sphere = gpu.load_merl(args.sphere_merl) if args.sphere_merl else gpu.upload_merl(synth.make_table("ggx_tab", seed=11))
+        if args.sphere_rgl:
+            sphere = gpu.upload_rgl(synth.make_rgl_fields(seed=3, n_phi=1, n_theta=8, res=32, res_ndf=64, res_sigma=32)) if args.sphere_rgl == "synthetic" \
+                else gpu.load_rgl(args.sphere_rgl)
+        else:
+            sphere = gpu.load_merl(args.sphere_merl) if args.sphere_merl else gpu.upload_merl(synth.make_table("ggx_tab", seed=11))
         ground = gpu.load_merl(args.ground_merl) if args.ground_merl else gpu.upload_merl(synth.make_table("ggx_tab", seed=5))
         assert (sphere, ground) == (0, 1)
         shade = wavefront.GpuShade(gpu)

@@ -21,3 +21,31 @@ class OracleShade:
             for o, r in zip(outs, res):
                 o[sel] = torch.from_numpy(r).to(wi.device)
         return tuple(outs)
+
+
+class OracleShadeRglSphere:
+    """Material 0 (the sphere) is an RGL adaptive-parameterisation material, material 1 (the disc) a MERL table."""
+
+    def __init__(self, rgl_fields, planar):
+        self.rgl = orc.OracleRgl(rgl_fields)
+        self.table = orc.OracleTable(planar)
+
+    def __call__(self, wi, wo, u, mat, queue, count):
+        n = wi.shape[0]
+        k = int(count.item())
+        sel = queue[:k].long()
+        outs = [torch.zeros((n, 3)), torch.zeros(n), torch.zeros((n, 3)), torch.zeros(n), torch.zeros((n, 3))]
+        outs = [o.to(wi.device) for o in outs]
+        if k:
+            cpu = lambda t: np.ascontiguousarray(t[sel].cpu().numpy())
+            a, b, c, m = cpu(wi), cpu(wo), cpu(u), cpu(mat)
+            res = [np.array(r) for r in orc.eval_sample_multi([self.table, self.table], a, b, c, m)]     # id 1: the table; id 0 overwritten below
+            on = m == 0
+            if on.any():
+                rgb, pdf = self.rgl.eval_pdf(a[on], b[on])
+                wo2, pdf2, w = self.rgl.sample(a[on], c[on])
+                for r, v in zip(res, (rgb, pdf, wo2, pdf2, w)):
+                    r[on] = v
+            for o, r in zip(outs, res):
+                o[sel] = torch.from_numpy(r).to(wi.device)
+        return tuple(outs)
