@@ -106,8 +106,8 @@ def parse(argv=None):
     p.add_argument("--layout", type=int, default=-1, help="table layout (MRL_OPT_TABLE_LAYOUT); -1 = library default")
     p.add_argument("--arena-mb", type=int, default=-1,
                    help="MRL_OPT_TABLE_ARENA_MB: place the tables back to back in one device allocation of this size; -1 (default): 20 GB for "
-                        "--config resident100 (address translation bounds that launch; one arena removes the slow mode of its process-to-process "
-                        "spread: profiles/r03_arena_ab.txt), none otherwise; 0: one allocation per table")
+                        "--config resident100 and 4 GB for mixed16_256m (address translation bounds those launches; one arena removes the slow mode "
+                        "of the process-to-process spread and is worth 5 %: profiles/r03_arena_ab.txt), none otherwise; 0: one allocation per table")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-reps", type=int, default=5, help="repetitions of each CPU baseline leg (median is reported)")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the separately reported RCCL gather leg")
@@ -320,7 +320,7 @@ def main():
         gpu.set_option(host.OPT_TABLE_LAYOUT, host.LAYOUT_ROWS)     # one texel per lookup: the compact layout wins
 
     if args.arena_mb < 0:
-        args.arena_mb = 20480 if args.config == "resident100" else 0
+        args.arena_mb = {"resident100": 20480, "mixed16_256m": 4096}.get(args.config, 0)
     if args.arena_mb:
         gpu.set_option(host.OPT_TABLE_ARENA_MB, args.arena_mb)
     GGX = (0.1, (0.143, 0.375, 1.442), (3.983, 2.386, 1.603))      # BASELINE config 3: alpha 0.1, gold-like eta / k
