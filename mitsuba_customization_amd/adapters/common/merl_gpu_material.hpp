@@ -70,6 +70,12 @@ public:
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_NODE, key.node), "mrl_set_option(node)");
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_DISK_MAP, key.disk_map), "mrl_set_option(disk_map)");
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_SAMPLING, key.sampling), "mrl_set_option(sampling)");
+        // scenes with many measured materials: MERL_TABLE_ARENA_MB=<MB> places their tables back to back in one device
+        // allocation (multi-table launches are bound by address translation)
+        if (const char *mb = std::getenv("MERL_TABLE_ARENA_MB")) {
+            const long v = std::atol(mb);
+            if (v > 0) check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_TABLE_ARENA_MB, (int)v), "mrl_set_option(table arena)");
+        }
     }
     ~Context()
     {
