@@ -254,61 +254,79 @@ MRL_HD void reduce_signs(int reduction, float wix, float wiy, float &sx, float &
     sx = reduction == 4 ? (__builtin_signbit(wix) ? 1.0f : -1.0f) : sy;
 }
 
-// eval (f cos theta_o, RGB) and / or pdf of one unit; every output zero outside the upper hemisphere
+// What eval / pdf / sample share about the incident direction: wi in the stored part of the azimuth, normalised; its angles; the
+// parameter slices around them (vndf, luminance and rgb share the parameter grids)
+struct Incident { Vec3d wi; float fx, fy; double theta_i, phi_i; Slices sv; };
+
+MRL_HD bool incident(const RglDev &b, float wix, float wiy, float wiz, Incident &in)
+{
+    reduce_signs(b.reduction, wix, wiy, in.fx, in.fy);
+    in.wi = { (double)(wix * in.fx), (double)(wiy * in.fy), (double)wiz };
+    if (!unit3(in.wi)) return false;
+    in.theta_i = elevation(in.wi); in.phi_i = azimuth(in.wi.y, in.wi.x);
+    in.sv = find_slices(b.vndf, in.phi_i, in.theta_i);
+    return true;
+}
+
+// eval (f cos theta_o, RGB) and / or pdf for an incident direction that is above the horizon; wo as the caller holds it
 template <bool WANT_RGB, bool WANT_PDF>
-MRL_HD void eval_pdf(const RglDev &b, float wix, float wiy, float wiz, float wox, float woy, float woz, float rgb[3], float &pdf)
+MRL_HD void eval_pdf_at(const RglDev &b, const Incident &in, float wox, float woy, float woz, float rgb[3], float &pdf)
 {
     rgb[0] = rgb[1] = rgb[2] = 0.0f; pdf = 0.0f;
-    if (!(wiz > 0.0f) || !(woz > 0.0f)) return;
-    float fx, fy;
-    reduce_signs(b.reduction, wix, wiy, fx, fy);
-    Vec3d wi = { (double)(wix * fx), (double)(wiy * fy), (double)wiz }, wo = { (double)(wox * fx), (double)(woy * fy), (double)woz };
-    if (!unit3(wi) || !unit3(wo)) return;
+    if (!(woz > 0.0f)) return;
+    const Vec3d &wi = in.wi;
+    Vec3d wo = { (double)(wox * in.fx), (double)(woy * in.fy), (double)woz };
+    if (!unit3(wo)) return;
     Vec3d m;
     {
 #pragma clang fp contract(off)
         m.x = wi.x + wo.x; m.y = wi.y + wo.y; m.z = wi.z + wo.z;
     }
     if (!unit3(m)) return;
-    const double theta_i = elevation(wi), phi_i = azimuth(wi.y, wi.x);
     const double theta_m = elevation(m), phi_m = azimuth(m.y, m.x);
-    const double u_wi_x = theta2u(theta_i), u_wi_y = phi2u(phi_i);
     const double u_m_x = theta2u(theta_m);
-    double u_m_y = phi2u(b.isotropic ? phi_m - phi_i : phi_m);
+    double u_m_y = phi2u(b.isotropic ? phi_m - in.phi_i : phi_m);
     u_m_y -= floor(u_m_y);
-    const Slices sv = find_slices(b.vndf, phi_i, theta_i);          // vndf, luminance and rgb share the parameter grids
     double sx, sy;
-    const double vndf_pdf = warp_invert(b.vndf, sv, u_m_x, u_m_y, sx, sy);
+    const double vndf_pdf = warp_invert(b.vndf, in.sv, u_m_x, u_m_y, sx, sy);
     if constexpr (WANT_RGB) {
         double scale = 1.0;
         if (b.jacobian) {
             const Slices one = single_slice();
-            scale = fast::div_fast(warp_eval(b.ndf, one, u_m_x, u_m_y), 4.0 * warp_eval(b.sigma, one, u_wi_x, u_wi_y));
+            scale = fast::div_fast(warp_eval(b.ndf, one, u_m_x, u_m_y), 4.0 * warp_eval(b.sigma, one, theta2u(in.theta_i), phi2u(in.phi_i)));
         }
         for (int c = 0; c < 3; ++c) {
-            double v = warp_eval(b.rgb, sv, sx, sy, c);
+            double v = warp_eval(b.rgb, in.sv, sx, sy, c);
             v = v < 0.0 ? 0.0 : v;
             rgb[c] = (float)(v * scale);
         }
     }
     if constexpr (WANT_PDF) {
-        const double lum_pdf = warp_eval(b.luminance, sv, sx, sy);
+        const double lum_pdf = warp_eval(b.luminance, in.sv, sx, sy);
         const double sin_theta_m = fast::sqrt_fast(m.x * m.x + m.y * m.y);
         const double jac = fmax(2.0 * kPi * kPi * u_m_x * sin_theta_m, 1e-6) * 4.0 * (wi.x * m.x + wi.y * m.y + wi.z * m.z);
         pdf = (float)fast::div_fast(vndf_pdf * lum_pdf, jac);
     }
 }
 
+// eval (f cos theta_o, RGB) and / or pdf of one unit; every output zero outside the upper hemisphere
+template <bool WANT_RGB, bool WANT_PDF>
+MRL_HD void eval_pdf(const RglDev &b, float wix, float wiy, float wiz, float wox, float woy, float woz, float rgb[3], float &pdf)
+{
+    rgb[0] = rgb[1] = rgb[2] = 0.0f; pdf = 0.0f;
+    Incident in;
+    if (!(wiz > 0.0f) || !(woz > 0.0f) || !incident(b, wix, wiy, wiz, in)) return;
+    eval_pdf_at<WANT_RGB, WANT_PDF>(b, in, wox, woy, woz, rgb, pdf);
+}
+
 MRL_HD void sample(const RglDev &b, float wix, float wiy, float wiz, float u0, float u1, float wo_out[3], float &pdf_out, float weight[3])
 {
     wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
-    if (!(wiz > 0.0f)) return;
-    float fx, fy;
-    reduce_signs(b.reduction, wix, wiy, fx, fy);
-    Vec3d wi = { (double)(wix * fx), (double)(wiy * fy), (double)wiz };
-    if (!unit3(wi)) return;
-    const double theta_i = elevation(wi), phi_i = azimuth(wi.y, wi.x);
-    const Slices sv = find_slices(b.vndf, phi_i, theta_i);
+    Incident in;
+    if (!(wiz > 0.0f) || !incident(b, wix, wiy, wiz, in)) return;
+    const Vec3d &wi = in.wi;
+    const Slices &sv = in.sv;
+    const float fx = in.fx, fy = in.fy;
     double sx, sy, umx, umy;
     (void)warp_sample(b.luminance, sv, (double)u1, (double)u0, sx, sy);
     (void)warp_sample(b.vndf, sv, sx, sy, umx, umy);
@@ -331,7 +349,7 @@ MRL_HD void sample(const RglDev &b, float wix, float wiy, float wiz, float u0, f
     const float wof[3] = { (float)((2.0 * c * m.x - wi.x) * (double)fx), (float)((2.0 * c * m.y - wi.y) * (double)fy), (float)(2.0 * c * m.z - wi.z) };
     if (!(wof[2] > 0.0f) || !(c > 0.0)) return;
     float f[3], p;
-    eval_pdf<true, true>(b, wix, wiy, wiz, wof[0], wof[1], wof[2], f, p);
+    eval_pdf_at<true, true>(b, in, wof[0], wof[1], wof[2], f, p);          // at the Float direction that is returned
     if (!(p > 0.0f)) return;
     wo_out[0] = wof[0]; wo_out[1] = wof[1]; wo_out[2] = wof[2];
     pdf_out = p;
