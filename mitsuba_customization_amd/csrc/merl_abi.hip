@@ -18,6 +18,7 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 #include "merl_kernels.hpp"
 #include "merl_rgl.hpp"
@@ -1365,6 +1366,230 @@ int mrl_material_release(mrl_ctx *ctx, int id)
     m.bytes = 0;
     return MRL_OK;
 }
+
+} // extern "C" (reopened below)
+
+// ---- on-disk cache of a material's device image (second half) ----------------------------------------
+// What is resident for a material — the texel image in its device layout, the sampling marginal, the conditional sampling rows; for an
+// RGL material the cell-brick image with its running integrals — written as it is, so that a later process makes the material
+// resident with one read and one copy: no parse, no re-layout kernel, no quadrature / prefix-scan kernels, no host normalisation.
+// A file is untrusted input: every size is recomputed from the header's shapes (never taken from the file), an RGL descriptor is
+// rebuilt from the shapes, and the payload carries a checksum.  What the payload's VALUES say is data (a table), not structure.
+namespace {
+
+struct ImageHeader {
+    char magic[8];                       // "MRLIMG\1\0"
+    uint32_t header_bytes, kind, layout, n_ch, param, lookup, node, n_ti;
+    int32_t dims[3];
+    int32_t rgl_shape[8];                // n_phi n_theta res_x res_y res_ndf_x res_ndf_y res_sigma_x res_sigma_y
+    int32_t rgl_flags[2];                // jacobian, reserved
+    uint64_t texel_bytes, sampling_doubles, sampling2d_doubles, checksum;
+};
+constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 1, 0 };
+
+uint64_t image_checksum(const void *p, size_t bytes, uint64_t h)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    for (; i < bytes; ++i) { h = (h ^ b[i]) * 0x100000001B3ull; }
+    return h;
+}
+
+// device bytes of a table material's texel image, from its descriptor
+size_t texel_image_bytes(const mrl::MaterialDev &d)
+{
+    const size_t plane = (size_t)d.n_th * d.n_td * d.n_pd;
+    if (d.kind == mrl::KIND_TABLE_NCH) return plane * mrl::nch_brick_float4s(d.n_ch) * sizeof(float4);
+    return (d.layout == mrl::LAYOUT_BRICK ? plane * 8 : (size_t)(d.n_th + 1) * (d.n_td + 1) * (d.n_pd + 1)) * sizeof(float4);
+}
+
+size_t rows_image_bytes(const mrl::MaterialDev &d) { return (size_t)(d.n_th + 1) * (d.n_td + 1) * (d.n_pd + 1) * sizeof(float4); }
+
+mrl::RglFields rgl_shapes_of(const int32_t s[8], int jacobian)
+{
+    mrl::RglFields f;
+    std::memset(&f, 0, sizeof f);
+    f.n_phi = s[0]; f.n_theta = s[1]; f.res[0] = s[2]; f.res[1] = s[3]; f.res_ndf[0] = s[4]; f.res_ndf[1] = s[5]; f.res_sigma[0] = s[6]; f.res_sigma[1] = s[7];
+    f.jacobian = jacobian;
+    return f;
+}
+
+} // namespace
+
+extern "C" {
+
+int mrl_material_save_image(mrl_ctx *ctx, int id, const char *path)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
+    if (!path) return fail(ctx, MRL_ERR_INVALID, "null path");
+    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
+    const MaterialHost &mh = ctx->materials[(size_t)id];
+    const mrl::MaterialDev &d = mh.dev;
+    if (d.kind == mrl::KIND_GGX) return fail(ctx, MRL_ERR_MATERIAL, "an analytic material has no image to cache");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    ImageHeader h;
+    std::memset(&h, 0, sizeof h);
+    std::memcpy(h.magic, kImageMagic, 8);
+    h.header_bytes = (uint32_t)sizeof h; h.kind = (uint32_t)d.kind; h.layout = (uint32_t)d.layout; h.n_ch = (uint32_t)d.n_ch; h.param = (uint32_t)d.param;
+    h.lookup = (uint32_t)ctx->opts.lookup; h.node = (uint32_t)ctx->opts.node; h.n_ti = (uint32_t)d.n_ti;
+    h.dims[0] = d.n_th; h.dims[1] = d.n_td; h.dims[2] = d.n_pd;
+    if (d.kind == mrl::KIND_RGL) {
+        const mrl::RglDev &r = mh.rgl;
+        const int32_t shape[8] = { r.vndf.n_phi, r.vndf.n_theta, r.vndf.nx, r.vndf.ny, r.ndf.nx, r.ndf.ny, r.sigma.nx, r.sigma.ny };
+        std::memcpy(h.rgl_shape, shape, sizeof shape);
+        h.rgl_flags[0] = r.jacobian;
+        mrl::RglLayout l;
+        h.texel_bytes = mrl::rgl_plan_layout(rgl_shapes_of(shape, r.jacobian), l) * sizeof(float);
+    } else {
+        // RGB tables travel in the compact rows form whatever the context's layout (a brick image is 7.8 x larger than the rows image
+        // and reads slower than the source file parses); n-channel tables have one layout
+        const bool rgb = d.kind != mrl::KIND_TABLE_NCH;
+        if (rgb) h.layout = (uint32_t)mrl::LAYOUT_ROWS;
+        h.texel_bytes = rgb ? rows_image_bytes(d) : texel_image_bytes(d);
+        h.sampling_doubles = 3 * (uint64_t)d.n_th + 2;
+        h.sampling2d_doubles = mh.d_sampling2d ? (uint64_t)d.n_ti * (2 * (uint64_t)d.n_th + 1) : 0;
+    }
+    std::vector<char> payload;
+    try { payload.resize((size_t)h.texel_bytes + (size_t)(h.sampling_doubles + h.sampling2d_doubles) * sizeof(double)); }
+    catch (const std::bad_alloc &) { return fail(ctx, MRL_ERR_OOM, "image buffer"); }
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (d.kind != mrl::KIND_RGL && d.kind != mrl::KIND_TABLE_NCH && d.layout == mrl::LAYOUT_BRICK) {
+        float4 *d_rows = nullptr;
+        MRL_ALLOC(ctx, hipMalloc((void **)&d_rows, (size_t)h.texel_bytes));
+        hipError_t e = mrl::launch_bricks_to_rows(mh.d_texels, h.dims, d.param, d_rows, ctx->compute_units, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(payload.data(), d_rows, (size_t)h.texel_bytes, hipMemcpyDeviceToHost);
+        (void)hipFree(d_rows);
+        MRL_HIP(ctx, e);
+    } else {
+        MRL_HIP(ctx, hipMemcpy(payload.data(), mh.d_texels, (size_t)h.texel_bytes, hipMemcpyDeviceToHost));
+    }
+    if (h.sampling_doubles) MRL_HIP(ctx, hipMemcpy(payload.data() + h.texel_bytes, mh.d_sampling, (size_t)h.sampling_doubles * sizeof(double), hipMemcpyDeviceToHost));
+    if (h.sampling2d_doubles)
+        MRL_HIP(ctx, hipMemcpy(payload.data() + h.texel_bytes + h.sampling_doubles * sizeof(double), mh.d_sampling2d, (size_t)h.sampling2d_doubles * sizeof(double), hipMemcpyDeviceToHost));
+    h.checksum = image_checksum(payload.data(), payload.size(), 0xCBF29CE484222325ull);
+    // written under a private name and renamed into place: a reader never sees half a file
+    const std::string tmp = std::string(path) + ".tmp." + std::to_string((long long)::getpid());
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return fail(ctx, MRL_ERR_IO, std::string("cannot create ") + tmp);
+    const bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 && (payload.empty() || std::fwrite(payload.data(), 1, payload.size(), f) == payload.size());
+    const bool closed = std::fclose(f) == 0;
+    if (!ok || !closed || std::rename(tmp.c_str(), path) != 0) { (void)std::remove(tmp.c_str()); return fail(ctx, MRL_ERR_IO, std::string("cannot write ") + path); }
+    return MRL_OK;
+}
+
+int mrl_material_load_image(mrl_ctx *ctx, const char *path, int *out_id)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    MRL_GUARD(ctx);
+    if (!path || !out_id) return fail(ctx, MRL_ERR_INVALID, "null argument");
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(ctx, MRL_ERR_IO, std::string("cannot open ") + path);
+    ImageHeader h;
+    auto refuse = [&](const std::string &why) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, why + " (" + path + ")"); };
+    if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, kImageMagic, 8) != 0 || h.header_bytes != sizeof h) return refuse("not a material image of this library version");
+    const bool is_rgl = h.kind == (uint32_t)mrl::KIND_RGL, is_nch = h.kind == (uint32_t)mrl::KIND_TABLE_NCH;
+    if (!is_rgl && !is_nch && h.kind != (uint32_t)mrl::KIND_MERL && h.kind != (uint32_t)mrl::KIND_TABLE) return refuse("unknown material kind");
+    mrl::MaterialDev d;
+    std::memset(&d, 0, sizeof d);
+    d.kind = (int)h.kind;
+    uint64_t texel_bytes = 0, sampling_doubles = 0, sampling2d_doubles = 0;
+    mrl::RglFields shapes;
+    mrl::RglLayout layout;
+    if (is_rgl) {
+        shapes = rgl_shapes_of(h.rgl_shape, h.rgl_flags[0] != 0);
+        if (const char *why = mrl::rgl_check_shapes(shapes)) return refuse(std::string("RGL image: ") + why);
+        texel_bytes = mrl::rgl_plan_layout(shapes, layout) * sizeof(float);
+        d.n_ch = 3; d.n_th = shapes.n_phi; d.n_td = shapes.n_theta; d.n_pd = shapes.res[0];
+    } else {
+        if (h.dims[0] < 1 || h.dims[1] < 1 || h.dims[2] < 1 || (long long)h.dims[0] * h.dims[1] * h.dims[2] > (1LL << 28)) return refuse("table dims out of range");
+        if (h.layout > 1 || h.param > (uint32_t)mrl::PARAM_STANDARD_FULL || (is_nch ? (h.n_ch < 1 || h.n_ch > (uint32_t)mrl::kMaxChannels || h.layout != (uint32_t)mrl::LAYOUT_BRICK) : h.n_ch != 3))
+            return refuse("bad layout / parameterisation / channel count");
+        d.n_th = h.dims[0]; d.n_td = h.dims[1]; d.n_pd = h.dims[2];
+        d.layout = (int)h.layout; d.n_ch = (int)h.n_ch; d.param = (int)h.param;
+        d.row_td = d.n_pd + 1; d.row_th = (d.n_td + 1) * (d.n_pd + 1);
+        if (!is_nch) {
+            if (h.layout != (uint32_t)mrl::LAYOUT_ROWS) return refuse("RGB table images are stored in the rows form");
+            d.layout = ctx->table_layout;                     // what it becomes on this context
+            // the conditional sampling rows were integrated through the table's lookup: under other lookup options they are another table
+            if (h.sampling2d_doubles && ((int)h.lookup != ctx->opts.lookup || (int)h.node != ctx->opts.node))
+                return refuse("the image's conditional sampling rows were built under other lookup / node options");
+            if (h.n_ti != (uint32_t)mrl::kSamplingIncidentBins && h.sampling2d_doubles) return refuse("bad incident-bin count");
+        }
+        texel_bytes = is_nch ? texel_image_bytes(d) : rows_image_bytes(d);
+        sampling_doubles = 3 * (uint64_t)d.n_th + 2;
+        sampling2d_doubles = (!is_nch && h.sampling2d_doubles) ? (uint64_t)mrl::kSamplingIncidentBins * (2 * (uint64_t)d.n_th + 1) : 0;
+    }
+    if (h.texel_bytes != texel_bytes || h.sampling_doubles != sampling_doubles || h.sampling2d_doubles != sampling2d_doubles) return refuse("sizes do not follow from the shapes");
+    const size_t payload_bytes = (size_t)texel_bytes + (size_t)(sampling_doubles + sampling2d_doubles) * sizeof(double);
+    if (std::fseek(f, 0, SEEK_END) != 0 || (unsigned long long)std::ftell(f) != sizeof h + payload_bytes || std::fseek(f, (long)sizeof h, SEEK_SET) != 0) return refuse("file length does not match the header");
+    std::vector<char> payload;
+    try { payload.resize(payload_bytes); } catch (const std::bad_alloc &) { std::fclose(f); return fail(ctx, MRL_ERR_OOM, "image buffer"); }
+    if (payload_bytes && std::fread(payload.data(), 1, payload_bytes, f) != payload_bytes) return refuse("short read");
+    std::fclose(f);
+    if (image_checksum(payload.data(), payload.size(), 0xCBF29CE484222325ull) != h.checksum) return fail(ctx, MRL_ERR_FORMAT, std::string("checksum mismatch (") + path + ")");
+    MRL_HIP(ctx, hipSetDevice(ctx->device));
+    MaterialHost m;
+    const bool expand = !is_rgl && !is_nch && d.layout == mrl::LAYOUT_BRICK;      // rows on disk, bricks on this context
+    const size_t image_bytes = is_rgl ? ((size_t)texel_bytes + 255) / 256 * 256 : (expand ? texel_image_bytes(d) : (size_t)texel_bytes);
+    m.bytes = image_bytes + (is_rgl ? sizeof(mrl::RglDev) : 0) + (size_t)(sampling_doubles + sampling2d_doubles) * sizeof(double);
+    int rc = budget_check(ctx, m.bytes + (expand ? (size_t)texel_bytes : 0));
+    if (rc != MRL_OK) return rc;
+    hipError_t e;
+    if (is_rgl || is_nch) e = hipMalloc((void **)&m.d_texels, image_bytes + (is_rgl ? sizeof(mrl::RglDev) : 0));
+    else e = table_alloc(ctx, image_bytes, &m.d_texels, &m.in_arena);
+    bool oom = e == hipErrorOutOfMemory;
+    if (e == hipSuccess && expand) {
+        float4 *d_rows = nullptr;
+        e = hipMalloc((void **)&d_rows, (size_t)texel_bytes);
+        oom = oom || e == hipErrorOutOfMemory;
+        if (e == hipSuccess) e = hipMemcpyAsync(d_rows, payload.data(), (size_t)texel_bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = mrl::launch_rows_to_bricks(d_rows, h.dims, m.d_texels, ctx->compute_units, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (d_rows) (void)hipFree(d_rows);
+    } else if (e == hipSuccess) {
+        e = hipMemcpy(m.d_texels, payload.data(), (size_t)texel_bytes, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && is_rgl) {
+        // isotropy and the stored part of the azimuth follow from the phi_i grid, which is the image's first n_phi floats
+        shapes.phi_i = (const float *)payload.data();
+        m.rgl = mrl::rgl_descriptor(shapes, layout, (const float *)m.d_texels);
+        if (m.rgl.reduction != 1 && m.rgl.reduction != 2 && m.rgl.reduction != 4) e = hipErrorInvalidValue;
+        else e = hipMemcpy((char *)m.d_texels + image_bytes, &m.rgl, sizeof m.rgl, hipMemcpyHostToDevice);
+        d.rgl = (const char *)m.d_texels + image_bytes;
+    }
+    if (e == hipSuccess && sampling_doubles) {
+        e = hipMalloc((void **)&m.d_sampling, (size_t)sampling_doubles * sizeof(double));
+        oom = oom || e == hipErrorOutOfMemory;
+        if (e == hipSuccess) e = hipMemcpy(m.d_sampling, payload.data() + texel_bytes, (size_t)sampling_doubles * sizeof(double), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && sampling2d_doubles) {
+        e = hipMalloc((void **)&m.d_sampling2d, (size_t)sampling2d_doubles * sizeof(double));
+        oom = oom || e == hipErrorOutOfMemory;
+        if (e == hipSuccess) e = hipMemcpy(m.d_sampling2d, payload.data() + texel_bytes + sampling_doubles * sizeof(double), (size_t)sampling2d_doubles * sizeof(double), hipMemcpyHostToDevice);
+    }
+    auto drop = [&]() {
+        if (is_rgl || is_nch) { if (m.d_texels) (void)hipFree(m.d_texels); } else table_free(ctx, m.d_texels, m.in_arena);
+        if (m.d_sampling) (void)hipFree(m.d_sampling);
+        if (m.d_sampling2d) (void)hipFree(m.d_sampling2d);
+    };
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        drop();
+        return fail(ctx, oom ? MRL_ERR_OOM : (e == hipErrorInvalidValue ? MRL_ERR_FORMAT : MRL_ERR_HIP), std::string("image upload: ") + hipGetErrorString(e));
+    }
+    d.texels = m.d_texels; d.sampling = m.d_sampling; d.sampling2d = m.d_sampling2d; d.n_ti = sampling2d_doubles ? mrl::kSamplingIncidentBins : 0;
+    m.dev = d;
+    rc = place_material(ctx, m, out_id);
+    if (rc != MRL_OK) { drop(); return rc; }
+    return MRL_OK;
+}
+
+} // extern "C"
+
+extern "C" {
 
 int mrl_memory_info(const mrl_ctx *ctx, size_t *material_bytes, size_t *workspace_bytes, size_t *device_free, size_t *device_total)
 {

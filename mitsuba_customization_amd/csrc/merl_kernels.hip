@@ -779,6 +779,40 @@ __global__ __launch_bounds__(kBlock) void k_build_rows(const double *planar, int
     }
 }
 
+// ---- layout to layout (the on-disk image cache keeps RGB tables in the compact rows form, whatever the context's layout) ----
+// rows -> bricks: a cell's eight corners are eight texels of the padded rows image (its extra texels ARE the clamps / the phi wrap)
+__global__ __launch_bounds__(kBlock) void k_rows_to_bricks(const float4 *rows, int n_th, int n_td, int n_pd, float4 *bricks)
+{
+    const size_t cells = (size_t)n_th * n_td * n_pd, D = n_td + 1, P = n_pd + 1;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < cells; c += stride) {
+        const size_t ip = c % (size_t)n_pd, id = (c / (size_t)n_pd) % (size_t)n_td, ih = c / ((size_t)n_pd * n_td);
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 t = rows[((ih + (size_t)(k >> 2)) * D + id + (size_t)((k >> 1) & 1)) * P + ip + (size_t)(k & 1)];
+            v[3 * k] = t.x; v[3 * k + 1] = t.y; v[3 * k + 2] = t.z;
+        }
+#pragma unroll
+        for (int pad = 24; pad < 32; ++pad) v[pad] = 0.0f;
+        float4 *dst = bricks + c * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+}
+// bricks -> rows: corner 0 of a cell is the cell's own texel; the padding texels repeat the last one / wrap phi as k_build_rows does
+__global__ __launch_bounds__(kBlock) void k_bricks_to_rows(const float4 *bricks, int n_th, int n_td, int n_pd, int phi_periodic, float4 *rows)
+{
+    const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1, total = H * D * P;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+        const size_t ip = t % P, id = (t / P) % D, ih = t / (P * D);
+        const size_t sh = ih < (size_t)n_th ? ih : n_th - 1, sd = id < (size_t)n_td ? id : n_td - 1, sp = ip == (size_t)n_pd ? (phi_periodic ? 0 : n_pd - 1) : ip;
+        const float4 q = bricks[((sh * n_td + sd) * n_pd + sp) * 8];
+        rows[t] = make_float4(q.x, q.y, q.z, 0.0f);
+    }
+}
+
 // ---- the conditional sampling table P(theta_h | theta_i) (definition: oracle/merl_oracle.h, "survey form") -------------
 // Built on the device from the RESIDENT table, through the kernels' own lookup.  Pass 1, one wave per (incident bin i,
 // theta_h bin j): its 64 lanes are the K_s x K_p = 4 x 16 quadrature midpoints of the bin; lane -> BRDF mass at its
@@ -1104,6 +1138,19 @@ hipError_t launch_partition_materials(const int32_t *mat, size_t n, int K, uint3
     hipLaunchKernelGGL(k_material_bases, dim3(1), block, 0, stream, totals, K, offsets, counts);
     hipLaunchKernelGGL(k_add_material_bases, dim3(grid_for((size_t)chunks * K, compute_units)), block, 0, stream, table, (size_t)chunks * K, K, offsets);
     hipLaunchKernelGGL((k_partition_materials<true>), grid, block, lds, stream, mat, n, K, chunk_len, table, queue);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_to_bricks(const float4 *d_rows, const int dims[3], float4 *d_bricks, int compute_units, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_rows_to_bricks, dim3(grid_for((size_t)dims[0] * dims[1] * dims[2], compute_units)), dim3(kBlock), 0, stream,
+                       d_rows, dims[0], dims[1], dims[2], d_bricks);
+    return hipGetLastError();
+}
+hipError_t launch_bricks_to_rows(const float4 *d_bricks, const int dims[3], int param, float4 *d_rows, int compute_units, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_bricks_to_rows, dim3(grid_for((size_t)(dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1), compute_units)), dim3(kBlock), 0, stream,
+                       d_bricks, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), d_rows);
     return hipGetLastError();
 }
 

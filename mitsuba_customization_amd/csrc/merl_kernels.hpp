@@ -55,6 +55,9 @@ hipError_t launch_partition_materials(const int32_t *mat, size_t n, int K, uint3
 // a1: planar f64 table (device copy of the file payload) -> padded rows or bricks
 hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, int param, float4 *d_out,
                               int compute_units, hipStream_t stream);
+// one RGB table layout to the other (the on-disk image cache stores the rows form): padded rows <-> bricks, same Float values
+hipError_t launch_rows_to_bricks(const float4 *d_rows, const int dims[3], float4 *d_bricks, int compute_units, hipStream_t stream);
+hipError_t launch_bricks_to_rows(const float4 *d_bricks, const int dims[3], int param, float4 *d_rows, int compute_units, hipStream_t stream);
 // the conditional sampling table P(theta_h | theta_i) of a resident RGB table (MRL_OPT_SAMPLING = 2): a quadrature kernel
 // and a prefix-scan kernel; d_rows: n_ti x (2 n_th + 1) doubles, d_work: n_ti x n_th doubles
 constexpr int kSamplingIncidentBins = 32;
@@ -79,6 +82,8 @@ struct RglLayout { size_t phi, theta, cells[5], cond[5], rows[5]; };     // floa
 int rgl_reduction(const RglFields &f);                                   // 1, 2, 4: the part of the azimuth an anisotropic file stores
 const char *rgl_check_fields(const RglFields &f);                        // nullptr, or what is wrong
 RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob); // normalised tables + running integrals, host f64
+size_t rgl_plan_layout(const RglFields &f, RglLayout &l);                 // the same layout from the shapes alone; returns the image size in floats
+const char *rgl_check_shapes(const RglFields &f);                        // the shape part of rgl_check_fields (no array is read)
 RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base);
 // r != nullptr: a single-material launch; r == nullptr: a batch with material ids (a.mat) — the units whose id names an RGL material
 // are evaluated and written, every other unit is left as it is.  indexed: walk the queue a.idx / a.idx_count

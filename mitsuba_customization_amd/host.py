@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     "mrl_eval_queue_nch", "mrl_sample_queue_nch", "mrl_eval_pdf_queue_nch", "mrl_eval_sample_queue_nch",
     "mrl_tensor_file_open", "mrl_tensor_file_close", "mrl_tensor_file_last_error", "mrl_tensor_file_field_count", "mrl_tensor_file_find",
     "mrl_tensor_file_field_info", "mrl_tensor_file_field_data", "mrl_tensor_file_read_f64", "mrl_material_load_tensor_table",
-    "mrl_material_upload_rgl", "mrl_material_load_rgl",
+    "mrl_material_upload_rgl", "mrl_material_load_rgl", "mrl_material_save_image", "mrl_material_load_image",
     "mrl_group_init", "mrl_group_destroy", "mrl_group_size", "mrl_group_transport", "mrl_group_last_error", "mrl_group_context",
     "mrl_group_set_option", "mrl_group_material_load_merl", "mrl_group_material_upload_f64", "mrl_group_material_upload_table",
     "mrl_group_material_ggx", "mrl_group_material_upload_rgl", "mrl_group_material_load_rgl", "mrl_group_material_release", "mrl_tile_bounds", "mrl_chunk_bounds", "mrl_chunk_steps",
@@ -225,6 +225,8 @@ def load_library(path: Optional[str] = None):
     L.mrl_material_load_tensor_table.argtypes = [vp, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mrl_material_upload_rgl.argtypes = [vp, C.POINTER(RglFields), C.POINTER(C.c_int)]
     L.mrl_material_load_rgl.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
+    L.mrl_material_save_image.argtypes = [vp, C.c_int, C.c_char_p]
+    L.mrl_material_load_image.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     szp = C.POINTER(C.c_size_t)
     L.mrl_group_init.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.mrl_group_destroy.argtypes = [vp]
@@ -396,6 +398,15 @@ class MerlHip:
         if rc != 0:
             detail = self._lib.mrl_tensor_file_last_error(None).decode() or self._lib.mrl_last_error(self._ctx).decode()
             raise MerlHipError(rc, "mrl_material_load_rgl", detail)
+        return mid.value
+
+    def save_image(self, mid: int, path: str):
+        """The material's device image to disk (mrl_material_save_image): tables, n-channel tables, RGL materials."""
+        self._check(self._lib.mrl_material_save_image(self._ctx, mid, path.encode()), "mrl_material_save_image")
+
+    def load_image(self, path: str) -> int:
+        mid = C.c_int()
+        self._check(self._lib.mrl_material_load_image(self._ctx, path.encode(), C.byref(mid)), "mrl_material_load_image")
         return mid.value
 
     def material_count(self) -> int:

@@ -367,3 +367,41 @@ def test_mitsuba3_measured_plugin_evaluates_an_rgl_file(built, tmp_path, n_phi):
     table = os.path.join(os.path.dirname(__file__), "golden", "tensor_table_c5.bsdf")
     r = subprocess.run([drv, plug, table, pairs, out, str(m)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 5 and "phi_i" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("host", ["06", "3"])
+def test_plugins_load_through_the_image_cache(built, merl_file, oracle, tmp_path, host):
+    """MERL_IMAGE_CACHE_DIR: the first instance writes the table's device image, later processes become resident from it (no parse, no
+    re-layout, no sampling-table kernels) and answer with the same bits; a damaged image is refused by the library and rewritten."""
+    n, m = 5000, 50
+    wi, wo, u = oracle.generate_pairs(0x5EED, 31337, n)
+    pairs = str(tmp_path / "pairs.bin")
+    _write_pairs(pairs, wi, wo, u)
+    drv = os.path.join(built, "driver06" if host == "06" else "driver3")
+    plug = os.path.join(built, "plugins06" if host == "06" else "plugins3", "merl.so")
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    env = dict(os.environ, MERL_IMAGE_CACHE_DIR=str(cache))
+
+    def run(tag, e):
+        out = str(tmp_path / (tag + ".bin"))
+        r = subprocess.run([drv, plug, merl_file, pairs, out, str(m)], capture_output=True, text=True, timeout=300, env=e)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return open(out, "rb").read()
+
+    plain = run("plain", dict(os.environ))
+    assert not list(cache.iterdir())
+    first = run("first", env)
+    images = list(cache.iterdir())
+    assert len(images) == 1 and images[0].suffix == ".mrlimg" and 24_000_000 < images[0].stat().st_size < 26_000_000
+    stamp = images[0].stat().st_mtime_ns
+    second = run("second", env)
+    assert first == plain and second == plain and images[0].stat().st_mtime_ns == stamp          # read, not rewritten
+    data = bytearray(images[0].read_bytes()); data[-100] ^= 1
+    images[0].write_bytes(bytes(data))
+    third = run("third", env)
+    assert third == plain and images[0].read_bytes() != bytes(data)                                # refused (checksum), loaded from the source, rewritten
+    os.utime(merl_file)                                                                            # a touched source is another image
+    run("fourth", env)
+    assert len(list(cache.iterdir())) == 2

@@ -1,0 +1,152 @@
+"""mrl_material_save_image / mrl_material_load_image: the on-disk cache of a material's device image.  A material
+loaded from its image in another context answers with the bits of the original; altered, truncated or mismatched files are refused."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _outputs(g, mid, n, n_ch=0, sampling=0):
+    from mitsuba_customization_amd import host
+    g.set_option(host.OPT_SAMPLING, sampling)
+    wi, wo, u = g.generate_pairs(0xCAFE, 0, n)
+    if n_ch:
+        return [t.cpu().numpy() for t in g.eval_sample_nch(wi, wo, u, n_ch, material=mid)]
+    return [t.cpu().numpy() for t in g.eval_sample(wi, wo, u, material=mid)]
+
+
+@pytest.mark.parametrize("what", ["merl_bricks", "merl_rows", "table_standard", "nch5", "rgl_iso", "rgl_quarter"])
+def test_a_material_loaded_from_its_image_gives_the_same_bits(tables, tmp_path, what):
+    from mitsuba_customization_amd import host, synth
+    path = str(tmp_path / (what + ".mrlimg"))
+    n = 20000
+    layout = host.LAYOUT_ROWS if what == "merl_rows" else host.LAYOUT_BRICK
+    n_ch = 5 if what == "nch5" else 0
+    modes = (0, 1, 2) if what in ("merl_bricks", "merl_rows", "table_standard") else (0,)
+
+    def make(g):
+        if what.startswith("merl"):
+            return g.upload_merl(tables("ggx_tab", 2))
+        if what == "table_standard":
+            g.set_option(host.OPT_TABLE_PARAM, 1)
+            mid = g.upload_table(tables("noise", 4, (12, 10, 18)), (0.5, 2.0, 1.25))
+            g.set_option(host.OPT_TABLE_PARAM, 0)
+            return mid
+        if what == "nch5":
+            return g.upload_table_nch(synth.make_table_nch("spectral", 5, 9, (10, 8, 12)), [1.0, 0.5, 2.0, 1.5, 0.25])
+        return g.upload_rgl(synth.make_rgl_fields(seed=31, n_phi=1, n_theta=5, res=9) if what == "rgl_iso"
+                            else synth.make_rgl_fields(seed=32, n_phi=3, n_theta=3, res=6, reduction=4))
+
+    with host.MerlHip(0) as g:
+        g.set_option(host.OPT_TABLE_LAYOUT, layout)
+        mid = make(g)
+        want = {s: _outputs(g, mid, n, n_ch, s) for s in modes}
+        info = g.material_info(mid)
+        used = g.memory_info()["table_bytes"]
+        g.save_image(mid, path)
+        assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+    with host.MerlHip(0) as g:
+        g.set_option(host.OPT_TABLE_LAYOUT, layout)
+        g.ggx(0.3, (1, 1, 1), (2, 2, 2))                                       # the image does not depend on the slot it came from
+        mid = g.load_image(path)
+        assert mid == 1 and g.material_info(mid) == info and g.memory_info()["table_bytes"] == used
+        for s in modes:
+            for a, b in zip(_outputs(g, mid, n, n_ch, s), want[s]):
+                assert np.array_equal(a.view(np.int32), b.view(np.int32)), (what, s)
+        if what == "table_standard":
+            assert g.material_param(mid) == 1
+        g.release_material(mid)
+        assert g.memory_info()["table_bytes"] == 0
+
+
+def test_altered_truncated_and_mismatched_images_are_refused(tables, tmp_path):
+    from mitsuba_customization_amd import host, synth
+    good = str(tmp_path / "good.mrlimg")
+    rgl = str(tmp_path / "rgl.mrlimg")
+    with host.MerlHip(0) as g:
+        mid = g.upload_table(tables("noise", 4, (6, 5, 8)), (1.0, 1.0, 1.0))
+        g.save_image(mid, good)
+        g.save_image(g.upload_rgl(synth.make_rgl_fields(seed=33, n_phi=1, n_theta=3, res=5)), rgl)
+        ggx = g.ggx(0.3, (1, 1, 1), (2, 2, 2))
+        with pytest.raises(host.MerlHipError) as e:
+            g.save_image(ggx, str(tmp_path / "x"))
+        assert e.value.status == host.ERR_MATERIAL
+        with pytest.raises(host.MerlHipError):
+            g.save_image(99, str(tmp_path / "x"))
+        count, used = g.material_count(), g.memory_info()["table_bytes"]
+        raw = open(good, "rb").read()
+        raw_rgl = open(rgl, "rb").read()
+
+        def refused(data, needle, status=host.ERR_FORMAT):
+            p = str(tmp_path / "bad.mrlimg")
+            open(p, "wb").write(data)
+            with pytest.raises(host.MerlHipError) as e:
+                g.load_image(p)
+            assert e.value.status == status and needle in str(e.value), str(e.value)
+            assert g.material_count() == count and g.memory_info()["table_bytes"] == used
+
+        refused(b"", "not a material image")
+        refused(b"MRLIMG\x02\x00" + raw[8:], "not a material image")
+        refused(raw[:-1], "file length")
+        refused(raw + b"\0", "file length")
+        flipped = bytearray(raw); flipped[-5] ^= 0x10
+        refused(bytes(flipped), "checksum")
+        off_dims = 8 + 8 * 4                                    # magic, then eight uint32, then dims[3]
+        assert struct.unpack_from("<3i", raw, off_dims) == (6, 5, 8)
+        big = bytearray(raw); struct.pack_into("<i", big, off_dims, 60)
+        refused(bytes(big), "sizes do not follow")
+        neg = bytearray(raw); struct.pack_into("<i", neg, off_dims, -6)
+        refused(bytes(neg), "dims out of range")
+        kind = bytearray(raw); struct.pack_into("<I", kind, 12, 2)          # claims to be an analytic material
+        refused(bytes(kind), "unknown material kind")
+        # an RGL image whose shapes are inflated: the sizes no longer follow
+        off_shape = off_dims + 12
+        assert struct.unpack_from("<4i", raw_rgl, off_shape) == (1, 3, 5, 5)
+        grown = bytearray(raw_rgl); struct.pack_into("<i", grown, off_shape + 8, 500)
+        refused(bytes(grown), "sizes do not follow")
+        huge = bytearray(raw_rgl); struct.pack_into("<i", huge, off_shape + 8, 50000)
+        refused(bytes(huge), "RGL image")
+        with pytest.raises(host.MerlHipError) as e:
+            g.load_image(str(tmp_path / "missing.mrlimg"))
+        assert e.value.status == host.ERR_IO
+        assert g.load_image(good) == count                      # the context is as it was, and still loads a good image
+    # conditional sampling rows are tied to the lookup options they were integrated under
+    with host.MerlHip(0) as g:
+        g.set_option(host.OPT_NODE, 1)
+        with pytest.raises(host.MerlHipError) as e:
+            g.load_image(good)
+        assert "options" in str(e.value)
+
+
+def test_rgb_table_images_are_layout_independent(tables, tmp_path):
+    """RGB tables travel in the compact rows form: an image written by a brick context enters a rows context and the other way round,
+    and the four combinations answer with the same bits (the layouts hold the same Float texels)."""
+    from mitsuba_customization_amd import host
+    n = 30000
+    outs = {}
+    for src, name in ((host.LAYOUT_BRICK, "bricks"), (host.LAYOUT_ROWS, "rows")):
+        path = str(tmp_path / (name + ".mrlimg"))
+        with host.MerlHip(0) as g:
+            g.set_option(host.OPT_TABLE_LAYOUT, src)
+            mid = g.upload_merl(tables("ggx_tab", 6))
+            outs[name] = _outputs(g, mid, n)
+            g.save_image(mid, path)
+        assert os.path.getsize(path) < 26_000_000                # 91 x 91 x 181 x 16 B + the sampling tables, whatever the source layout
+        for dst in (host.LAYOUT_BRICK, host.LAYOUT_ROWS):
+            with host.MerlHip(0) as g:
+                g.set_option(host.OPT_TABLE_LAYOUT, dst)
+                mid = g.load_image(path)
+                assert g.memory_info()["table_bytes"] >= (186_000_000 if dst == host.LAYOUT_BRICK else 24_000_000)
+                for s in (0, 2):
+                    got = _outputs(g, mid, n, sampling=s)
+                    if s == 0:
+                        for a, b in zip(got, outs[name]):
+                            assert np.array_equal(a.view(np.int32), b.view(np.int32)), (name, dst)
+    for a, b in zip(outs["bricks"], outs["rows"]):
+        assert np.array_equal(a.view(np.int32), b.view(np.int32))
+    # and the two files hold the same payload: the texels of a brick context, taken back to rows, are the rows context's texels
+    a, b = open(str(tmp_path / "bricks.mrlimg"), "rb").read(), open(str(tmp_path / "rows.mrlimg"), "rb").read()
+    assert len(a) == len(b) and a[-24_000_000:] == b[-24_000_000:]

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Row a1 (table load + HBM re-layout): seconds per MERL table through mrl_material_load_merl (file -> bricks) and
-mrl_material_upload_f64 (host array -> bricks), and the release that undoes it.   python tools/load_rates.py"""
+mrl_material_upload_f64 (host array -> bricks), the release that undoes it — and the on-disk cache of the device image
+(mrl_material_save_image / _load_image) beside each, for tables in both layouts and for an RGL file.
+    python tools/load_rates.py > profiles/r03_load_rates.json"""
 import json
 import os
 import sys
@@ -31,6 +33,36 @@ with tempfile.TemporaryDirectory() as d:
             t0 = time.perf_counter()
             ids = [g.upload_merl(tab) for _ in range(20)]
             t_up = (time.perf_counter() - t0) / 20
+            img = os.path.join(d, name + ".mrlimg")
+            t0 = time.perf_counter()
+            g.save_image(ids[0], img)
+            t_save = time.perf_counter() - t0
+            for i in ids:
+                g.release_material(i)
+            g.release_material(g.load_image(img))                  # warm the page cache, like the source file's
+            t0 = time.perf_counter()
+            ids = [g.load_image(img) for _ in range(20)]
+            t_img = (time.perf_counter() - t0) / 20
             res[name] = {"load_file_ms": round(t_file * 1e3, 2), "upload_array_ms": round(t_up * 1e3, 2), "release_ms": round(t_rel * 1e3, 2),
-                         "file_MBps": round(35.0 / t_file, 0), "tables_per_s": round(1 / t_file, 1)}
+                         "file_MBps": round(35.0 / t_file, 0), "tables_per_s": round(1 / t_file, 1),
+                         "image_bytes": os.path.getsize(img), "save_image_ms": round(t_save * 1e3, 2), "load_image_ms": round(t_img * 1e3, 2)}
+    # an RGL file of the database's isotropic shape: parse + host normalisation / running integrals against the image
+    rgl = os.path.join(d, "iso_rgb.bsdf")
+    synth.write_tensor_file(rgl, synth.make_rgl_fields(seed=9, n_phi=1, n_theta=8, res=32, res_ndf=128, res_sigma=64))
+    with host.MerlHip(0) as g:
+        g.release_material(g.load_rgl(rgl))
+        t0 = time.perf_counter()
+        ids = [g.load_rgl(rgl) for _ in range(20)]
+        t_file = (time.perf_counter() - t0) / 20
+        img = os.path.join(d, "iso.mrlimg")
+        g.save_image(ids[0], img)
+        for i in ids:
+            g.release_material(i)
+        g.release_material(g.load_image(img))
+        t0 = time.perf_counter()
+        ids = [g.load_image(img) for _ in range(20)]
+        t_img = (time.perf_counter() - t0) / 20
+        res["rgl_isotropic_8x32x32"] = {"file_bytes": os.path.getsize(rgl), "load_file_ms": round(t_file * 1e3, 2),
+                                        "image_bytes": os.path.getsize(img), "load_image_ms": round(t_img * 1e3, 2)}
+    res["library"] = host.build_info()
 print(json.dumps(res, indent=1))
