@@ -183,15 +183,14 @@ int mrl_material_upload_rgl(mrl_ctx *ctx, const mrl_rgl_fields *fields, int *out
 /* the same from a tensor_file container holding the fields under their RGL names (phi_i, theta_i, ndf, sigma, vndf,
  * luminance, rgb, jacobian); why a file was refused: mrl_tensor_file_last_error(NULL) or mrl_last_error(ctx) */
 int mrl_material_load_rgl(mrl_ctx *ctx, const char *path, int *out_id);
-/* On-disk cache of a material's DEVICE image: what is resident for the material — the texel image in its device
- * layout (bricks or rows), the sampling marginal, the conditional sampling rows; for an RGL material the cell-brick image with its
- * running integrals — written as it is, so that another process makes the material resident with one read and one copy: no parse,
- * no re-layout / quadrature / prefix-scan kernels, no host normalisation.  Table, n-channel and RGL materials; not analytic ones.
- * An image is tied to this library version, to the context-wide table layout and (when it holds conditional sampling rows) to the
- * lookup / node options it was built under: anything else is refused with MRL_ERR_FORMAT, as are truncated or altered files (every
- * size is recomputed from the header's shapes, the payload carries a checksum).  Worth it where the image is smaller than or as
- * cheap as the source: rows-layout tables (24 MB against a 35 MB file), RGL files; a brick image (187 MB) reads slower than the
- * 35 MB file re-lays out. */
+/* On-disk cache of a material's DEVICE image: what is resident for the material — the texels as Float (RGB tables
+ * in the compact rows form, 24 MB for a MERL table, whatever the context's layout: a brick context expands them on the device), the
+ * sampling marginal, the conditional sampling rows; for an RGL material the cell-brick image with its running integrals — written so that
+ * another process makes the material resident with one read and one copy: no parse, no re-layout of the f64 payload, no quadrature /
+ * prefix-scan kernels, no host normalisation.  5.5 ms instead of 12.4 per MERL table.  Table, n-channel and RGL materials;
+ * not analytic ones.  An image is tied to this library version and (when it holds conditional sampling rows) to the lookup / node options
+ * it was built under: anything else is refused with MRL_ERR_FORMAT, as are truncated or altered files (every size is recomputed from
+ * the header's shapes, the payload carries a checksum); the context is then as it was. */
 int mrl_material_save_image(mrl_ctx *ctx, int id, const char *path);
 int mrl_material_load_image(mrl_ctx *ctx, const char *path, int *out_id);
 /* number of material SLOTS (live + released); ids are slot indices */
