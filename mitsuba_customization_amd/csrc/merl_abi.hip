@@ -22,6 +22,7 @@
 
 #include "merl_kernels.hpp"
 #include "merl_rgl.hpp"
+#include "merl_image_file.hpp"
 #include "merl_scalar_host.hpp"
 #include "merl_host_table.hpp"
 
@@ -1377,24 +1378,10 @@ int mrl_material_release(mrl_ctx *ctx, int id)
 // rebuilt from the shapes, and the payload carries a checksum.  What the payload's VALUES say is data (a table), not structure.
 namespace {
 
-struct ImageHeader {
-    char magic[8];                       // "MRLIMG\1\0"
-    uint32_t header_bytes, kind, layout, n_ch, param, lookup, node, n_ti;
-    int32_t dims[3];
-    int32_t rgl_shape[8];                // n_phi n_theta res_x res_y res_ndf_x res_ndf_y res_sigma_x res_sigma_y
-    int32_t rgl_flags[2];                // jacobian, reserved
-    uint64_t texel_bytes, sampling_doubles, sampling2d_doubles, checksum;
-};
-constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 1, 0 };
-
-uint64_t image_checksum(const void *p, size_t bytes, uint64_t h)
-{
-    const unsigned char *b = (const unsigned char *)p;
-    size_t i = 0;
-    for (; i + 8 <= bytes; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
-    for (; i < bytes; ++i) { h = (h ^ b[i]) * 0x100000001B3ull; }
-    return h;
-}
+using mrl::ImageHeader;
+using mrl::kImageMagic;
+using mrl::image_checksum;
+using mrl::rgl_shapes_of;
 
 // device bytes of a table material's texel image, from its descriptor
 size_t texel_image_bytes(const mrl::MaterialDev &d)
@@ -1405,15 +1392,6 @@ size_t texel_image_bytes(const mrl::MaterialDev &d)
 }
 
 size_t rows_image_bytes(const mrl::MaterialDev &d) { return (size_t)(d.n_th + 1) * (d.n_td + 1) * (d.n_pd + 1) * sizeof(float4); }
-
-mrl::RglFields rgl_shapes_of(const int32_t s[8], int jacobian)
-{
-    mrl::RglFields f;
-    std::memset(&f, 0, sizeof f);
-    f.n_phi = s[0]; f.n_theta = s[1]; f.res[0] = s[2]; f.res[1] = s[3]; f.res_ndf[0] = s[4]; f.res_ndf[1] = s[5]; f.res_sigma[0] = s[6]; f.res_sigma[1] = s[7];
-    f.jacobian = jacobian;
-    return f;
-}
 
 } // namespace
 
@@ -1469,7 +1447,7 @@ int mrl_material_save_image(mrl_ctx *ctx, int id, const char *path)
     if (h.sampling_doubles) MRL_HIP(ctx, hipMemcpy(payload.data() + h.texel_bytes, mh.d_sampling, (size_t)h.sampling_doubles * sizeof(double), hipMemcpyDeviceToHost));
     if (h.sampling2d_doubles)
         MRL_HIP(ctx, hipMemcpy(payload.data() + h.texel_bytes + h.sampling_doubles * sizeof(double), mh.d_sampling2d, (size_t)h.sampling2d_doubles * sizeof(double), hipMemcpyDeviceToHost));
-    h.checksum = image_checksum(payload.data(), payload.size(), 0xCBF29CE484222325ull);
+    h.checksum = image_checksum(payload.data(), payload.size(), mrl::kImageChecksumSeed);
     // written under a private name and renamed into place: a reader never sees half a file
     const std::string tmp = std::string(path) + ".tmp." + std::to_string((long long)::getpid());
     FILE *f = std::fopen(tmp.c_str(), "wb");
@@ -1489,47 +1467,32 @@ int mrl_material_load_image(mrl_ctx *ctx, const char *path, int *out_id)
     if (!f) return fail(ctx, MRL_ERR_IO, std::string("cannot open ") + path);
     ImageHeader h;
     auto refuse = [&](const std::string &why) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, why + " (" + path + ")"); };
-    if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, kImageMagic, 8) != 0 || h.header_bytes != sizeof h) return refuse("not a material image of this library version");
-    const bool is_rgl = h.kind == (uint32_t)mrl::KIND_RGL, is_nch = h.kind == (uint32_t)mrl::KIND_TABLE_NCH;
-    if (!is_rgl && !is_nch && h.kind != (uint32_t)mrl::KIND_MERL && h.kind != (uint32_t)mrl::KIND_TABLE) return refuse("unknown material kind");
+    if (std::fread(&h, sizeof h, 1, f) != 1) return refuse("not a material image of this library version");
+    if (std::fseek(f, 0, SEEK_END) != 0) return refuse("seek failed");
+    const long long file_bytes = (long long)std::ftell(f);
+    // everything the header implies, computed from its shapes (merl_image_file.hpp: the part that is fuzzed on the CPU)
+    mrl::ImagePlan plan;
+    if (const char *why = mrl::image_plan(h, (unsigned long long)file_bytes, ctx->opts.lookup, ctx->opts.node, plan)) return refuse(why);
+    if (std::fseek(f, (long)sizeof h, SEEK_SET) != 0) return refuse("seek failed");
+    const bool is_rgl = plan.is_rgl, is_nch = plan.is_nch;
+    const uint64_t texel_bytes = plan.texel_bytes, sampling_doubles = plan.sampling_doubles, sampling2d_doubles = plan.sampling2d_doubles;
+    const size_t payload_bytes = plan.payload_bytes;
+    mrl::RglFields shapes = plan.shapes;
+    const mrl::RglLayout layout = plan.layout;
     mrl::MaterialDev d;
     std::memset(&d, 0, sizeof d);
     d.kind = (int)h.kind;
-    uint64_t texel_bytes = 0, sampling_doubles = 0, sampling2d_doubles = 0;
-    mrl::RglFields shapes;
-    mrl::RglLayout layout;
-    if (is_rgl) {
-        shapes = rgl_shapes_of(h.rgl_shape, h.rgl_flags[0] != 0);
-        if (const char *why = mrl::rgl_check_shapes(shapes)) return refuse(std::string("RGL image: ") + why);
-        texel_bytes = mrl::rgl_plan_layout(shapes, layout) * sizeof(float);
-        d.n_ch = 3; d.n_th = shapes.n_phi; d.n_td = shapes.n_theta; d.n_pd = shapes.res[0];
-    } else {
-        if (h.dims[0] < 1 || h.dims[1] < 1 || h.dims[2] < 1 || (long long)h.dims[0] * h.dims[1] * h.dims[2] > (1LL << 28)) return refuse("table dims out of range");
-        if (h.layout > 1 || h.param > (uint32_t)mrl::PARAM_STANDARD_FULL || (is_nch ? (h.n_ch < 1 || h.n_ch > (uint32_t)mrl::kMaxChannels || h.layout != (uint32_t)mrl::LAYOUT_BRICK) : h.n_ch != 3))
-            return refuse("bad layout / parameterisation / channel count");
-        d.n_th = h.dims[0]; d.n_td = h.dims[1]; d.n_pd = h.dims[2];
-        d.layout = (int)h.layout; d.n_ch = (int)h.n_ch; d.param = (int)h.param;
+    d.n_th = plan.dims[0]; d.n_td = plan.dims[1]; d.n_pd = plan.dims[2];
+    d.n_ch = plan.n_ch; d.param = plan.param;
+    if (!is_rgl) {
+        d.layout = is_nch ? mrl::LAYOUT_BRICK : ctx->table_layout;         // an RGB table becomes what this context holds
         d.row_td = d.n_pd + 1; d.row_th = (d.n_td + 1) * (d.n_pd + 1);
-        if (!is_nch) {
-            if (h.layout != (uint32_t)mrl::LAYOUT_ROWS) return refuse("RGB table images are stored in the rows form");
-            d.layout = ctx->table_layout;                     // what it becomes on this context
-            // the conditional sampling rows were integrated through the table's lookup: under other lookup options they are another table
-            if (h.sampling2d_doubles && ((int)h.lookup != ctx->opts.lookup || (int)h.node != ctx->opts.node))
-                return refuse("the image's conditional sampling rows were built under other lookup / node options");
-            if (h.n_ti != (uint32_t)mrl::kSamplingIncidentBins && h.sampling2d_doubles) return refuse("bad incident-bin count");
-        }
-        texel_bytes = is_nch ? texel_image_bytes(d) : rows_image_bytes(d);
-        sampling_doubles = 3 * (uint64_t)d.n_th + 2;
-        sampling2d_doubles = (!is_nch && h.sampling2d_doubles) ? (uint64_t)mrl::kSamplingIncidentBins * (2 * (uint64_t)d.n_th + 1) : 0;
     }
-    if (h.texel_bytes != texel_bytes || h.sampling_doubles != sampling_doubles || h.sampling2d_doubles != sampling2d_doubles) return refuse("sizes do not follow from the shapes");
-    const size_t payload_bytes = (size_t)texel_bytes + (size_t)(sampling_doubles + sampling2d_doubles) * sizeof(double);
-    if (std::fseek(f, 0, SEEK_END) != 0 || (unsigned long long)std::ftell(f) != sizeof h + payload_bytes || std::fseek(f, (long)sizeof h, SEEK_SET) != 0) return refuse("file length does not match the header");
     std::vector<char> payload;
     try { payload.resize(payload_bytes); } catch (const std::bad_alloc &) { std::fclose(f); return fail(ctx, MRL_ERR_OOM, "image buffer"); }
     if (payload_bytes && std::fread(payload.data(), 1, payload_bytes, f) != payload_bytes) return refuse("short read");
     std::fclose(f);
-    if (image_checksum(payload.data(), payload.size(), 0xCBF29CE484222325ull) != h.checksum) return fail(ctx, MRL_ERR_FORMAT, std::string("checksum mismatch (") + path + ")");
+    if (image_checksum(payload.data(), payload.size(), mrl::kImageChecksumSeed) != h.checksum) return fail(ctx, MRL_ERR_FORMAT, std::string("checksum mismatch (") + path + ")");
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     MaterialHost m;
     const bool expand = !is_rgl && !is_nch && d.layout == mrl::LAYOUT_BRICK;      // rows on disk, bricks on this context

@@ -1,0 +1,156 @@
+// merl_image_file.hpp — the on-disk image of a material (mrl_material_save_image / _load_image): header, checksum, and the plan of
+// what a header's shapes imply.  Pure host C++ (no HIP type, no allocation proportional to anything a file claims): the part of the
+// loader that reads untrusted bytes, kept apart so that it is fuzzed under AddressSanitizer / UBSan on the CPU
+// (tests/image_file_fuzz.cpp).  Every size is COMPUTED here from the shapes; the loader then demands that the header's own size
+// fields and the file's length agree with them.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+namespace mrl {
+
+// ---- shapes of an RGL material and the layout of its cell-brick image (merl_rgl.hip builds the image, merl_rgl.hpp reads it) ----
+struct RglFields {                   // host arrays, as the file holds them (x fastest; res[] = { nx, ny })
+    int n_phi, n_theta;
+    const float *phi_i, *theta_i;
+    int res_ndf[2], res_sigma[2], res[2];
+    const float *ndf, *sigma, *vndf, *luminance, *rgb;
+    int jacobian;
+};
+struct RglLayout { size_t phi, theta, cells[5], cond[5], rows[5]; };     // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
+
+inline const char *rgl_check_shapes(const RglFields &f)
+{
+    if (f.n_phi < 1 || f.n_theta < 1 || f.n_phi > 4096 || f.n_theta > 4096) return "phi_i / theta_i: 1..4096 nodes each";
+    for (int k = 0; k < 2; ++k)
+        if (f.res_ndf[k] < 2 || f.res_sigma[k] < 2 || f.res[k] < 2 || f.res_ndf[k] > 8192 || f.res_sigma[k] > 8192 || f.res[k] > 8192)
+            return "every table needs 2..8192 nodes per axis";
+    const size_t slices = (size_t)f.n_phi * (size_t)f.n_theta, per = (size_t)f.res[0] * (size_t)f.res[1];
+    if (slices * per * 3 > ((size_t)1 << 28)) return "tables too large (more than 2^28 values)";
+    return nullptr;
+}
+
+struct WarpOffsets { size_t cells = 0, cond = 0, rows = 0; };
+// where one function's tables go: `at` is the running size of the image in floats (every table starts on a 16-byte boundary)
+inline WarpOffsets plan_warp(size_t &at, int nx, int ny, size_t slices, int n_ch, bool distribution)
+{
+    const size_t cells = (size_t)(nx - 1) * (size_t)(ny - 1);
+    auto grow = [&](size_t floats) { const size_t off = (at + 3) / 4 * 4; at = off + floats; return off; };
+    WarpOffsets off;
+    off.cells = grow(cells * 4 * (size_t)n_ch * slices);
+    if (distribution) {
+        off.cond = grow(cells * 2 * slices);
+        off.rows = grow((size_t)(ny - 1) * 4 * slices);
+    }
+    return off;
+}
+
+// the image's layout from the shapes alone; returns the image's size in floats
+inline size_t rgl_plan_layout(const RglFields &f, RglLayout &l)
+{
+    const size_t slices = (size_t)f.n_phi * (size_t)f.n_theta;
+    size_t at = (size_t)f.n_phi + (size_t)f.n_theta;
+    l.phi = 0; l.theta = (size_t)f.n_phi;
+    auto put = [&](int which, const int res[2], size_t n, int n_ch, bool distribution) {
+        const WarpOffsets o = plan_warp(at, res[0], res[1], n, n_ch, distribution);
+        l.cells[which] = o.cells; l.cond[which] = o.cond; l.rows[which] = o.rows;
+    };
+    put(0, f.res_ndf, 1, 1, false);
+    put(1, f.res_sigma, 1, 1, false);
+    put(2, f.res, slices, 1, true);
+    put(3, f.res, slices, 1, true);
+    put(4, f.res, slices, 3, false);
+    return at;
+}
+
+// ---- n-channel bricks: float4s per cell ----
+inline size_t nch_brick_float4s(int n_ch) { return n_ch == 1 ? 2 : n_ch == 2 ? 4 : 8 * (size_t)((n_ch + 3) / 4); }
+
+// ---- the file ----
+struct ImageHeader {
+    char magic[8];                       // "MRLIMG\1\0"
+    uint32_t header_bytes, kind, layout, n_ch, param, lookup, node, n_ti;
+    int32_t dims[3];
+    int32_t rgl_shape[8];                // n_phi n_theta res_x res_y res_ndf_x res_ndf_y res_sigma_x res_sigma_y
+    int32_t rgl_flags[2];                // jacobian, reserved
+    uint64_t texel_bytes, sampling_doubles, sampling2d_doubles, checksum;
+};
+constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 1, 0 };
+constexpr uint64_t kImageChecksumSeed = 0xCBF29CE484222325ull;
+// the kinds and layouts an image can name (values of mrl::Kind / mrl::Layout / mrl::Param, repeated here so that this header needs no HIP)
+constexpr uint32_t kImgKindMerl = 0, kImgKindTable = 1, kImgKindNch = 4, kImgKindRgl = 5, kImgLayoutRows = 0, kImgLayoutBrick = 1, kImgParamLast = 2;
+constexpr int kImgMaxChannels = 32, kImgIncidentBins = 32;
+
+inline uint64_t image_checksum(const void *p, size_t bytes, uint64_t h)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    for (; i < bytes; ++i) { h = (h ^ b[i]) * 0x100000001B3ull; }
+    return h;
+}
+
+inline RglFields rgl_shapes_of(const int32_t s[8], int jacobian)
+{
+    RglFields f;
+    std::memset(&f, 0, sizeof f);
+    f.n_phi = s[0]; f.n_theta = s[1]; f.res[0] = s[2]; f.res[1] = s[3]; f.res_ndf[0] = s[4]; f.res_ndf[1] = s[5]; f.res_sigma[0] = s[6]; f.res_sigma[1] = s[7];
+    f.jacobian = jacobian;
+    return f;
+}
+
+// What a header implies.  RGB table images hold the padded rows form whatever layout they came from.
+struct ImagePlan {
+    bool is_rgl = false, is_nch = false, has_rows2d = false;
+    int dims[3] = { 0, 0, 0 }, n_ch = 0, param = 0;
+    RglFields shapes;
+    RglLayout layout;
+    uint64_t texel_bytes = 0, sampling_doubles = 0, sampling2d_doubles = 0;
+    size_t payload_bytes = 0;
+};
+
+// nullptr and a filled plan, or why the header cannot be an image this library wrote.  file_bytes: the file's length.
+// ctx_lookup / ctx_node: the loading context's options (conditional sampling rows are tied to them).
+inline const char *image_plan(const ImageHeader &h, unsigned long long file_bytes, int ctx_lookup, int ctx_node, ImagePlan &p)
+{
+    if (std::memcmp(h.magic, kImageMagic, 8) != 0 || h.header_bytes != sizeof(ImageHeader)) return "not a material image of this library version";
+    p = ImagePlan();
+    p.is_rgl = h.kind == kImgKindRgl; p.is_nch = h.kind == kImgKindNch;
+    if (!p.is_rgl && !p.is_nch && h.kind != kImgKindMerl && h.kind != kImgKindTable) return "unknown material kind";
+    if (p.is_rgl) {
+        p.shapes = rgl_shapes_of(h.rgl_shape, h.rgl_flags[0] != 0);
+        if (const char *why = rgl_check_shapes(p.shapes)) return why;
+        p.texel_bytes = (uint64_t)rgl_plan_layout(p.shapes, p.layout) * sizeof(float);
+        p.n_ch = 3; p.dims[0] = p.shapes.n_phi; p.dims[1] = p.shapes.n_theta; p.dims[2] = p.shapes.res[0];
+    } else {
+        for (int k = 0; k < 3; ++k)
+            if (h.dims[k] < 1 || h.dims[k] > (1 << 28)) return "table dims out of range";           // each one first: the product below must not overflow
+        if ((uint64_t)h.dims[0] * (uint64_t)h.dims[1] > ((uint64_t)1 << 28) || (uint64_t)h.dims[0] * (uint64_t)h.dims[1] * (uint64_t)h.dims[2] > ((uint64_t)1 << 28))
+            return "table dims out of range";
+        if (h.layout > kImgLayoutBrick || h.param > kImgParamLast) return "bad layout / parameterisation";
+        if (p.is_nch ? (h.n_ch < 1 || h.n_ch > (uint32_t)kImgMaxChannels || h.layout != kImgLayoutBrick) : (h.n_ch != 3 || h.layout != kImgLayoutRows))
+            return "bad channel count / layout for the kind (RGB tables are stored in the rows form)";
+        if (h.kind == kImgKindMerl && h.param != 0) return "a MERL table is in half / difference angles";
+        for (int k = 0; k < 3; ++k) p.dims[k] = h.dims[k];
+        p.n_ch = (int)h.n_ch; p.param = (int)h.param;
+        const uint64_t plane = (uint64_t)h.dims[0] * (uint64_t)h.dims[1] * (uint64_t)h.dims[2];
+        p.texel_bytes = p.is_nch ? plane * nch_brick_float4s(p.n_ch) * 16 : (uint64_t)(h.dims[0] + 1) * (uint64_t)(h.dims[1] + 1) * (uint64_t)(h.dims[2] + 1) * 16;
+        p.sampling_doubles = 3 * (uint64_t)h.dims[0] + 2;
+        p.has_rows2d = !p.is_nch && h.sampling2d_doubles != 0;
+        if (p.has_rows2d) {
+            if (h.n_ti != (uint32_t)kImgIncidentBins) return "bad incident-bin count";
+            // the conditional rows were integrated through the table's lookup: under other lookup options they are another table
+            if ((int)h.lookup != ctx_lookup || (int)h.node != ctx_node) return "the image's conditional sampling rows were built under other lookup / node options";
+            p.sampling2d_doubles = (uint64_t)kImgIncidentBins * (2 * (uint64_t)h.dims[0] + 1);
+        }
+    }
+    if (h.texel_bytes != p.texel_bytes || h.sampling_doubles != p.sampling_doubles || h.sampling2d_doubles != p.sampling2d_doubles) return "sizes do not follow from the shapes";
+    const uint64_t payload = p.texel_bytes + (p.sampling_doubles + p.sampling2d_doubles) * 8;
+    if (payload > ((uint64_t)1 << 40)) return "image too large";
+    p.payload_bytes = (size_t)payload;
+    if (file_bytes != sizeof(ImageHeader) + payload) return "file length does not match the header";
+    return nullptr;
+}
+
+} // namespace mrl

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "merl_device.hpp"
+#include "merl_image_file.hpp"       // RglFields / RglLayout, rgl_plan_layout, nch_brick_float4s: shapes -> sizes, pure host
 
 namespace mrl {
 
@@ -64,26 +65,16 @@ constexpr int kSamplingIncidentBins = 32;
 hipError_t launch_build_sampling2d(const MaterialDev &m, const Options &opts, int n_ti, double *d_rows, double *d_work, hipStream_t stream);
 // ---- n-channel tables (merl_nch.hip): a.out_rgb / a.out_weight hold n x n_ch values ----
 constexpr int kMaxChannels = 32;
-size_t nch_brick_float4s(int n_ch);                      // float4s per cell: 2 (1 ch), 4 (2 ch), 8 * ceil(n_ch / 4)
+// nch_brick_float4s(n_ch): float4s per cell: 2 (1 ch), 4 (2 ch), 8 * ceil(n_ch / 4)  (merl_image_file.hpp)
 // mode: 0 eval, 2 sample, 3 eval+sample, 4 eval+pdf (pdf alone: the RGB pdf kernel serves every table kind)
 hipError_t launch_batch_nch(int mode, const BatchArgs &a, bool multi, int n_ch, int compute_units, hipStream_t stream);
 hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale, const int dims[3], int n_ch, int param, float4 *d_out,
                                   int compute_units, hipStream_t stream);
 // ---- the adaptive-parameterisation measured BSDF (merl_rgl.hip; RGL *.bsdf) ----
 struct RglDev;
-struct RglFields {                   // host arrays, as the file holds them (x fastest; res[] = { nx, ny })
-    int n_phi, n_theta;
-    const float *phi_i, *theta_i;
-    int res_ndf[2], res_sigma[2], res[2];
-    const float *ndf, *sigma, *vndf, *luminance, *rgb;
-    int jacobian;
-};
-struct RglLayout { size_t phi, theta, cells[5], cond[5], rows[5]; };     // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
 int rgl_reduction(const RglFields &f);                                   // 1, 2, 4: the part of the azimuth an anisotropic file stores
 const char *rgl_check_fields(const RglFields &f);                        // nullptr, or what is wrong
 RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob); // normalised tables + running integrals, host f64
-size_t rgl_plan_layout(const RglFields &f, RglLayout &l);                 // the same layout from the shapes alone; returns the image size in floats
-const char *rgl_check_shapes(const RglFields &f);                        // the shape part of rgl_check_fields (no array is read)
 RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base);
 // r != nullptr: a single-material launch; r == nullptr: a batch with material ids (a.mat) — the units whose id names an RGL material
 // are evaluated and written, every other unit is left as it is.  indexed: walk the queue a.idx / a.idx_count

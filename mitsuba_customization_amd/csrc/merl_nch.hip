@@ -430,11 +430,6 @@ hipError_t launch_nch_mode(const BatchArgs &a, bool multi, bool indexed, int n_c
 
 } // namespace
 
-size_t nch_brick_float4s(int n_ch)
-{
-    return n_ch == 1 ? 2 : n_ch == 2 ? 4 : 8 * (size_t)((n_ch + 3) / 4);
-}
-
 hipError_t launch_batch_nch(int mode, const BatchArgs &a, bool multi, int n_ch, int compute_units, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;

@@ -99,21 +99,6 @@ bool ascending(const float *p, int n)
 // the corner bricks (normalised if a distribution) and, for distributions, the running integrals `cond` (along x, node rows
 // row / row + 1 side by side) and `rows` (marginal cdf before / after the cell row, totals of its two node rows) — all rounded
 // to Float once from f64 sums, in the oracle's loop order.  src: [slices][n_ch][ny][nx].
-struct WarpOffsets { size_t cells = 0, cond = 0, rows = 0; };
-// where one function's tables go: `at` is the running size of the image in floats
-WarpOffsets plan_warp(size_t &at, int nx, int ny, size_t slices, int n_ch, bool distribution)
-{
-    const size_t cells = (size_t)(nx - 1) * (size_t)(ny - 1);
-    auto grow = [&](size_t floats) { const size_t off = (at + 3) / 4 * 4; at = off + floats; return off; };
-    WarpOffsets off;
-    off.cells = grow(cells * 4 * (size_t)n_ch * slices);
-    if (distribution) {
-        off.cond = grow(cells * 2 * slices);
-        off.rows = grow((size_t)(ny - 1) * 4 * slices);
-    }
-    return off;
-}
-
 WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, int ny, size_t slices, int n_ch, bool distribution)
 {
     const size_t per = (size_t)nx * ny, cells = (size_t)(nx - 1) * (size_t)(ny - 1);
@@ -175,17 +160,6 @@ int rgl_reduction(const RglFields &f)
     return span > 0.0 ? (int)std::floor(2.0 * kPi / span + 0.5) : 0;
 }
 
-const char *rgl_check_shapes(const RglFields &f)
-{
-    if (f.n_phi < 1 || f.n_theta < 1 || f.n_phi > 4096 || f.n_theta > 4096) return "phi_i / theta_i: 1..4096 nodes each";
-    for (int k = 0; k < 2; ++k)
-        if (f.res_ndf[k] < 2 || f.res_sigma[k] < 2 || f.res[k] < 2 || f.res_ndf[k] > 8192 || f.res_sigma[k] > 8192 || f.res[k] > 8192)
-            return "every table needs 2..8192 nodes per axis";
-    const size_t slices = (size_t)f.n_phi * (size_t)f.n_theta, per = (size_t)f.res[0] * (size_t)f.res[1];
-    if (slices * per * 3 > ((size_t)1 << 28)) return "tables too large (more than 2^28 values)";
-    return nullptr;
-}
-
 const char *rgl_check_fields(const RglFields &f)
 {
     if (const char *why = rgl_check_shapes(f)) return why;
@@ -204,25 +178,6 @@ const char *rgl_check_fields(const RglFields &f)
         if (reduction != 1 && reduction != 2 && reduction != 4) return "anisotropic file: phi_i must span the whole azimuth, a half or a quarter of it";
     }
     return nullptr;
-}
-
-// the image's layout from the shapes alone (the on-disk image cache rebuilds a descriptor from a file's header with it, never from
-// offsets a file claims); returns the image's size in floats
-size_t rgl_plan_layout(const RglFields &f, RglLayout &l)
-{
-    const size_t slices = (size_t)f.n_phi * (size_t)f.n_theta;
-    size_t at = (size_t)f.n_phi + (size_t)f.n_theta;
-    l.phi = 0; l.theta = (size_t)f.n_phi;
-    auto put = [&](int which, const int res[2], size_t n, int n_ch, bool distribution) {
-        const WarpOffsets o = plan_warp(at, res[0], res[1], n, n_ch, distribution);
-        l.cells[which] = o.cells; l.cond[which] = o.cond; l.rows[which] = o.rows;
-    };
-    put(0, f.res_ndf, 1, 1, false);
-    put(1, f.res_sigma, 1, 1, false);
-    put(2, f.res, slices, 1, true);
-    put(3, f.res, slices, 1, true);
-    put(4, f.res, slices, 3, false);
-    return at;
 }
 
 RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob)

@@ -108,7 +108,7 @@ def test_altered_truncated_and_mismatched_images_are_refused(tables, tmp_path):
         grown = bytearray(raw_rgl); struct.pack_into("<i", grown, off_shape + 8, 500)
         refused(bytes(grown), "sizes do not follow")
         huge = bytearray(raw_rgl); struct.pack_into("<i", huge, off_shape + 8, 50000)
-        refused(bytes(huge), "RGL image")
+        refused(bytes(huge), "nodes per axis")
         with pytest.raises(host.MerlHipError) as e:
             g.load_image(str(tmp_path / "missing.mrlimg"))
         assert e.value.status == host.ERR_IO

@@ -53,3 +53,14 @@ def test_tensor_file_reader_is_clean_under_asan_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe, str(tmp_path / "fuzz.bsdf")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "tensor fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ missing")
+def test_image_file_header_planning_is_clean_under_asan_ubsan(tmp_path):
+    """The part of mrl_material_load_image that reads untrusted bytes (csrc/merl_image_file.hpp: header -> plan, pure host C++): a million
+    corrupted headers against right and wrong file lengths under AddressSanitizer + UBSan; whatever is accepted must be self-consistent."""
+    exe = str(tmp_path / "image_fuzz")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-fno-omit-frame-pointer", "-o", exe, os.path.join(ROOT, "tests", "image_file_fuzz.cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and "image header fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
