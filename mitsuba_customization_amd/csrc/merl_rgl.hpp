@@ -168,17 +168,15 @@ MRL_HD double warp_sample(const WarpDev &w, const Slices &s, double ux, double u
     const double y = clamp01(invert_linear(r0, r1, uy));
     ux *= (1.0 - y) * r0 + y * r1;
     lo = 0; hi = nx - 2;
+    double below = 0.0;                                      // the conditional cdf at column lo - 1: every step that raises lo has just read it
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         const D2 p = fetch2(s, w.cond, per_c, row * (nx - 1) + mid);
         const double c = (1.0 - y) * p.x + y * p.y;
-        if (c < ux) lo = mid + 1; else hi = mid;
+        if (c < ux) { lo = mid + 1; below = c; } else hi = mid;
     }
     const int col = lo;
-    if (col > 0) {
-        const D2 p = fetch2(s, w.cond, per_c, row * (nx - 1) + col - 1);
-        ux -= (1.0 - y) * p.x + y * p.y;
-    }
+    if (col > 0) ux -= below;
     const D4 q = fetch4(s, w.cells, per_c, row * (nx - 1) + col);
     const double c0 = (1.0 - y) * q.x + y * q.z, c1 = (1.0 - y) * q.y + y * q.w;
     const double x = clamp01(invert_linear(c0, c1, ux));
