@@ -113,8 +113,9 @@ enum mrl_option {
     MRL_OPT_TABLE_ARENA_MB = 11, /* one device allocation of this many MiB that the RGB tables uploaded from now on are placed in back
                                   to back (2 MiB aligned) while it has room, instead of one allocation per table; a table
                                   that does not fit gets its own.  Released tables return their space when the arena
-                                  empties.  Settable while no table lives in it; 0 frees it.  Measured effect on the
-                                  100-table launch: DESIGN.md §6 (address translation bounds that launch). */
+                                  empties.  Settable while no table lives in it; 0 frees it.  The arena is asked for as
+                                  physically contiguous memory (plain device memory if the driver refuses).  Measured effect
+                                  on the 100-table launch: DESIGN.md §6 (address translation bounds that launch). */
     MRL_OPT_MEMORY_LIMIT_MB = 7 /* budget for the context's resident material data (tables + sampling marginals), in MiB;
                                   0 (default) = no budget, the device's free memory is the limit.  An upload that would
                                   exceed the budget — or the device — fails with MRL_ERR_OOM and leaves the context as it

@@ -1175,7 +1175,13 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
             if (value > 0) {
                 const size_t bytes = (size_t)value << 20;
                 if (budget_check(ctx, bytes) != MRL_OK) return MRL_ERR_OOM;
-                MRL_ALLOC(ctx, hipMalloc((void **)&ctx->arena, bytes));
+                // physically contiguous when the driver can give that (larger translation fragments: launches over many tables are
+                // bound by address translation); MRL_ARENA_CONTIGUOUS=0 is the A/B switch
+                const char *contiguous = std::getenv("MRL_ARENA_CONTIGUOUS");
+                if (!contiguous || std::atoi(contiguous) != 0) {
+                    if (hipExtMallocWithFlags((void **)&ctx->arena, bytes, hipDeviceMallocContiguous) != hipSuccess) { (void)hipGetLastError(); ctx->arena = nullptr; }
+                }
+                if (!ctx->arena) MRL_ALLOC(ctx, hipMalloc((void **)&ctx->arena, bytes));
                 ctx->arena_bytes = bytes;
             }
             return MRL_OK;
