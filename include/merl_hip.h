@@ -116,6 +116,10 @@ enum mrl_option {
                                   empties.  Settable while no table lives in it; 0 frees it.  The arena is asked for as
                                   physically contiguous memory (plain device memory if the driver refuses).  Measured effect
                                   on the 100-table launch: DESIGN.md §6 (address translation bounds that launch). */
+    MRL_OPT_RGL_SEARCH = 12,   /* where a single-material launch on an RGL material reads the two distributions' search tables
+                                  (conditional / marginal running integrals): 0 (default) a copy in the CU's LDS when they fit
+                                  (125 KB for the database's isotropic 8 x 32 x 32 shape), 1 always memory.  Same results bit
+                                  for bit; the option exists so that both paths can be measured and tested. */
     MRL_OPT_MEMORY_LIMIT_MB = 7 /* budget for the context's resident material data (tables + sampling marginals), in MiB;
                                   0 (default) = no budget, the device's free memory is the limit.  An upload that would
                                   exceed the budget — or the device — fails with MRL_ERR_OOM and leaves the context as it

@@ -203,6 +203,7 @@ struct mrl_ctx {
     int table_param = 0;             // parameterisation of customized_measurement tables uploaded from now on (mrl::Param)
     size_t host_chunk = (size_t)1 << 22;
     int block_map = 0;               // MRL_OPT_BLOCK_MAP
+    int rgl_search = 0;              // MRL_OPT_RGL_SEARCH
     int host_threads = 4;            // MRL_OPT_HOST_THREADS: copy threads of the pipelined host-array path; 0 = staged hipMemcpy path
     HostPipe pipe;
     void *d_stage = nullptr;
@@ -630,7 +631,7 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
     const DeviceCall d = device_call(ctx, c);
     const mrl::BatchArgs &a = d.args;
     if (!d.multi && a.single.kind == mrl::KIND_RGL) {         // adaptive-parameterisation material: its own kernel
-        MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, &ctx->materials[(size_t)c.single_id].rgl, false, ctx->compute_units, ctx->stream));
+        MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, &ctx->materials[(size_t)c.single_id].rgl, false, ctx->rgl_search, ctx->compute_units, ctx->stream));
         return MRL_OK;
     }
     if (c.n_ch > 0 && c.mode != 1) {                          // n-channel tables: their own kernels (pdf is channel-free)
@@ -656,12 +657,12 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
         MRL_HIP(ctx, mrl::launch_batch_queue(c.mode, qa, false, ctx->compute_units, ctx->stream));
         qa.idx = q_ggx; qa.idx_count = totals + 1;
         MRL_HIP(ctx, mrl::launch_batch_queue(c.mode, qa, true, ctx->compute_units, ctx->stream));
-        if (d.has_rgl) MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, nullptr, false, ctx->compute_units, ctx->stream));
+        if (d.has_rgl) MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, nullptr, false, ctx->rgl_search, ctx->compute_units, ctx->stream));
         return MRL_OK;
     }
     MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->kernel_variant, ctx->table_layout, has_ggx, has_table, ctx->compute_units, ctx->stream));
     // the context holds RGL materials: their units (zeros so far) are evaluated by a second launch on the same stream
-    if (multi && d.has_rgl) MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, nullptr, false, ctx->compute_units, ctx->stream));
+    if (multi && d.has_rgl) MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, nullptr, false, ctx->rgl_search, ctx->compute_units, ctx->stream));
     return MRL_OK;
 }
 
@@ -811,7 +812,7 @@ int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uin
     DeviceCall d = device_call(ctx, c);
     d.args.idx = queue; d.args.idx_count = queue_count;
     if (!d.multi && d.args.single.kind == mrl::KIND_RGL) {
-        MRL_HIP(ctx, mrl::launch_rgl(c.mode, d.args, &ctx->materials[(size_t)c.single_id].rgl, true, ctx->compute_units, ctx->stream));
+        MRL_HIP(ctx, mrl::launch_rgl(c.mode, d.args, &ctx->materials[(size_t)c.single_id].rgl, true, ctx->rgl_search, ctx->compute_units, ctx->stream));
         return MRL_OK;
     }
     if (c.n_ch > 0 && c.mode != 1) {                          // n-channel tables: the same kernels walk the queue
@@ -819,7 +820,7 @@ int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uin
         return MRL_OK;
     }
     MRL_HIP(ctx, mrl::launch_batch_indexed(c.mode, d.args, d.multi, ctx->table_layout, d.has_ggx, d.has_table, ctx->compute_units, ctx->stream));
-    if (d.multi && d.has_rgl) MRL_HIP(ctx, mrl::launch_rgl(c.mode, d.args, nullptr, true, ctx->compute_units, ctx->stream));
+    if (d.multi && d.has_rgl) MRL_HIP(ctx, mrl::launch_rgl(c.mode, d.args, nullptr, true, ctx->rgl_search, ctx->compute_units, ctx->stream));
     return MRL_OK;
 }
 
@@ -1188,6 +1189,7 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
         }
         case MRL_OPT_HOST_THREADS: if (value < 0 || value > 64) break; ctx->host_threads = value; return MRL_OK;
         case MRL_OPT_BLOCK_MAP: if (value < 0 || value > 1) break; ctx->block_map = value; return MRL_OK;
+        case MRL_OPT_RGL_SEARCH: if (value < 0 || value > 1) break; ctx->rgl_search = value; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: if (value < 1) break; ctx->host_chunk = (size_t)value; return MRL_OK;
         case MRL_OPT_TABLE_PARAM: if (value < 0 || value > 2) break; ctx->table_param = value; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: {
@@ -1217,6 +1219,7 @@ int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
         case MRL_OPT_TABLE_ARENA_MB: *value = (int)(ctx->arena_bytes >> 20); return MRL_OK;
         case MRL_OPT_HOST_THREADS: *value = ctx->host_threads; return MRL_OK;
         case MRL_OPT_BLOCK_MAP: *value = ctx->block_map; return MRL_OK;
+        case MRL_OPT_RGL_SEARCH: *value = ctx->rgl_search; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: *value = (int)ctx->host_chunk; return MRL_OK;
         case MRL_OPT_TABLE_PARAM: *value = ctx->table_param; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: *value = ctx->table_layout; return MRL_OK;
@@ -1617,8 +1620,8 @@ int mrl_material_host_table(mrl_ctx *ctx, int id, mrl_host_table **out)
         mrl::WarpDev *all[5] = { &t->rgl.ndf, &t->rgl.sigma, &t->rgl.vndf, &t->rgl.luminance, &t->rgl.rgb };
         for (mrl::WarpDev *w : all) {
             w->cells = (const float4 *)(to + ((const char *)w->cells - from));
-            if (w->cond) w->cond = (const float2 *)(to + ((const char *)w->cond - from));
-            if (w->rows) w->rows = (const float4 *)(to + ((const char *)w->rows - from));
+            if (w->cond2) w->cond2 = (const float4 *)(to + ((const char *)w->cond2 - from));
+            if (w->margq) w->margq = (const float4 *)(to + ((const char *)w->margq - from));
             w->phi = (const float *)(to + ((const char *)w->phi - from)); w->theta = (const float *)(to + ((const char *)w->theta - from));
         }
         t->m = mh.dev;

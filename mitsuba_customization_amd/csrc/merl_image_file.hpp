@@ -18,7 +18,7 @@ struct RglFields {                   // host arrays, as the file holds them (x f
     const float *ndf, *sigma, *vndf, *luminance, *rgb;
     int jacobian;
 };
-struct RglLayout { size_t phi, theta, cells[5], cond[5], rows[5]; };     // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
+struct RglLayout { size_t phi, theta, cells[5], cond2[5], margq[5]; };   // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
 
 inline const char *rgl_check_shapes(const RglFields &f)
 {
@@ -31,17 +31,20 @@ inline const char *rgl_check_shapes(const RglFields &f)
     return nullptr;
 }
 
-struct WarpOffsets { size_t cells = 0, cond = 0, rows = 0; };
+struct WarpOffsets { size_t cells = 0, cond2 = 0, margq = 0; };
+// the search tables of a distribution are stored per parameter BRACKET (merl_rgl.hpp, WarpDev): brackets along theta / phi
+inline size_t rgl_theta_brackets(int n_theta) { return n_theta > 1 ? (size_t)n_theta - 1 : 1; }
+inline size_t rgl_phi_brackets(int n_phi) { return n_phi > 1 ? (size_t)n_phi - 1 : 1; }
 // where one function's tables go: `at` is the running size of the image in floats (every table starts on a 16-byte boundary)
-inline WarpOffsets plan_warp(size_t &at, int nx, int ny, size_t slices, int n_ch, bool distribution)
+inline WarpOffsets plan_warp(size_t &at, int nx, int ny, int n_phi, int n_theta, int n_ch, bool distribution)
 {
-    const size_t cells = (size_t)(nx - 1) * (size_t)(ny - 1);
+    const size_t cells = (size_t)(nx - 1) * (size_t)(ny - 1), slices = (size_t)n_phi * (size_t)n_theta;
     auto grow = [&](size_t floats) { const size_t off = (at + 3) / 4 * 4; at = off + floats; return off; };
     WarpOffsets off;
     off.cells = grow(cells * 4 * (size_t)n_ch * slices);
     if (distribution) {
-        off.cond = grow(cells * 2 * slices);
-        off.rows = grow((size_t)(ny - 1) * 4 * slices);
+        off.cond2 = grow(cells * 4 * (size_t)n_phi * rgl_theta_brackets(n_theta));
+        off.margq = grow((size_t)(ny - 1) * 4 * rgl_phi_brackets(n_phi) * rgl_theta_brackets(n_theta));
     }
     return off;
 }
@@ -49,18 +52,17 @@ inline WarpOffsets plan_warp(size_t &at, int nx, int ny, size_t slices, int n_ch
 // the image's layout from the shapes alone; returns the image's size in floats
 inline size_t rgl_plan_layout(const RglFields &f, RglLayout &l)
 {
-    const size_t slices = (size_t)f.n_phi * (size_t)f.n_theta;
     size_t at = (size_t)f.n_phi + (size_t)f.n_theta;
     l.phi = 0; l.theta = (size_t)f.n_phi;
-    auto put = [&](int which, const int res[2], size_t n, int n_ch, bool distribution) {
-        const WarpOffsets o = plan_warp(at, res[0], res[1], n, n_ch, distribution);
-        l.cells[which] = o.cells; l.cond[which] = o.cond; l.rows[which] = o.rows;
+    auto put = [&](int which, const int res[2], int n_phi, int n_theta, int n_ch, bool distribution) {
+        const WarpOffsets o = plan_warp(at, res[0], res[1], n_phi, n_theta, n_ch, distribution);
+        l.cells[which] = o.cells; l.cond2[which] = o.cond2; l.margq[which] = o.margq;
     };
-    put(0, f.res_ndf, 1, 1, false);
-    put(1, f.res_sigma, 1, 1, false);
-    put(2, f.res, slices, 1, true);
-    put(3, f.res, slices, 1, true);
-    put(4, f.res, slices, 3, false);
+    put(0, f.res_ndf, 1, 1, 1, false);
+    put(1, f.res_sigma, 1, 1, 1, false);
+    put(2, f.res, f.n_phi, f.n_theta, 1, true);
+    put(3, f.res, f.n_phi, f.n_theta, 1, true);
+    put(4, f.res, f.n_phi, f.n_theta, 3, false);
     return at;
 }
 
@@ -69,14 +71,14 @@ inline size_t nch_brick_float4s(int n_ch) { return n_ch == 1 ? 2 : n_ch == 2 ? 4
 
 // ---- the file ----
 struct ImageHeader {
-    char magic[8];                       // "MRLIMG\1\0"
+    char magic[8];                       // "MRLIMG\2\0" (2: RGL search tables in the bracket form)
     uint32_t header_bytes, kind, layout, n_ch, param, lookup, node, n_ti;
     int32_t dims[3];
     int32_t rgl_shape[8];                // n_phi n_theta res_x res_y res_ndf_x res_ndf_y res_sigma_x res_sigma_y
     int32_t rgl_flags[2];                // jacobian, reserved
     uint64_t texel_bytes, sampling_doubles, sampling2d_doubles, checksum;
 };
-constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 1, 0 };
+constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 2, 0 };
 constexpr uint64_t kImageChecksumSeed = 0xCBF29CE484222325ull;
 // the kinds and layouts an image can name (values of mrl::Kind / mrl::Layout / mrl::Param, repeated here so that this header needs no HIP)
 constexpr uint32_t kImgKindMerl = 0, kImgKindTable = 1, kImgKindNch = 4, kImgKindRgl = 5, kImgLayoutRows = 0, kImgLayoutBrick = 1, kImgParamLast = 2;

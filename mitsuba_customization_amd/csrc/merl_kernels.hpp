@@ -77,8 +77,10 @@ const char *rgl_check_fields(const RglFields &f);                        // null
 RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob); // normalised tables + running integrals, host f64
 RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base);
 // r != nullptr: a single-material launch; r == nullptr: a batch with material ids (a.mat) — the units whose id names an RGL material
-// are evaluated and written, every other unit is left as it is.  indexed: walk the queue a.idx / a.idx_count
-hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev *r, bool indexed, int compute_units, hipStream_t stream);
+// are evaluated and written, every other unit is left as it is.  indexed: walk the queue a.idx / a.idx_count.
+// search (MRL_OPT_RGL_SEARCH): 0 = a single-material launch reads the distributions' search tables from a copy in LDS when they fit
+// a CU's LDS, 1 = always from memory (the results are the same bits)
+hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev *r, bool indexed, int search, int compute_units, hipStream_t stream);
 // ---- one-unit calls (merl_scalar.hip): a bounded-lifetime service kernel answers requests posted in pinned host memory ----
 struct ScalarBoard;
 struct ScalarArgs {

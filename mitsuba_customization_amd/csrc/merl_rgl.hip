@@ -18,32 +18,112 @@ namespace mrl {
 namespace {
 
 constexpr int kRglBlock = 256;
+// the LDS variant: ONE workgroup per CU holds the file's search tables (up to 160 KB) — 4 waves per SIMD for eval and for pdf alone, 3 for the fused modes and the
+// modes with a sample() (which carries two visited cells through its eval: 130 - 170 VGPRs)
+constexpr int rgl_lds_block(int mode) { return mode >= 2 ? 768 : 1024; }
 
-// MULTI: a batch with a material id per unit — the lanes whose id names an RGL material evaluate it through the descriptor
-// stored behind that material's image (read on demand: a few more cache-resident loads per lookup) and overwrite the zeros
-// the table / GGX kernel of the same call left there; every other lane skips.  Launched after that kernel, on the same stream.
-template <int MODE>
-__device__ __forceinline__ void rgl_unit(const BatchArgs &a, const RglDev &r, size_t i)
+// ---- the search tables in LDS ----
+// Slice by slice (a bracket's float4 taken apart while it is copied): cond [slices][cell] float2, marg [slices][ny - 1] float, for vndf
+// and then luminance.  A ds_read gather of 64 scattered addresses costs a tenth of the global one (LDS has no tag lookup per line),
+// and these are the reads sample() is made of: 2 x (log2 ny + log2 nx) dependent steps per unit and slice.
+extern __shared__ float4 rgl_lds[];
+
+struct SearchLds {
+    unsigned cond_at, marg_at;          // float2 / float index of the table's first element in rgl_lds
+    int per_c, per_r;
+    __device__ __forceinline__ rgl::D2 cond(const rgl::Slices &s, int cell) const
+    {
+#pragma clang fp contract(off)
+        const float2 *t = (const float2 *)rgl_lds + cond_at;
+        const float2 q0 = t[s.s[0] * (unsigned)per_c + (unsigned)cell];
+        rgl::D2 v = { s.w[0] * (double)q0.x, s.w[0] * (double)q0.y };
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if ((s.mask >> k) & 1) {
+                const float2 q = t[s.s[k] * (unsigned)per_c + (unsigned)cell];
+                v.x = __builtin_fma(s.w[k], (double)q.x, v.x); v.y = __builtin_fma(s.w[k], (double)q.y, v.y);
+            }
+        return v;
+    }
+    __device__ __forceinline__ double marg(const rgl::Slices &s, int row) const
+    {
+#pragma clang fp contract(off)
+        const float *t = (const float *)rgl_lds + marg_at;
+        double v = s.w[0] * (double)t[s.s[0] * (unsigned)per_r + (unsigned)row];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if ((s.mask >> k) & 1) v = __builtin_fma(s.w[k], (double)t[s.s[k] * (unsigned)per_r + (unsigned)row], v);
+        return v;
+    }
+};
+
+// bytes of LDS the two distributions' search tables take, slice by slice (16-B aligned pieces)
+size_t lds_bytes_of(const RglDev &r)
+{
+    const WarpDev &w = r.vndf;
+    const size_t slices = (size_t)w.n_phi * (size_t)w.n_theta, per_c = (size_t)(w.nx - 1) * (size_t)(w.ny - 1), per_r = (size_t)(w.ny - 1);
+    const size_t cond = (slices * per_c * 8 + 15) / 16 * 16, marg = (slices * per_r * 4 + 15) / 16 * 16;
+    return 2 * (cond + marg);
+}
+
+// one distribution's tables: memory (bracket form) -> LDS (slice form); every thread of the block takes part
+__device__ __forceinline__ SearchLds stage_search(const WarpDev &w, unsigned &at_float4, int block)
+{
+    const int per_c = (w.nx - 1) * (w.ny - 1), per_r = w.ny - 1, slices = w.n_phi * w.n_theta;
+    const int tb = w.n_theta > 1 ? w.n_theta - 1 : 1, pb = w.n_phi > 1 ? w.n_phi - 1 : 1;
+    SearchLds t;
+    t.per_c = per_c; t.per_r = per_r;
+    t.cond_at = at_float4 * 2;                                   // in float2
+    at_float4 += (unsigned)((slices * per_c + 1) / 2);
+    t.marg_at = at_float4 * 4;                                   // in float
+    at_float4 += (unsigned)((slices * per_r + 3) / 4);
+    float2 *cond = (float2 *)rgl_lds + t.cond_at;
+    float *marg = (float *)rgl_lds + t.marg_at;
+    for (int k = threadIdx.x; k < slices * per_c; k += block) {
+        const int sl = k / per_c, cell = k - sl * per_c, ip = sl / w.n_theta, it = sl - ip * w.n_theta;
+        const int itb = it < tb ? it : tb - 1;
+        const float4 v = w.cond2[(unsigned)(ip * tb + itb) * (unsigned)per_c + (unsigned)cell];
+        cond[k] = it > itb ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+    }
+    for (int k = threadIdx.x; k < slices * per_r; k += block) {
+        const int sl = k / per_r, row = k - sl * per_r, ip = sl / w.n_theta, it = sl - ip * w.n_theta;
+        const int itb = it < tb ? it : tb - 1, ipb = ip < pb ? ip : pb - 1;
+        const float4 v = w.margq[(unsigned)(ipb * tb + itb) * (unsigned)per_r + (unsigned)row];
+        const int c = (ip - ipb) + 2 * (it - itb);
+        marg[k] = c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
+    }
+    return t;
+}
+
+// One unit.  What depends on the incident direction alone — its angles, the parameter bracket, the projected area — is formed once
+// and serves the eval, the pdf and the sample of the unit.
+template <int MODE, class Search>
+__device__ __forceinline__ void rgl_unit(const BatchArgs &a, const RglDev &r, const Search &tv, const Search &tl, size_t i)
 {
     constexpr bool has_eval = MODE == 0 || MODE == 3 || MODE == 4, has_pdf = MODE == 1 || MODE == 3 || MODE == 4,
                    has_sample = MODE == 2 || MODE == 3;
     const float wix = a.wi[3 * i], wiy = a.wi[3 * i + 1], wiz = a.wi[3 * i + 2];
+    rgl::Incident in;
+    const bool up = wiz > 0.0f && rgl::incident<has_eval || has_sample>(r, wix, wiy, wiz, in);
     if constexpr (has_eval || has_pdf) {
         const float wox = a.wo[3 * i], woy = a.wo[3 * i + 1], woz = a.wo[3 * i + 2];
-        float rgb[3], pdf;
-        rgl::eval_pdf<has_eval, has_pdf>(r, wix, wiy, wiz, wox, woy, woz, rgb, pdf);
+        float rgb[3] = { 0.0f, 0.0f, 0.0f }, pdf = 0.0f;
+        if (up) rgl::eval_pdf_at<has_eval, has_pdf>(r, tv, in, wox, woy, woz, rgb, pdf);
         if constexpr (has_eval) { a.out_rgb[3 * i] = rgb[0]; a.out_rgb[3 * i + 1] = rgb[1]; a.out_rgb[3 * i + 2] = rgb[2]; }
         if constexpr (has_pdf) a.out_pdf[i] = pdf;
     }
     if constexpr (has_sample) {
-        float wo2[3], pdf2, w[3];
-        rgl::sample(r, wix, wiy, wiz, a.u[2 * i], a.u[2 * i + 1], wo2, pdf2, w);
+        float wo2[3] = { 0.0f, 0.0f, 0.0f }, pdf2 = 0.0f, w[3] = { 0.0f, 0.0f, 0.0f };
+        if (up) rgl::sample_at(r, tv, tl, in, a.u[2 * i], a.u[2 * i + 1], wo2, pdf2, w);
         a.out_wo[3 * i] = wo2[0]; a.out_wo[3 * i + 1] = wo2[1]; a.out_wo[3 * i + 2] = wo2[2];
         a.out_pdf2[i] = pdf2;
         a.out_weight[3 * i] = w[0]; a.out_weight[3 * i + 1] = w[1]; a.out_weight[3 * i + 2] = w[2];
     }
 }
 
+// MULTI: a batch with a material id per unit — the lanes whose id names an RGL material evaluate it through the descriptor
+// stored behind that material's image (read on demand: a few more cache-resident loads per lookup) and overwrite the zeros
+// the table / GGX kernel of the same call left there; every other lane skips.  Launched after that kernel, on the same stream.
 template <int MODE, bool INDEXED, bool MULTI>
 __global__ __launch_bounds__(kRglBlock) void k_rgl(BatchArgs a, RglDev r)
 {
@@ -57,16 +137,64 @@ __global__ __launch_bounds__(kRglBlock) void k_rgl(BatchArgs a, RglDev r)
             if (id < 0 || id >= a.n_materials) continue;
             const MaterialDev &m = a.materials[id];
             if (m.kind != KIND_RGL) continue;
-            rgl_unit<MODE>(a, *(const RglDev *)m.rgl, i);
+            const RglDev &rm = *(const RglDev *)m.rgl;
+            rgl_unit<MODE>(a, rm, rgl::SearchMem(rm.vndf), rgl::SearchMem(rm.luminance), i);
         } else {
-            rgl_unit<MODE>(a, r, i);
+            rgl_unit<MODE>(a, r, rgl::SearchMem(r.vndf), rgl::SearchMem(r.luminance), i);
         }
     }
 }
 
-template <int MODE>
-hipError_t launch_mode(const BatchArgs &a, const RglDev *r, bool indexed, int compute_units, hipStream_t stream)
+// The single-material launch when the file's search tables fit a CU's LDS: one workgroup per CU copies them in (once: the grid is
+// persistent) and every search step of every unit is a ds_read.  Same functions, same sums, same bits as k_rgl.
+template <int MODE, bool INDEXED>
+__global__ __launch_bounds__(rgl_lds_block(MODE)) void k_rgl_lds(BatchArgs a, RglDev r)
 {
+    constexpr int kRglLdsBlock = rgl_lds_block(MODE);
+    unsigned at = 0;
+    const SearchLds tv = stage_search(r.vndf, at, kRglLdsBlock);
+    const SearchLds tl = stage_search(r.luminance, at, kRglLdsBlock);
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * kRglLdsBlock;
+    size_t n_items = a.n;
+    if constexpr (INDEXED) { const size_t c = (size_t)*a.idx_count; n_items = c < a.n ? c : a.n; }
+    for (size_t j = (size_t)blockIdx.x * kRglLdsBlock + threadIdx.x; j < n_items; j += stride) {
+        const size_t i = INDEXED ? (size_t)a.idx[j] : j;
+        rgl_unit<MODE>(a, r, tv, tl, i);
+    }
+}
+
+int lds_limit()
+{
+    static const int limit = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        return v;
+    }();
+    return limit;
+}
+
+template <int MODE>
+hipError_t launch_mode(const BatchArgs &a, const RglDev *r, bool indexed, int search, int compute_units, hipStream_t stream)
+{
+    // LDS variant: a single-material launch large enough to pay for the copy (one image of the search tables per CU)
+    if (r && search == 0 && a.n >= (size_t)1 << 15) {
+        const size_t need = lds_bytes_of(*r);
+        if (need <= (size_t)lds_limit()) {
+            constexpr int kRglLdsBlock = rgl_lds_block(MODE);
+            size_t blocks = (a.n + kRglLdsBlock - 1) / kRglLdsBlock;
+            if (blocks > (size_t)compute_units) blocks = (size_t)compute_units;
+            const dim3 grid((unsigned)blocks), block(kRglLdsBlock);
+            if (indexed) {
+                (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+                hipLaunchKernelGGL((k_rgl_lds<MODE, true>), grid, block, need, stream, a, *r);
+            } else {
+                (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+                hipLaunchKernelGGL((k_rgl_lds<MODE, false>), grid, block, need, stream, a, *r);
+            }
+            return hipGetLastError();
+        }
+    }
     size_t blocks = (a.n + kRglBlock - 1) / kRglBlock;
     const size_t cap = (size_t)compute_units * 8;
     if (blocks > cap) blocks = cap;
@@ -96,17 +224,19 @@ bool ascending(const float *p, int n)
 }
 
 // appends one function's tables to the image (offsets in floats, each a multiple of 4 so that the vectors are 16-B aligned):
-// the corner bricks (normalised if a distribution) and, for distributions, the running integrals `cond` (along x, node rows
-// row / row + 1 side by side) and `rows` (marginal cdf before / after the cell row, totals of its two node rows) — all rounded
-// to Float once from f64 sums, in the oracle's loop order.  src: [slices][n_ch][ny][nx].
-WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, int ny, size_t slices, int n_ch, bool distribution)
+// the corner bricks (normalised if a distribution) and, for distributions, the running integrals in the BRACKET form the
+// kernels search — `cond2` (along x, node rows row / row + 1, the two theta slices of a bracket side by side) and `margq` (the
+// marginal cdf after the cell row, the four slices of a (phi, theta) bracket side by side) — all rounded to Float once from
+// f64 sums, in the oracle's loop order.  src: [n_phi][n_theta][n_ch][ny][nx].
+WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, int ny, int n_phi, int n_theta, int n_ch, bool distribution)
 {
-    const size_t per = (size_t)nx * ny, cells = (size_t)(nx - 1) * (size_t)(ny - 1);
+    const size_t per = (size_t)nx * ny, cells = (size_t)(nx - 1) * (size_t)(ny - 1), slices = (size_t)n_phi * (size_t)n_theta;
+    const size_t per_cond = (size_t)ny * (size_t)(nx - 1), per_marg = (size_t)(ny - 1);
     size_t at = blob.size();
-    const WarpOffsets off = plan_warp(at, nx, ny, slices, n_ch, distribution);
+    const WarpOffsets off = plan_warp(at, nx, ny, n_phi, n_theta, n_ch, distribution);
     blob.resize(at, 0.0f);
-    std::vector<double> cond((size_t)ny * (size_t)(nx - 1)), marg((size_t)(ny - 1));
-    std::vector<float> node(per), condf(cond.size()), margf(marg.size());
+    std::vector<double> cond(per_cond), marg(per_marg);
+    std::vector<float> node(per), condf(distribution ? per_cond * slices : 0), margf(distribution ? per_marg * slices : 0);
     for (size_t s = 0; s < slices; ++s)
         for (int ch = 0; ch < n_ch; ++ch) {
             const float *src = src_all + per * (s * (size_t)n_ch + (size_t)ch);
@@ -125,8 +255,8 @@ WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, 
                     marg[(size_t)y] = sum;
                 }
                 norm = sum > 0.0 ? 1.0 / sum : 1.0;
-                for (size_t k = 0; k < cond.size(); ++k) condf[k] = (float)(cond[k] * norm);
-                for (size_t k = 0; k < marg.size(); ++k) margf[k] = (float)(marg[k] * norm);
+                for (size_t k = 0; k < per_cond; ++k) condf[s * per_cond + k] = (float)(cond[k] * norm);
+                for (size_t k = 0; k < per_marg; ++k) margf[s * per_marg + k] = (float)(marg[k] * norm);
             }
             for (size_t k = 0; k < per; ++k) node[k] = (float)((double)src[k] * norm);
             for (int y = 0; y < ny - 1; ++y)
@@ -135,18 +265,31 @@ WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, 
                     float *q = &blob[off.cells + ((s * cells + cell) * (size_t)n_ch + (size_t)ch) * 4];
                     q[0] = node[(size_t)y * nx + x]; q[1] = node[(size_t)y * nx + x + 1];
                     q[2] = node[(size_t)(y + 1) * nx + x]; q[3] = node[(size_t)(y + 1) * nx + x + 1];
-                    if (distribution) {
-                        float *c = &blob[off.cond + (s * cells + cell) * 2];
-                        c[0] = condf[(size_t)y * (size_t)(nx - 1) + (size_t)x]; c[1] = condf[(size_t)(y + 1) * (size_t)(nx - 1) + (size_t)x];
-                    }
-                }
-            if (distribution)
-                for (int y = 0; y < ny - 1; ++y) {
-                    float *r = &blob[off.rows + (s * (size_t)(ny - 1) + (size_t)y) * 4];
-                    r[0] = y > 0 ? margf[(size_t)y - 1] : 0.0f; r[1] = margf[(size_t)y];
-                    r[2] = condf[(size_t)y * (size_t)(nx - 1) + (size_t)(nx - 2)]; r[3] = condf[(size_t)(y + 1) * (size_t)(nx - 1) + (size_t)(nx - 2)];
                 }
         }
+    if (distribution) {
+        const int tb = n_theta > 1 ? n_theta - 1 : 1, pb = n_phi > 1 ? n_phi - 1 : 1;
+        for (int ip = 0; ip < n_phi; ++ip)
+            for (int it = 0; it < tb; ++it) {
+                const size_t s0 = (size_t)ip * n_theta + it, s1 = n_theta > 1 ? s0 + 1 : s0;
+                float *c = &blob[off.cond2 + ((size_t)ip * tb + it) * cells * 4];
+                for (int y = 0; y < ny - 1; ++y)
+                    for (int x = 0; x < nx - 1; ++x, c += 4) {
+                        const size_t lo = (size_t)y * (size_t)(nx - 1) + (size_t)x, hi = lo + (size_t)(nx - 1);
+                        c[0] = condf[s0 * per_cond + lo]; c[1] = condf[s0 * per_cond + hi];
+                        c[2] = condf[s1 * per_cond + lo]; c[3] = condf[s1 * per_cond + hi];
+                    }
+            }
+        for (int ip = 0; ip < pb; ++ip)
+            for (int it = 0; it < tb; ++it) {
+                const size_t dp = n_phi > 1 ? (size_t)n_theta : 0, dt = n_theta > 1 ? 1 : 0, s0 = (size_t)ip * n_theta + it;
+                float *m = &blob[off.margq + ((size_t)ip * tb + it) * per_marg * 4];
+                for (size_t y = 0; y < per_marg; ++y, m += 4) {
+                    m[0] = margf[s0 * per_marg + y]; m[1] = margf[(s0 + dp) * per_marg + y];
+                    m[2] = margf[(s0 + dt) * per_marg + y]; m[3] = margf[(s0 + dp + dt) * per_marg + y];
+                }
+            }
+    }
     return off;
 }
 
@@ -183,20 +326,19 @@ const char *rgl_check_fields(const RglFields &f)
 RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob)
 {
     blob.clear();
-    const size_t slices = (size_t)f.n_phi * (size_t)f.n_theta;
     RglLayout l;
     l.phi = 0; l.theta = (size_t)f.n_phi;
     blob.insert(blob.end(), f.phi_i, f.phi_i + f.n_phi);
     blob.insert(blob.end(), f.theta_i, f.theta_i + f.n_theta);
-    auto put = [&](int which, const float *src, const int res[2], size_t n, int n_ch, bool distribution) {
-        const WarpOffsets o = append_warp(blob, src, res[0], res[1], n, n_ch, distribution);
-        l.cells[which] = o.cells; l.cond[which] = o.cond; l.rows[which] = o.rows;
+    auto put = [&](int which, const float *src, const int res[2], int n_phi, int n_theta, int n_ch, bool distribution) {
+        const WarpOffsets o = append_warp(blob, src, res[0], res[1], n_phi, n_theta, n_ch, distribution);
+        l.cells[which] = o.cells; l.cond2[which] = o.cond2; l.margq[which] = o.margq;
     };
-    put(0, f.ndf, f.res_ndf, 1, 1, false);
-    put(1, f.sigma, f.res_sigma, 1, 1, false);
-    put(2, f.vndf, f.res, slices, 1, true);
-    put(3, f.luminance, f.res, slices, 1, true);
-    put(4, f.rgb, f.res, slices, 3, false);
+    put(0, f.ndf, f.res_ndf, 1, 1, 1, false);
+    put(1, f.sigma, f.res_sigma, 1, 1, 1, false);
+    put(2, f.vndf, f.res, f.n_phi, f.n_theta, 1, true);
+    put(3, f.luminance, f.res, f.n_phi, f.n_theta, 1, true);
+    put(4, f.rgb, f.res, f.n_phi, f.n_theta, 3, false);
     return l;
 }
 
@@ -206,8 +348,8 @@ RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base)
     auto warp = [&](int which, const int res[2], int n_phi, int n_theta, int n_ch, bool distribution) {
         WarpDev w;
         w.cells = (const float4 *)(base + l.cells[which]);
-        w.cond = distribution ? (const float2 *)(base + l.cond[which]) : nullptr;
-        w.rows = distribution ? (const float4 *)(base + l.rows[which]) : nullptr;
+        w.cond2 = distribution ? (const float4 *)(base + l.cond2[which]) : nullptr;
+        w.margq = distribution ? (const float4 *)(base + l.margq[which]) : nullptr;
         w.phi = base + l.phi; w.theta = base + l.theta;
         w.nx = res[0]; w.ny = res[1]; w.n_phi = n_phi; w.n_theta = n_theta; w.n_ch = n_ch;
         w.normalized = distribution ? 1 : 0;
@@ -225,15 +367,15 @@ RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base)
     return r;
 }
 
-hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev *r, bool indexed, int compute_units, hipStream_t stream)
+hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev *r, bool indexed, int search, int compute_units, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     switch (mode) {
-        case 0: return launch_mode<0>(a, r, indexed, compute_units, stream);
-        case 1: return launch_mode<1>(a, r, indexed, compute_units, stream);
-        case 2: return launch_mode<2>(a, r, indexed, compute_units, stream);
-        case 3: return launch_mode<3>(a, r, indexed, compute_units, stream);
-        case 4: return launch_mode<4>(a, r, indexed, compute_units, stream);
+        case 0: return launch_mode<0>(a, r, indexed, search, compute_units, stream);
+        case 1: return launch_mode<1>(a, r, indexed, search, compute_units, stream);
+        case 2: return launch_mode<2>(a, r, indexed, search, compute_units, stream);
+        case 3: return launch_mode<3>(a, r, indexed, search, compute_units, stream);
+        case 4: return launch_mode<4>(a, r, indexed, search, compute_units, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -8,7 +8,7 @@
 // (phi_i, theta_i) of the incident direction:
 //     ndf, sigma                  plain 2-D tables (microfacet normal density, projected area)
 //     vndf, luminance             normalised 2-D distributions per (phi_i, theta_i) node, with running integrals for
-//                                 sampling (`cond`: along x per node row, `marg`: over rows)
+//                                 sampling (conditional: along x per node row, marginal: over rows)
 //     rgb                         the measured values in the warped domain, per (phi_i, theta_i, channel)
 // eval(wi, wo):  m = (wi + wo) normalised;  u_m = (sqrt(2 theta_m / pi), (phi_m [- phi_i]) / 2pi + 1/2);
 //                s = vndf.invert(u_m);  f cos = rgb(s) * ndf(u_m) / (4 sigma(u_wi))
@@ -17,9 +17,24 @@
 //                AT the Float direction that is returned (so pdf(wi, sample.wo) == sample.pdf and weight == eval / pdf).
 // Math in f64 on Float tables with the table path's own building blocks (v_rcp / v_rsq seeds + one Newton step, the
 // pi/8-rotated atan polynomial, Taylor sin / cos: relative error ~1e-15 each) in place of ocml's correctly rounded
-// division, sqrt, asin, atan2, sin and cos (735 VALU instructions per eval, 93 VGPRs; the outputs are rounded to Float
-// anyway).  One lane per unit; every table read is a per-lane gather from an image of 1 - 50 MB (L2 resident), and the
-// gathers are what bounds the kernel (the texture addresser is 80 % busy, see WarpDev) — not VALU, not HBM.
+// division, sqrt, asin, atan2, sin and cos.  One lane per unit.
+//
+// What bounds the kernel and what this file does about it (profiles/r03_rgl_pmc.json, r04_rgl_pmc.json): the
+// cost is the number of SCATTERED lane-addresses the CU's texture addresser resolves (one load instruction of 64 lanes that
+// touch ~50 lines costs ~80 cycles of a CU whatever its width), not bytes and not arithmetic.  Hence
+//   * cell bricks: what a lookup needs about a cell sits in ONE aligned 16-B vector per table and parameter slice;
+//   * the SEARCH tables (conditional and marginal running integrals — ten dependent reads per sample() and slice in the
+//     textbook form) are stored for the BRACKET, not the slice: the two theta_i slices of a bracket side by side in one
+//     float4 (`cond2`), the four slices of a (phi_i, theta_i) bracket's marginal in one float4 (`margq`) — one load where
+//     round 3 issued two / four — and are read through a policy (`Search`): from memory (SearchMem: host images, batches
+//     with material ids, files too large for a CU's LDS) or from a copy in LDS (merl_rgl.hip: a `ds_read` gather costs a
+//     tenth of a scattered global one);
+//   * sample() hands the cells its two searches ended in to the eval / pdf it reports at the returned direction
+//     (`Found`): the inverse warp of a point the forward warp has just produced lands in the same cell (but for one unit in
+//     ~10^5, which re-reads), so its three table reads and the luminance lookup are not issued again;
+//   * what depends on the incident direction alone (angles, parameter bracket, projected area) is formed once per unit.
+// Every blend is spelt with explicit FMAs and contraction is off: which multiply the compiler would fuse depends on the
+// inlining context, and the entry points (separate, fused, queue, batch with ids, LDS or memory) must agree bit for bit.
 #pragma once
 #include "merl_device.hpp"
 #include "merl_table_fast.hpp"     // rcp_nr / div_fast / sqrt_fast / rsqrt_pos / atan2_q1: the table path's f64 building blocks
@@ -28,13 +43,12 @@
 namespace mrl {
 
 // One piecewise-bilinear function.  Slices are row-major in (phi, theta); a slice is (ny - 1) x (nx - 1) cells, x fastest.
-// Everything a lookup needs about a cell sits in ONE aligned vector per table, so that a lane issues one load where the
-// node-major file layout needs four (the kernel is bound by the number of scattered lane-addresses the CU's texture
-// addresser resolves, not by VALU or bytes: DESIGN.md §5c, profiles/r03_rgl_pmc.json):
 struct WarpDev {
     const float4 *cells;    // [slices][cell][n_ch]  the cell's four corner values (v00, v10, v01, v11), normalised if a distribution
-    const float2 *cond;     // [slices][cell]        running integrals along x, up to node col + 1, of node rows (row, row + 1)
-    const float4 *rows;     // [slices][ny - 1]      (marginal cdf before the row, after the row, total of node row `row`, of `row + 1`)
+    // distributions only — the search tables, per parameter BRACKET (tb = max(n_theta - 1, 1), pb = max(n_phi - 1, 1)):
+    const float4 *cond2;    // [n_phi][tb][cell]   running integrals along x, up to node col + 1, of node rows (row, row + 1):
+                            //                     .xy of slice (ip, it), .zw of slice (ip, it + 1) (of (ip, it) again when n_theta = 1)
+    const float4 *margq;    // [pb][tb][ny - 1]    marginal cdf after the cell row, of slices (ip, it) (ip+1, it) (ip, it+1) (ip+1, it+1)
     const float *phi, *theta;   // ascending parameter grids (unused when the count is 1)
     int nx, ny, n_phi, n_theta, n_ch;
     int normalized;
@@ -50,12 +64,14 @@ struct RglDev {
 namespace rgl {
 
 // the four parameter slices around (phi_i, theta_i) and their weights, phi fastest (the order the oracle sums in); `mask`
-// says which entries exist (a grid of one node has no upper neighbour) — uniform over a launch, so fetch()'s tests are
-// scalar branches and the arrays stay in registers
-struct Slices { unsigned s[4]; double w[4]; int mask; };
+// says which entries exist (a grid of one node has no upper neighbour) — uniform over a launch, so the tests on it are
+// scalar branches and the arrays stay in registers.  pair[]: the theta bracket's index in cond2 for phi node ip / ip + 1;
+// quad: the (phi, theta) bracket's index in margq.
+struct Slices { unsigned s[4]; double w[4]; int mask; unsigned pair[2], quad; };
 
 MRL_HD void bracket(const float *grid, int n, double p, int &i, double &t)
 {
+#pragma clang fp contract(off)
     // largest i in [0, n - 2] with grid[i] <= p
     int lo = 0, hi = n - 1;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((double)grid[mid] <= p) lo = mid; else hi = mid; }
@@ -67,17 +83,21 @@ MRL_HD void bracket(const float *grid, int n, double p, int &i, double &t)
 
 MRL_HD Slices find_slices(const WarpDev &w, double phi_i, double theta_i)
 {
+#pragma clang fp contract(off)
     int ip = 0, it = 0;
     double tp = 0.0, tt = 0.0;
     if (w.n_phi > 1) bracket(w.phi, w.n_phi, phi_i, ip, tp);
     if (w.n_theta > 1) bracket(w.theta, w.n_theta, theta_i, it, tt);
     const int ip1 = w.n_phi > 1 ? ip + 1 : ip, it1 = w.n_theta > 1 ? it + 1 : it;
+    const int tb = w.n_theta > 1 ? w.n_theta - 1 : 1;
     Slices out;
     out.s[0] = (unsigned)(ip * w.n_theta + it);  out.w[0] = (1.0 - tp) * (1.0 - tt);
     out.s[1] = (unsigned)(ip1 * w.n_theta + it); out.w[1] = tp * (1.0 - tt);
     out.s[2] = (unsigned)(ip * w.n_theta + it1); out.w[2] = (1.0 - tp) * tt;
     out.s[3] = (unsigned)(ip1 * w.n_theta + it1); out.w[3] = tp * tt;
     out.mask = 1 | (w.n_phi > 1 ? 2 : 0) | (w.n_theta > 1 ? 4 : 0) | (w.n_phi > 1 && w.n_theta > 1 ? 8 : 0);
+    out.pair[0] = (unsigned)(ip * tb + it); out.pair[1] = (unsigned)(ip1 * tb + it);
+    out.quad = (unsigned)(ip * tb + it);
     return out;
 }
 
@@ -86,44 +106,62 @@ MRL_HD Slices single_slice()
     Slices out;
     for (int k = 0; k < 4; ++k) { out.s[k] = 0u; out.w[k] = 0.0; }
     out.w[0] = 1.0; out.mask = 1;
+    out.pair[0] = out.pair[1] = out.quad = 0u;
     return out;
 }
 
-// weighted sums over the parameter slices, component by component in slice order (what the oracle's scalar loop does);
-// 32-bit offsets: a function's tables hold at most 2^28 values (rgl_check_fields)
+// weighted sums over the parameter slices, component by component in slice order (what the oracle's scalar loop does; the
+// first term is a product, every later one an explicit FMA); 32-bit offsets: a function's tables hold at most 2^28 values
 struct D4 { double x, y, z, w; };
 struct D2 { double x, y; };
 MRL_HD D4 fetch4(const Slices &s, const float4 *base, int per_slice, int index, int stride = 1, int offset = 0)
 {
-    D4 v = { 0.0, 0.0, 0.0, 0.0 };
+#pragma clang fp contract(off)
+    const float4 q0 = base[(s.s[0] * (unsigned)per_slice + (unsigned)index) * (unsigned)stride + (unsigned)offset];
+    D4 v = { s.w[0] * (double)q0.x, s.w[0] * (double)q0.y, s.w[0] * (double)q0.z, s.w[0] * (double)q0.w };
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 1; k < 4; ++k)
         if ((s.mask >> k) & 1) {
             const float4 q = base[(s.s[k] * (unsigned)per_slice + (unsigned)index) * (unsigned)stride + (unsigned)offset];
-            v.x += s.w[k] * (double)q.x; v.y += s.w[k] * (double)q.y; v.z += s.w[k] * (double)q.z; v.w += s.w[k] * (double)q.w;
+            v.x = __builtin_fma(s.w[k], (double)q.x, v.x); v.y = __builtin_fma(s.w[k], (double)q.y, v.y);
+            v.z = __builtin_fma(s.w[k], (double)q.z, v.z); v.w = __builtin_fma(s.w[k], (double)q.w, v.w);
         }
     return v;
 }
-MRL_HD D2 fetch2(const Slices &s, const float2 *base, int per_slice, int index)
-{
-    D2 v = { 0.0, 0.0 };
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if ((s.mask >> k) & 1) {
-            const float2 q = base[s.s[k] * (unsigned)per_slice + (unsigned)index];
-            v.x += s.w[k] * (double)q.x; v.y += s.w[k] * (double)q.y;
+
+// The search tables of one distribution read from memory: one load serves the two theta slices of a bracket (cond2) or all
+// four slices (margq).  The same sums, in the same order, as a slice-by-slice read.
+struct SearchMem {
+    const float4 *cond2, *margq;
+    int per_c, per_r;
+    MRL_HD explicit SearchMem(const WarpDev &w) : cond2(w.cond2), margq(w.margq), per_c((w.nx - 1) * (w.ny - 1)), per_r(w.ny - 1) {}
+    // the conditional running integrals of node rows (row, row + 1) up to node col + 1, cell = row (nx - 1) + col
+    MRL_HD D2 cond(const Slices &s, int cell) const
+    {
+#pragma clang fp contract(off)
+        const float4 a = cond2[s.pair[0] * (unsigned)per_c + (unsigned)cell];
+        D2 v = { s.w[0] * (double)a.x, s.w[0] * (double)a.y };
+        float4 b = a;
+        if (s.mask & 2) {
+            b = cond2[s.pair[1] * (unsigned)per_c + (unsigned)cell];
+            v.x = __builtin_fma(s.w[1], (double)b.x, v.x); v.y = __builtin_fma(s.w[1], (double)b.y, v.y);
         }
-    return v;
-}
-// the marginal cdf after row `index` alone (the row search)
-MRL_HD double fetch_marg(const Slices &s, const float4 *rows, int per_slice, int index)
-{
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if ((s.mask >> k) & 1) v += s.w[k] * (double)rows[s.s[k] * (unsigned)per_slice + (unsigned)index].y;
-    return v;
-}
+        if (s.mask & 4) { v.x = __builtin_fma(s.w[2], (double)a.z, v.x); v.y = __builtin_fma(s.w[2], (double)a.w, v.y); }
+        if (s.mask & 8) { v.x = __builtin_fma(s.w[3], (double)b.z, v.x); v.y = __builtin_fma(s.w[3], (double)b.w, v.y); }
+        return v;
+    }
+    // the marginal cdf after cell row `row`
+    MRL_HD double marg(const Slices &s, int row) const
+    {
+#pragma clang fp contract(off)
+        const float4 q = margq[s.quad * (unsigned)per_r + (unsigned)row];
+        double v = s.w[0] * (double)q.x;
+        if (s.mask & 2) v = __builtin_fma(s.w[1], (double)q.y, v);
+        if (s.mask & 4) v = __builtin_fma(s.w[2], (double)q.z, v);
+        if (s.mask & 8) v = __builtin_fma(s.w[3], (double)q.w, v);
+        return v;
+    }
+};
 
 MRL_HD int clamp_cell(double p, int last)
 {
@@ -131,13 +169,34 @@ MRL_HD int clamp_cell(double p, int last)
     return i < 0 ? 0 : (i > last ? last : i);
 }
 
-MRL_HD double warp_eval(const WarpDev &w, const Slices &s, double x_in, double y_in, int channel = 0)
+// (1 - t) a + t b
+MRL_HD double lerp(double t, double a, double b)
 {
+#pragma clang fp contract(off)
+    return __builtin_fma(t, b, (1.0 - t) * a);
+}
+
+// What a search (or an inverse warp) knows about the cell it ended in: the blended corner values, the conditional
+// integrals left of the cell (node rows row / row + 1; zero in column 0), the marginal below the row (zero in row 0) and
+// the totals of the two node rows.  sample() passes it on to the eval / pdf at the direction it returns.
+struct Found { int row, col; D4 q; D2 left; double before, r0, r1; };
+
+MRL_HD double bilinear(const D4 &q, double fx, double fy)
+{
+    return lerp(fy, lerp(fx, q.x, q.y), lerp(fx, q.z, q.w));
+}
+
+// a plain lookup; `known` (may be null): a cell of this table whose corner values are already held
+MRL_HD double warp_eval(const WarpDev &w, const Slices &s, double x_in, double y_in, int channel = 0, const Found *known = nullptr)
+{
+#pragma clang fp contract(off)
     const double px = x_in * (double)(w.nx - 1), py = y_in * (double)(w.ny - 1);
     const int ox = clamp_cell(px, w.nx - 2), oy = clamp_cell(py, w.ny - 2);
     const double fx = px - (double)ox, fy = py - (double)oy;
-    const D4 q = fetch4(s, w.cells, (w.nx - 1) * (w.ny - 1), oy * (w.nx - 1) + ox, w.n_ch, channel);
-    const double v = (1.0 - fy) * ((1.0 - fx) * q.x + fx * q.y) + fy * ((1.0 - fx) * q.z + fx * q.w);
+    D4 q;
+    if (known && known->row == oy && known->col == ox) q = known->q;
+    else q = fetch4(s, w.cells, (w.nx - 1) * (w.ny - 1), oy * (w.nx - 1) + ox, w.n_ch, channel);
+    const double v = bilinear(q, fx, fy);
     return w.normalized ? v * (double)(w.nx - 1) * (double)(w.ny - 1) : v;
 }
 
@@ -147,75 +206,95 @@ MRL_HD double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 // position in [0, 1] at which a density running linearly from c0 to c1 has accumulated the mass u
 MRL_HD double invert_linear(double c0, double c1, double u)
 {
+#pragma clang fp contract(off)
     const bool is_const = fabs(c0 - c1) < 1e-4 * (c0 + c1);
-    const double num = is_const ? 2.0 * u : c0 - safe_sqrt(c0 * c0 - 2.0 * u * (c0 - c1));
+    const double num = is_const ? 2.0 * u : c0 - safe_sqrt(__builtin_fma(-2.0 * u, c0 - c1, c0 * c0));
     const double den = is_const ? c0 + c1 : c0 - c1;
     return den != 0.0 ? fast::div_fast(num, den) : 0.0;
 }
 
-// uniform sample -> position; returns the density there
-MRL_HD double warp_sample(const WarpDev &w, const Slices &s, double ux, double uy, double &x_out, double &y_out)
+// uniform sample -> position; returns the density there and what it found on the way
+template <class Search>
+MRL_HD double warp_sample(const WarpDev &w, const Search &t, const Slices &s, double ux, double uy, double &x_out, double &y_out, Found &f)
 {
+#pragma clang fp contract(off)
     const int nx = w.nx, ny = w.ny;
-    const int per_r = ny - 1, per_c = (ny - 1) * (nx - 1);
+    const int per_c = (ny - 1) * (nx - 1);
     ux = clamp01(ux); uy = clamp01(uy);
     int lo = 0, hi = ny - 2;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (fetch_marg(s, w.rows, per_r, mid) < uy) lo = mid + 1; else hi = mid; }
-    const int row = lo;
-    const D4 rw = fetch4(s, w.rows, per_r, row);                // (cdf before the row, after it, r0, r1)
-    if (row > 0) uy -= rw.x;
-    const double r0 = rw.z, r1 = rw.w;
-    const double y = clamp01(invert_linear(r0, r1, uy));
-    ux *= (1.0 - y) * r0 + y * r1;
-    lo = 0; hi = nx - 2;
-    double below = 0.0;                                      // the conditional cdf at column lo - 1: every step that raises lo has just read it
+    double before = 0.0;                                     // the marginal cdf below row lo: every step that raises lo has just read it
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        const D2 p = fetch2(s, w.cond, per_c, row * (nx - 1) + mid);
-        const double c = (1.0 - y) * p.x + y * p.y;
-        if (c < ux) { lo = mid + 1; below = c; } else hi = mid;
+        const double c = t.marg(s, mid);
+        if (c < uy) { lo = mid + 1; before = c; } else hi = mid;
+    }
+    const int row = lo;
+    uy -= before;
+    const D2 tot = t.cond(s, row * (nx - 1) + nx - 2);       // the totals of node rows (row, row + 1)
+    const double r0 = tot.x, r1 = tot.y;
+    const double y = clamp01(invert_linear(r0, r1, uy));
+    ux *= lerp(y, r0, r1);
+    lo = 0; hi = nx - 2;
+    D2 left = { 0.0, 0.0 };                                  // the conditional integrals left of column lo, likewise
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const D2 p = t.cond(s, row * (nx - 1) + mid);
+        if (lerp(y, p.x, p.y) < ux) { lo = mid + 1; left = p; } else hi = mid;
     }
     const int col = lo;
-    if (col > 0) ux -= below;
+    ux -= lerp(y, left.x, left.y);
     const D4 q = fetch4(s, w.cells, per_c, row * (nx - 1) + col);
-    const double c0 = (1.0 - y) * q.x + y * q.z, c1 = (1.0 - y) * q.y + y * q.w;
+    const double c0 = lerp(y, q.x, q.z), c1 = lerp(y, q.y, q.w);
     const double x = clamp01(invert_linear(c0, c1, ux));
     x_out = fast::div_fast((double)col + x, (double)(nx - 1));
     y_out = fast::div_fast((double)row + y, (double)(ny - 1));
-    return ((1.0 - x) * c0 + x * c1) * (double)(nx - 1) * (double)(ny - 1);
+    f.row = row; f.col = col; f.q = q; f.left = left; f.before = before; f.r0 = r0; f.r1 = r1;
+    return lerp(x, c0, c1) * (double)(nx - 1) * (double)(ny - 1);
 }
 
-// position -> the uniform sample that maps to it; returns the density at the position
-MRL_HD double warp_invert(const WarpDev &w, const Slices &s, double x_in, double y_in, double &ux_out, double &uy_out)
+// position -> the uniform sample that maps to it; returns the density at the position.  `known` (may be null): the cell a
+// forward warp of this table ended in — when the position lies in it nothing is read.
+template <class Search>
+MRL_HD double warp_invert(const WarpDev &w, const Search &t, const Slices &s, double x_in, double y_in, double &ux_out, double &uy_out,
+                          const Found *known = nullptr)
 {
+#pragma clang fp contract(off)
     const int nx = w.nx, ny = w.ny;
-    const int per_r = ny - 1, per_c = (ny - 1) * (nx - 1);
+    const int per_c = (ny - 1) * (nx - 1);
     const double px = x_in * (double)(nx - 1), py = y_in * (double)(ny - 1);
     const int col = clamp_cell(px, nx - 2), row = clamp_cell(py, ny - 2);
     const double x = px - (double)col, y = py - (double)row;
-    const D4 q = fetch4(s, w.cells, per_c, row * (nx - 1) + col);
-    const double c0 = (1.0 - y) * q.x + y * q.z, c1 = (1.0 - y) * q.y + y * q.w;
-    const double pdf = ((1.0 - x) * c0 + x * c1) * (double)(nx - 1) * (double)(ny - 1);
-    double sx = x * (c0 + 0.5 * x * (c1 - c0));
-    if (col > 0) {
-        const D2 p = fetch2(s, w.cond, per_c, row * (nx - 1) + col - 1);
-        sx += (1.0 - y) * p.x + y * p.y;
+    D4 q;
+    D2 left = { 0.0, 0.0 };
+    double before = 0.0, r0, r1;
+    if (known && known->row == row && known->col == col) {
+        q = known->q; left = known->left; before = known->before; r0 = known->r0; r1 = known->r1;
+    } else {
+        q = fetch4(s, w.cells, per_c, row * (nx - 1) + col);
+        if (col > 0) left = t.cond(s, row * (nx - 1) + col - 1);
+        const D2 tot = t.cond(s, row * (nx - 1) + nx - 2);
+        r0 = tot.x; r1 = tot.y;
+        if (row > 0) before = t.marg(s, row - 1);
     }
-    const D4 rw = fetch4(s, w.rows, per_r, row);
-    const double r0 = rw.z, r1 = rw.w;
-    const double tot = (1.0 - y) * r0 + y * r1;
+    const double c0 = lerp(y, q.x, q.z), c1 = lerp(y, q.y, q.w);
+    const double pdf = lerp(x, c0, c1) * (double)(nx - 1) * (double)(ny - 1);
+    const double sx = __builtin_fma(x, __builtin_fma(0.5 * x, c1 - c0, c0), lerp(y, left.x, left.y));
+    const double tot = lerp(y, r0, r1);
     ux_out = tot > 0.0 ? fast::div_fast(sx, tot) : 0.0;
-    double sy = y * (r0 + 0.5 * y * (r1 - r0));
-    if (row > 0) sy += rw.x;
-    uy_out = sy;
+    uy_out = __builtin_fma(y, __builtin_fma(0.5 * y, r1 - r0, r0), before);
     return pdf;
 }
 
 // polar angle of a unit direction of the upper hemisphere (d.z > 0): atan2(|d_xy|, d_z), well conditioned at the pole
-MRL_HD double elevation(const Vec3d &d) { return fast::atan2_q1<false>(fast::sqrt_fast(d.x * d.x + d.y * d.y), d.z); }
+MRL_HD double elevation(const Vec3d &d)
+{
+#pragma clang fp contract(off)
+    return fast::atan2_q1<false>(fast::sqrt_fast(__builtin_fma(d.x, d.x, d.y * d.y)), d.z);
+}
 // atan2(y, x) over the full circle, IEEE signs (atan2(+-0, -x) = +-pi, atan2(+-0, +-0) = +-0 or +-pi)
 MRL_HD double azimuth(double y, double x)
 {
+#pragma clang fp contract(off)
     const bool neg_x = __builtin_signbit(x), neg_y = __builtin_signbit(y);
     const double t = (x == 0.0 && y == 0.0) ? 0.0 : fast::atan2_q1<false>(__builtin_fabs(y), __builtin_fabs(x));
     const double r = neg_x ? kPi - t : t;
@@ -253,46 +332,48 @@ MRL_HD void reduce_signs(int reduction, float wix, float wiy, float &sx, float &
 }
 
 // What eval / pdf / sample share about the incident direction: wi in the stored part of the azimuth, normalised; its angles; the
-// parameter slices around them (vndf, luminance and rgb share the parameter grids)
-struct Incident { Vec3d wi; float fx, fy; double theta_i, phi_i; Slices sv; };
+// parameter slices around them (vndf, luminance and rgb share the parameter grids); four times the projected area (the
+// jacobian's denominator: a function of wi alone)
+struct Incident { Vec3d wi; float fx, fy; double theta_i, phi_i, sigma4; Slices sv; };
 
+template <bool WANT_SIGMA>
 MRL_HD bool incident(const RglDev &b, float wix, float wiy, float wiz, Incident &in)
 {
+#pragma clang fp contract(off)
     reduce_signs(b.reduction, wix, wiy, in.fx, in.fy);
     in.wi = { (double)(wix * in.fx), (double)(wiy * in.fy), (double)wiz };
     if (!unit3(in.wi)) return false;
     in.theta_i = elevation(in.wi); in.phi_i = azimuth(in.wi.y, in.wi.x);
     in.sv = find_slices(b.vndf, in.phi_i, in.theta_i);
+    in.sigma4 = 1.0;
+    if constexpr (WANT_SIGMA)
+        if (b.jacobian) in.sigma4 = 4.0 * warp_eval(b.sigma, single_slice(), theta2u(in.theta_i), phi2u(in.phi_i));
     return true;
 }
 
-// eval (f cos theta_o, RGB) and / or pdf for an incident direction that is above the horizon; wo as the caller holds it
-template <bool WANT_RGB, bool WANT_PDF>
-MRL_HD void eval_pdf_at(const RglDev &b, const Incident &in, float wox, float woy, float woz, float rgb[3], float &pdf)
+// eval (f cos theta_o, RGB) and / or pdf for an incident direction that is above the horizon; wo as the caller holds it.
+// tv: where vndf's search tables are read; fv / fl (may be null): the cells of vndf / luminance a sample() has just visited.
+template <bool WANT_RGB, bool WANT_PDF, class Search>
+MRL_HD void eval_pdf_at(const RglDev &b, const Search &tv, const Incident &in, float wox, float woy, float woz, float rgb[3], float &pdf,
+                        const Found *fv = nullptr, const Found *fl = nullptr)
 {
+#pragma clang fp contract(off)
     rgb[0] = rgb[1] = rgb[2] = 0.0f; pdf = 0.0f;
     if (!(woz > 0.0f)) return;
     const Vec3d &wi = in.wi;
     Vec3d wo = { (double)(wox * in.fx), (double)(woy * in.fy), (double)woz };
     if (!unit3(wo)) return;
-    Vec3d m;
-    {
-#pragma clang fp contract(off)
-        m.x = wi.x + wo.x; m.y = wi.y + wo.y; m.z = wi.z + wo.z;
-    }
+    Vec3d m = { wi.x + wo.x, wi.y + wo.y, wi.z + wo.z };
     if (!unit3(m)) return;
     const double theta_m = elevation(m), phi_m = azimuth(m.y, m.x);
     const double u_m_x = theta2u(theta_m);
     double u_m_y = phi2u(b.isotropic ? phi_m - in.phi_i : phi_m);
     u_m_y -= floor(u_m_y);
     double sx, sy;
-    const double vndf_pdf = warp_invert(b.vndf, in.sv, u_m_x, u_m_y, sx, sy);
+    const double vndf_pdf = warp_invert(b.vndf, tv, in.sv, u_m_x, u_m_y, sx, sy, fv);
     if constexpr (WANT_RGB) {
         double scale = 1.0;
-        if (b.jacobian) {
-            const Slices one = single_slice();
-            scale = fast::div_fast(warp_eval(b.ndf, one, u_m_x, u_m_y), 4.0 * warp_eval(b.sigma, one, theta2u(in.theta_i), phi2u(in.phi_i)));
-        }
+        if (b.jacobian) scale = fast::div_fast(warp_eval(b.ndf, single_slice(), u_m_x, u_m_y), in.sigma4);
         for (int c = 0; c < 3; ++c) {
             double v = warp_eval(b.rgb, in.sv, sx, sy, c);
             v = v < 0.0 ? 0.0 : v;
@@ -300,34 +381,26 @@ MRL_HD void eval_pdf_at(const RglDev &b, const Incident &in, float wox, float wo
         }
     }
     if constexpr (WANT_PDF) {
-        const double lum_pdf = warp_eval(b.luminance, in.sv, sx, sy);
-        const double sin_theta_m = fast::sqrt_fast(m.x * m.x + m.y * m.y);
-        const double jac = fmax(2.0 * kPi * kPi * u_m_x * sin_theta_m, 1e-6) * 4.0 * (wi.x * m.x + wi.y * m.y + wi.z * m.z);
+        const double lum_pdf = warp_eval(b.luminance, in.sv, sx, sy, 0, fl);
+        const double sin_theta_m = fast::sqrt_fast(__builtin_fma(m.x, m.x, m.y * m.y));
+        const double jac = fmax(2.0 * kPi * kPi * u_m_x * sin_theta_m, 1e-6) * 4.0 * __builtin_fma(wi.x, m.x, __builtin_fma(wi.y, m.y, wi.z * m.z));
         pdf = (float)fast::div_fast(vndf_pdf * lum_pdf, jac);
     }
 }
 
-// eval (f cos theta_o, RGB) and / or pdf of one unit; every output zero outside the upper hemisphere
-template <bool WANT_RGB, bool WANT_PDF>
-MRL_HD void eval_pdf(const RglDev &b, float wix, float wiy, float wiz, float wox, float woy, float woz, float rgb[3], float &pdf)
+// sample() for an incident direction that is above the horizon
+template <class Search>
+MRL_HD void sample_at(const RglDev &b, const Search &tv, const Search &tl, const Incident &in, float u0, float u1,
+                      float wo_out[3], float &pdf_out, float weight[3])
 {
-    rgb[0] = rgb[1] = rgb[2] = 0.0f; pdf = 0.0f;
-    Incident in;
-    if (!(wiz > 0.0f) || !(woz > 0.0f) || !incident(b, wix, wiy, wiz, in)) return;
-    eval_pdf_at<WANT_RGB, WANT_PDF>(b, in, wox, woy, woz, rgb, pdf);
-}
-
-MRL_HD void sample(const RglDev &b, float wix, float wiy, float wiz, float u0, float u1, float wo_out[3], float &pdf_out, float weight[3])
-{
+#pragma clang fp contract(off)
     wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
-    Incident in;
-    if (!(wiz > 0.0f) || !incident(b, wix, wiy, wiz, in)) return;
     const Vec3d &wi = in.wi;
-    const Slices &sv = in.sv;
     const float fx = in.fx, fy = in.fy;
     double sx, sy, umx, umy;
-    (void)warp_sample(b.luminance, sv, (double)u1, (double)u0, sx, sy);
-    (void)warp_sample(b.vndf, sv, sx, sy, umx, umy);
+    Found fl, fv;
+    (void)warp_sample(b.luminance, tl, in.sv, (double)u1, (double)u0, sx, sy, fl);
+    (void)warp_sample(b.vndf, tv, in.sv, sx, sy, umx, umy, fv);
     // m = (theta_m, phi_m) with theta_m = umx^2 pi/2 and phi_m = (2 umy - 1) pi [+ phi_i]: sin / cos of 2 pi (umx^2 / 4) and
     // of 2 pi umy - pi; the isotropic offset is a rotation by wi's own azimuth (cos, sin = wi_xy / |wi_xy|), no second sincos
     double st, ct, sp, cp;
@@ -335,23 +408,43 @@ MRL_HD void sample(const RglDev &b, float wix, float wiy, float wiz, float u0, f
     fast::sincos_2pi(umy, sp, cp);
     sp = -sp; cp = -cp;
     if (b.isotropic) {
-        const double rho2 = wi.x * wi.x + wi.y * wi.y;
+        const double rho2 = __builtin_fma(wi.x, wi.x, wi.y * wi.y);
         const double rr = rho2 > 0.0 ? fast::rsqrt_pos(rho2) : 0.0;
         const double ci = rho2 > 0.0 ? wi.x * rr : (__builtin_signbit(wi.x) ? -1.0 : 1.0), si = wi.y * rr;
-        const double c2 = cp * ci - sp * si, s2 = sp * ci + cp * si;
+        const double c2 = __builtin_fma(cp, ci, -(sp * si)), s2 = __builtin_fma(sp, ci, cp * si);
         cp = c2; sp = s2;
     }
     const Vec3d m = { cp * st, sp * st, ct };
-    const double c = wi.x * m.x + wi.y * m.y + wi.z * m.z;
+    const double c = __builtin_fma(wi.x, m.x, __builtin_fma(wi.y, m.y, wi.z * m.z));
     // (the direction drawn in the stored part of the azimuth goes back through the same sign flips)
-    const float wof[3] = { (float)((2.0 * c * m.x - wi.x) * (double)fx), (float)((2.0 * c * m.y - wi.y) * (double)fy), (float)(2.0 * c * m.z - wi.z) };
+    const float wof[3] = { (float)(__builtin_fma(2.0 * c, m.x, -wi.x) * (double)fx), (float)(__builtin_fma(2.0 * c, m.y, -wi.y) * (double)fy),
+                           (float)__builtin_fma(2.0 * c, m.z, -wi.z) };
     if (!(wof[2] > 0.0f) || !(c > 0.0)) return;
     float f[3], p;
-    eval_pdf_at<true, true>(b, in, wof[0], wof[1], wof[2], f, p);          // at the Float direction that is returned
+    eval_pdf_at<true, true>(b, tv, in, wof[0], wof[1], wof[2], f, p, &fv, &fl);          // at the Float direction that is returned
     if (!(p > 0.0f)) return;
     wo_out[0] = wof[0]; wo_out[1] = wof[1]; wo_out[2] = wof[2];
     pdf_out = p;
     weight[0] = f[0] / p; weight[1] = f[1] / p; weight[2] = f[2] / p;
+}
+
+// ---- one unit through the image in memory (host images: mrl_host_*; tests/rgl_host_harness.hip) ----
+// eval (f cos theta_o, RGB) and / or pdf of one unit; every output zero outside the upper hemisphere
+template <bool WANT_RGB, bool WANT_PDF>
+MRL_HD void eval_pdf(const RglDev &b, float wix, float wiy, float wiz, float wox, float woy, float woz, float rgb[3], float &pdf)
+{
+    rgb[0] = rgb[1] = rgb[2] = 0.0f; pdf = 0.0f;
+    Incident in;
+    if (!(wiz > 0.0f) || !(woz > 0.0f) || !incident<WANT_RGB>(b, wix, wiy, wiz, in)) return;
+    eval_pdf_at<WANT_RGB, WANT_PDF>(b, SearchMem(b.vndf), in, wox, woy, woz, rgb, pdf);
+}
+
+MRL_HD void sample(const RglDev &b, float wix, float wiy, float wiz, float u0, float u1, float wo_out[3], float &pdf_out, float weight[3])
+{
+    wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
+    Incident in;
+    if (!(wiz > 0.0f) || !incident<true>(b, wix, wiy, wiz, in)) return;
+    sample_at(b, SearchMem(b.vndf), SearchMem(b.luminance), in, u0, u1, wo_out, pdf_out, weight);
 }
 
 } // namespace rgl

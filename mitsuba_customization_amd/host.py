@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("MRL_LIB_PATH") or os.path.join(_PKG, "lib", "libmerl_
 OPT_LOOKUP, OPT_NODE, OPT_DISK_MAP, OPT_KERNEL, OPT_HOST_CHUNK, OPT_TABLE_LAYOUT, OPT_SAMPLING, OPT_MEMORY_LIMIT_MB, OPT_HOST_THREADS, OPT_BLOCK_MAP = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_TABLE_PARAM = 10
 OPT_TABLE_ARENA_MB = 11
+OPT_RGL_SEARCH = 12           # 0: RGL search tables from LDS when they fit (default), 1: always from memory
 PARAM_HALF_DIFF, PARAM_STANDARD, PARAM_STANDARD_FULL = 0, 1, 2          # enum mrl_param
 SAMPLING_COSINE, SAMPLING_TABLE, SAMPLING_TABLE_2D = 0, 1, 2
 LAYOUT_ROWS, LAYOUT_BRICK = 0, 1

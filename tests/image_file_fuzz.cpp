@@ -61,8 +61,12 @@ static bool consistent(const ImageHeader &h, unsigned long long file_bytes, cons
         for (int w = 0; w < 5; ++w) {
             if (p.layout.cells[w] % 4 != 0 || p.layout.cells[w] + cells[w] * 4 > floats) return false;
             if (w == 2 || w == 3) {
-                if (p.layout.cond[w] % 4 != 0 || p.layout.cond[w] + cells[w] * 2 > floats) return false;
-                if (p.layout.rows[w] % 4 != 0 || p.layout.rows[w] + (uint64_t)(f.res[1] - 1) * slices * 4 > floats) return false;
+                // the search tables are stored per parameter bracket: n_phi x max(n_theta - 1, 1) float4 per cell, and
+                // max(n_phi - 1, 1) x max(n_theta - 1, 1) float4 per cell row
+                const uint64_t tb = f.n_theta > 1 ? f.n_theta - 1 : 1, pb = f.n_phi > 1 ? f.n_phi - 1 : 1;
+                const uint64_t per_c = (uint64_t)(f.res[0] - 1) * (f.res[1] - 1);
+                if (p.layout.cond2[w] % 4 != 0 || p.layout.cond2[w] + per_c * (uint64_t)f.n_phi * tb * 4 > floats) return false;
+                if (p.layout.margq[w] % 4 != 0 || p.layout.margq[w] + (uint64_t)(f.res[1] - 1) * pb * tb * 4 > floats) return false;
             }
         }
         if (p.layout.theta + (uint64_t)f.n_theta > floats) return false;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """What the adaptive-parameterisation (RGL) material costs: eval, pdf, sample and the fused eval+sample unit over 16M units,
-for a file of the database's isotropic shape (8 theta_i nodes, 32 x 32 warps, 128 x 128 ndf) and an anisotropic one.   python tools/rgl_rates.py > profiles/r03_rgl_rates.json"""
+for a file of the database's isotropic shape (8 theta_i nodes, 32 x 32 warps, 128 x 128 ndf) and an anisotropic one; each with the
+search tables in LDS where they fit (the default) and read from memory (MRL_OPT_RGL_SEARCH = 1).   python tools/rgl_rates.py > profiles/r04_rgl_rates.json"""
 import json
 import os
 import sys
@@ -19,16 +20,21 @@ with host.MerlHip(0) as g:
                         ("anisotropic_16x8x32x32", dict(n_phi=16, n_theta=8, res=32, res_ndf=128, res_sigma=64))):
         mid = g.upload_rgl(synth.make_rgl_fields(seed=9, **shape))
         row = {"image_bytes": g.memory_info()["table_bytes"]}
-        for what, call in (("eval", lambda: g.eval(wi, wo, material=mid)), ("pdf", lambda: g.pdf(wi, wo, material=mid)),
-                           ("sample", lambda: g.sample(wi, u, material=mid)), ("eval_sample", lambda: g.eval_sample(wi, wo, u, material=mid))):
-            for _ in range(2):
-                out = call()
-            torch.cuda.synchronize()
-            g.timer_start()
-            for _ in range(5):
-                out = call()
-            ms = g.timer_stop() / 5
-            row[what] = {"ms": round(ms, 3), "G_units_per_s": round(n / ms / 1e6, 3)}
+        for search in (0, 1):
+            g.set_option(host.OPT_RGL_SEARCH, search)
+            sub = {}
+            for what, call in (("eval", lambda: g.eval(wi, wo, material=mid)), ("pdf", lambda: g.pdf(wi, wo, material=mid)),
+                               ("sample", lambda: g.sample(wi, u, material=mid)), ("eval_sample", lambda: g.eval_sample(wi, wo, u, material=mid))):
+                for _ in range(2):
+                    out = call()
+                torch.cuda.synchronize()
+                g.timer_start()
+                for _ in range(5):
+                    out = call()
+                ms = g.timer_stop() / 5
+                sub[what] = {"ms": round(ms, 3), "G_units_per_s": round(n / ms / 1e6, 3)}
+            row["search_lds_if_it_fits" if search == 0 else "search_memory"] = sub
+        g.set_option(host.OPT_RGL_SEARCH, 0)
         res[name] = row
         g.release_material(mid)
     # a batch with material ids: a MERL-sized table, an analytic material and two RGL files, one quarter of the units each
