@@ -413,6 +413,8 @@ def _rgl_lib():
         L.rgl_bsdf_free.argtypes = [C.POINTER(RglBsdf)]
         L.rgl_eval_pdf_batch.argtypes = [C.POINTER(RglBsdf), fp, fp, C.c_size_t, fp, fp]
         L.rgl_sample_batch.argtypes = [C.POINTER(RglBsdf), fp, fp, C.c_size_t, fp, fp, fp]
+        L.rgl_half_vector.argtypes = [C.POINTER(RglBsdf), fp, fp, dp, dp]; L.rgl_half_vector.restype = C.c_int
+        L.rgl_eval_pdf_half.argtypes = [C.POINTER(RglBsdf), dp, dp, fp, fp]
         L._rgl_ready = True
     return L
 
@@ -487,6 +489,60 @@ class OracleRgl:
         wo = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32); w = np.empty((n, 3), np.float32)
         _rgl_lib().rgl_sample_batch(C.byref(self.c), pwi, pu, n, wo.ctypes.data_as(fp), pdf.ctypes.data_as(fp), w.ctypes.data_as(fp))
         return wo, pdf, w
+
+    def half_vector(self, wi, wo):
+        """One pair: (wi normalised in the stored part of the azimuth, m = wi + wo unnormalised) as the oracle's f64 arithmetic forms
+        them, or None when the pair evaluates to zero."""
+        fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        a = np.ascontiguousarray(wi, np.float32); b = np.ascontiguousarray(wo, np.float32)
+        d = np.empty(3, np.float64); m = np.empty(3, np.float64)
+        ok = _rgl_lib().rgl_half_vector(C.byref(self.c), a.ctypes.data_as(fp), b.ctypes.data_as(fp), d.ctypes.data_as(dp), m.ctypes.data_as(dp))
+        return (d, m) if ok else None
+
+    def eval_pdf_half(self, wi_unit, m):
+        """One pair from the normalised incident direction and the unnormalised half vector (f64): (rgb[3], pdf)."""
+        fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        d = np.ascontiguousarray(wi_unit, np.float64); h = np.ascontiguousarray(m, np.float64)
+        rgb = np.empty(3, np.float32); pdf = C.c_float()
+        _rgl_lib().rgl_eval_pdf_half(C.byref(self.c), d.ctypes.data_as(dp), h.ctypes.data_as(dp), rgb.ctypes.data_as(fp), C.byref(pdf))
+        return rgb, np.float32(pdf.value)
+
+    def conditioning_range(self, wi, wo, ulps=8.0):
+        """[lo, hi] of (rgb[3], pdf) over the box of half vectors the f64 arithmetic can land on: each of m's transverse components
+        carries the rounding of two normalisations and a sum, `ulps` x 1.1e-16 absolute (directions are O(1)).  eval / pdf are not
+        multilinear in m (and not monotonic in its azimuth once the box is as large as the transverse length), so the box is
+        SAMPLED: corners, edge midpoints, centre and 16 points on its circumscribed circle; None when the pair is zero."""
+        hv = self.half_vector(wi, wo)
+        if hv is None:
+            return None
+        d, m = hv
+        eta = ulps * 1.1e-16
+        offsets = [(dx, dy) for dx in (-eta, 0.0, eta) for dy in (-eta, 0.0, eta)]
+        offsets += [(1.4142 * eta * np.cos(a), 1.4142 * eta * np.sin(a)) for a in np.arange(16) * (np.pi / 8) + 0.1]
+        vals = []
+        for dx, dy in offsets:
+            rgb, pdf = self.eval_pdf_half(d, (m[0] + dx, m[1] + dy, m[2]))
+            vals.append(np.concatenate([rgb.astype(np.float64), [float(pdf)]]))
+        vals = np.array(vals)
+        return vals.min(0), vals.max(0)
+
+    def in_conditioning_range(self, what, got, wi, wo):
+        """Is `got` — one unit's "eval" (3), "pdf" (1) or "weight" (3: eval / pdf) — where an evaluation of this ill-conditioned pair
+        can land?  The sampled range of conditioning_range, widened on either side by a quarter of its width (the samples need not
+        hit the extremes) and by 2e-6 relative."""
+        r = self.conditioning_range(wi, wo)
+        if r is None:
+            return False
+        lo, hi = r
+        if what == "eval":
+            lo, hi = lo[:3], hi[:3]
+        elif what == "pdf":
+            lo, hi = lo[3:4], hi[3:4]
+        else:
+            lo, hi = lo[:3] / max(hi[3], 1e-300), hi[:3] / max(lo[3], 1e-300)
+        g = np.asarray(got, np.float64).reshape(-1)
+        slack = 0.25 * (hi - lo) + 2e-6 * np.abs(hi) + 1e-30
+        return bool(np.all((g >= lo - slack) & (g <= hi + slack)))
 
     def __del__(self):
         try:

@@ -257,16 +257,15 @@ static void reduce_pair(const rgl_bsdf *b, double wi[3], double wo[3], double fl
     wi[0] *= sx; wi[1] *= sy; wo[0] *= sx; wo[1] *= sy;
 }
 
-void rgl_eval_pdf(const rgl_bsdf *b, const float wi_f[3], const float wo_f[3], float rgb[3], float *pdf_out)
+/* eval / pdf from the normalised incident direction (already in the stored part of the azimuth) and the UNNORMALISED half vector
+ * m = wi + wo.  rgl_eval_pdf below is this after its prelude; the tests call it directly to measure conditioning: for a
+ * near-mirror pair m's transverse part is the difference of two normalisations and carries their rounding errors (a few 1e-16
+ * absolute on a length that can be 1e-9), so they evaluate it over the box of half vectors the f64 arithmetic can land on. */
+void rgl_eval_pdf_half(const rgl_bsdf *b, const double wi[3], const double m_in[3], float rgb[3], float *pdf_out)
 {
     rgb[0] = rgb[1] = rgb[2] = 0.0f;
     if (pdf_out) *pdf_out = 0.0f;
-    if (!(wi_f[2] > 0.0f) || !(wo_f[2] > 0.0f)) return;
-    double wi[3] = { wi_f[0], wi_f[1], wi_f[2] }, wo[3] = { wo_f[0], wo_f[1], wo_f[2] };
-    double flip[2];
-    reduce_pair(b, wi, wo, flip);
-    if (!unit3(wi) || !unit3(wo)) return;
-    double m[3] = { wi[0] + wo[0], wi[1] + wo[1], wi[2] + wo[2] };
+    double m[3] = { m_in[0], m_in[1], m_in[2] };
     if (!unit3(m)) return;
     const double theta_i = elevation(wi), phi_i = atan2(wi[1], wi[0]);
     const double theta_m = elevation(m), phi_m = atan2(m[1], m[0]);
@@ -289,6 +288,27 @@ void rgl_eval_pdf(const rgl_bsdf *b, const float wi_f[3], const float wo_f[3], f
         const double jac = fmax(2.0 * M_PI * M_PI * u_m[0] * sin_theta_m, 1e-6) * 4.0 * (wi[0] * m[0] + wi[1] * m[1] + wi[2] * m[2]);
         *pdf_out = (float)(vndf_pdf * lum_pdf / jac);
     }
+}
+
+/* the prelude alone: wi, wo in the stored part of the azimuth and normalised, m = wi + wo; 0 when the pair evaluates to zero */
+int rgl_half_vector(const rgl_bsdf *b, const float wi_f[3], const float wo_f[3], double wi[3], double m[3])
+{
+    if (!(wi_f[2] > 0.0f) || !(wo_f[2] > 0.0f)) return 0;
+    double wo[3] = { wo_f[0], wo_f[1], wo_f[2] }, flip[2];
+    wi[0] = wi_f[0]; wi[1] = wi_f[1]; wi[2] = wi_f[2];
+    reduce_pair(b, wi, wo, flip);
+    if (!unit3(wi) || !unit3(wo)) return 0;
+    m[0] = wi[0] + wo[0]; m[1] = wi[1] + wo[1]; m[2] = wi[2] + wo[2];
+    return 1;
+}
+
+void rgl_eval_pdf(const rgl_bsdf *b, const float wi_f[3], const float wo_f[3], float rgb[3], float *pdf_out)
+{
+    rgb[0] = rgb[1] = rgb[2] = 0.0f;
+    if (pdf_out) *pdf_out = 0.0f;
+    double wi[3], m[3];
+    if (!rgl_half_vector(b, wi_f, wo_f, wi, m)) return;
+    rgl_eval_pdf_half(b, wi, m, rgb, pdf_out);
 }
 
 void rgl_sample(const rgl_bsdf *b, const float wi_f[3], const float u[2], float wo_out[3], float *pdf_out, float weight[3])

@@ -36,6 +36,10 @@ int  rgl_bsdf_init(rgl_bsdf *b, int n_phi, int n_theta, const float *phi_i, cons
 void rgl_bsdf_free(rgl_bsdf *b);
 /* eval: f cos(theta_o) (RGB); pdf_out may be NULL */
 void rgl_eval_pdf(const rgl_bsdf *b, const float wi[3], const float wo[3], float rgb[3], float *pdf_out);
+/* rgl_eval_pdf in its two steps (for the tests' conditioning range): the prelude — both directions into the stored part of the
+ * azimuth, normalised, m = wi + wo unnormalised; returns 0 when the pair evaluates to zero — and the evaluation from (wi, m) */
+int  rgl_half_vector(const rgl_bsdf *b, const float wi_f[3], const float wo_f[3], double wi[3], double m[3]);
+void rgl_eval_pdf_half(const rgl_bsdf *b, const double wi[3], const double m[3], float rgb[3], float *pdf_out);
 void rgl_sample(const rgl_bsdf *b, const float wi[3], const float u[2], float wo[3], float *pdf, float weight[3]);
 void rgl_eval_pdf_batch(const rgl_bsdf *b, const float *wi, const float *wo, size_t n, float *rgb, float *pdf);
 void rgl_sample_batch(const rgl_bsdf *b, const float *wi, const float *u, size_t n, float *wo, float *pdf, float *weight);

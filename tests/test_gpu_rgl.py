@@ -1,8 +1,13 @@
 """The adaptive-parameterisation measured BSDF (RGL *.bsdf fields; upstream Mitsuba 3 `measured`) on the GPU against the
 CPU restatement oracle/rgl_oracle.c.  PARITY UNPINNED: no RGL file and no upstream source exist offline; the oracle is pinned
 by the self-consistency KATs of tests/test_rgl_cpu.py only, and the tables are synthetic (synth.make_rgl_fields).
-Tolerance: 1e-6 relative (+1e-7 of the output's scale) — both sides compute in f64 on the same Float tables and differ by
-FMA contraction and libm-vs-ocml rounding before one rounding to Float."""
+Tolerance: north_star's — |gpu - oracle| <= 1e-6 |oracle| for EVERY value (both sides compute in f64 on the same Float tables
+and differ by FMA use and libm-vs-polynomial rounding before one rounding to Float).  The one family that cannot meet it is
+ill-conditioned on BOTH sides: for a near-mirror pair the half vector's transverse part is the difference of two
+normalisations (1e-16 of rounding on a length that can be 1e-9), its azimuth then carries a handful of significant bits
+whichever arithmetic forms it.  A value outside 1e-6 must lie inside the range the ORACLE spans over that rounding box
+(OracleRgl.in_conditioning_range: 8 f64 ulps on the half vector's transverse components, 25 sample points, widened by a
+quarter of its width — the analogue of test_gpu_parity.py::_conditioning_range for the tables)."""
 import numpy as np
 import pytest
 
@@ -15,11 +20,22 @@ CASES = [dict(seed=1, n_phi=1, n_theta=6, res=12, res_ndf=16, res_sigma=8),     
          dict(seed=5, n_phi=3, n_theta=3, res=6, res_ndf=6, res_sigma=4, reduction=4)]   # phi_i in [-pi, -pi/2]: two mirror planes
 
 
-def _close(a, b, what):
+def _close(a, b, what, orc=None, wi=None, wo=None, max_ill=0):
+    """Every value within 1e-6 relative of the oracle's.  With (orc, wi, wo): a unit that is not must be ill-conditioned — all of
+    its values inside the oracle's own rounding range — and there may be at most max_ill such units.  `what`: "eval" (n x 3),
+    "pdf" (n), "weight" (n x 3: eval / pdf)."""
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    scale = max(float(np.abs(b).max()), 1e-30)
-    err = np.abs(a - b) / (np.abs(b) + 1e-1 * scale)
-    assert float(err.max()) < 1e-6, (what, float(err.max()), int(err.argmax()))
+    ok = np.abs(a - b) <= 1e-6 * np.abs(b) + 1e-30
+    if ok.all():
+        return 0
+    rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-30)
+    assert orc is not None, (what, float(rel.max()), int(rel.argmax()))
+    bad = np.nonzero(~ok.reshape(a.shape[0], -1).all(axis=1))[0]
+    assert bad.size <= max_ill, (what, bad.size, float(rel.max()))
+    kind = "pdf" if "pdf" in what else what
+    for i in bad:
+        assert orc.in_conditioning_range(kind, a[i], wi[i], wo[i]), (what, int(i), a[i].tolist(), b[i].tolist(), orc.conditioning_range(wi[i], wo[i]))
+    return int(bad.size)
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"phi{c['n_phi']}_theta{c['n_theta']}_res{c['res']}_red{c.get('reduction', 1)}")
@@ -39,7 +55,7 @@ def test_eval_pdf_sample_match_the_oracle(case):
         pdf = g.pdf(wi_t, wo_t, material=mid).cpu().numpy()
         o_rgb, o_pdf = orc.eval_pdf(wi, wo)
         assert float(o_rgb.max()) > 0 and float(o_pdf.max()) > 0
-        _close(rgb, o_rgb, "eval"); _close(pdf, o_pdf, "pdf")
+        _close(rgb, o_rgb, "eval", orc, wi, wo, max_ill=2); _close(pdf, o_pdf, "pdf", orc, wi, wo, max_ill=2)
         wo2, pdf2, w = (t.cpu().numpy() for t in g.sample(wi_t, u_t, material=mid))
         o_wo2, o_pdf2, o_w = orc.sample(wi, u)
         live = o_pdf2 > 0
@@ -50,14 +66,24 @@ def test_eval_pdf_sample_match_the_oracle(case):
         # eval / pdf are steep functions of direction near the specular peak: compare what each side reports AT ITS OWN direction
         # with the oracle evaluated there
         c_rgb, c_pdf = orc.eval_pdf(wi[both], wo2[both])
-        _close(pdf2[both], c_pdf, "sample pdf")
-        _close(w[both], c_rgb / c_pdf[:, None], "sample weight")
+        _close(pdf2[both], c_pdf, "sample pdf", orc, wi[both], wo2[both], max_ill=2)
+        _close(w[both], c_rgb / c_pdf[:, None], "weight", orc, wi[both], wo2[both], max_ill=2)
         # the fused entry points agree bit for bit with the separate ones
         f_rgb, f_pdf = g.eval_pdf(wi_t, wo_t, material=mid)
         assert np.array_equal(f_rgb.cpu().numpy().view(np.int32), rgb.view(np.int32)) and np.array_equal(f_pdf.cpu().numpy().view(np.int32), pdf.view(np.int32))
         es = [t.cpu().numpy() for t in g.eval_sample(wi_t, wo_t, u_t, material=mid)]
         for got, want in zip(es, (rgb, pdf, wo2, pdf2, w)):
             assert np.array_equal(got.view(np.int32), want.view(np.int32))
+        # the search tables read from memory (bracket form) instead of the copy in LDS: the same bits from every entry point
+        assert g.get_option(host.OPT_RGL_SEARCH) == 0
+        g.set_option(host.OPT_RGL_SEARCH, 1)
+        for got, want in zip([t.cpu().numpy() for t in g.eval_sample(wi_t, wo_t, u_t, material=mid)], (rgb, pdf, wo2, pdf2, w)):
+            assert np.array_equal(got.view(np.int32), want.view(np.int32))
+        for got, want in zip([t.cpu().numpy() for t in g.sample(wi_t, u_t, material=mid)], (wo2, pdf2, w)):
+            assert np.array_equal(got.view(np.int32), want.view(np.int32))
+        assert np.array_equal(g.eval(wi_t, wo_t, material=mid).cpu().numpy().view(np.int32), rgb.view(np.int32))
+        assert np.array_equal(g.pdf(wi_t, wo_t, material=mid).cpu().numpy().view(np.int32), pdf.view(np.int32))
+        g.set_option(host.OPT_RGL_SEARCH, 0)
         # pdf(wi, sample.wo) == sample.pdf, weight == eval / pdf — on the device's own outputs
         import torch
         wo2_t = torch.from_numpy(wo2).to(wi_t.device)
@@ -209,4 +235,64 @@ def test_rgl_golden_fixtures(name):
     assert float(np.abs(wo2 - z["wo2"])[(pdf2 > 0) & (z["pdf2"] > 0)].max()) < 5e-7
     same = (wo2.view(np.int32) == z["wo2"].view(np.int32)).all(axis=1) & (pdf2 > 0)
     assert same.mean() > 0.6
-    _close(pdf2[same], z["pdf2"][same], "sample pdf"); _close(w[same], z["weight"][same], "sample weight")
+    _close(pdf2[same], z["pdf2"][same], "sample pdf"); _close(w[same], z["weight"][same], "weight")
+
+
+def _near_mirror_pairs(rng, n):
+    """Pairs around the specular configuration wo = (-wi.x, -wi.y, wi.z): the exact mirror direction in Float, and that direction
+    moved by 1 .. 64 Float ulps in one or two components; incidences from the normal to grazing (cos theta_i down to 1e-4)."""
+    z = np.concatenate([rng.uniform(0.05, 1.0, n // 2), 10.0 ** rng.uniform(-4, -1.3, n - n // 2)])
+    phi = rng.uniform(0, 2 * np.pi, n)
+    r = np.sqrt(np.maximum(1.0 - z * z, 0.0))
+    wi = np.stack([r * np.cos(phi), r * np.sin(phi), z], 1).astype(np.float32)
+    wo = wi * np.array([-1, -1, 1], np.float32)
+    k = rng.choice([0, 1, 2, 5, 17, 64], n)
+    axis = rng.integers(0, 3, n)
+    both = rng.random(n) < 0.3
+    bits = wo.view(np.int32).copy()
+    rows = np.arange(n)
+    bits[rows, axis] += k * rng.choice([-1, 1], n)
+    bits[rows[both], (axis[both] + 1) % 3] += k[both]
+    wo = bits.view(np.float32)
+    wo[:, 2] = np.abs(wo[:, 2])
+    return wi, np.ascontiguousarray(wo)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3]], ids=["isotropic", "anisotropic", "half_azimuth"])
+def test_near_mirror_pairs_lie_in_the_oracles_rounding_range(case):
+    """The ill-conditioned family, bounded: every value of every near-mirror pair is within 1e-6 of the oracle or inside the range the
+    oracle itself spans over the rounding box of its half vector; and the well-conditioned majority (transverse half-vector length
+    above 1e-6) meets 1e-6 without exception."""
+    import torch
+    from mitsuba_customization_amd import host, synth
+    from oracle.binding import OracleRgl
+    fields = synth.make_rgl_fields(**case)
+    orc = OracleRgl(fields)
+    wi, wo = _near_mirror_pairs(np.random.default_rng(4242 + case["seed"]), 20000)
+    with host.MerlHip(0) as g:
+        mid = g.upload_rgl(fields)
+        rgb, pdf = (t.cpu().numpy() for t in g.eval_pdf(torch.from_numpy(wi).cuda(), torch.from_numpy(wo).cuda(), material=mid))
+    o_rgb, o_pdf = orc.eval_pdf(wi, wo)
+    assert float(o_pdf.max()) > 0 and np.isfinite(rgb).all() and np.isfinite(pdf).all()
+    a = wi.astype(np.float64); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = wo.astype(np.float64); b /= np.linalg.norm(b, axis=1, keepdims=True)
+    m = a + b
+    t = np.hypot(m[:, 0], m[:, 1]) / np.linalg.norm(m, axis=1)
+    well = t > 1e-6
+    assert 0.2 < well.mean() < 0.98
+    _close(rgb[well], o_rgb[well], "eval"); _close(pdf[well], o_pdf[well], "pdf")
+    n_ill = _close(rgb[~well], o_rgb[~well], "eval", orc, wi[~well], wo[~well], max_ill=int((~well).sum()))
+    n_ill += _close(pdf[~well], o_pdf[~well], "pdf", orc, wi[~well], wo[~well], max_ill=int((~well).sum()))
+    print(f"near-mirror pairs: {int((~well).sum())} with a transverse half vector below 1e-6, {n_ill} values beyond 1e-6, all inside the oracle's rounding range")
+
+
+def test_parity_soak_measure_at_a_few_rounds():
+    """tools/fuzz_parity_rgl.py's measure (random file shapes and entry points; strict 1e-6 relative, the conditioning range for the
+    rest) at 8 rounds x 2^15 units: nothing outside."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_parity_rgl", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "fuzz_parity_rgl.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    res = mod.soak(8, 1 << 15)
+    assert res["outside_the_oracles_rounding_range"] == {k: 0 for k in res["outside_the_oracles_rounding_range"]}, res
+    assert res["sampled_above_horizon_mismatches"] <= 2 and res["beyond_1e-6 (direction: 5e-7 absolute)"]["direction_abs"] == 0, res
+    assert res["beyond_1e-6 (direction: 5e-7 absolute)"]["eval"] == 0 and res["beyond_1e-6 (direction: 5e-7 absolute)"]["pdf"] == 0, res

@@ -1,15 +1,18 @@
 #!/bin/bash
-# What bounds the RGL kernels: SQ issue / wait counters and the texture addresser / L1 (TA, TCP) busy counters of
-# tools/rgl_rates.py's launches (counters only with --kernel-trace, one group per run).
-#   usage (GPU box): bash tools/pmc_rgl.sh <outdir>
+# What bounds the RGL kernels: SQ issue / wait / LDS counters and the texture addresser / L1 (TA, TCP) counters of the four entry
+# points, per file shape (isotropic 8 x 32 x 32, anisotropic 16 x 8 x 32 x 32) and search mode (tables in LDS / in memory) —
+# counters only with --kernel-trace, one group per run (MI355X guide).
+#   usage (GPU box): bash tools/pmc_rgl.sh <outdir>      then: python3 tools/pmc_rgl_summary.py <outdir> > profiles/r04_rgl_pmc.json
 set -o pipefail
 OUT=$(realpath -m "$1"); REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$OUT"; cd /tmp && export TMPDIR=/tmp
-run() { local name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$REPO/tools/rgl_rates.py" > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
-  echo "pass $name ok"; }
-run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD &&
-run sq2 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM GRBM_GUI_ACTIVE SQ_INSTS_VALU_TRANS_F64 &&
-run ta TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum || exit 1
-python3 "$REPO/tools/pmc_summary.py" "$OUT" k_rgl > "$OUT/summary.json" || true
+run() { local cfg=$1 shape=$2 search=$3 name=$4; shift 4
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$cfg/$name" -- python3 "$REPO/tools/rgl_pmc_driver.py" $shape $search > "$OUT/$cfg.$name.log" 2>&1 || { echo "pass $cfg $name failed"; tail -5 "$OUT/$cfg.$name.log"; return 1; }
+  echo "pass $cfg $name ok"; }
+for cfg in isotropic:lds isotropic:memory anisotropic:memory; do
+  shape=${cfg%%:*}; search=${cfg##*:}; c=${shape}_${search}
+  run $c $shape $search sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD &&
+  run $c $shape $search sq2 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT &&
+  run $c $shape $search ta TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum || exit 1
+done
 echo ok

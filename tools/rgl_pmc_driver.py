@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""One RGL material, one search mode, the four entry points three times each over 16M random units: the process tools/pmc_rgl.sh
+profiles (kernel names then tell the entry points apart; file shape and search mode are the run's).
+    python tools/rgl_pmc_driver.py isotropic|anisotropic lds|memory"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from mitsuba_customization_amd import host, synth
+
+shape = {"isotropic": dict(n_phi=1, n_theta=8, res=32, res_ndf=128, res_sigma=64),
+         "anisotropic": dict(n_phi=16, n_theta=8, res=32, res_ndf=128, res_sigma=64)}[sys.argv[1]]
+search = {"lds": 0, "memory": 1}[sys.argv[2]]
+n = 16 << 20
+with host.MerlHip(0) as g:
+    g.use_torch_stream()
+    g.set_option(host.OPT_RGL_SEARCH, search)
+    wi, wo, u = g.generate_pairs(0x5EED, 0, n)
+    mid = g.upload_rgl(synth.make_rgl_fields(seed=9, **shape))
+    for _ in range(3):
+        g.eval(wi, wo, material=mid); g.pdf(wi, wo, material=mid); g.sample(wi, u, material=mid); g.eval_sample(wi, wo, u, material=mid)
+    torch.cuda.synchronize()
+print("ok")
