@@ -79,6 +79,7 @@ enum mrl_status {
  * its half-vector lobe is flat there (p_h = cos(theta_h) / pi) — valid, not variance-reducing. */
 enum mrl_param { MRL_PARAM_HALF_DIFF = 0, MRL_PARAM_STANDARD = 1, MRL_PARAM_STANDARD_FULL = 2 };
 
+enum mrl_negative { MRL_NEGATIVE_CLAMP = 0, MRL_NEGATIVE_KEEP = 1, MRL_NEGATIVE_RENORMALISE = 2 };
 enum mrl_option {
     MRL_OPT_LOOKUP = 0,        /* 0 nearest (BRDFRead), 1 trilinear (default) */
     MRL_OPT_NODE = 1,          /* trilinear node position: 0 integer coordinate (default), 1 texel centre */
@@ -120,6 +121,21 @@ enum mrl_option {
                                   (conditional / marginal running integrals): 0 (default) a copy in the CU's LDS when they fit
                                   (125 KB for the database's isotropic 8 x 32 x 32 shape), 1 always memory.  Same results bit
                                   for bit; the option exists so that both paths can be measured and tested. */
+    MRL_OPT_COSINE_FACTOR = 13, /* SURVEY.md Appendix B 4 — does the plugin's eval() multiply the BRDF by cos(theta_o)?  0 (default,
+                                  upstream Mitsuba's convention): eval() = f cos(theta_o); 1: eval() = f alone — from eval() and from
+                                  the eval() inside sample()'s weight (weight == eval / pdf stays true).  Table materials (MERL,
+                                  customized_measurement, n-channel); GGX and RGL materials follow their upstream plugins, whose
+                                  convention is known.  May be changed at any time (it is applied per call). */
+    MRL_OPT_NEGATIVE = 14,     /* SURVEY.md Appendix B 2 — what a negative stored value (MERL's marker for a sample that was not
+                                  measured) does to a lookup (enum mrl_negative): 0 MRL_NEGATIVE_CLAMP (default) it counts as 0;
+                                  1 MRL_NEGATIVE_KEEP it is used as stored (what BRDFRead itself does — it only prints a warning):
+                                  eval() can come out negative; 2 MRL_NEGATIVE_RENORMALISE it is left out: a trilinear lookup blends
+                                  the valid corners only and divides by their weight, per channel (0 when no corner is valid), a
+                                  nearest lookup returns 0.  Clamping happens when a table's image is built, so 0 <-> {1, 2} can only
+                                  be switched while the context holds no table (1 <-> 2 at any time); the sampling marginals
+                                  (MRL_OPT_SAMPLING) are built from clamped values under every setting.  With 2 the batch calls run the
+                                  generic kernel for nearest lookups and rows-layout tables and the LDS-DMA kernel for trilinear lookups
+                                  on bricks, whatever MRL_OPT_KERNEL says. */
     MRL_OPT_MEMORY_LIMIT_MB = 7 /* budget for the context's resident material data (tables + sampling marginals), in MiB;
                                   0 (default) = no budget, the device's free memory is the limit.  An upload that would
                                   exceed the budget — or the device — fails with MRL_ERR_OOM and leaves the context as it

@@ -48,13 +48,17 @@ inline void check(mrl_ctx *ctx, int rc, const char *what)
 struct ContextKey {
     int device, lookup, node, disk_map;
     int sampling = 0;              // 0 cosine hemisphere, 1 table importance sampling (MRL_OPT_SAMPLING)
+    int cosine = 0;                // MRL_OPT_COSINE_FACTOR: 0 eval() = f cos(theta_o), 1 eval() = f      
+    int negative = 0;              // MRL_OPT_NEGATIVE: 0 clamp, 1 keep, 2 skip and renormalise             
     bool operator<(const ContextKey &o) const
     {
         if (device != o.device) return device < o.device;
         if (lookup != o.lookup) return lookup < o.lookup;
         if (node != o.node) return node < o.node;
         if (disk_map != o.disk_map) return disk_map < o.disk_map;
-        return sampling < o.sampling;
+        if (sampling != o.sampling) return sampling < o.sampling;
+        if (cosine != o.cosine) return cosine < o.cosine;
+        return negative < o.negative;
     }
 };
 
@@ -72,6 +76,8 @@ public:
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_NODE, key.node), "mrl_set_option(node)");
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_DISK_MAP, key.disk_map), "mrl_set_option(disk_map)");
         check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_SAMPLING, key.sampling), "mrl_set_option(sampling)");
+        check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_COSINE_FACTOR, key.cosine), "mrl_set_option(cosine factor)");
+        check(m_ctx, mrl_set_option(m_ctx, MRL_OPT_NEGATIVE, key.negative), "mrl_set_option(negative values)");     // before the first table
         // scenes with many measured materials: MERL_TABLE_ARENA_MB=<MB> places their tables back to back in one device
         // allocation (multi-table launches are bound by address translation)
         if (const char *mb = std::getenv("MERL_TABLE_ARENA_MB")) {
@@ -193,8 +199,8 @@ inline std::string image_cache_name(const std::string &source, const std::string
     struct stat st;
     if (::stat(source.c_str(), &st) != 0) return std::string();
     char tag[512];
-    std::snprintf(tag, sizeof tag, "|%lld|%lld.%09ld|%s|l%d|n%d", (long long)st.st_size, (long long)st.st_mtim.tv_sec, (long)st.st_mtim.tv_nsec,
-                  what.c_str(), key.lookup, key.node);
+    std::snprintf(tag, sizeof tag, "|%lld|%lld.%09ld|%s|l%d|n%d|v%d", (long long)st.st_size, (long long)st.st_mtim.tv_sec, (long)st.st_mtim.tv_nsec,
+                  what.c_str(), key.lookup, key.node, key.negative == 0 ? 0 : 1);        // (an image holds clamped or raw values)
     unsigned long long h = 0xCBF29CE484222325ull;
     for (const std::string &part : { source, std::string(tag) })
         for (unsigned char c : part) h = (h ^ c) * 0x100000001B3ull;
@@ -428,6 +434,21 @@ inline bool parse_scalar_cpu(const std::string &s)
     if (s == "cpu") return true;
     if (s == "gpu") return false;
     throw Error(MRL_ERR_INVALID, "scalar must be \"cpu\" or \"gpu\", got \"" + s + "\"");
+}
+// `cosine_factor` — does eval() include cos(theta_o)?
+inline int parse_cosine_factor(const std::string &s)
+{
+    if (s == "included" || s == "true") return 0;
+    if (s == "omitted" || s == "false") return 1;
+    throw Error(MRL_ERR_INVALID, "cosine_factor must be \"included\" or \"omitted\", got \"" + s + "\"");
+}
+// `negative_values` — what a negative stored value (a sample that was not measured) does to a lookup
+inline int parse_negative_values(const std::string &s)
+{
+    if (s == "clamp") return MRL_NEGATIVE_CLAMP;
+    if (s == "keep") return MRL_NEGATIVE_KEEP;
+    if (s == "renormalize" || s == "renormalise") return MRL_NEGATIVE_RENORMALISE;
+    throw Error(MRL_ERR_INVALID, "negative_values must be \"clamp\", \"keep\" or \"renormalize\", got \"" + s + "\"");
 }
 inline int parse_node(const std::string &s)
 {

@@ -40,6 +40,9 @@ public:
         m_key.node = merl_gpu::parse_node(props.getString("node", "integer"));
         m_key.disk_map = 0;                       // Mitsuba 0.6's squareToUniformDiskConcentric flavour
         m_key.sampling = merl_gpu::parse_sampling(props.getString("sampling", "cosine"));
+        // the conventions only the missing reference source could settle, as properties
+        m_key.cosine = merl_gpu::parse_cosine_factor(props.getString("cosine_factor", "included"));
+        m_key.negative = merl_gpu::parse_negative_values(props.getString("negative_values", "clamp"));
     }
 
     // Unserialising constructor (network rendering: the scene object arrives at a worker as a stream).  The
@@ -54,7 +57,10 @@ public:
         m_key.node = stream->readInt();
         m_key.disk_map = 0;
         m_key.sampling = stream->readInt();
-        if (m_key.lookup < 0 || m_key.lookup > 1 || m_key.node < 0 || m_key.node > 1 || m_key.sampling < 0 || m_key.sampling > 2)
+        m_key.cosine = stream->readInt();
+        m_key.negative = stream->readInt();
+        if (m_key.lookup < 0 || m_key.lookup > 1 || m_key.node < 0 || m_key.node > 1 || m_key.sampling < 0 || m_key.sampling > 2 ||
+            m_key.cosine < 0 || m_key.cosine > 1 || m_key.negative < 0 || m_key.negative > 2)
             throw merl_gpu::Error(MRL_ERR_INVALID, "corrupt serialised BSDF");
     }
 
@@ -67,6 +73,8 @@ public:
         stream->writeInt(m_key.lookup);
         stream->writeInt(m_key.node);
         stream->writeInt(m_key.sampling);
+        stream->writeInt(m_key.cosine);
+        stream->writeInt(m_key.negative);
     }
 
     void configure() override

@@ -50,6 +50,9 @@ public:
         m_key.node = merl_gpu::parse_node(props.string("node", "integer"));
         m_key.disk_map = 1;                       // Mitsuba 3's square_to_uniform_disk_concentric flavour
         m_key.sampling = merl_gpu::parse_sampling(props.string("sampling", "cosine"));
+        // the conventions only the missing reference source could settle, as properties
+        m_key.cosine = merl_gpu::parse_cosine_factor(props.string("cosine_factor", "included"));
+        m_key.negative = merl_gpu::parse_negative_values(props.string("negative_values", "clamp"));
         m_cpu_scalar = merl_gpu::parse_scalar_cpu(props.string("scalar", "cpu"));
         this->m_flags = BSDFFlags::GlossyReflection | BSDFFlags::FrontSide;
         this->m_components.push_back(this->m_flags);

@@ -59,6 +59,19 @@ int main(int argc, char **argv)
     if (argc > 11) props.set_string("parameterization", argv[11]);
     // where the scalar virtual calls evaluate: MERL_DRIVER_SCALAR = cpu | gpu (unset: the plugin's default, cpu)
     if (const char *sc = std::getenv("MERL_DRIVER_SCALAR")) props.set_string("scalar", sc);
+    // further string properties: MERL_DRIVER_PROPS = name=value[,name=value ...]  (e.g. cosine_factor=omitted,negative_values=keep)
+    if (const char *more = std::getenv("MERL_DRIVER_PROPS")) {
+        std::string all(more);
+        size_t at = 0;
+        while (at < all.size()) {
+            size_t end = all.find(',', at);
+            if (end == std::string::npos) end = all.size();
+            const std::string item = all.substr(at, end - at);
+            const size_t eq = item.find('=');
+            if (eq != std::string::npos) props.set_string(item.substr(0, eq), item.substr(eq + 1));
+            at = end + 1;
+        }
+    }
     ScalarBSDF *bsdf = nullptr;
     try {
         bsdf = static_cast<ScalarBSDF *>(create(props));

@@ -40,6 +40,7 @@ struct MaterialHost {
     size_t bytes = 0;                // device bytes this material holds (table + sampling marginal)
     mrl::RglDev rgl{};               // KIND_RGL: the five functions' descriptor (pointers into d_texels)
     bool released = false;           // tombstone left by mrl_material_release; the slot may be reused
+    int rows_lookup = 1, rows_node = 0;      // the lookup / node options the conditional sampling rows were integrated under (at upload)
 };
 
 // Row marginal for table importance sampling (definition: oracle/merl_oracle.h):
@@ -197,7 +198,7 @@ struct mrl_ctx {
     size_t memory_limit = 0;         // MRL_OPT_MEMORY_LIMIT_MB in bytes; 0 = none
     // what a tombstone points at: one all-zero cell (valid in both layouts) + a 1-row sampling marginal
     void *d_dummy = nullptr;
-    mrl::Options opts{ 1, 0, 0, 0 };
+    mrl::Options opts{ 1, 0, 0, 0, 0, 0 };
     int kernel_variant = 3;          // MRL_OPT_KERNEL default: cooperative LDS-DMA brick fetch
     int table_layout = 1;            // layout of tables uploaded from now on (mrl::Layout)
     int table_param = 0;             // parameterisation of customized_measurement tables uploaded from now on (mrl::Param)
@@ -425,7 +426,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     hipError_t e = table_alloc(ctx, out_texels * sizeof(float4), &m.d_texels, &m.in_arena);
     const bool oom = e == hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMemcpyAsync(d_planar, planar, 3 * plane * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = mrl::launch_build_table(d_planar, dims, scale, layout, param, m.d_texels, ctx->compute_units, ctx->stream);
+    if (e == hipSuccess) e = mrl::launch_build_table(d_planar, dims, scale, layout, param, ctx->opts.negative == mrl::NEGATIVE_CLAMP, m.d_texels, ctx->compute_units, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_planar);
     if (e != hipSuccess) {
@@ -473,6 +474,7 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
         }
         m.dev.sampling2d = m.d_sampling2d;
         m.dev.n_ti = n_ti;
+        m.rows_lookup = ctx->opts.lookup; m.rows_node = ctx->opts.node;
         m.bytes += (size_t)n_ti * (2 * (size_t)n_th + 1) * sizeof(double);
     }
     rc = place_material(ctx, m, out_id);
@@ -893,7 +895,7 @@ int upload_table_nch(mrl_ctx *ctx, const double *planar, const int dims[3], int 
     const bool oom = e == hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMemcpyAsync(d_planar, planar, (size_t)n_ch * plane * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_scale, scale, (size_t)n_ch * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = mrl::launch_build_table_nch(d_planar, d_scale, dims, n_ch, ctx->table_param, m.d_texels, ctx->compute_units, ctx->stream);
+    if (e == hipSuccess) e = mrl::launch_build_table_nch(d_planar, d_scale, dims, n_ch, ctx->table_param, ctx->opts.negative == mrl::NEGATIVE_CLAMP, m.d_texels, ctx->compute_units, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_planar);
     if (e != hipSuccess) {
@@ -1190,6 +1192,17 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
         case MRL_OPT_HOST_THREADS: if (value < 0 || value > 64) break; ctx->host_threads = value; return MRL_OK;
         case MRL_OPT_BLOCK_MAP: if (value < 0 || value > 1) break; ctx->block_map = value; return MRL_OK;
         case MRL_OPT_RGL_SEARCH: if (value < 0 || value > 1) break; ctx->rgl_search = value; return MRL_OK;
+        case MRL_OPT_COSINE_FACTOR: if (value < 0 || value > 1) break; ctx->opts.cosine = value; return MRL_OK;
+        case MRL_OPT_NEGATIVE: {
+            if (value < 0 || value > 2) break;
+            // the policy decides what a table's image holds (clamped or raw values): context-wide, like the layout
+            if ((value == mrl::NEGATIVE_CLAMP) != (ctx->opts.negative == mrl::NEGATIVE_CLAMP))
+                for (const auto &m : ctx->materials)
+                    if (!m.released && (m.dev.kind == mrl::KIND_MERL || m.dev.kind == mrl::KIND_TABLE || m.dev.kind == mrl::KIND_TABLE_NCH))
+                        return fail(ctx, MRL_ERR_INVALID, "clamping negative values is decided when a table is built: set MRL_OPT_NEGATIVE before the first table is uploaded");
+            ctx->opts.negative = value;
+            return MRL_OK;
+        }
         case MRL_OPT_HOST_CHUNK: if (value < 1) break; ctx->host_chunk = (size_t)value; return MRL_OK;
         case MRL_OPT_TABLE_PARAM: if (value < 0 || value > 2) break; ctx->table_param = value; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: {
@@ -1220,6 +1233,8 @@ int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
         case MRL_OPT_HOST_THREADS: *value = ctx->host_threads; return MRL_OK;
         case MRL_OPT_BLOCK_MAP: *value = ctx->block_map; return MRL_OK;
         case MRL_OPT_RGL_SEARCH: *value = ctx->rgl_search; return MRL_OK;
+        case MRL_OPT_COSINE_FACTOR: *value = ctx->opts.cosine; return MRL_OK;
+        case MRL_OPT_NEGATIVE: *value = ctx->opts.negative; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: *value = (int)ctx->host_chunk; return MRL_OK;
         case MRL_OPT_TABLE_PARAM: *value = ctx->table_param; return MRL_OK;
         case MRL_OPT_TABLE_LAYOUT: *value = ctx->table_layout; return MRL_OK;
@@ -1420,7 +1435,9 @@ int mrl_material_save_image(mrl_ctx *ctx, int id, const char *path)
     std::memset(&h, 0, sizeof h);
     std::memcpy(h.magic, kImageMagic, 8);
     h.header_bytes = (uint32_t)sizeof h; h.kind = (uint32_t)d.kind; h.layout = (uint32_t)d.layout; h.n_ch = (uint32_t)d.n_ch; h.param = (uint32_t)d.param;
-    h.lookup = (uint32_t)ctx->opts.lookup; h.node = (uint32_t)ctx->opts.node; h.n_ti = (uint32_t)d.n_ti;
+    // (the conditional rows are stamped with the options they were integrated under — at upload —, not with today's)
+    h.lookup = (uint32_t)mh.rows_lookup; h.node = (uint32_t)mh.rows_node; h.n_ti = (uint32_t)d.n_ti;
+    h.negative = d.kind == mrl::KIND_RGL ? 0u : (uint32_t)ctx->opts.negative;
     h.dims[0] = d.n_th; h.dims[1] = d.n_td; h.dims[2] = d.n_pd;
     if (d.kind == mrl::KIND_RGL) {
         const mrl::RglDev &r = mh.rgl;
@@ -1481,7 +1498,7 @@ int mrl_material_load_image(mrl_ctx *ctx, const char *path, int *out_id)
     const long long file_bytes = (long long)std::ftell(f);
     // everything the header implies, computed from its shapes (merl_image_file.hpp: the part that is fuzzed on the CPU)
     mrl::ImagePlan plan;
-    if (const char *why = mrl::image_plan(h, (unsigned long long)file_bytes, ctx->opts.lookup, ctx->opts.node, plan)) return refuse(why);
+    if (const char *why = mrl::image_plan(h, (unsigned long long)file_bytes, ctx->opts.lookup, ctx->opts.node, ctx->opts.negative, plan)) return refuse(why);
     if (std::fseek(f, (long)sizeof h, SEEK_SET) != 0) return refuse("seek failed");
     const bool is_rgl = plan.is_rgl, is_nch = plan.is_nch;
     const uint64_t texel_bytes = plan.texel_bytes, sampling_doubles = plan.sampling_doubles, sampling2d_doubles = plan.sampling2d_doubles;
@@ -1554,6 +1571,7 @@ int mrl_material_load_image(mrl_ctx *ctx, const char *path, int *out_id)
     }
     d.texels = m.d_texels; d.sampling = m.d_sampling; d.sampling2d = m.d_sampling2d; d.n_ti = sampling2d_doubles ? mrl::kSamplingIncidentBins : 0;
     m.dev = d;
+    m.rows_lookup = (int)h.lookup; m.rows_node = (int)h.node;
     rc = place_material(ctx, m, out_id);
     if (rc != MRL_OK) { drop(); return rc; }
     return MRL_OK;

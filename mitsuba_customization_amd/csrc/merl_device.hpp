@@ -99,7 +99,15 @@ struct Options {
     int node;      // 0 integer node, 1 texel centre
     int disk_map;  // 0 Mitsuba 0.6, 1 Mitsuba 3
     int sampling;  // 0 cosine hemisphere (upstream convention), 1 table importance sampling
+    int cosine;    // MRL_OPT_COSINE_FACTOR: 0 eval() = f cos(theta_o) (upstream convention), 1 eval() = f
+    int negative;  // MRL_OPT_NEGATIVE: what a negative stored value does to a lookup — 0 clamped to 0 when the table is built,
+                   // 1 kept as stored, 2 left out and the valid corners renormalised
 };
+enum Negative : int { NEGATIVE_CLAMP = 0, NEGATIVE_KEEP = 1, NEGATIVE_RENORMALISE = 2 };
+// how a lookup treats the texels it blends: as stored (clamped at build time under NEGATIVE_CLAMP, raw otherwise); clamped at
+// lookup time (the sampling-table builders on a raw table: a density needs a non-negative mass); valid corners only
+enum Blend : int { BLEND_STORED = 0, BLEND_CLAMP = 1, BLEND_RENORMALISE = 2 };
+MRL_HD int blend_of(const Options &o) { return o.negative == NEGATIVE_RENORMALISE ? BLEND_RENORMALISE : BLEND_STORED; }
 
 struct Vec3d { double x, y, z; };
 
@@ -198,17 +206,54 @@ MRL_HD Rgbf blend_brick(const float4 &q0, const float4 &q1, const float4 &q2, co
     return { A.x + B.y, A.y + C.x, B.x + C.y };
 }
 
+// MRL_OPT_NEGATIVE = 2 ("skip and renormalise"): a negative texel is a sample that was not measured; the
+// lookup blends the valid corners only and divides by their weight, per channel — sum_k w_k v_k [v_k >= 0] / sum_k w_k [v_k >= 0],
+// 0 when no corner is valid.  In f64 on the Float corner weights (the quotient of two eight-term Float sums would spend the whole
+// 1e-6 margin); every entry point runs this one function.
+MRL_HD Rgbf blend_brick_valid(const float4 &q0, const float4 &q1, const float4 &q2, const float4 &q3, const float4 &q4,
+                              const float4 &q5, const CornerWeights &c)
+{
+#pragma clang fp contract(off)
+    const float f[24] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
+                          q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w };
+    double num[3] = { 0.0, 0.0, 0.0 }, den[3] = { 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double w = (double)c.w[k];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float v = f[3 * k + ch];
+            const bool ok = v >= 0.0f;
+            num[ch] = __builtin_fma(ok ? w : 0.0, (double)v, num[ch]);
+            den[ch] += ok ? w : 0.0;
+        }
+    }
+    return { den[0] > 0.0 ? (float)(num[0] / den[0]) : 0.0f, den[1] > 0.0 ? (float)(num[1] / den[1]) : 0.0f,
+             den[2] > 0.0 ? (float)(num[2] / den[2]) : 0.0f };
+}
+
+MRL_HD float4 max0(const float4 &q) { return make_float4(__builtin_fmaxf(q.x, 0.0f), __builtin_fmaxf(q.y, 0.0f), __builtin_fmaxf(q.z, 0.0f), __builtin_fmaxf(q.w, 0.0f)); }
+
+// the blend of one brick under a policy (enum Blend; wave-uniform)
+MRL_HD Rgbf blend_brick_as(int blend, const float4 &q0, const float4 &q1, const float4 &q2, const float4 &q3, const float4 &q4,
+                           const float4 &q5, const CornerWeights &c)
+{
+    if (blend == BLEND_RENORMALISE) return blend_brick_valid(q0, q1, q2, q3, q4, q5, c);
+    if (blend == BLEND_CLAMP) return blend_brick(max0(q0), max0(q1), max0(q2), max0(q3), max0(q4), max0(q5), c);
+    return blend_brick(q0, q1, q2, q3, q4, q5, c);
+}
+
+// blend: BLEND_STORED returns the texel as stored; the other two policies have nothing to blend and return it clamped at 0
 template <int LAYOUT>
-MRL_HD Rgbf lookup_nearest_t(const MaterialDev &m, const Coords &c)
+MRL_HD Rgbf lookup_nearest_t(const MaterialDev &m, const Coords &c, int blend = BLEND_STORED)
 {
     int ih = clampi(trunc_i(c.xh), 0, m.n_th - 1);
     int id = clampi(trunc_i(c.xd), 0, m.n_td - 1);
     int ip = clampi(trunc_i(c.xp), 0, m.n_pd - 1);
-    if constexpr (LAYOUT == LAYOUT_BRICK) {
-        const float4 t = m.texels[(((size_t)ih * m.n_td + id) * m.n_pd + ip) * 8];     // corner 0 = the texel itself
-        return { t.x, t.y, t.z };
-    }
-    float4 t = m.texels[(size_t)ih * m.row_th + (size_t)id * m.row_td + ip];
+    float4 t;
+    if constexpr (LAYOUT == LAYOUT_BRICK) t = m.texels[(((size_t)ih * m.n_td + id) * m.n_pd + ip) * 8];     // corner 0 = the texel itself
+    else t = m.texels[(size_t)ih * m.row_th + (size_t)id * m.row_td + ip];
+    if (blend != BLEND_STORED) t = max0(t);
     return { t.x, t.y, t.z };
 }
 
@@ -253,7 +298,7 @@ MRL_HD void split_phi(bool periodic, double x, int n, int &i0, double &f)
 }
 
 template <int LAYOUT>
-MRL_HD Rgbf lookup_trilinear_t(const MaterialDev &m, const Coords &c, int node)
+MRL_HD Rgbf lookup_trilinear_t(const MaterialDev &m, const Coords &c, int node, int blend = BLEND_STORED)
 {
 #pragma clang fp contract(off)
     const double shift = node ? 0.5 : 0.0;
@@ -266,7 +311,7 @@ MRL_HD Rgbf lookup_trilinear_t(const MaterialDev &m, const Coords &c, int node)
         // k_table_dma's (entry points agree bit for bit)
         const float4 *q = m.texels + (((size_t)h0 * m.n_td + d0) * m.n_pd + p0) * 8;
         const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
-        return blend_brick(q0, q1, q2, q3, q4, q5, corner_weights(fh, fd, fp));
+        return blend_brick_as(blend, q0, q1, q2, q3, q4, q5, corner_weights(fh, fd, fp));
     }
     const float4 *b = m.texels + ((size_t)h0 * m.row_th + (size_t)d0 * m.row_td + p0);
     // issue all eight 16-B gathers before any use
@@ -276,20 +321,20 @@ MRL_HD Rgbf lookup_trilinear_t(const MaterialDev &m, const Coords &c, int node)
     const float4 t110 = b[m.row_th + m.row_td], t111 = b[m.row_th + m.row_td + 1];
     // the eight texels in brick order (corner-major RGB) through the SAME blend: a rows-layout table, a brick table and the
     // host image of either give the same bits for the same coordinates
-    return blend_brick(make_float4(t000.x, t000.y, t000.z, t001.x), make_float4(t001.y, t001.z, t010.x, t010.y),
-                       make_float4(t010.z, t011.x, t011.y, t011.z), make_float4(t100.x, t100.y, t100.z, t101.x),
-                       make_float4(t101.y, t101.z, t110.x, t110.y), make_float4(t110.z, t111.x, t111.y, t111.z),
-                       corner_weights(fh, fd, fp));
+    return blend_brick_as(blend, make_float4(t000.x, t000.y, t000.z, t001.x), make_float4(t001.y, t001.z, t010.x, t010.y),
+                          make_float4(t010.z, t011.x, t011.y, t011.z), make_float4(t100.x, t100.y, t100.z, t101.x),
+                          make_float4(t101.y, t101.z, t110.x, t110.y), make_float4(t110.z, t111.x, t111.y, t111.z),
+                          corner_weights(fh, fd, fp));
 }
 
 // runtime-layout wrappers (generic kernel)
-MRL_HD Rgbf lookup_nearest(const MaterialDev &m, const Coords &c)
+MRL_HD Rgbf lookup_nearest(const MaterialDev &m, const Coords &c, int blend = BLEND_STORED)
 {
-    return m.layout == LAYOUT_BRICK ? lookup_nearest_t<LAYOUT_BRICK>(m, c) : lookup_nearest_t<LAYOUT_ROWS>(m, c);
+    return m.layout == LAYOUT_BRICK ? lookup_nearest_t<LAYOUT_BRICK>(m, c, blend) : lookup_nearest_t<LAYOUT_ROWS>(m, c, blend);
 }
-MRL_HD Rgbf lookup_trilinear(const MaterialDev &m, const Coords &c, int node)
+MRL_HD Rgbf lookup_trilinear(const MaterialDev &m, const Coords &c, int node, int blend = BLEND_STORED)
 {
-    return m.layout == LAYOUT_BRICK ? lookup_trilinear_t<LAYOUT_BRICK>(m, c, node) : lookup_trilinear_t<LAYOUT_ROWS>(m, c, node);
+    return m.layout == LAYOUT_BRICK ? lookup_trilinear_t<LAYOUT_BRICK>(m, c, node, blend) : lookup_trilinear_t<LAYOUT_ROWS>(m, c, node, blend);
 }
 
 // BRDF value (no cosine) of a table material for unit in/out
@@ -297,7 +342,7 @@ MRL_HD Rgbf table_brdf(const MaterialDev &m, const Options &o, const Vec3d &in, 
 {
     Coords c = m.param == PARAM_HALF_DIFF ? half_diff_coords(in, out, m.n_th, m.n_td, m.n_pd)
                                           : standard_coords(in, out, m.param, m.n_th, m.n_td, m.n_pd);
-    return o.lookup ? lookup_trilinear(m, c, o.node) : lookup_nearest(m, c);
+    return o.lookup ? lookup_trilinear(m, c, o.node, blend_of(o)) : lookup_nearest(m, c, blend_of(o));
 }
 
 // ---- a6: cosine-hemisphere sampling, pinned f32 sequence (bit-identical to oracle/merl_oracle.c) --
@@ -538,10 +583,10 @@ MRL_HD double rcp_nr(double x)
 // NaN / inf directions: the floors and guards of this file would turn them into finite garbage; an f64 CPU evaluation
 // propagates NaN instead, so the cosine factor is poisoned when a component of either input is not finite.
 // wi_sum = wix + wiy + wiz is shared by the two lookups of a unit.
-MRL_HD float cos_or_nan32(float wi_sum, float wox, float woy, float woz)
+MRL_HD float cos_or_nan32(float wi_sum, float wox, float woy, float woz, bool no_cosine = false)
 {
     const float t = wi_sum + (wox + woy + woz);                     // NaN or inf iff some component is
-    return (__builtin_fabsf(t) <= 3.0e38f) ? woz : __builtin_nanf("");
+    return (__builtin_fabsf(t) <= 3.0e38f) ? (no_cosine ? 1.0f : woz) : __builtin_nanf("");
 }
 MRL_HD double cos_or_nan(float wix, float wiy, float wiz, float wox, float woy, float woz)
 {
@@ -551,11 +596,12 @@ MRL_HD double cos_or_nan(float wix, float wiy, float wiz, float wox, float woy, 
 // a5 tail: rgb = f cos(theta_o) in Float (the plugin's own arithmetic: Spectrum * Float); zero for a pair that fails the
 // cosine guards (texels are finite by construction, so the factor 0 is enough), NaN where an input component is not
 // finite and the guards pass
-MRL_HD void eval_tail(const Rgbf &v, float wi_sum, float wiz, float wox, float woy, float woz, float rgb[3])
+// no_cosine (MRL_OPT_COSINE_FACTOR = 1, wave-uniform): the factor is 1 — eval() returns f alone
+MRL_HD void eval_tail(const Rgbf &v, float wi_sum, float wiz, float wox, float woy, float woz, float rgb[3], bool no_cosine = false)
 {
 #pragma clang fp contract(off)
     const bool valid = (wiz > 0.0f) && (woz > 0.0f);
-    const float c32 = cos_or_nan32(wi_sum, wox, woy, woz);
+    const float c32 = cos_or_nan32(wi_sum, wox, woy, woz, no_cosine);
     const float c = valid ? c32 : 0.0f;
     rgb[0] = v.r * c; rgb[1] = v.g * c; rgb[2] = v.b * c;
 }
@@ -566,12 +612,12 @@ MRL_HD void eval_tail(const Rgbf &v, float wi_sum, float wiz, float wox, float w
 // (tests/test_gpu_fullsize.py checks weight == eval / pdf bit for bit on 64M units).  Zero when the sample is invalid
 // or its pdf is zero.
 MRL_HD void sample_tail(const Rgbf &v, float wi_sum, float wiz, float sx, float sy, float sz, float p, bool table_sampling,
-                                            float wo[3], float &pdf, float weight[3])
+                                            float wo[3], float &pdf, float weight[3], bool no_cosine = false)
 {
 #pragma clang fp contract(off)
     const bool valid = (wiz > 0.0f) && (!table_sampling || p > 0.0f);
     const bool has = valid && (p > 0.0f);
-    const float c32 = cos_or_nan32(wi_sum, sx, sy, sz);
+    const float c32 = cos_or_nan32(wi_sum, sx, sy, sz, no_cosine);
     const float c = has ? c32 : 0.0f;
     const double pd = (double)(has ? p : 1.0f);
     double y = rcp_seed(pd);
@@ -595,7 +641,7 @@ MRL_HD void unit_eval(const MaterialDev &m, const Options &o,
     if (!(wiz > 0.0f) || !(woz > 0.0f)) return;
     Vec3d in = normalized(wix, wiy, wiz), out = normalized(wox, woy, woz);
     if (m.kind != KIND_GGX) {
-        fast::eval_tail(table_brdf(m, o, in, out), (wix + wiy + wiz), wiz, wox, woy, woz, rgb);
+        fast::eval_tail(table_brdf(m, o, in, out), (wix + wiy + wiz), wiz, wox, woy, woz, rgb, o.cosine != 0);
         return;
     }
     const Rgbd v = ggx_eval(m, in, out);
@@ -636,7 +682,7 @@ MRL_HD void unit_sample(const MaterialDev &m, const Options &o,
         p = z > 0.0f ? z * kInvPiF : 0.0f;
     }
     Vec3d in = normalized(wix, wiy, wiz), out = normalized(x, y, z);
-    fast::sample_tail(table_brdf(m, o, in, out), (wix + wiy + wiz), wiz, x, y, z, p, o.sampling != 0, wo, pdf, weight);
+    fast::sample_tail(table_brdf(m, o, in, out), (wix + wiy + wiz), wiz, x, y, z, p, o.sampling != 0, wo, pdf, weight, o.cosine != 0);
 }
 
 // ---- synthetic inputs, bit-identical to the oracle's generator ---------------

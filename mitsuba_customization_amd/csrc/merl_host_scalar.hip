@@ -33,7 +33,7 @@ template <int LOOKUP>
 MRL_HOST_FAST inline void host_eval_pdf(const mrl_host_table *t, const float wi[3], const float wo[3], float rgb[3], float *pdf)
 {
     const Vec3 in = mrl::fast::normalize_f32(wi[0], wi[1], wi[2]);
-    mrl::fast::unit_eval<LOOKUP, mrl::LAYOUT_ROWS>(t->m, t->opts, in, wi[0], wi[1], wi[2], wo[0], wo[1], wo[2], rgb);
+    mrl::fast::unit_eval<LOOKUP, mrl::LAYOUT_ROWS, true>(t->m, t->opts, in, wi[0], wi[1], wi[2], wo[0], wo[1], wo[2], rgb);
     if (pdf) {
         float p = (wi[2] > 0.0f && wo[2] > 0.0f) ? wo[2] * mrl::kInvPiF : 0.0f;
         if (t->opts.sampling && p > 0.0f) p = (float)mrl::fast::table_pdf(t->m, in, mrl::fast::normalize_f32(wo[0], wo[1], wo[2]), wo[2], t->opts.sampling);
@@ -45,7 +45,7 @@ template <int LOOKUP>
 MRL_HOST_FAST inline void host_sample(const mrl_host_table *t, const float wi[3], const float u[2], float wo[3], float *pdf, float weight[3])
 {
     const Vec3 in = mrl::fast::normalize_f32(wi[0], wi[1], wi[2]);
-    mrl::fast::unit_sample<LOOKUP, mrl::LAYOUT_ROWS>(t->m, t->opts, in, wi[0], wi[1], wi[2], u[0], u[1], wo, *pdf, weight);
+    mrl::fast::unit_sample<LOOKUP, mrl::LAYOUT_ROWS, true>(t->m, t->opts, in, wi[0], wi[1], wi[2], u[0], u[1], wo, *pdf, weight);
 }
 
 // the adaptive-parameterisation material: the kernels' per-unit functions (merl_rgl.hpp) over the host copy of the image

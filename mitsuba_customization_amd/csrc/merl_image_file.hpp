@@ -76,6 +76,7 @@ struct ImageHeader {
     int32_t dims[3];
     int32_t rgl_shape[8];                // n_phi n_theta res_x res_y res_ndf_x res_ndf_y res_sigma_x res_sigma_y
     int32_t rgl_flags[2];                // jacobian, reserved
+    uint32_t negative;                   // MRL_OPT_NEGATIVE the table was built under: 0 = negative values were clamped to 0, 1 / 2 = the image holds them
     uint64_t texel_bytes, sampling_doubles, sampling2d_doubles, checksum;
 };
 constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 2, 0 };
@@ -113,8 +114,9 @@ struct ImagePlan {
 };
 
 // nullptr and a filled plan, or why the header cannot be an image this library wrote.  file_bytes: the file's length.
-// ctx_lookup / ctx_node: the loading context's options (conditional sampling rows are tied to them).
-inline const char *image_plan(const ImageHeader &h, unsigned long long file_bytes, int ctx_lookup, int ctx_node, ImagePlan &p)
+// ctx_lookup / ctx_node: the loading context's options (conditional sampling rows are tied to them); ctx_negative: its MRL_OPT_NEGATIVE
+// (an image of clamped values serves a clamping context only, an image of raw values the two others).
+inline const char *image_plan(const ImageHeader &h, unsigned long long file_bytes, int ctx_lookup, int ctx_node, int ctx_negative, ImagePlan &p)
 {
     if (std::memcmp(h.magic, kImageMagic, 8) != 0 || h.header_bytes != sizeof(ImageHeader)) return "not a material image of this library version";
     p = ImagePlan();
@@ -131,6 +133,7 @@ inline const char *image_plan(const ImageHeader &h, unsigned long long file_byte
         if ((uint64_t)h.dims[0] * (uint64_t)h.dims[1] > ((uint64_t)1 << 28) || (uint64_t)h.dims[0] * (uint64_t)h.dims[1] * (uint64_t)h.dims[2] > ((uint64_t)1 << 28))
             return "table dims out of range";
         if (h.layout > kImgLayoutBrick || h.param > kImgParamLast) return "bad layout / parameterisation";
+        if (h.negative > 2 || (h.negative == 0) != (ctx_negative == 0)) return "the image's table was built under another MRL_OPT_NEGATIVE (clamped against raw values)";
         if (p.is_nch ? (h.n_ch < 1 || h.n_ch > (uint32_t)kImgMaxChannels || h.layout != kImgLayoutBrick) : (h.n_ch != 3 || h.layout != kImgLayoutRows))
             return "bad channel count / layout for the kind (RGB tables are stored in the rows form)";
         if (h.kind == kImgKindMerl && h.param != 0) return "a MERL table is in half / difference angles";

@@ -264,12 +264,15 @@ __device__ __forceinline__ uint32_t brick_cell(const MaterialDev &m, const Coord
     return (uint32_t)((h0 * m.n_td + d0) * m.n_pd + p0);
 }
 
-__device__ __forceinline__ Rgbf brick_interp(const float4 *lds_slots, unsigned lane, const BrickWeights &w)
+// POLICY = false: the plain blend, no branch (the headline instantiation); true: MRL_OPT_NEGATIVE's policy (wave-uniform)
+template <bool POLICY>
+__device__ __forceinline__ Rgbf brick_interp(const float4 *lds_slots, unsigned lane, const BrickWeights &w, int blend)
 {
     const unsigned f = brick_swz(lane);
     const float4 *q = lds_slots + 8u * lane;
     const float4 q0 = q[0u ^ f], q1 = q[1u ^ f], q2 = q[2u ^ f], q3 = q[3u ^ f], q4 = q[4u ^ f], q5 = q[5u ^ f];
-    return blend_brick(q0, q1, q2, q3, q4, q5, corner_weights(w.fh, w.fd, w.fp));
+    if constexpr (POLICY) return blend_brick_as(blend, q0, q1, q2, q3, q4, q5, corner_weights(w.fh, w.fd, w.fp));
+    else return blend_brick(q0, q1, q2, q3, q4, q5, corner_weights(w.fh, w.fd, w.fp));
 }
 
 // One unit's registers while it travels through the DMA kernels.
@@ -290,8 +293,9 @@ struct TileIn {
 // Table lanes of one wave: transform, cooperative brick copy, blend.  EVERY lane of the wave must call
 // it (the copy is wave-wide); lanes whose material is not a table pass is_table = false, take part with
 // a harmless source and keep their outputs untouched.
-// STD: the launch may meet tables in one of the standard parameterisations (BatchArgs::any_standard); without it the kernel
-// is the half/diff-only code (A/B on one box: the wave-uniform parameterisation branch costs the headline launch 0.5 %).
+// STD: the launch may meet tables in one of the standard parameterisations (BatchArgs::any_standard) or runs under
+// MRL_OPT_NEGATIVE = 2 (the renormalising blend); without it the kernel is the half/diff-only code with the plain blend
+// (A/B on one box: the wave-uniform parameterisation branch costs the headline launch 0.5 %).
 template <int MODE, bool MULTI, bool GGX, bool STD>
 __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDev &m, bool is_table, UnitIO &io,
                                             const fast::Vec3 &in, float4 *ldsA, float4 *ldsB, uint32_t *pageA, uint32_t *pageB, unsigned lane)
@@ -339,9 +343,9 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
     // lookup's are still in flight) and the sample blend for the rest.  Own wave only: no barrier.
 
     if constexpr (HAS_EVAL) {
-        const Rgbf v = brick_interp(ldsA, lane, wA);
+        const Rgbf v = brick_interp<STD>(ldsA, lane, wA, blend_of(a.opts));
         if (!GGX || is_table) {
-            fast::eval_tail(v, io.wi_sum, io.wiz, io.wox, io.woy, io.woz, io.rgb);
+            fast::eval_tail(v, io.wi_sum, io.wiz, io.wox, io.woy, io.woz, io.rgb, a.opts.cosine != 0);
             if constexpr (mode_pdf(MODE)) {
                 const bool valid = (io.wiz > 0.0f) && (io.woz > 0.0f);
                 io.pdf = valid ? io.woz * kInvPiF : 0.0f;
@@ -350,8 +354,8 @@ __device__ __forceinline__ void table_lanes(const BatchArgs &a, const MaterialDe
         }
     }
     if constexpr (HAS_SAMPLE) {
-        const Rgbf v = brick_interp(ldsB, lane, wB);
-        if (!GGX || is_table) fast::sample_tail(v, io.wi_sum, io.wiz, sx, sy, sz, sp, a.opts.sampling != 0, io.wo2, io.pdf2, io.w);
+        const Rgbf v = brick_interp<STD>(ldsB, lane, wB, blend_of(a.opts));
+        if (!GGX || is_table) fast::sample_tail(v, io.wi_sum, io.wiz, sx, sy, sz, sp, a.opts.sampling != 0, io.wo2, io.pdf2, io.w, a.opts.cosine != 0);
     }
 }
 
@@ -735,14 +739,16 @@ __global__ __launch_bounds__(kBlock) void k_add_material_bases(uint32_t *table, 
 }
 
 // ---- a1: table re-layout on the device (planar f64 file order -> HBM layout), one thread per output texel/brick ----
-__device__ __forceinline__ float scaled_texel(const double *planar, size_t plane, size_t index, int ch, double scale)
+// clamp (MRL_OPT_NEGATIVE = 0, the default): MERL's negative "not measured" markers become 0 in the image; otherwise the value
+// stays as the file holds it (kept, or recognised and left out by the renormalising blend)
+__device__ __forceinline__ float scaled_texel(const double *planar, size_t plane, size_t index, int ch, double scale, int clamp)
 {
     const double v = planar[index + (size_t)ch * plane] * scale;
-    return v > 0.0 ? (float)v : 0.0f;                         // MERL's negative "below horizon" markers clamp to 0
+    return (v > 0.0 || !clamp) ? (float)v : 0.0f;
 }
 
 __global__ __launch_bounds__(kBlock) void k_build_bricks(const double *planar, int n_th, int n_td, int n_pd, int phi_periodic,
-                                                        double s0, double s1, double s2, float4 *bricks)
+                                                        double s0, double s1, double s2, int clamp, float4 *bricks)
 {
     const size_t cells = (size_t)n_th * n_td * n_pd, plane = cells;
     const size_t stride = (size_t)gridDim.x * kBlock;
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(kBlock) void k_build_bricks(const double *planar, i
             const int sh = min(ih + (k >> 2), n_th - 1), sd = min(id + ((k >> 1) & 1), n_td - 1), sp = phi_periodic ? (ip + (k & 1)) % n_pd : min(ip + (k & 1), n_pd - 1);
             const size_t src = ((size_t)sh * n_td + sd) * n_pd + sp;
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) v[3 * k + ch] = scaled_texel(planar, plane, src, ch, scale[ch]);
+            for (int ch = 0; ch < 3; ++ch) v[3 * k + ch] = scaled_texel(planar, plane, src, ch, scale[ch], clamp);
         }
 #pragma unroll
         for (int pad = 24; pad < 32; ++pad) v[pad] = 0.0f;
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(kBlock) void k_build_bricks(const double *planar, i
 }
 
 __global__ __launch_bounds__(kBlock) void k_build_rows(const double *planar, int n_th, int n_td, int n_pd, int phi_periodic,
-                                                      double s0, double s1, double s2, float4 *rows)
+                                                      double s0, double s1, double s2, int clamp, float4 *rows)
 {
     const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1, total = H * D * P, plane = (size_t)n_th * n_td * n_pd;
     const size_t stride = (size_t)gridDim.x * kBlock;
@@ -774,8 +780,8 @@ __global__ __launch_bounds__(kBlock) void k_build_rows(const double *planar, int
         const size_t ip = t % P, id = (t / P) % D, ih = t / (P * D);
         const size_t sh = ih < (size_t)n_th ? ih : n_th - 1, sd = id < (size_t)n_td ? id : n_td - 1, sp = ip == (size_t)n_pd ? (phi_periodic ? 0 : n_pd - 1) : ip;
         const size_t src = (sh * n_td + sd) * n_pd + sp;
-        rows[t] = make_float4(scaled_texel(planar, plane, src, 0, s0), scaled_texel(planar, plane, src, 1, s1),
-                              scaled_texel(planar, plane, src, 2, s2), 0.0f);
+        rows[t] = make_float4(scaled_texel(planar, plane, src, 0, s0, clamp), scaled_texel(planar, plane, src, 1, s1, clamp),
+                              scaled_texel(planar, plane, src, 2, s2, clamp), 0.0f);
     }
 }
 
@@ -839,7 +845,8 @@ __global__ __launch_bounds__(64) void k_sampling2d_mass(MaterialDev m, Options o
         const fast::Dir out = { 2.0 * c * hx - in.x, 2.0 * c * hy, 2.0 * c * ct - in.z, 1.0 };
         if (c > 0.0 && ct > 0.0 && out.z > 0.0) {
             const fast::TableMaps maps(m);
-            const Rgbf f = lookup_trilinear_t<LAYOUT>(m, maps(in, out), o.node);
+            // (the mass of a density: clamped values, whatever eval() does with negative texels)
+            const Rgbf f = lookup_trilinear_t<LAYOUT>(m, maps(in, out), o.node, o.negative == NEGATIVE_CLAMP ? BLEND_STORED : BLEND_CLAMP);
             const double lum = 0.2126 * (double)f.r + 0.7152 * (double)f.g + 0.0722 * (double)f.b;
             v = lum * out.z * 4.0 * c / (2.0 * ct);
         }
@@ -938,7 +945,8 @@ void launch_table2(const BatchArgs &a, int lookup, int layout, dim3 grid, dim3 b
 // the LDS-DMA kernel in its half/diff-only or its every-parameterisation build (BatchArgs::any_standard); MODE, g, b, stream, a in scope
 #define MRL_DMA_LAUNCH(MULTI_, GGX_, INDEXED_)                                                                         \
     do {                                                                                                               \
-        if (a.any_standard) hipLaunchKernelGGL((k_table_dma<MODE, MULTI_, true, GGX_, INDEXED_, true>), g, b, 0, stream, a);  \
+        if (a.any_standard || a.opts.negative == NEGATIVE_RENORMALISE)                                                 \
+            hipLaunchKernelGGL((k_table_dma<MODE, MULTI_, true, GGX_, INDEXED_, true>), g, b, 0, stream, a);           \
         else                hipLaunchKernelGGL((k_table_dma<MODE, MULTI_, true, GGX_, INDEXED_, false>), g, b, 0, stream, a); \
     } while (0)
 
@@ -979,7 +987,8 @@ hipError_t launch_mode(const BatchArgs &a, bool multi, int variant, int layout, 
             return hipGetLastError();
         }
     }
-    if (tuned) {
+    // (k_table blends the texels as stored: a renormalising context's nearest lookups / rows-layout tables take the generic kernel)
+    if (tuned && a.opts.negative != NEGATIVE_RENORMALISE) {
         launch_table<MODE>(a, multi, variant >= 2, a.opts.lookup, layout, grid, block, stream);
     } else {
         if (multi) hipLaunchKernelGGL((k_batch<MODE, true>), grid, block, 0, stream, a);
@@ -1154,16 +1163,16 @@ hipError_t launch_bricks_to_rows(const float4 *d_bricks, const int dims[3], int 
     return hipGetLastError();
 }
 
-hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, int param, float4 *d_out,
+hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, int param, int clamp, float4 *d_out,
                               int compute_units, hipStream_t stream)
 {
     const size_t cells = (size_t)dims[0] * dims[1] * dims[2];
     if (layout == LAYOUT_BRICK)
         hipLaunchKernelGGL(k_build_bricks, dim3(grid_for(cells, compute_units)), dim3(kBlock), 0, stream, d_planar, dims[0], dims[1], dims[2],
-                           (int)param_phi_periodic(param), scale[0], scale[1], scale[2], d_out);
+                           (int)param_phi_periodic(param), scale[0], scale[1], scale[2], clamp, d_out);
     else
         hipLaunchKernelGGL(k_build_rows, dim3(grid_for((size_t)(dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1), compute_units)), dim3(kBlock), 0, stream,
-                           d_planar, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), scale[0], scale[1], scale[2], d_out);
+                           d_planar, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), scale[0], scale[1], scale[2], clamp, d_out);
     return hipGetLastError();
 }
 

@@ -53,8 +53,8 @@ void material_partition_geometry(size_t n, int compute_units, uint32_t *chunks, 
 // work: chunks*K + K uint32; queue: n uint32; offsets: K + 1; counts: K (all device)
 hipError_t launch_partition_materials(const int32_t *mat, size_t n, int K, uint32_t *queue, uint32_t *offsets, uint32_t *counts,
                                       uint32_t *work, uint32_t chunks, uint32_t chunk_len, int compute_units, hipStream_t stream);
-// a1: planar f64 table (device copy of the file payload) -> padded rows or bricks
-hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, int param, float4 *d_out,
+// a1: planar f64 table (device copy of the file payload) -> padded rows or bricks; clamp: negative values become 0 (MRL_OPT_NEGATIVE = 0)
+hipError_t launch_build_table(const double *d_planar, const int dims[3], const double scale[3], int layout, int param, int clamp, float4 *d_out,
                               int compute_units, hipStream_t stream);
 // one RGB table layout to the other (the on-disk image cache stores the rows form): padded rows <-> bricks, same Float values
 hipError_t launch_rows_to_bricks(const float4 *d_rows, const int dims[3], float4 *d_bricks, int compute_units, hipStream_t stream);
@@ -68,7 +68,7 @@ constexpr int kMaxChannels = 32;
 // nch_brick_float4s(n_ch): float4s per cell: 2 (1 ch), 4 (2 ch), 8 * ceil(n_ch / 4)  (merl_image_file.hpp)
 // mode: 0 eval, 2 sample, 3 eval+sample, 4 eval+pdf (pdf alone: the RGB pdf kernel serves every table kind)
 hipError_t launch_batch_nch(int mode, const BatchArgs &a, bool multi, int n_ch, int compute_units, hipStream_t stream);
-hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale, const int dims[3], int n_ch, int param, float4 *d_out,
+hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale, const int dims[3], int n_ch, int param, int clamp, float4 *d_out,
                                   int compute_units, hipStream_t stream);
 // ---- the adaptive-parameterisation measured BSDF (merl_rgl.hip; RGL *.bsdf) ----
 struct RglDev;

@@ -96,8 +96,10 @@ __device__ __forceinline__ void nch_copy(uint64_t brick_addr, float4 *lds_slots,
 }
 
 // this lane's brick out of LDS -> up to CPAD channel values
+// renorm (MRL_OPT_NEGATIVE = 2, wave-uniform): a negative value marks a sample that was not measured — the valid corners only, divided
+// by their weight (0 when none is valid); nearest lookups arrive here with all weight on corner 0 and come out as max(v, 0)
 template <int CPAD>
-__device__ __forceinline__ void nch_blend(const float4 *lds_slots, unsigned lane, const NchWeights &w, double out[CPAD])
+__device__ __forceinline__ void nch_blend(const float4 *lds_slots, unsigned lane, const NchWeights &w, double out[CPAD], bool renorm)
 {
     constexpr int S = 2 * CPAD;
     const unsigned f = nch_swz<S>(lane);
@@ -107,6 +109,20 @@ __device__ __forceinline__ void nch_blend(const float4 *lds_slots, unsigned lane
     for (int p = 0; p < S; ++p) {
         const float4 t = q[(unsigned)p ^ f];
         v[4 * p] = t.x; v[4 * p + 1] = t.y; v[4 * p + 2] = t.z; v[4 * p + 3] = t.w;
+    }
+    if (renorm) {
+#pragma unroll
+        for (int ch = 0; ch < CPAD; ++ch) {
+            double num = 0.0, den = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float t = v[k * CPAD + ch];
+                const double wk = t >= 0.0f ? w.w[k] : 0.0;
+                num += wk * (double)t; den += wk;
+            }
+            out[ch] = den > 0.0 ? num / den : 0.0;
+        }
+        return;
     }
 #pragma unroll
     for (int ch = 0; ch < CPAD; ++ch) {
@@ -142,6 +158,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
     const int groups = CPAD == 4 ? (n_ch + 3) / 4 : 1;
     const size_t stride = (size_t)gridDim.x * kNchBlock;
     const size_t n_items = nch_item_count<INDEXED>(a);
+    const bool renorm = a.opts.negative == NEGATIVE_RENORMALISE;       // wave-uniform
     for (size_t base = (size_t)blockIdx.x * kNchBlock + wave * 64u; base < n_items; base += stride) {
         const size_t j = base + lane;
         const bool active = j < n_items;
@@ -192,8 +209,8 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
         const bool validA = (wiz > 0.0f) && (woz > 0.0f);
         const bool validB = (wiz > 0.0f) && (!a.opts.sampling || sp > 0.0f);
         const bool hasB = validB && (sp > 0.0f);
-        const double cA = fast::cos_or_nan(wix, wiy, wiz, wox, woy, woz);
-        const double cB = fast::cos_or_nan(wix, wiy, wiz, sx, sy, sz);
+        const double cA = (double)fast::cos_or_nan32(wix + wiy + wiz, wox, woy, woz, a.opts.cosine != 0);
+        const double cB = (double)fast::cos_or_nan32(wix + wiy + wiz, sx, sy, sz, a.opts.cosine != 0);
         const float ps = hasB ? sp : 1.0f;
 
         for (int g = 0; g < groups; ++g) {                    // wave-uniform trip count
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
             const int first = CPAD == 4 ? 4 * g : 0;
             if constexpr (HAS_EVAL) {
                 double v[CPAD];
-                nch_blend<CPAD>(ldsA, lane, wA, v);
+                nch_blend<CPAD>(ldsA, lane, wA, v, renorm);
                 if (active) {
 #pragma unroll
                     for (int ch = 0; ch < CPAD; ++ch)
@@ -212,7 +229,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch(BatchArgs a, int n_ch)
             }
             if constexpr (HAS_SAMPLE) {
                 double v[CPAD];
-                nch_blend<CPAD>(ldsB, lane, wB, v);
+                nch_blend<CPAD>(ldsB, lane, wB, v, renorm);
                 if (active) {
 #pragma unroll
                     for (int ch = 0; ch < CPAD; ++ch)
@@ -260,6 +277,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
     const int groups = (n_ch + 3) / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t n_items = nch_item_count<INDEXED>(a);
+    const bool renorm = a.opts.negative == NEGATIVE_RENORMALISE;       // wave-uniform
     for (size_t base = (size_t)blockIdx.x * blockDim.x + wave * 64u; base < n_items; base += stride) {
         const size_t j = base + lane;
         const bool active = j < n_items;
@@ -299,7 +317,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
                 nch_copy<S>((uint64_t)(texels + ((size_t)cell * groups + g) * S), dma, lane);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 double v[4];
-                nch_blend<4>(dma, lane, w, v);
+                nch_blend<4>(dma, lane, w, v, renorm);
 #pragma unroll
                 for (int ch = 0; ch < 4; ++ch)
                     if (4 * g + ch < n_ch) stage[lane * row + 4 * g + ch] = keep ? (float)(v[ch] * factor) / divide : 0.0f;
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
 
         if constexpr (HAS_EVAL) {
             const bool valid = (wiz > 0.0f) && (woz > 0.0f);
-            const double c = fast::cos_or_nan(wix, wiy, wiz, wox, woy, woz);
+            const double c = (double)fast::cos_or_nan32(wix + wiy + wiz, wox, woy, woz, a.opts.cosine != 0);
             lookup(fast::dir_f32(wox, woy, woz), valid, c, 1.0f, a.out_rgb);
             if constexpr (mode_pdf(MODE)) {
                 float p = valid ? woz * kInvPiF : 0.0f;
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
             }
             const bool valid = (wiz > 0.0f) && (!a.opts.sampling || sp > 0.0f);
             const bool has = valid && (sp > 0.0f);
-            const double c = fast::cos_or_nan(wix, wiy, wiz, sx, sy, sz);
+            const double c = (double)fast::cos_or_nan32(wix + wiy + wiz, sx, sy, sz, a.opts.cosine != 0);
             lookup(fast::dir_f32(sx, sy, sz), has, c, has ? sp : 1.0f, a.out_weight);
             if (active) {
                 const float wo2[3] = { valid ? sx : 0.0f, valid ? sy : 0.0f, valid ? sz : 0.0f };
@@ -364,7 +382,7 @@ __global__ __launch_bounds__(kNchBlock) void k_table_nch_wide(BatchArgs a, int n
 // ---- upload: planar f64 (n_ch planes, file order) -> n-channel bricks.  One thread per (cell, channel group). ----
 template <int CPAD>
 __global__ __launch_bounds__(kNchBlock) void k_build_bricks_nch(const double *planar, const double *scale, int n_th, int n_td, int n_pd,
-                                                               int phi_periodic, int n_ch, float4 *bricks)
+                                                               int phi_periodic, int n_ch, int clamp, float4 *bricks)
 {
     constexpr int S = 2 * CPAD;
     const int groups = CPAD == 4 ? (n_ch + 3) / 4 : 1;
@@ -386,7 +404,7 @@ __global__ __launch_bounds__(kNchBlock) void k_build_bricks_nch(const double *pl
                 float out = 0.0f;
                 if (cidx < n_ch) {
                     const double x = planar[src + (size_t)cidx * plane] * scale[cidx];
-                    out = x > 0.0 ? (float)x : 0.0f;          // negatives clamp to 0, as in the RGB path
+                    out = (x > 0.0 || !clamp) ? (float)x : 0.0f;          // negatives clamp to 0 unless MRL_OPT_NEGATIVE keeps them, as in the RGB path
                 }
                 v[k * CPAD + ch] = out;
             }
@@ -444,7 +462,7 @@ hipError_t launch_batch_nch(int mode, const BatchArgs &a, bool multi, int n_ch, 
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale, const int dims[3], int n_ch, int param, float4 *d_out,
+hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale, const int dims[3], int n_ch, int param, int clamp, float4 *d_out,
                                   int compute_units, hipStream_t stream)
 {
     const size_t cells = (size_t)dims[0] * dims[1] * dims[2];
@@ -453,9 +471,9 @@ hipError_t launch_build_table_nch(const double *d_planar, const double *d_scale,
     if (blocks > (size_t)compute_units * 8) blocks = (size_t)compute_units * 8;
     if (blocks < 1) blocks = 1;
     const dim3 g((unsigned)blocks), b(kNchBlock);
-    if (n_ch == 1)      hipLaunchKernelGGL((k_build_bricks_nch<1>), g, b, 0, stream, d_planar, d_scale, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), n_ch, d_out);
-    else if (n_ch == 2) hipLaunchKernelGGL((k_build_bricks_nch<2>), g, b, 0, stream, d_planar, d_scale, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), n_ch, d_out);
-    else                hipLaunchKernelGGL((k_build_bricks_nch<4>), g, b, 0, stream, d_planar, d_scale, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), n_ch, d_out);
+    if (n_ch == 1)      hipLaunchKernelGGL((k_build_bricks_nch<1>), g, b, 0, stream, d_planar, d_scale, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), n_ch, clamp, d_out);
+    else if (n_ch == 2) hipLaunchKernelGGL((k_build_bricks_nch<2>), g, b, 0, stream, d_planar, d_scale, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), n_ch, clamp, d_out);
+    else                hipLaunchKernelGGL((k_build_bricks_nch<4>), g, b, 0, stream, d_planar, d_scale, dims[0], dims[1], dims[2], (int)param_phi_periodic(param), n_ch, clamp, d_out);
     return hipGetLastError();
 }
 

@@ -55,12 +55,12 @@ __device__ __forceinline__ void table_unit(const MaterialDev &m, const Options &
     // k_table<MODE_EVAL_SAMPLE>'s lane, verbatim; a half the caller did not ask for is skipped (its outputs are zero)
     const fast::Vec3 in = fast::normalize_f32(wix, wiy, wiz);
     if (want != kWantSampleOnly) {
-        fast::unit_eval<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, wox, woy, woz, out);
+        fast::unit_eval<LOOKUP, LAYOUT, true>(m, o, in, wix, wiy, wiz, wox, woy, woz, out);
         float pdf = (wiz > 0.0f && woz > 0.0f) ? woz * kInvPiF : 0.0f;
         if (o.sampling && pdf > 0.0f) pdf = (float)fast::table_pdf(m, in, fast::normalize_f32(wox, woy, woz), woz, o.sampling);
         out[3] = pdf;
     }
-    if (want != kWantEvalOnly) fast::unit_sample<LOOKUP, LAYOUT>(m, o, in, wix, wiy, wiz, u0, u1, out + 4, out[7], out + 8);
+    if (want != kWantEvalOnly) fast::unit_sample<LOOKUP, LAYOUT, true>(m, o, in, wix, wiy, wiz, u0, u1, out + 4, out[7], out + 8);
 }
 
 __device__ __forceinline__ void ggx_unit(const MaterialDev &m, int want, float wix, float wiy, float wiz, float wox, float woy, float woz,

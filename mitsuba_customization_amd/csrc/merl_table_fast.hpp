@@ -188,22 +188,26 @@ struct TableMaps {
 // BRDF value (no cosine).  LOOKUP and LAYOUT are compile-time so that the eval lookup and the
 // sample lookup of a unit stay in ONE basic block: their gathers are then all in flight together
 // (a wave-uniform runtime branch here halves the memory-level parallelism and doubles the time).
-template <int LOOKUP, int LAYOUT>
+// POLICY: the lookup follows MRL_OPT_NEGATIVE's renormalising blend when the option asks for it (one-unit callers); false: the
+// texels are blended as stored and no branch enters the block (k_table — the batch calls send a renormalising context to the
+// generic kernel or the LDS-DMA kernel instead)
+template <int LOOKUP, int LAYOUT, bool POLICY = false>
 MRL_HD Rgbf table_brdf(const MaterialDev &m, const Options &o, const Vec3 &in, const Dir &out)
 {
     const TableMaps k(m);
     const Coords c = k(in, out);
-    if constexpr (LOOKUP) return lookup_trilinear_t<LAYOUT>(m, c, o.node);
-    else return lookup_nearest_t<LAYOUT>(m, c);
+    const int blend = POLICY ? blend_of(o) : (int)BLEND_STORED;
+    if constexpr (LOOKUP) return lookup_trilinear_t<LAYOUT>(m, c, o.node, blend);
+    else return lookup_nearest_t<LAYOUT>(m, c, blend);
 }
 
 // a5: eval (cosine included); valid == false gives zeros
-template <int LOOKUP, int LAYOUT>
+template <int LOOKUP, int LAYOUT, bool POLICY = false>
 MRL_HD void unit_eval(const MaterialDev &m, const Options &o, const Vec3 &in,
                                           float wix, float wiy, float wiz, float wox, float woy, float woz, float rgb[3])
 {
-    const Rgbf v = table_brdf<LOOKUP, LAYOUT>(m, o, in, dir_f32(wox, woy, woz));
-    eval_tail(v, (wix + wiy + wiz), wiz, wox, woy, woz, rgb);
+    const Rgbf v = table_brdf<LOOKUP, LAYOUT, POLICY>(m, o, in, dir_f32(wox, woy, woz));
+    eval_tail(v, (wix + wiy + wiz), wiz, wox, woy, woz, rgb, o.cosine != 0);
 }
 
 // ---- table importance sampling, tuned forms of merl_device.hpp::table_pdf / table_sample_dir ----
@@ -245,7 +249,7 @@ MRL_HD void table_sample_dir(const MaterialDev &m, int disk_map, const Vec3 &in,
 }
 
 // a6: sample
-template <int LOOKUP, int LAYOUT>
+template <int LOOKUP, int LAYOUT, bool POLICY = false>
 MRL_HD void unit_sample(const MaterialDev &m, const Options &o, const Vec3 &in,
                                             float wix, float wiy, float wiz,
                                             float u0, float u1, float wo[3], float &pdf, float weight[3])
@@ -260,8 +264,8 @@ MRL_HD void unit_sample(const MaterialDev &m, const Options &o, const Vec3 &in,
         square_to_cosine_hemisphere(o.disk_map, u0, u1, x, y, z);
         p = z > 0.0f ? z * kInvPiF : 0.0f;
     }
-    const Rgbf v = table_brdf<LOOKUP, LAYOUT>(m, o, in, dir_f32(x, y, z));
-    sample_tail(v, (wix + wiy + wiz), wiz, x, y, z, p, o.sampling != 0, wo, pdf, weight);
+    const Rgbf v = table_brdf<LOOKUP, LAYOUT, POLICY>(m, o, in, dir_f32(x, y, z));
+    sample_tail(v, (wix + wiy + wiz), wiz, x, y, z, p, o.sampling != 0, wo, pdf, weight, o.cosine != 0);
 }
 
 } // namespace fast

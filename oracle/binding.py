@@ -18,10 +18,12 @@ LOOKUP_NEAREST, LOOKUP_TRILINEAR = 0, 1
 NODE_INTEGER, NODE_CENTER = 0, 1
 DISK_MITSUBA06, DISK_MITSUBA3 = 0, 1
 PARAM_HALF_DIFF, PARAM_STANDARD, PARAM_STANDARD_FULL = 0, 1, 2
+COSINE_INCLUDED, COSINE_OMITTED = 0, 1
+NEGATIVE_CLAMP, NEGATIVE_KEEP, NEGATIVE_RENORMALISE = 0, 1, 2
 
 
 class Opts(C.Structure):
-    _fields_ = [("lookup", C.c_int), ("node", C.c_int), ("disk_map", C.c_int)]
+    _fields_ = [("lookup", C.c_int), ("node", C.c_int), ("disk_map", C.c_int), ("cosine", C.c_int), ("negative", C.c_int)]
 
 
 class Table(C.Structure):
@@ -121,8 +123,8 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def make_opts(lookup=LOOKUP_TRILINEAR, node=NODE_INTEGER, disk_map=DISK_MITSUBA06) -> Opts:
-    return Opts(lookup, node, disk_map)
+def make_opts(lookup=LOOKUP_TRILINEAR, node=NODE_INTEGER, disk_map=DISK_MITSUBA06, cosine=COSINE_INCLUDED, negative=NEGATIVE_CLAMP) -> Opts:
+    return Opts(lookup, node, disk_map, cosine, negative)
 
 
 class OracleTable:

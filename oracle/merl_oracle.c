@@ -172,14 +172,33 @@ void orc_coords(const orc_table *t, double th, double td, double pd, double *x_t
  * a4 — table fetch.  Texel = scaled value, negatives (MERL's below-horizon
  * markers) clamped to 0 BEFORE interpolation.
  * ---------------------------------------------------------------------------------------- */
-static void texel(const orc_table *t, int ith, int itd, int ipd, double rgb[3])
+static void texel_raw(const orc_table *t, int ith, int itd, int ipd, double rgb[3])
 {
     size_t n = (size_t)t->n_th * t->n_td * t->n_pd;
     size_t ind = (size_t)ipd + (size_t)t->n_pd * ((size_t)itd + (size_t)t->n_td * (size_t)ith);
-    for (int c = 0; c < 3; ++c) {
-        double v = t->data[ind + c * n] * t->scale[c];
-        rgb[c] = v > 0.0 ? v : 0.0;
-    }
+    for (int c = 0; c < 3; ++c) rgb[c] = t->data[ind + c * n] * t->scale[c];
+}
+static void texel(const orc_table *t, int ith, int itd, int ipd, double rgb[3])
+{
+    texel_raw(t, ith, itd, ipd, rgb);
+    for (int c = 0; c < 3; ++c) rgb[c] = rgb[c] > 0.0 ? rgb[c] : 0.0;
+}
+/* one channel of one corner into the running sums of a lookup, under the negative-value policy (merl_oracle.h):
+ * num += w v (clamped / as stored / only if valid), den += w (RENORMALISE: only if valid) */
+static void corner_accumulate(int negative, double w, double v, double *num, double *den)
+{
+    if (negative == ORC_NEGATIVE_KEEP) { *num += w * v; *den += w; }
+    else if (negative == ORC_NEGATIVE_RENORMALISE) { if (v >= 0.0) { *num += w * v; *den += w; } }
+    else { *num += w * (v > 0.0 ? v : 0.0); *den += w; }
+}
+static double corner_finish(int negative, double num, double den)
+{
+    if (negative != ORC_NEGATIVE_RENORMALISE) return num;
+    return den > 0.0 ? num / den : 0.0;
+}
+static double nearest_value(int negative, double v)
+{
+    return negative == ORC_NEGATIVE_KEEP ? v : (v > 0.0 ? v : 0.0);
 }
 
 /* split a continuous coordinate into (i0, i1, f) for a clamped axis */
@@ -217,7 +236,8 @@ static void split_phi(int param, double x, int n, int *i0, int *i1, double *f)
 void orc_lookup(const orc_table *t, const orc_opts *o, double th, double td, double pd, double rgb[3])
 {
     if (o->lookup == ORC_LOOKUP_NEAREST) {
-        texel(t, orc_theta_half_index(t, th), orc_theta_diff_index(t, td), orc_phi_diff_index(t, pd), rgb);
+        texel_raw(t, orc_theta_half_index(t, th), orc_theta_diff_index(t, td), orc_phi_diff_index(t, pd), rgb);
+        for (int c = 0; c < 3; ++c) rgb[c] = nearest_value(o->negative, rgb[c]);
         return;
     }
     double shift = o->node == ORC_NODE_CENTER ? 0.5 : 0.0;
@@ -229,15 +249,16 @@ void orc_lookup(const orc_table *t, const orc_opts *o, double th, double td, dou
     split_phi(t->param, xp - shift, t->n_pd, &p0, &p1, &fp);
     const int hs[2] = { h0, h1 }, ds[2] = { d0, d1 }, ps[2] = { p0, p1 };
     const double wh[2] = { 1.0 - fh, fh }, wd[2] = { 1.0 - fd, fd }, wp[2] = { 1.0 - fp, fp };
-    rgb[0] = rgb[1] = rgb[2] = 0.0;
+    double num[3] = { 0.0, 0.0, 0.0 }, den[3] = { 0.0, 0.0, 0.0 };
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b)
             for (int c = 0; c < 2; ++c) {
                 double v[3];
-                texel(t, hs[a], ds[b], ps[c], v);
+                texel_raw(t, hs[a], ds[b], ps[c], v);
                 double w = wh[a] * wd[b] * wp[c];
-                rgb[0] += w * v[0]; rgb[1] += w * v[1]; rgb[2] += w * v[2];
+                for (int k = 0; k < 3; ++k) corner_accumulate(o->negative, w, v[k], &num[k], &den[k]);
             }
+    for (int k = 0; k < 3; ++k) rgb[k] = corner_finish(o->negative, num[k], den[k]);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -254,7 +275,7 @@ static void eval_f64(const orc_table *t, const orc_opts *o, const float wi[3], c
     double a[3];
     orc_table_angles(t, in, out, a);
     orc_lookup(t, o, a[0], a[1], a[2], rgb);
-    double c = (double)wo[2];
+    double c = o->cosine == ORC_COSINE_OMITTED ? 1.0 : (double)wo[2];
     rgb[0] *= c; rgb[1] *= c; rgb[2] *= c;
 }
 
@@ -483,6 +504,7 @@ int orc_build_sampling2d(const orc_table *t, const orc_opts *o, int n_i, orc_sam
     out->n_i = n_i;
     orc_opts lo = *o;
     lo.lookup = 1;                                            /* the mass is measured with the interpolated table */
+    lo.negative = ORC_NEGATIVE_CLAMP;                         /* ... of clamped values, whatever eval() does with negative ones */
     for (int i = 0; i < n_i; ++i) {
         orc_sampling *r = &out->rows[i];
         r->n = n;
@@ -620,14 +642,16 @@ static orc_table dims_view(const orc_table_nch *t)
     return v;
 }
 
-static void texel_nch(const orc_table_nch *t, int ith, int itd, int ipd, double *out)
+static void texel_nch_raw(const orc_table_nch *t, int ith, int itd, int ipd, double *out)
 {
     size_t n = (size_t)t->n_th * t->n_td * t->n_pd;
     size_t ind = (size_t)ipd + (size_t)t->n_pd * ((size_t)itd + (size_t)t->n_td * (size_t)ith);
-    for (int c = 0; c < t->n_ch; ++c) {
-        double v = t->data[ind + (size_t)c * n] * t->scale[c];
-        out[c] = v > 0.0 ? v : 0.0;
-    }
+    for (int c = 0; c < t->n_ch; ++c) out[c] = t->data[ind + (size_t)c * n] * t->scale[c];
+}
+static void texel_nch(const orc_table_nch *t, int ith, int itd, int ipd, double *out)
+{
+    texel_nch_raw(t, ith, itd, ipd, out);
+    for (int c = 0; c < t->n_ch; ++c) out[c] = out[c] > 0.0 ? out[c] : 0.0;
 }
 
 #define ORC_MAX_CH 64
@@ -636,7 +660,8 @@ void orc_lookup_nch(const orc_table_nch *t, const orc_opts *o, double th, double
 {
     const orc_table dv = dims_view(t);
     if (o->lookup == ORC_LOOKUP_NEAREST) {
-        texel_nch(t, orc_theta_half_index(&dv, th), orc_theta_diff_index(&dv, td), orc_phi_diff_index(&dv, pd), out);
+        texel_nch_raw(t, orc_theta_half_index(&dv, th), orc_theta_diff_index(&dv, td), orc_phi_diff_index(&dv, pd), out);
+        for (int c = 0; c < t->n_ch; ++c) out[c] = nearest_value(o->negative, out[c]);
         return;
     }
     double shift = o->node == ORC_NODE_CENTER ? 0.5 : 0.0;
@@ -648,15 +673,17 @@ void orc_lookup_nch(const orc_table_nch *t, const orc_opts *o, double th, double
     split_phi(t->param, xp - shift, t->n_pd, &p0, &p1, &fp);
     const int hs[2] = { h0, h1 }, ds[2] = { d0, d1 }, ps[2] = { p0, p1 };
     const double wh[2] = { 1.0 - fh, fh }, wd[2] = { 1.0 - fd, fd }, wp[2] = { 1.0 - fp, fp };
-    for (int c = 0; c < t->n_ch; ++c) out[c] = 0.0;
+    double den[ORC_MAX_CH];
+    for (int c = 0; c < t->n_ch; ++c) out[c] = den[c] = 0.0;
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b)
             for (int c = 0; c < 2; ++c) {
                 double v[ORC_MAX_CH];
-                texel_nch(t, hs[a], ds[b], ps[c], v);
+                texel_nch_raw(t, hs[a], ds[b], ps[c], v);
                 double w = wh[a] * wd[b] * wp[c];
-                for (int k = 0; k < t->n_ch; ++k) out[k] += w * v[k];
+                for (int k = 0; k < t->n_ch; ++k) corner_accumulate(o->negative, w, v[k], &out[k], &den[k]);
             }
+    for (int k = 0; k < t->n_ch; ++k) out[k] = corner_finish(o->negative, out[k], den[k]);
 }
 
 void orc_eval_nch(const orc_table_nch *t, const orc_opts *o, const float wi[3], const float wo[3], float *out)
@@ -669,7 +696,8 @@ void orc_eval_nch(const orc_table_nch *t, const orc_opts *o, const float wi[3], 
     const orc_table dv = dims_view(t);
     orc_table_angles(&dv, in, od, a);
     orc_lookup_nch(t, o, a[0], a[1], a[2], v);
-    for (int c = 0; c < t->n_ch; ++c) out[c] = (float)(v[c] * (double)wo[2]);
+    const double cosine = o->cosine == ORC_COSINE_OMITTED ? 1.0 : (double)wo[2];
+    for (int c = 0; c < t->n_ch; ++c) out[c] = (float)(v[c] * cosine);
 }
 
 void orc_sample_nch(const orc_table_nch *t, const orc_opts *o, const float wi[3], const float u[2],

@@ -44,10 +44,23 @@ enum { ORC_DISK_MITSUBA06 = 0, ORC_DISK_MITSUBA3 = 1 }; /* concentric-disk flavo
  * direction is the normal).  Nearest lookup truncates, trilinear uses the node convention of orc_opts, as for MERL. */
 enum { ORC_PARAM_HALF_DIFF = 0, ORC_PARAM_STANDARD = 1, ORC_PARAM_STANDARD_FULL = 2 };
 
+/* does the plugin's eval() multiply the BRDF by cos(theta_o)?  Upstream's convention says yes (the
+ * default); OMITTED returns f alone — from eval() and from the eval() inside sample()'s weight (weight == eval / pdf stays true). */
+enum { ORC_COSINE_INCLUDED = 0, ORC_COSINE_OMITTED = 1 };
+/* what a negative stored value (MERL's marker for a sample that was not measured) does to a lookup:
+ *   CLAMP         it counts as 0 (the default; interpolation runs on the clamped values);
+ *   KEEP          it is used as it is stored (BRDFRead itself: it only prints a warning) — eval() can come out negative;
+ *   RENORMALISE   it is left out: a trilinear lookup blends the valid corners only and divides by their weight,
+ *                 sum_k w_k v_k [v_k >= 0] / sum_k w_k [v_k >= 0] per channel (0 when no corner is valid); nearest: 0.
+ * The sampling marginals of §8f item 2 are built from clamped values under every setting (a density needs a non-negative mass). */
+enum { ORC_NEGATIVE_CLAMP = 0, ORC_NEGATIVE_KEEP = 1, ORC_NEGATIVE_RENORMALISE = 2 };
+
 typedef struct orc_opts {
     int lookup;       /* ORC_LOOKUP_* */
     int node;         /* ORC_NODE_*   */
     int disk_map;     /* ORC_DISK_*   */
+    int cosine;       /* ORC_COSINE_*   (0: the default) */
+    int negative;     /* ORC_NEGATIVE_* (0: the default) */
 } orc_opts;
 
 /* A measured table in MERL parameterisation with free dims (customized_measurement = same
@@ -82,7 +95,7 @@ int orc_phi_diff_index(const orc_table *t, double phi_diff);
 void orc_coords(const orc_table *t, double theta_half, double theta_diff, double phi_diff,
                 double *x_th, double *x_td, double *x_pd);
 
-/* ---- a4: lookup (scaled, negatives clamped to 0) ---- */
+/* ---- a4: lookup (scaled; negatives per orc_opts.negative, clamped to 0 by default) ---- */
 void orc_lookup(const orc_table *t, const orc_opts *o,
                 double theta_half, double theta_diff, double phi_diff, double rgb[3]);
 

@@ -65,7 +65,37 @@ def rgl_cases():
                             wi=wi, wo=wo, u=u, rgb=rgb, pdf=pdf, wo2=wo2, pdf2=pdf2, weight=w)
 
 
+def option_cases():
+    """SURVEY.md Appendix B 2 and 4 as options (MRL_OPT_COSINE_FACTOR, MRL_OPT_NEGATIVE): one fixture per non-default value.  Both
+    synthetic tables carry MERL's -1 markers (24 % of the GGX-shaped table's texels — the below-horizon configurations —, 2 % of the
+    noise table's), so the three policies give three different answers next to them."""
+    for name, kind, seed, lookup, cosine, negative, first in (("opt_no_cosine_ggxtab", "ggx_tab", 2, 1, 1, 0, 160_000),
+                                                              ("opt_negative_keep_noise", "noise", 9, 1, 0, 1, 170_000),
+                                                              ("opt_negative_renormalise_ggxtab", "ggx_tab", 4, 1, 0, 2, 180_000),
+                                                              ("opt_negative_renormalise_noise_nearest", "noise", 9, 0, 0, 2, 190_000),
+                                                              ("opt_negative_keep_no_cosine_noise_nearest", "noise", 12, 0, 1, 1, 200_000)):
+        tab = synth.make_table(kind, seed)
+        T = ob.OracleTable(tab)
+        wi, wo, u = ob.generate_pairs(0x5EED, first, N)
+        o = ob.make_opts(lookup, 0, 0, cosine=cosine, negative=negative)
+        rgb, pdf, wo2, pdf2, w = ob.eval_sample_multi([T], wi, wo, u, None, o)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), table_kind=kind, table_seed=seed, lookup=lookup, node=0, disk_map=0,
+                            cosine=cosine, negative=negative, wi=wi, wo=wo, u=u, rgb=rgb, pdf=pdf, wo2=wo2, pdf2=pdf2, weight=w)
+    # an n-channel table under the renormalising blend
+    tab = synth.make_table_nch("spectral", 6, 5, (18, 14, 20))
+    scale = [0.5 + 0.25 * c for c in range(6)]
+    T = ob.OracleTableNch(tab, scale)
+    wi, wo, u = ob.generate_pairs(0x5EED, 210_000, N)
+    val, pdf, wo2, pdf2, w = ob.eval_sample_nch([T], wi, wo, u, None, ob.make_opts(1, 0, 0, cosine=1, negative=2))
+    np.savez_compressed(os.path.join(HERE, "opt_nch_c6_renormalise_no_cosine.npz"), table_kind="spectral", table_seed=5, n_ch=6, dims=np.array((18, 14, 20)),
+                        scale=np.array(scale), lookup=1, node=0, disk_map=0, sampling=0, cosine=1, negative=2, wi=wi, wo=wo, u=u,
+                        rgb=val, pdf=pdf, wo2=wo2, pdf2=pdf2, weight=w)
+
+
 def main():
+    if "--options-only" in sys.argv:                   # the older fixtures stay byte-identical in git
+        return option_cases()
+    option_cases()
     if "--rgl-only" in sys.argv:                       # the older fixtures stay byte-identical in git
         return rgl_cases()
     rgl_cases()

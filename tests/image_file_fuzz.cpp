@@ -85,11 +85,11 @@ int main()
     const int n_good = (int)(sizeof good / sizeof good[0]);
     ImagePlan p;
     for (int i = 0; i < n_good; ++i) {
-        const char *why = image_plan(good[i], length_of(good[i]), 1, 0, p);
+        const char *why = image_plan(good[i], length_of(good[i]), 1, 0, 0, p);
         if (why || !consistent(good[i], length_of(good[i]), p)) { std::fprintf(stderr, "well-formed header %d refused: %s\n", i, why ? why : "inconsistent plan"); return 1; }
-        if (!image_plan(good[i], length_of(good[i]) - 1, 1, 0, p) || !image_plan(good[i], length_of(good[i]) + 1, 1, 0, p)) { std::fprintf(stderr, "wrong length accepted\n"); return 1; }
+        if (!image_plan(good[i], length_of(good[i]) - 1, 1, 0, 0, p) || !image_plan(good[i], length_of(good[i]) + 1, 1, 0, 0, p)) { std::fprintf(stderr, "wrong length accepted\n"); return 1; }
     }
-    if (!image_plan(good[0], length_of(good[0]), 0, 0, p) || !image_plan(good[0], length_of(good[0]), 1, 1, p)) { std::fprintf(stderr, "foreign lookup options accepted\n"); return 1; }
+    if (!image_plan(good[0], length_of(good[0]), 0, 0, 0, p) || !image_plan(good[0], length_of(good[0]), 1, 1, 0, p)) { std::fprintf(stderr, "foreign lookup options accepted\n"); return 1; }
     long accepted = 0, refused = 0;
     for (long round = 0; round < 1000000; ++round) {
         ImageHeader h = good[rnd() % n_good];
@@ -102,7 +102,7 @@ int main()
         else { b[rnd() % sizeof h] = (unsigned char)rnd(); }
         // the length the (possibly corrupted) header itself claims — the case that must be decided on the shapes — or a random one
         const unsigned long long len = (rnd() % 4) ? length_of(h) : rnd() % (1ull << 36);
-        const char *why = image_plan(h, len, 1, 0, p);
+        const char *why = image_plan(h, len, 1, 0, 0, p);
         if (!why) {
             ++accepted;
             if (!consistent(h, len, p)) { std::fprintf(stderr, "round %ld: an inconsistent plan was accepted\n", round); return 1; }

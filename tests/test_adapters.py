@@ -217,6 +217,34 @@ def test_plugin_table_sampling_property(built, merl_file, oracle, tables, tmp_pa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("host,disk", [("06", 0), ("3", 1)])
+@pytest.mark.parametrize("props,cosine,negative", [("cosine_factor=omitted", 1, 0), ("negative_values=keep", 0, 1), ("negative_values=renormalize,cosine_factor=omitted", 1, 2)])
+def test_plugin_convention_properties(built, merl_file, oracle, tables, tmp_path, host, disk, props, cosine, negative):
+    """SURVEY.md Appendix B 4 and 2 as plugin properties: <string name="cosine_factor" value="included|omitted"/> and
+    <string name="negative_values" value="clamp|keep|renormalize"/> — scalar virtual calls (on the CPU) and the batch path answer
+    with the oracle's values under the same convention."""
+    n, m = 8000, 400
+    wi, wo, u = oracle.generate_pairs(0x5EED, 777 + cosine + 2 * negative, n)
+    pairs, out = str(tmp_path / "pairs.bin"), str(tmp_path / "out.bin")
+    _write_pairs(pairs, wi, wo, u)
+    drv = os.path.join(built, "driver06" if host == "06" else "driver3")
+    plug = os.path.join(built, "plugins06" if host == "06" else "plugins3", "merl.so")
+    r = subprocess.run([drv, plug, merl_file, pairs, out, str(m), "trilinear"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MERL_DRIVER_PROPS=props))
+    assert r.returncode == 0, r.stdout + r.stderr
+    scalar, batch = _read_out(out, m, n)
+    want = oracle.eval_sample_multi([oracle.OracleTable(tables("ggx_tab", 0))], wi, wo, u, None,
+                                    oracle.make_opts(lookup=1, disk_map=disk, cosine=cosine, negative=negative))
+    default = oracle.eval_sample_multi([oracle.OracleTable(tables("ggx_tab", 0))], wi, wo, u, None, oracle.make_opts(lookup=1, disk_map=disk))
+    assert not np.array_equal(want[0], default[0])                  # the property changes the answer
+    _check(batch, want)
+    _check(scalar, tuple(w[:m] for w in want))
+    r = subprocess.run([drv, plug, merl_file, pairs, out, str(m), "trilinear"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MERL_DRIVER_PROPS="negative_values=sometimes"))
+    assert r.returncode != 0 and "negative_values" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("host", ["06", "3"])
 def test_plugin_instances_share_one_resident_table_and_release_it(built, merl_file, tables, tmp_path, host):
     """Two <bsdf> elements naming the same .binary hold ONE table in HBM; 50 create/destroy cycles leave free memory flat."""

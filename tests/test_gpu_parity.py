@@ -332,6 +332,8 @@ def test_golden_fixtures(tables, oracle):
         with host.MerlHip(0) as g:
             set_opts(g, int(z["lookup"]), int(z["node"]), int(z["disk_map"]))
             g.set_option(host.OPT_SAMPLING, sampling)
+            g.set_option(host.OPT_COSINE_FACTOR, int(z["cosine"]) if "cosine" in z else 0)
+            g.set_option(host.OPT_NEGATIVE, int(z["negative"]) if "negative" in z else 0)
             if kind == "ggx":
                 mid = g.ggx(float(z["alpha"]), z["eta"].tolist(), z["k"].tolist())
             elif "dims" in z:
