@@ -664,7 +664,10 @@ int mrl_group_link_test(mrl_group *g, size_t bytes, int transport, int root, mrl
         };
         for (size_t i = 0; i < n; ++i) { const uint32_t v = (uint32_t)(i * 2654435761u) ^ (uint32_t)(r * 0x9E3779B9u); std::memcpy(&h_src[i], &v, 4); }
         hip(hipSetDevice(m.device), "hipSetDevice") && hip(hipMalloc((void **)&src, n * sizeof(float)), "hipMalloc(src)") &&
-            hip(hipMemcpy(src, h_src.data(), n * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(src)") &&
+            hip(hipMemcpy(src, h_src.data(), n * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(src)");
+        // the events belong to the device whose stream they are recorded on (an event cannot be recorded on another device's
+        // stream: hipErrorInvalidHandle): the root's for RCCL — ncclRecv ends the transfer there —, the peer's for a device copy
+        if (status == MRL_OK) hip(hipSetDevice(transport == MRL_TRANSPORT_RCCL ? R.device : m.device), "hipSetDevice") &&
             hip(hipEventCreate(&e0), "hipEventCreate") && hip(hipEventCreate(&e1), "hipEventCreate");
         if (status == MRL_OK) hip(hipSetDevice(R.device), "hipSetDevice") && hip(hipMalloc((void **)&dst, n * sizeof(float)), "hipMalloc(dst)") &&
             hip(hipMemset(dst, 0, n * sizeof(float)), "hipMemset(dst)") && hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
