@@ -49,6 +49,20 @@ def source_hash() -> str:
     return h.hexdigest()[:12]
 
 
+def _compile_objects(srcs, objdir: str, flags) -> list:
+    """One object per translation unit, compiled side by side (hipcc takes ~10-60 s per file: the kernels dominate)."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
+    objs = [os.path.join(objdir, os.path.basename(s) + ".o") for s in srcs]
+
+    def one(pair):
+        src, obj = pair
+        subprocess.check_call([HIPCC] + flags + ["-c", "-o", obj, src], cwd=PKG)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(len(srcs), max(1, (os.cpu_count() or 2) - 1))) as pool:
+        return list(pool.map(one, zip(srcs, objs)))
+
+
 def build_lib(force: bool = False, asm: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     srcs, deps = lib_sources()
@@ -60,12 +74,15 @@ def build_lib(force: bool = False, asm: bool = False) -> str:
             fcntl.flock(lock, fcntl.LOCK_EX)
             if force or _newer(LIB, deps):
                 tmp = f"{LIB}.{os.getpid()}.tmp"
+                objdir = os.path.join(LIBDIR, f"obj.{os.getpid()}")
                 try:
-                    subprocess.check_call([HIPCC] + HIP_FLAGS + [f'-DMRL_SOURCE_HASH="{source_hash()}"', "-shared", "-o", tmp] + srcs, cwd=PKG)
+                    objs = _compile_objects(srcs, objdir, HIP_FLAGS + [f'-DMRL_SOURCE_HASH="{source_hash()}"'])
+                    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs, cwd=PKG)
                     os.replace(tmp, LIB)
                 finally:
                     if os.path.exists(tmp):
                         os.remove(tmp)
+                    shutil.rmtree(objdir, ignore_errors=True)
     if asm:
         out = os.path.join(LIBDIR, "asm")
         os.makedirs(out, exist_ok=True)

@@ -1,226 +1,11 @@
 // merl_abi.hip — the C ABI of libmerl_hip.so (include/merl_hip.h): context, material tables,
 // host/device pointer plumbing, launches.  No CPU evaluation path exists here: every batch
 // entry point ends in a gfx950 kernel launch or an error.
-#include "../../include/merl_hip.h"
+#include "merl_ctx.hpp"
 
-#include <hip/hip_runtime.h>
+namespace mrlabi {
 
-#include <algorithm>
-#include <atomic>
-#include <condition_variable>
-#include <functional>
-#include <mutex>
-#include <thread>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-#include <unistd.h>
 
-#include "merl_kernels.hpp"
-#include "merl_rgl.hpp"
-#include "merl_image_file.hpp"
-#include "merl_scalar_host.hpp"
-#include "merl_host_table.hpp"
-
-namespace {
-
-constexpr int kMerlDims[3] = { 90, 90, 180 };
-constexpr double kMerlScale[3] = { 1.0 / 1500.0, 1.15 / 1500.0, 1.66 / 1500.0 };
-
-struct MaterialHost {
-    mrl::MaterialDev dev;
-    float4 *d_texels = nullptr;
-    bool in_arena = false;           // d_texels is a slice of the context's table arena (MRL_OPT_TABLE_ARENA_MB): not freed on its own
-    double *d_sampling = nullptr;
-    double *d_sampling2d = nullptr;  // P(theta_h | theta_i) rows (RGB tables), built on the device at upload
-    size_t bytes = 0;                // device bytes this material holds (table + sampling marginal)
-    mrl::RglDev rgl{};               // KIND_RGL: the five functions' descriptor (pointers into d_texels)
-    bool released = false;           // tombstone left by mrl_material_release; the slot may be reused
-    int rows_lookup = 1, rows_node = 0;      // the lookup / node options the conditional sampling rows were integrated under (at upload)
-};
-
-// Row marginal for table importance sampling (definition: oracle/merl_oracle.h):
-// s[n+1] = sin^2(theta_i), cdf[n+1], c[n]; computed on the host in f64, in the file's loop order.
-std::vector<double> build_sampling(const double *planar, int n_th, int n_td, int n_pd, const double scale[3], int param)
-{
-    const size_t plane = (size_t)n_th * n_td * n_pd;
-    std::vector<double> D((size_t)n_th), out(3 * (size_t)n_th + 2);
-    double *s = out.data(), *cdf = s + (n_th + 1), *c = cdf + (n_th + 1);
-    double mean = 0.0;
-    for (int i = 0; i < n_th; ++i) {
-        double acc = 0.0;
-        const double *row = planar + (size_t)i * n_td * n_pd;
-        for (size_t k = 0; k < (size_t)n_td * n_pd; ++k) {
-            const double r = std::max(row[k] * scale[0], 0.0), g = std::max(row[k + plane] * scale[1], 0.0), b = std::max(row[k + 2 * plane] * scale[2], 0.0);
-            acc += 0.2126 * r + 0.7152 * g + 0.0722 * b;
-        }
-        D[(size_t)i] = acc / ((double)n_td * (double)n_pd);
-        mean += D[(size_t)i];
-    }
-    mean /= (double)n_th;
-    if (param != mrl::PARAM_HALF_DIFF) mean = 0.0;                    // the rows are not theta_h: flat lobe (oracle/merl_oracle.h)
-    for (int i = 0; i < n_th; ++i) D[(size_t)i] = mean > 0.0 ? D[(size_t)i] + 0.01 * mean : 1.0;
-    const double kHalfPi = 3.14159265358979323846 / 2.0;
-    for (int i = 0; i <= n_th; ++i) {
-        const double r = (double)i / (double)n_th, sn = std::sin(r * r * kHalfPi);
-        s[i] = i == n_th ? 1.0 : sn * sn;
-    }
-    double Z = 0.0;
-    for (int i = 0; i < n_th; ++i) Z += D[(size_t)i] * (s[i + 1] - s[i]);
-    double run = 0.0;
-    for (int i = 0; i < n_th; ++i) {
-        cdf[i] = run / Z;
-        run += D[(size_t)i] * (s[i + 1] - s[i]);
-        c[i] = D[(size_t)i] / (3.14159265358979323846 * Z);
-    }
-    cdf[n_th] = 1.0;
-    return out;
-}
-
-} // namespace
-
-// ---- pipelined host-array path -------------------------------------------------------------------------------------
-// A host that holds plain (pageable) arrays — what a CPU renderer hands over — used to be staged with hipMemcpyAsync,
-// which the runtime serialises through one bounce buffer at ~11 GB/s (140-150 M units/s).  Instead: a few copy threads
-// move chunk c+1 of the caller's arrays into pinned, device-mapped buffers and chunk c-1 of the results out of them,
-// while the kernel of chunk c reads and writes the pinned buffers over PCIe itself (zero copy, no staging in HBM).
-struct CopyPool {
-    struct Seg { void *dst; const void *src; size_t bytes; };
-    std::vector<std::thread> workers;
-    std::mutex mu;
-    std::condition_variable wake, done;
-    std::vector<Seg> segs;
-    size_t next = 0, finished = 0;
-    uint64_t generation = 0;
-    bool quit = false;
-
-    void start(int n)
-    {
-        for (int t = 0; t < n; ++t)
-            workers.emplace_back([this]() {
-                uint64_t seen = 0;
-                for (;;) {
-                    std::unique_lock<std::mutex> lk(mu);
-                    wake.wait(lk, [&]() { return quit || (generation != seen && next < segs.size()) || (generation != seen && segs.empty()); });
-                    if (quit) return;
-                    if (next >= segs.size()) { seen = generation; continue; }
-                    while (next < segs.size()) {
-                        const Seg sg = segs[next++];
-                        lk.unlock();
-                        std::memcpy(sg.dst, sg.src, sg.bytes);
-                        lk.lock();
-                        if (++finished == segs.size()) done.notify_all();
-                    }
-                    seen = generation;
-                }
-            });
-    }
-    // copies every segment, split into slices so that all workers (and the caller) share the work; returns when done
-    void run(const std::vector<Seg> &whole)
-    {
-        constexpr size_t kSlice = (size_t)2 << 20;
-        std::vector<Seg> sliced;
-        for (const Seg &w : whole)
-            for (size_t off = 0; off < w.bytes; off += kSlice)
-                sliced.push_back({ (char *)w.dst + off, (const char *)w.src + off, std::min(kSlice, w.bytes - off) });
-        if (sliced.empty()) return;
-        if (workers.empty()) { for (const Seg &sg : sliced) std::memcpy(sg.dst, sg.src, sg.bytes); return; }
-        std::unique_lock<std::mutex> lk(mu);
-        segs = std::move(sliced); next = 0; finished = 0; ++generation;
-        wake.notify_all();
-        while (next < segs.size()) {                              // the caller copies too
-            const Seg sg = segs[next++];
-            lk.unlock();
-            std::memcpy(sg.dst, sg.src, sg.bytes);
-            lk.lock();
-            ++finished;
-        }
-        done.wait(lk, [&]() { return finished == segs.size(); });
-        segs.clear();
-    }
-    void stop()
-    {
-        { std::lock_guard<std::mutex> lk(mu); quit = true; }
-        wake.notify_all();
-        for (auto &t : workers) t.join();
-        workers.clear();
-    }
-};
-
-struct HostPipe {
-    char *pin[2] = { nullptr, nullptr };             // per slot: inputs then outputs of one chunk
-    size_t slot_bytes = 0;
-    hipEvent_t done[2] = { nullptr, nullptr };
-    CopyPool pool;
-    int threads = -1;                                // workers the pool was started with
-};
-
-// the device side of the one-unit call service (merl_scalar_host.hpp): where the mailbox lives and how an instance of
-// the service kernel is put on its own stream
-struct ScalarDevice {
-    mrl_ctx *ctx = nullptr;
-    mrl::ScalarBoard *b = nullptr;           // pinned, coherent host memory; nullptr until the first scalar call
-    mrl::ScalarBoard *b_dev = nullptr;       // the same memory as the device addresses it
-    hipStream_t stream = nullptr;            // non-blocking: batch launches on the context's stream never queue behind an instance
-    uint64_t lifetime_ticks = 50000;         // 500 us of the 100 MHz wall clock
-    std::atomic<bool> ok{ true };
-    mrl::ScalarBoard *board() { return b; }
-    bool launch(uint32_t gen);
-    bool healthy() { return ok.load(std::memory_order_relaxed); }
-};
-using ScalarSvc = mrl::ScalarService<ScalarDevice>;
-
-struct mrl_ctx {
-    // every entry point that touches the context takes this lock: calls from several host threads are safe and serialise
-    // (device-pointer calls only enqueue, so the lock is held for microseconds; host-array calls hold it for their duration)
-    mutable std::recursive_mutex mu;
-    int device = 0;
-    int compute_units = 256;
-    std::string device_name;
-    size_t total_mem = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // kind-partitioned mixed batches: [2][queue_cap] unit indices + partition work area behind them
-    uint32_t *d_queues = nullptr;
-    size_t queue_cap = 0;
-    // mrl_partition_by_material: per-chunk count table + totals
-    uint32_t *d_part_work = nullptr;
-    size_t part_work_cap = 0;
-    std::vector<MaterialHost> materials;
-    mrl::MaterialDev *d_materials = nullptr;
-    size_t d_materials_cap = 0;
-    size_t material_bytes = 0;       // sum of MaterialHost::bytes over live materials
-    size_t memory_limit = 0;         // MRL_OPT_MEMORY_LIMIT_MB in bytes; 0 = none
-    // what a tombstone points at: one all-zero cell (valid in both layouts) + a 1-row sampling marginal
-    void *d_dummy = nullptr;
-    mrl::Options opts{ 1, 0, 0, 0, 0, 0 };
-    int kernel_variant = 3;          // MRL_OPT_KERNEL default: cooperative LDS-DMA brick fetch
-    int table_layout = 1;            // layout of tables uploaded from now on (mrl::Layout)
-    int table_param = 0;             // parameterisation of customized_measurement tables uploaded from now on (mrl::Param)
-    size_t host_chunk = (size_t)1 << 22;
-    int block_map = 0;               // MRL_OPT_BLOCK_MAP
-    int rgl_search = 0;              // MRL_OPT_RGL_SEARCH
-    int host_threads = 4;            // MRL_OPT_HOST_THREADS: copy threads of the pipelined host-array path; 0 = staged hipMemcpy path
-    HostPipe pipe;
-    void *d_stage = nullptr;
-    size_t d_stage_bytes = 0;
-    ScalarDevice scalar_dev;
-    std::atomic<ScalarSvc *> scalar{ nullptr };      // created by the first mrl_scalar_eval_sample
-    // MRL_OPT_TABLE_ARENA_MB: one device allocation that RGB tables are placed in back to back (2 MiB aligned)
-    char *arena = nullptr;
-    size_t arena_bytes = 0, arena_used = 0;
-    int arena_live = 0;              // tables currently placed in it; the bump pointer rewinds when the last one leaves
-    std::string last_error;
-};
-
-namespace {
-
-#define MRL_GUARD(ctx) std::lock_guard<std::recursive_mutex> mrl_guard_((ctx)->mu)
 
 int fail(mrl_ctx *ctx, int status, const std::string &msg)
 {
@@ -228,25 +13,7 @@ int fail(mrl_ctx *ctx, int status, const std::string &msg)
     return status;
 }
 
-#define MRL_HIP(ctx, expr)                                                                   \
-    do {                                                                                     \
-        hipError_t _e = (expr);                                                              \
-        if (_e != hipSuccess) {                                                              \
-            (void)hipGetLastError();                                                         \
-            return fail((ctx), MRL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-        }                                                                                    \
-    } while (0)
 
-// an allocation: out-of-memory is its own status (MRL_ERR_OOM), everything else MRL_ERR_HIP
-#define MRL_ALLOC(ctx, expr)                                                                 \
-    do {                                                                                     \
-        hipError_t _e = (expr);                                                              \
-        if (_e != hipSuccess) {                                                              \
-            (void)hipGetLastError();                                                         \
-            return fail((ctx), _e == hipErrorOutOfMemory ? MRL_ERR_OOM : MRL_ERR_HIP,        \
-                        std::string(#expr) + ": " + hipGetErrorString(_e));                  \
-        }                                                                                    \
-    } while (0)
 
 // 1 = the device can dereference it (device, managed or pinned/registered host), 0 = plain host
 int pointer_kind(const void *p)
@@ -326,18 +93,6 @@ mrl::MaterialDev tombstone_dev(const mrl_ctx *ctx)
     return d;
 }
 
-// Whoever changes what a running service instance reads (the material array, the tables behind it, the options) holds one
-// of these: no scalar call is in flight and no instance is running while it lives (merl_scalar_host.hpp, "writer").
-struct ScalarPause {
-    ScalarSvc *svc;
-    explicit ScalarPause(mrl_ctx *ctx) : svc(ctx->scalar.load(std::memory_order_acquire))
-    {
-        if (svc && !svc->pause()) ctx->scalar_dev.ok.store(false, std::memory_order_relaxed);
-    }
-    ~ScalarPause() { if (svc) svc->resume(); }
-    ScalarPause(const ScalarPause &) = delete;
-    ScalarPause &operator=(const ScalarPause &) = delete;
-};
 
 // MRL_ERR_OOM when `need` more bytes of material data would exceed the context's budget or the device's free memory
 int budget_check(mrl_ctx *ctx, size_t need)
@@ -396,569 +151,9 @@ void table_free(mrl_ctx *ctx, float4 *p, bool in_arena)
     if (--ctx->arena_live == 0) ctx->arena_used = 0;         // a bump allocator: space comes back when the arena empties
 }
 
-// planar f64 (file layout) -> padded, texel-interleaved RGBA f32 in HBM.
-// Row layout [n_th+1][n_td+1][n_pd+1]: the extra theta rows repeat the last row (clamp), the
-// extra phi texel repeats texel 0 (phi_d is periodic with period pi), so the kernel's "+1"
-// neighbours never need a clamp or a wrap.  Scales applied and negatives clamped here, once.
-int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const double scale[3], int kind, int *out_id)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (!planar || !dims || !scale || !out_id) return fail(ctx, MRL_ERR_INVALID, "null argument");
-    const int n_th = dims[0], n_td = dims[1], n_pd = dims[2];
-    if (n_th < 1 || n_td < 1 || n_pd < 1 || (long long)n_th * n_td * n_pd > (1LL << 28))
-        return fail(ctx, MRL_ERR_INVALID, "table dims out of range");
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1;
-    const size_t plane = (size_t)n_th * n_td * n_pd;
-    const int layout = ctx->table_layout;
-    const int param = kind == mrl::KIND_MERL ? mrl::PARAM_HALF_DIFF : ctx->table_param;      // a MERL file is what it is
-    const size_t out_texels = layout == mrl::LAYOUT_BRICK ? plane * 8 : H * D * P;
-    const size_t sampling_doubles = 3 * (size_t)n_th + 2;
-    MaterialHost m;
-    m.bytes = out_texels * sizeof(float4) + sampling_doubles * sizeof(double);
-    // budget first: the resident image plus the transient planar copy the re-layout kernel reads
-    int rc = budget_check(ctx, m.bytes + 3 * plane * sizeof(double));
-    if (rc != MRL_OK) return rc;
-    // the file payload goes to the device as it is; a kernel scales, clamps and re-lays it out
-    double *d_planar = nullptr;
-    MRL_ALLOC(ctx, hipMalloc((void **)&d_planar, 3 * plane * sizeof(double)));
-    hipError_t e = table_alloc(ctx, out_texels * sizeof(float4), &m.d_texels, &m.in_arena);
-    const bool oom = e == hipErrorOutOfMemory;
-    if (e == hipSuccess) e = hipMemcpyAsync(d_planar, planar, 3 * plane * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = mrl::launch_build_table(d_planar, dims, scale, layout, param, ctx->opts.negative == mrl::NEGATIVE_CLAMP, m.d_texels, ctx->compute_units, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_planar);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        table_free(ctx, m.d_texels, m.in_arena);
-        return fail(ctx, oom ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
-    }
-    {
-        const std::vector<double> sampling = build_sampling(planar, n_th, n_td, n_pd, scale, param);
-        e = hipMalloc((void **)&m.d_sampling, sampling.size() * sizeof(double));
-        const bool oom2 = e == hipErrorOutOfMemory;
-        if (e == hipSuccess) e = hipMemcpy(m.d_sampling, sampling.data(), sampling.size() * sizeof(double), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            table_free(ctx, m.d_texels, m.in_arena);
-            if (m.d_sampling) (void)hipFree(m.d_sampling);
-            return fail(ctx, oom2 ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("sampling table upload: ") + hipGetErrorString(e));
-        }
-    }
-    std::memset(&m.dev, 0, sizeof m.dev);
-    m.dev.kind = kind;
-    m.dev.sampling = m.d_sampling;
-    m.dev.n_th = n_th; m.dev.n_td = n_td; m.dev.n_pd = n_pd;
-    m.dev.row_td = (int)P;
-    m.dev.row_th = (int)(D * P);
-    m.dev.texels = m.d_texels;
-    m.dev.layout = layout;
-    m.dev.n_ch = 3;
-    m.dev.param = param;
-    {
-        // the conditional sampling table, from the table that has just become resident (quadrature + prefix scan on the device)
-        const int n_ti = mrl::kSamplingIncidentBins;
-        double *d_work = nullptr;
-        e = hipMalloc((void **)&m.d_sampling2d, (size_t)n_ti * (2 * (size_t)n_th + 1) * sizeof(double));
-        const bool oom3 = e == hipErrorOutOfMemory;
-        if (e == hipSuccess) e = hipMalloc((void **)&d_work, (size_t)n_ti * (size_t)n_th * sizeof(double));
-        if (e == hipSuccess) e = mrl::launch_build_sampling2d(m.dev, ctx->opts, n_ti, m.d_sampling2d, d_work, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (d_work) (void)hipFree(d_work);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            table_free(ctx, m.d_texels, m.in_arena); (void)hipFree(m.d_sampling);
-            if (m.d_sampling2d) (void)hipFree(m.d_sampling2d);
-            return fail(ctx, oom3 ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("conditional sampling table: ") + hipGetErrorString(e));
-        }
-        m.dev.sampling2d = m.d_sampling2d;
-        m.dev.n_ti = n_ti;
-        m.rows_lookup = ctx->opts.lookup; m.rows_node = ctx->opts.node;
-        m.bytes += (size_t)n_ti * (2 * (size_t)n_th + 1) * sizeof(double);
-    }
-    rc = place_material(ctx, m, out_id);
-    if (rc != MRL_OK) { table_free(ctx, m.d_texels, m.in_arena); (void)hipFree(m.d_sampling); (void)hipFree(m.d_sampling2d); return rc; }
-    return MRL_OK;
-}
+} // namespace mrlabi
+using namespace mrlabi;
 
-// a1: MERL .binary reader: int32 dims[3], then 3*n planar doubles.  A customized_measurement
-// table may carry its payload as f32 instead (the file length says which); MERL files are f64 only.
-int read_table_file(mrl_ctx *ctx, const char *path, bool require_merl, std::vector<double> &data, int dims[3])
-{
-    if (!path) return fail(ctx, MRL_ERR_INVALID, "null path");
-    FILE *f = std::fopen(path, "rb");
-    if (!f) return fail(ctx, MRL_ERR_IO, std::string("cannot open ") + path);
-    int32_t d[3];
-    if (std::fread(d, sizeof(int32_t), 3, f) != 3) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "short header"); }
-    if (d[0] <= 0 || d[1] <= 0 || d[2] <= 0) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "non-positive dims"); }
-    long long n = (long long)d[0] * d[1] * d[2];
-    if (require_merl && n != 90LL * 90 * 180) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "dims do not match the MERL grid (90*90*360/2)"); }
-    if (n > (1LL << 28)) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "table too large"); }
-    bool f32_payload = false;
-    if (!require_merl && std::fseek(f, 0, SEEK_END) == 0) {
-        const long long bytes = (long long)std::ftell(f);
-        f32_payload = bytes == 12 + 3 * n * 4;
-        if (std::fseek(f, 12, SEEK_SET) != 0) { std::fclose(f); return fail(ctx, MRL_ERR_IO, "seek failed"); }
-    }
-    try { data.resize(3 * (size_t)n); } catch (const std::bad_alloc &) { std::fclose(f); return fail(ctx, MRL_ERR_OOM, "table buffer"); }
-    size_t got;
-    if (f32_payload) {
-        std::vector<float> narrow;
-        try { narrow.resize(data.size()); } catch (const std::bad_alloc &) { std::fclose(f); return fail(ctx, MRL_ERR_OOM, "table buffer"); }
-        got = std::fread(narrow.data(), sizeof(float), narrow.size(), f);
-        for (size_t i = 0; i < got; ++i) data[i] = (double)narrow[i];
-    } else {
-        got = std::fread(data.data(), sizeof(double), data.size(), f);
-    }
-    std::fclose(f);
-    if (got != data.size()) return fail(ctx, MRL_ERR_FORMAT, "truncated table payload");
-    if (require_merl) { dims[0] = kMerlDims[0]; dims[1] = kMerlDims[1]; dims[2] = kMerlDims[2]; }
-    else { dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2]; }
-    return MRL_OK;
-}
-
-// staging area of host-pointer calls: `units` units of `unit_bytes` each (80 B for RGB, 56 + 8 C for C channels)
-int ensure_stage(mrl_ctx *ctx, size_t units, size_t unit_bytes)
-{
-    if (units * unit_bytes <= ctx->d_stage_bytes) return MRL_OK;
-    if (ctx->d_stage) { MRL_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_stage); ctx->d_stage = nullptr; ctx->d_stage_bytes = 0; }
-    MRL_ALLOC(ctx, hipMalloc(&ctx->d_stage, units * unit_bytes));
-    ctx->d_stage_bytes = units * unit_bytes;
-    return MRL_OK;
-}
-
-struct BatchCall {
-    int mode;                                    // 0 eval, 1 pdf, 2 sample, 3 eval+sample, 4 eval+pdf
-    const float *wi, *wo, *u;
-    const int32_t *mat;
-    int32_t single_id;
-    size_t n;
-    float *out_rgb, *out_pdf, *out_wo, *out_pdf2, *out_weight;
-    int n_ch = 0;                                // 0: the RGB entry points; > 0: *_nch calls, out_rgb / out_weight are n x n_ch
-};
-
-inline bool call_has_eval(int mode) { return mode == 0 || mode == 3 || mode == 4; }
-inline bool call_has_pdf(int mode) { return mode == 1 || mode == 3 || mode == 4; }
-inline bool call_has_sample(int mode) { return mode == 2 || mode == 3; }
-
-constexpr size_t kMaxSegments = 256 * 8 + 64;     // partition_geometry caps segments at 8 per CU
-
-int ensure_queues(mrl_ctx *ctx, size_t units)
-{
-    if (units <= ctx->queue_cap) return MRL_OK;
-    if (ctx->d_queues) {
-        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_queues);
-        ctx->d_queues = nullptr; ctx->queue_cap = 0;
-    }
-    MRL_ALLOC(ctx, hipMalloc((void **)&ctx->d_queues, (2 * units + 4 * kMaxSegments + 2) * sizeof(uint32_t)));
-    ctx->queue_cap = units;
-    return MRL_OK;
-}
-
-// kernel arguments of a call whose pointers are all device-accessible
-struct DeviceCall {
-    mrl::BatchArgs args;
-    bool multi, has_ggx, has_table, has_rgl;
-};
-
-DeviceCall device_call(const mrl_ctx *ctx, const BatchCall &c)
-{
-    DeviceCall d;
-    mrl::BatchArgs &a = d.args;
-    std::memset(&a, 0, sizeof a);
-    a.wi = c.wi; a.wo = c.wo; a.u = c.u; a.mat = c.mat; a.n = c.n;
-    a.out_rgb = c.out_rgb; a.out_pdf = c.out_pdf; a.out_wo = c.out_wo; a.out_pdf2 = c.out_pdf2; a.out_weight = c.out_weight;
-    a.materials = ctx->d_materials;
-    a.n_materials = (int)ctx->materials.size();
-    a.opts = ctx->opts;
-    a.safe = tombstone_dev(ctx);
-    a.block_map = ctx->block_map;
-    d.multi = c.mat != nullptr;
-    if (!d.multi) a.single = ctx->materials[(size_t)c.single_id].dev;
-    d.has_ggx = d.has_table = d.has_rgl = false;
-    a.any_standard = 0;
-    for (const auto &m : ctx->materials) {
-        if (m.released) continue;
-        d.has_rgl = d.has_rgl || m.dev.kind == mrl::KIND_RGL;
-        if (d.multi && m.dev.kind != mrl::KIND_GGX && m.dev.param != mrl::PARAM_HALF_DIFF) a.any_standard = 1;
-        d.has_ggx = d.has_ggx || m.dev.kind == mrl::KIND_GGX;
-        d.has_table = d.has_table || m.dev.kind == mrl::KIND_MERL || m.dev.kind == mrl::KIND_TABLE ||
-                      (c.mode == 1 && m.dev.kind == mrl::KIND_TABLE_NCH);       // pdf serves n-channel tables too
-    }
-    if (!d.has_ggx && !d.has_table) d.has_table = true;        // only tombstones left: the table path renders them as zeros
-    if (!d.multi && a.single.kind != mrl::KIND_GGX && a.single.param != mrl::PARAM_HALF_DIFF) a.any_standard = 1;
-    return d;
-}
-
-// null-pointer and material checks shared by the whole-array and the queue entry points
-int check_call(mrl_ctx *ctx, const BatchCall &c)
-{
-    const bool has_eval = call_has_eval(c.mode), has_pdf = call_has_pdf(c.mode), has_sample = call_has_sample(c.mode);
-    const bool needs_wo = has_eval || has_pdf, needs_u = has_sample;
-    if (!c.wi || (needs_wo && !c.wo) || (needs_u && !c.u) || (has_eval && !c.out_rgb) || (has_pdf && !c.out_pdf) ||
-        (has_sample && (!c.out_wo || !c.out_pdf2 || !c.out_weight)))
-        return fail(ctx, MRL_ERR_INVALID, "null array argument");
-    if (ctx->materials.empty()) return fail(ctx, MRL_ERR_MATERIAL, "no material loaded");
-    if (!c.mat && (c.single_id < 0 || (size_t)c.single_id >= ctx->materials.size() || ctx->materials[(size_t)c.single_id].released))
-        return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
-    if (!c.mat) {
-        const mrl::MaterialDev &d = ctx->materials[(size_t)c.single_id].dev;
-        if (d.kind == mrl::KIND_RGL) {
-            if (c.n_ch > 0) return fail(ctx, MRL_ERR_MATERIAL, "an RGL material has three channels: use the RGB entry points");
-            return MRL_OK;
-        }
-        if (c.n_ch == 0 && c.mode != 1 && !mrl::kind_is_rgb_path(d.kind))               // pdf is channel-free
-            return fail(ctx, MRL_ERR_MATERIAL, "material has " + std::to_string(d.n_ch) + " channels: use the *_nch entry points");
-        if (c.n_ch > 0 && c.mode != 1 && (d.kind != mrl::KIND_TABLE_NCH || d.n_ch != c.n_ch))
-            return fail(ctx, MRL_ERR_MATERIAL, "material does not have " + std::to_string(c.n_ch) + " channels");
-    }
-    return MRL_OK;
-}
-
-// host-or-device kind of the arrays a call of this mode touches (-1: mixed)
-int call_pointer_kind(const BatchCall &c, const void *extra0 = nullptr, const void *extra1 = nullptr)
-{
-    const bool has_eval = call_has_eval(c.mode), has_pdf = call_has_pdf(c.mode), has_sample = call_has_sample(c.mode);
-    const bool needs_wo = has_eval || has_pdf, needs_u = has_sample;
-    return common_kind({ c.wi, needs_wo ? c.wo : nullptr, needs_u ? c.u : nullptr, c.mat, extra0, extra1,
-                         has_eval ? c.out_rgb : nullptr, has_pdf ? c.out_pdf : nullptr,
-                         has_sample ? c.out_wo : nullptr, has_sample ? c.out_pdf2 : nullptr,
-                         has_sample ? c.out_weight : nullptr });
-}
-
-int launch_device(mrl_ctx *ctx, const BatchCall &c)
-{
-    const DeviceCall d = device_call(ctx, c);
-    const mrl::BatchArgs &a = d.args;
-    if (!d.multi && a.single.kind == mrl::KIND_RGL) {         // adaptive-parameterisation material: its own kernel
-        MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, &ctx->materials[(size_t)c.single_id].rgl, false, ctx->rgl_search, ctx->compute_units, ctx->stream));
-        return MRL_OK;
-    }
-    if (c.n_ch > 0 && c.mode != 1) {                          // n-channel tables: their own kernels (pdf is channel-free)
-        MRL_HIP(ctx, mrl::launch_batch_nch(c.mode, a, d.multi, c.n_ch, ctx->compute_units, ctx->stream));
-        return MRL_OK;
-    }
-    const bool multi = d.multi, has_ggx = d.has_ggx, has_table = d.has_table;
-    // MRL_OPT_KERNEL >= 4: a batch that may mix table and analytic materials is split into one dense queue
-    // per kind (count / scan / partition, no atomics); each queue then runs through its dedicated kernel
-    if (multi && has_ggx && has_table && ctx->kernel_variant >= 4 && c.mode != 1 && ctx->table_layout == mrl::LAYOUT_BRICK &&
-        ctx->opts.lookup == 1 && c.n < ((size_t)1 << 32)) {
-        uint32_t segments = 0, seg_len = 0;
-        mrl::partition_geometry(c.n, ctx->compute_units, &segments, &seg_len);
-        if (segments > kMaxSegments) return fail(ctx, MRL_ERR_INVALID, "partition geometry");
-        int rc = ensure_queues(ctx, c.n);
-        if (rc != MRL_OK) return rc;
-        uint32_t *q_table = ctx->d_queues, *q_ggx = ctx->d_queues + ctx->queue_cap, *work = ctx->d_queues + 2 * ctx->queue_cap;
-        MRL_HIP(ctx, mrl::launch_partition_kinds(c.mat, c.n, ctx->d_materials, a.n_materials, q_table, q_ggx, work,
-                                                 segments, seg_len, ctx->stream));
-        const uint32_t *totals = work + 4 * (size_t)segments;
-        mrl::BatchArgs qa = a;
-        qa.idx = q_table; qa.idx_count = totals;
-        MRL_HIP(ctx, mrl::launch_batch_queue(c.mode, qa, false, ctx->compute_units, ctx->stream));
-        qa.idx = q_ggx; qa.idx_count = totals + 1;
-        MRL_HIP(ctx, mrl::launch_batch_queue(c.mode, qa, true, ctx->compute_units, ctx->stream));
-        if (d.has_rgl) MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, nullptr, false, ctx->rgl_search, ctx->compute_units, ctx->stream));
-        return MRL_OK;
-    }
-    MRL_HIP(ctx, mrl::launch_batch(c.mode, a, multi, ctx->kernel_variant, ctx->table_layout, has_ggx, has_table, ctx->compute_units, ctx->stream));
-    // the context holds RGL materials: their units (zeros so far) are evaluated by a second launch on the same stream
-    if (multi && d.has_rgl) MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, nullptr, false, ctx->rgl_search, ctx->compute_units, ctx->stream));
-    return MRL_OK;
-}
-
-// Host arrays, pipelined (see HostPipe): per chunk  copy-in (threads) -> kernel on the pinned slot (zero copy over PCIe)
-// -> copy-out (threads), double buffered so that the copies of chunks c+1 / c-1 overlap the kernel of chunk c.
-int run_host_pipelined(mrl_ctx *ctx, const BatchCall &c)
-{
-    const bool has_eval = call_has_eval(c.mode), has_pdf = call_has_pdf(c.mode), has_sample = call_has_sample(c.mode);
-    const bool needs_wo = has_eval || has_pdf, needs_u = has_sample;
-    const size_t C = c.n_ch > 0 ? (size_t)c.n_ch : 3;
-    const size_t unit_bytes = 56 + 8 * C;
-    const size_t chunk = std::min(std::min(c.n, ctx->host_chunk), (size_t)1 << 20);
-    HostPipe &hp = ctx->pipe;
-    if (chunk * unit_bytes > hp.slot_bytes) {
-        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int s = 0; s < 2; ++s) { if (hp.pin[s]) (void)hipHostFree(hp.pin[s]); hp.pin[s] = nullptr; }
-        hp.slot_bytes = 0;
-        for (int s = 0; s < 2; ++s) {
-            const hipError_t e = hipHostMalloc((void **)&hp.pin[s], chunk * unit_bytes, hipHostMallocMapped | hipHostMallocPortable);
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                for (int k = 0; k < 2; ++k) { if (hp.pin[k]) (void)hipHostFree(hp.pin[k]); hp.pin[k] = nullptr; }
-                return fail(ctx, MRL_ERR_OOM, std::string("pinned staging: ") + hipGetErrorString(e));
-            }
-        }
-        hp.slot_bytes = chunk * unit_bytes;
-    }
-    for (int s = 0; s < 2; ++s)
-        if (!hp.done[s]) MRL_HIP(ctx, hipEventCreateWithFlags(&hp.done[s], hipEventDisableTiming));
-    if (hp.threads != ctx->host_threads) {                   // the caller copies as well: n - 1 helpers
-        hp.pool.stop();
-        hp.pool.quit = false;
-        hp.pool.start(std::max(0, ctx->host_threads - 1));
-        hp.threads = ctx->host_threads;
-    }
-    struct Slot { float *wi, *wo, *u; int32_t *mat; float *pdf, *wo2, *pdf2, *rgb, *w; };
-    auto slot = [&](int s) {
-        char *b = hp.pin[s];
-        return Slot{ (float *)b, (float *)(b + 12 * chunk), (float *)(b + 24 * chunk), (int32_t *)(b + 32 * chunk), (float *)(b + 36 * chunk),
-                     (float *)(b + 40 * chunk), (float *)(b + 52 * chunk), (float *)(b + 56 * chunk), (float *)(b + (56 + 4 * C) * chunk) };
-    };
-    const size_t steps = (c.n + chunk - 1) / chunk;
-    for (size_t k = 0; k <= steps; ++k) {
-        if (k < steps) {                                      // copy-in + launch of chunk k
-            const int s = (int)(k & 1);
-            const size_t off = k * chunk, m = std::min(chunk, c.n - off);
-            const Slot sl = slot(s);
-            std::vector<CopyPool::Seg> in = { { sl.wi, c.wi + 3 * off, 12 * m } };
-            if (needs_wo) in.push_back({ sl.wo, c.wo + 3 * off, 12 * m });
-            if (needs_u) in.push_back({ sl.u, c.u + 2 * off, 8 * m });
-            if (c.mat) in.push_back({ sl.mat, c.mat + off, 4 * m });
-            hp.pool.run(in);                                  // slot s was last read by kernel k-2, whose event was waited for below
-            BatchCall d = c;
-            d.wi = sl.wi; d.wo = sl.wo; d.u = sl.u; d.mat = c.mat ? sl.mat : nullptr; d.n = m;
-            d.out_rgb = sl.rgb; d.out_pdf = sl.pdf; d.out_wo = sl.wo2; d.out_pdf2 = sl.pdf2; d.out_weight = sl.w;
-            const int rc = launch_device(ctx, d);
-            if (rc != MRL_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-            MRL_HIP(ctx, hipEventRecord(hp.done[s], ctx->stream));
-        }
-        if (k > 0) {                                          // copy-out of chunk k-1, while the kernel of chunk k runs
-            const int s = (int)((k - 1) & 1);
-            const size_t off = (k - 1) * chunk, m = std::min(chunk, c.n - off);
-            const Slot sl = slot(s);
-            MRL_HIP(ctx, hipEventSynchronize(hp.done[s]));
-            std::vector<CopyPool::Seg> out;
-            if (has_eval) out.push_back({ c.out_rgb + C * off, sl.rgb, 4 * C * m });
-            if (has_pdf) out.push_back({ c.out_pdf + off, sl.pdf, 4 * m });
-            if (has_sample) {
-                out.push_back({ c.out_wo + 3 * off, sl.wo2, 12 * m });
-                out.push_back({ c.out_pdf2 + off, sl.pdf2, 4 * m });
-                out.push_back({ c.out_weight + C * off, sl.w, 4 * C * m });
-            }
-            hp.pool.run(out);
-        }
-    }
-    return MRL_OK;
-}
-
-int run_batch(mrl_ctx *ctx, const BatchCall &c)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (c.n == 0) return MRL_OK;
-    const bool has_eval = call_has_eval(c.mode), has_pdf = call_has_pdf(c.mode), has_sample = call_has_sample(c.mode);
-    const bool needs_wo = has_eval || has_pdf, needs_u = has_sample;
-    int rc = check_call(ctx, c);
-    if (rc != MRL_OK) return rc;
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-
-    const int kind = call_pointer_kind(c);
-    if (kind < 0) return fail(ctx, MRL_ERR_POINTER_MIX, "host and device pointers mixed in one call");
-    if (kind == 1) return launch_device(ctx, c);
-
-    if (ctx->host_threads > 0) {
-        rc = run_host_pipelined(ctx, c);
-        if (rc != MRL_ERR_OOM) return rc;                     // no pinned memory to be had: fall back to the staged path
-        (void)hipGetLastError();
-    }
-    // host pointers: stage through HBM in chunks; returns when the outputs are on the host
-    const size_t C = c.n_ch > 0 ? (size_t)c.n_ch : 3;          // values per unit in out_rgb / out_weight
-    const size_t unit_bytes = 56 + 8 * C;
-    const size_t chunk = std::min(c.n, ctx->host_chunk);
-    rc = ensure_stage(ctx, chunk, unit_bytes);
-    if (rc != MRL_OK) return rc;
-    char *base = (char *)ctx->d_stage;
-    const size_t cu = chunk;
-    float *d_wi = (float *)base;               float *d_wo = (float *)(base + 12 * cu);
-    float *d_u = (float *)(base + 24 * cu);    int32_t *d_mat = (int32_t *)(base + 32 * cu);
-    float *d_pdf = (float *)(base + 36 * cu);  float *d_wo2 = (float *)(base + 40 * cu);
-    float *d_pdf2 = (float *)(base + 52 * cu); float *d_rgb = (float *)(base + 56 * cu);
-    float *d_w = (float *)(base + (56 + 4 * C) * cu);
-    for (size_t off = 0; off < c.n; off += chunk) {
-        const size_t m = std::min(chunk, c.n - off);
-        MRL_HIP(ctx, hipMemcpyAsync(d_wi, c.wi + 3 * off, 12 * m, hipMemcpyHostToDevice, ctx->stream));
-        if (needs_wo) MRL_HIP(ctx, hipMemcpyAsync(d_wo, c.wo + 3 * off, 12 * m, hipMemcpyHostToDevice, ctx->stream));
-        if (needs_u) MRL_HIP(ctx, hipMemcpyAsync(d_u, c.u + 2 * off, 8 * m, hipMemcpyHostToDevice, ctx->stream));
-        if (c.mat) MRL_HIP(ctx, hipMemcpyAsync(d_mat, c.mat + off, 4 * m, hipMemcpyHostToDevice, ctx->stream));
-        BatchCall d = c;
-        d.wi = d_wi; d.wo = d_wo; d.u = d_u; d.mat = c.mat ? d_mat : nullptr; d.n = m;
-        d.out_rgb = d_rgb; d.out_pdf = d_pdf; d.out_wo = d_wo2; d.out_pdf2 = d_pdf2; d.out_weight = d_w;
-        rc = launch_device(ctx, d);
-        if (rc != MRL_OK) return rc;
-        if (has_eval) MRL_HIP(ctx, hipMemcpyAsync(c.out_rgb + C * off, d_rgb, 4 * C * m, hipMemcpyDeviceToHost, ctx->stream));
-        if (has_pdf) MRL_HIP(ctx, hipMemcpyAsync(c.out_pdf + off, d_pdf, 4 * m, hipMemcpyDeviceToHost, ctx->stream));
-        if (has_sample) {
-            MRL_HIP(ctx, hipMemcpyAsync(c.out_wo + 3 * off, d_wo2, 12 * m, hipMemcpyDeviceToHost, ctx->stream));
-            MRL_HIP(ctx, hipMemcpyAsync(c.out_pdf2 + off, d_pdf2, 4 * m, hipMemcpyDeviceToHost, ctx->stream));
-            MRL_HIP(ctx, hipMemcpyAsync(c.out_weight + C * off, d_w, 4 * C * m, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    return MRL_OK;
-}
-
-// mrl_*_queue: a caller-built queue of unit indices with a device-side length
-int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uint32_t *queue_count)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (c.n == 0) return MRL_OK;
-    if (!queue || !queue_count) return fail(ctx, MRL_ERR_INVALID, "null array argument");
-    int rc = check_call(ctx, c);
-    if (rc != MRL_OK) return rc;
-    if (c.n > ((size_t)1 << 32)) return fail(ctx, MRL_ERR_INVALID, "queue capacity exceeds 2^32 (indices are uint32)");
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    if (call_pointer_kind(c, queue, queue_count) != 1) return fail(ctx, MRL_ERR_POINTER_MIX, "queue calls take device pointers only");
-    DeviceCall d = device_call(ctx, c);
-    d.args.idx = queue; d.args.idx_count = queue_count;
-    if (!d.multi && d.args.single.kind == mrl::KIND_RGL) {
-        MRL_HIP(ctx, mrl::launch_rgl(c.mode, d.args, &ctx->materials[(size_t)c.single_id].rgl, true, ctx->rgl_search, ctx->compute_units, ctx->stream));
-        return MRL_OK;
-    }
-    if (c.n_ch > 0 && c.mode != 1) {                          // n-channel tables: the same kernels walk the queue
-        MRL_HIP(ctx, mrl::launch_batch_nch(c.mode, d.args, d.multi, c.n_ch, ctx->compute_units, ctx->stream));
-        return MRL_OK;
-    }
-    MRL_HIP(ctx, mrl::launch_batch_indexed(c.mode, d.args, d.multi, ctx->table_layout, d.has_ggx, d.has_table, ctx->compute_units, ctx->stream));
-    if (d.multi && d.has_rgl) MRL_HIP(ctx, mrl::launch_rgl(c.mode, d.args, nullptr, true, ctx->rgl_search, ctx->compute_units, ctx->stream));
-    return MRL_OK;
-}
-
-
-// n-channel row marginal for table importance sampling: as build_sampling, with the plain mean over the channels in
-// place of the RGB luminance (oracle: orc_build_sampling_nch)
-std::vector<double> build_sampling_nch(const double *planar, int n_th, int n_td, int n_pd, int n_ch, const double *scale, int param)
-{
-    const size_t plane = (size_t)n_th * n_td * n_pd;
-    std::vector<double> D((size_t)n_th), out(3 * (size_t)n_th + 2);
-    double *s = out.data(), *cdf = s + (n_th + 1), *c = cdf + (n_th + 1);
-    double mean = 0.0;
-    for (int i = 0; i < n_th; ++i) {
-        double acc = 0.0;
-        const double *row = planar + (size_t)i * n_td * n_pd;
-        for (size_t k = 0; k < (size_t)n_td * n_pd; ++k) {
-            double sum = 0.0;
-            for (int ch = 0; ch < n_ch; ++ch) sum += std::max(row[k + (size_t)ch * plane] * scale[ch], 0.0);
-            acc += sum / (double)n_ch;
-        }
-        D[(size_t)i] = acc / ((double)n_td * (double)n_pd);
-        mean += D[(size_t)i];
-    }
-    mean /= (double)n_th;
-    if (param != mrl::PARAM_HALF_DIFF) mean = 0.0;                    // the rows are not theta_h: flat lobe (oracle/merl_oracle.h)
-    for (int i = 0; i < n_th; ++i) D[(size_t)i] = mean > 0.0 ? D[(size_t)i] + 0.01 * mean : 1.0;
-    const double kHalfPi = 3.14159265358979323846 / 2.0;
-    for (int i = 0; i <= n_th; ++i) {
-        const double r = (double)i / (double)n_th, sn = std::sin(r * r * kHalfPi);
-        s[i] = i == n_th ? 1.0 : sn * sn;
-    }
-    double Z = 0.0;
-    for (int i = 0; i < n_th; ++i) Z += D[(size_t)i] * (s[i + 1] - s[i]);
-    double run = 0.0;
-    for (int i = 0; i < n_th; ++i) {
-        cdf[i] = run / Z;
-        run += D[(size_t)i] * (s[i + 1] - s[i]);
-        c[i] = D[(size_t)i] / (3.14159265358979323846 * Z);
-    }
-    cdf[n_th] = 1.0;
-    return out;
-}
-
-// planar f64, n_ch planes -> n-channel bricks in HBM (merl_nch.hip).  n_ch == 3 is the RGB path (packed 96-B bricks).
-int upload_table_nch(mrl_ctx *ctx, const double *planar, const int dims[3], int n_ch, const double *scale, int *out_id)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (!planar || !dims || !out_id) return fail(ctx, MRL_ERR_INVALID, "null argument");
-    if (n_ch < 1 || n_ch > mrl::kMaxChannels) return fail(ctx, MRL_ERR_INVALID, "channel count must be 1.." + std::to_string(mrl::kMaxChannels));
-    std::vector<double> ones((size_t)n_ch, 1.0);
-    if (!scale) scale = ones.data();
-    if (n_ch == 3) return upload_table(ctx, planar, dims, scale, mrl::KIND_TABLE, out_id);
-    const int n_th = dims[0], n_td = dims[1], n_pd = dims[2];
-    if (n_th < 1 || n_td < 1 || n_pd < 1 || (long long)n_th * n_td * n_pd > (1LL << 28))
-        return fail(ctx, MRL_ERR_INVALID, "table dims out of range");
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t plane = (size_t)n_th * n_td * n_pd;
-    const size_t out_f4 = plane * mrl::nch_brick_float4s(n_ch);
-    const size_t sampling_doubles = 3 * (size_t)n_th + 2;
-    MaterialHost m;
-    m.bytes = out_f4 * sizeof(float4) + sampling_doubles * sizeof(double);
-    const size_t planar_bytes = ((size_t)n_ch * plane + (size_t)n_ch) * sizeof(double);       // payload + the channel scales
-    int rc = budget_check(ctx, m.bytes + planar_bytes);
-    if (rc != MRL_OK) return rc;
-    double *d_planar = nullptr;
-    MRL_ALLOC(ctx, hipMalloc((void **)&d_planar, planar_bytes));
-    double *d_scale = d_planar + (size_t)n_ch * plane;
-    hipError_t e = hipMalloc((void **)&m.d_texels, out_f4 * sizeof(float4));
-    const bool oom = e == hipErrorOutOfMemory;
-    if (e == hipSuccess) e = hipMemcpyAsync(d_planar, planar, (size_t)n_ch * plane * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_scale, scale, (size_t)n_ch * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = mrl::launch_build_table_nch(d_planar, d_scale, dims, n_ch, ctx->table_param, ctx->opts.negative == mrl::NEGATIVE_CLAMP, m.d_texels, ctx->compute_units, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_planar);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        if (m.d_texels) (void)hipFree(m.d_texels);
-        return fail(ctx, oom ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("n-channel table upload: ") + hipGetErrorString(e));
-    }
-    const std::vector<double> sampling = build_sampling_nch(planar, n_th, n_td, n_pd, n_ch, scale, ctx->table_param);
-    e = hipMalloc((void **)&m.d_sampling, sampling.size() * sizeof(double));
-    const bool oom2 = e == hipErrorOutOfMemory;
-    if (e == hipSuccess) e = hipMemcpy(m.d_sampling, sampling.data(), sampling.size() * sizeof(double), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipFree(m.d_texels);
-        if (m.d_sampling) (void)hipFree(m.d_sampling);
-        return fail(ctx, oom2 ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("sampling table upload: ") + hipGetErrorString(e));
-    }
-    std::memset(&m.dev, 0, sizeof m.dev);
-    m.dev.kind = mrl::KIND_TABLE_NCH;
-    m.dev.sampling = m.d_sampling;
-    m.dev.n_th = n_th; m.dev.n_td = n_td; m.dev.n_pd = n_pd;
-    m.dev.texels = m.d_texels;
-    m.dev.layout = mrl::LAYOUT_BRICK;
-    m.dev.n_ch = n_ch;
-    m.dev.param = ctx->table_param;
-    rc = place_material(ctx, m, out_id);
-    if (rc != MRL_OK) { (void)hipFree(m.d_texels); (void)hipFree(m.d_sampling); return rc; }
-    return MRL_OK;
-}
-
-// customized_measurement file with n_ch planes: int32 dims[3], then planar values as f64 or f32 (told apart by the file length)
-int read_table_file_nch(mrl_ctx *ctx, const char *path, int n_ch, std::vector<double> &data, int dims[3])
-{
-    if (!path) return fail(ctx, MRL_ERR_INVALID, "null path");
-    FILE *f = std::fopen(path, "rb");
-    if (!f) return fail(ctx, MRL_ERR_IO, std::string("cannot open ") + path);
-    int32_t d[3];
-    if (std::fread(d, sizeof(int32_t), 3, f) != 3) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "short header"); }
-    if (d[0] <= 0 || d[1] <= 0 || d[2] <= 0) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "non-positive dims"); }
-    const long long n = (long long)d[0] * d[1] * d[2];
-    if (n > (1LL << 28)) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "table too large"); }
-    if (std::fseek(f, 0, SEEK_END) != 0) { std::fclose(f); return fail(ctx, MRL_ERR_IO, "seek failed"); }
-    const long long bytes = (long long)std::ftell(f);
-    const bool f64_payload = bytes == 12 + (long long)n_ch * n * 8, f32_payload = bytes == 12 + (long long)n_ch * n * 4;
-    if (!f64_payload && !f32_payload) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, "file length matches neither an f64 nor an f32 payload of " + std::to_string(n_ch) + " channels"); }
-    if (std::fseek(f, 12, SEEK_SET) != 0) { std::fclose(f); return fail(ctx, MRL_ERR_IO, "seek failed"); }
-    try { data.resize((size_t)n_ch * (size_t)n); } catch (const std::bad_alloc &) { std::fclose(f); return fail(ctx, MRL_ERR_OOM, "table buffer"); }
-    size_t got;
-    if (f32_payload) {
-        std::vector<float> narrow;
-        try { narrow.resize(data.size()); } catch (const std::bad_alloc &) { std::fclose(f); return fail(ctx, MRL_ERR_OOM, "table buffer"); }
-        got = std::fread(narrow.data(), sizeof(float), narrow.size(), f);
-        for (size_t i = 0; i < got; ++i) data[i] = (double)narrow[i];
-    } else {
-        got = std::fread(data.data(), sizeof(double), data.size(), f);
-    }
-    std::fclose(f);
-    if (got != data.size()) return fail(ctx, MRL_ERR_FORMAT, "truncated table payload");
-    dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2];
-    return MRL_OK;
-}
-
-} // namespace
 
 bool ScalarDevice::launch(uint32_t gen)
 {
@@ -1277,310 +472,6 @@ int mrl_device_info(const mrl_ctx *ctx, char *name, size_t name_len, int *comput
     return MRL_OK;
 }
 
-int mrl_material_load_merl(mrl_ctx *ctx, const char *path, int *out_id)
-{
-    if (!ctx || !out_id) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    std::vector<double> data; int dims[3];
-    int rc = read_table_file(ctx, path, true, data, dims);
-    if (rc != MRL_OK) return rc;
-    return upload_table(ctx, data.data(), dims, kMerlScale, mrl::KIND_MERL, out_id);
-}
-
-int mrl_material_upload_f64(mrl_ctx *ctx, const double *planar_rgb, int *out_id)
-{
-    return upload_table(ctx, planar_rgb, kMerlDims, kMerlScale, mrl::KIND_MERL, out_id);
-}
-
-int mrl_material_upload_table(mrl_ctx *ctx, const double *planar_rgb, const int dims[3], const double scale[3], int *out_id)
-{
-    return upload_table(ctx, planar_rgb, dims, scale, mrl::KIND_TABLE, out_id);
-}
-
-int mrl_material_load_table(mrl_ctx *ctx, const char *path, const double scale[3], int *out_id)
-{
-    if (!ctx || !out_id || !scale) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    std::vector<double> data; int dims[3];
-    int rc = read_table_file(ctx, path, false, data, dims);
-    if (rc != MRL_OK) return rc;
-    return upload_table(ctx, data.data(), dims, scale, mrl::KIND_TABLE, out_id);
-}
-
-int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float k[3], int *out_id)
-{
-    if (!ctx || !eta || !k || !out_id) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (!(alpha > 0.0f)) return fail(ctx, MRL_ERR_INVALID, "alpha must be positive");
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    MaterialHost m;
-    std::memset(&m.dev, 0, sizeof m.dev);
-    m.dev.kind = mrl::KIND_GGX;
-    m.dev.n_ch = 3;
-    m.dev.alpha = (double)alpha;
-    for (int c = 0; c < 3; ++c) { m.dev.eta[c] = (double)eta[c]; m.dev.k[c] = (double)k[c]; }
-    return place_material(ctx, m, out_id);
-}
-
-// The adaptive-parameterisation measured BSDF (RGL *.bsdf fields): the host normalises the two distributions and forms
-// their running integrals (f64, once), the image goes to HBM as one allocation.  PARITY UNPINNED (merl_rgl.hpp).
-int mrl_material_upload_rgl(mrl_ctx *ctx, const mrl_rgl_fields *f, int *out_id)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (!f || !out_id) return fail(ctx, MRL_ERR_INVALID, "null argument");
-    mrl::RglFields h;
-    h.n_phi = f->n_phi; h.n_theta = f->n_theta; h.phi_i = f->phi_i; h.theta_i = f->theta_i;
-    for (int k = 0; k < 2; ++k) { h.res_ndf[k] = f->res_ndf[k]; h.res_sigma[k] = f->res_sigma[k]; h.res[k] = f->res[k]; }
-    h.ndf = f->ndf; h.sigma = f->sigma; h.vndf = f->vndf; h.luminance = f->luminance; h.rgb = f->rgb;
-    h.jacobian = f->jacobian;
-    if (const char *why = mrl::rgl_check_fields(h)) return fail(ctx, MRL_ERR_INVALID, std::string("RGL fields: ") + why);
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    std::vector<float> blob;
-    mrl::RglLayout layout;
-    try { layout = mrl::rgl_build_image(h, blob); } catch (const std::bad_alloc &) { return fail(ctx, MRL_ERR_OOM, "RGL image"); }
-    MaterialHost m;
-    const size_t image_bytes = (blob.size() * sizeof(float) + 255) / 256 * 256;          // the descriptor sits behind the image
-    m.bytes = image_bytes + sizeof(mrl::RglDev);
-    int rc = budget_check(ctx, m.bytes);
-    if (rc != MRL_OK) return rc;
-    hipError_t e = hipMalloc((void **)&m.d_texels, m.bytes);
-    const bool oom = e == hipErrorOutOfMemory;
-    if (e == hipSuccess) e = hipMemcpy(m.d_texels, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        m.rgl = mrl::rgl_descriptor(h, layout, (const float *)m.d_texels);
-        e = hipMemcpy((char *)m.d_texels + image_bytes, &m.rgl, sizeof m.rgl, hipMemcpyHostToDevice);
-    }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        if (m.d_texels) (void)hipFree(m.d_texels);
-        return fail(ctx, oom ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("RGL upload: ") + hipGetErrorString(e));
-    }
-    std::memset(&m.dev, 0, sizeof m.dev);
-    m.dev.kind = mrl::KIND_RGL;
-    m.dev.rgl = (const char *)m.d_texels + image_bytes;
-    m.dev.n_ch = 3;
-    m.dev.n_th = h.n_phi; m.dev.n_td = h.n_theta; m.dev.n_pd = h.res[0];     // what mrl_material_info reports
-    rc = place_material(ctx, m, out_id);
-    if (rc != MRL_OK) { (void)hipFree(m.d_texels); return rc; }
-    return MRL_OK;
-}
-
-int mrl_material_release(mrl_ctx *ctx, int id)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released)
-        return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    const ScalarPause quiet(ctx);                                // a service instance may be reading the table
-    int rc = ensure_dummy(ctx);
-    if (rc != MRL_OK) return rc;
-    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));             // launches in flight may still read the table
-    MaterialHost &m = ctx->materials[(size_t)id];
-    const MaterialHost before = m;
-    m.dev = tombstone_dev(ctx);
-    m.released = true;
-    rc = sync_material_array(ctx);                               // the device array must stop naming the table first
-    if (rc != MRL_OK) { m = before; return rc; }
-    table_free(ctx, before.d_texels, before.in_arena);
-    if (before.d_sampling) (void)hipFree(before.d_sampling);
-    if (before.d_sampling2d) (void)hipFree(before.d_sampling2d);
-    m.d_texels = nullptr; m.d_sampling = nullptr; m.d_sampling2d = nullptr;
-    ctx->material_bytes -= before.bytes;
-    m.bytes = 0;
-    return MRL_OK;
-}
-
-} // extern "C" (reopened below)
-
-// ---- on-disk cache of a material's device image (second half) ----------------------------------------
-// What is resident for a material — the texel image in its device layout, the sampling marginal, the conditional sampling rows; for an
-// RGL material the cell-brick image with its running integrals — written as it is, so that a later process makes the material
-// resident with one read and one copy: no parse, no re-layout kernel, no quadrature / prefix-scan kernels, no host normalisation.
-// A file is untrusted input: every size is recomputed from the header's shapes (never taken from the file), an RGL descriptor is
-// rebuilt from the shapes, and the payload carries a checksum.  What the payload's VALUES say is data (a table), not structure.
-namespace {
-
-using mrl::ImageHeader;
-using mrl::kImageMagic;
-using mrl::image_checksum;
-using mrl::rgl_shapes_of;
-
-// device bytes of a table material's texel image, from its descriptor
-size_t texel_image_bytes(const mrl::MaterialDev &d)
-{
-    const size_t plane = (size_t)d.n_th * d.n_td * d.n_pd;
-    if (d.kind == mrl::KIND_TABLE_NCH) return plane * mrl::nch_brick_float4s(d.n_ch) * sizeof(float4);
-    return (d.layout == mrl::LAYOUT_BRICK ? plane * 8 : (size_t)(d.n_th + 1) * (d.n_td + 1) * (d.n_pd + 1)) * sizeof(float4);
-}
-
-size_t rows_image_bytes(const mrl::MaterialDev &d) { return (size_t)(d.n_th + 1) * (d.n_td + 1) * (d.n_pd + 1) * sizeof(float4); }
-
-} // namespace
-
-extern "C" {
-
-int mrl_material_save_image(mrl_ctx *ctx, int id, const char *path)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (!path) return fail(ctx, MRL_ERR_INVALID, "null path");
-    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
-    const MaterialHost &mh = ctx->materials[(size_t)id];
-    const mrl::MaterialDev &d = mh.dev;
-    if (d.kind == mrl::KIND_GGX) return fail(ctx, MRL_ERR_MATERIAL, "an analytic material has no image to cache");
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    ImageHeader h;
-    std::memset(&h, 0, sizeof h);
-    std::memcpy(h.magic, kImageMagic, 8);
-    h.header_bytes = (uint32_t)sizeof h; h.kind = (uint32_t)d.kind; h.layout = (uint32_t)d.layout; h.n_ch = (uint32_t)d.n_ch; h.param = (uint32_t)d.param;
-    // (the conditional rows are stamped with the options they were integrated under — at upload —, not with today's)
-    h.lookup = (uint32_t)mh.rows_lookup; h.node = (uint32_t)mh.rows_node; h.n_ti = (uint32_t)d.n_ti;
-    h.negative = d.kind == mrl::KIND_RGL ? 0u : (uint32_t)ctx->opts.negative;
-    h.dims[0] = d.n_th; h.dims[1] = d.n_td; h.dims[2] = d.n_pd;
-    if (d.kind == mrl::KIND_RGL) {
-        const mrl::RglDev &r = mh.rgl;
-        const int32_t shape[8] = { r.vndf.n_phi, r.vndf.n_theta, r.vndf.nx, r.vndf.ny, r.ndf.nx, r.ndf.ny, r.sigma.nx, r.sigma.ny };
-        std::memcpy(h.rgl_shape, shape, sizeof shape);
-        h.rgl_flags[0] = r.jacobian;
-        mrl::RglLayout l;
-        h.texel_bytes = mrl::rgl_plan_layout(rgl_shapes_of(shape, r.jacobian), l) * sizeof(float);
-    } else {
-        // RGB tables travel in the compact rows form whatever the context's layout (a brick image is 7.8 x larger than the rows image
-        // and reads slower than the source file parses); n-channel tables have one layout
-        const bool rgb = d.kind != mrl::KIND_TABLE_NCH;
-        if (rgb) h.layout = (uint32_t)mrl::LAYOUT_ROWS;
-        h.texel_bytes = rgb ? rows_image_bytes(d) : texel_image_bytes(d);
-        h.sampling_doubles = 3 * (uint64_t)d.n_th + 2;
-        h.sampling2d_doubles = mh.d_sampling2d ? (uint64_t)d.n_ti * (2 * (uint64_t)d.n_th + 1) : 0;
-    }
-    std::vector<char> payload;
-    try { payload.resize((size_t)h.texel_bytes + (size_t)(h.sampling_doubles + h.sampling2d_doubles) * sizeof(double)); }
-    catch (const std::bad_alloc &) { return fail(ctx, MRL_ERR_OOM, "image buffer"); }
-    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (d.kind != mrl::KIND_RGL && d.kind != mrl::KIND_TABLE_NCH && d.layout == mrl::LAYOUT_BRICK) {
-        float4 *d_rows = nullptr;
-        MRL_ALLOC(ctx, hipMalloc((void **)&d_rows, (size_t)h.texel_bytes));
-        hipError_t e = mrl::launch_bricks_to_rows(mh.d_texels, h.dims, d.param, d_rows, ctx->compute_units, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess) e = hipMemcpy(payload.data(), d_rows, (size_t)h.texel_bytes, hipMemcpyDeviceToHost);
-        (void)hipFree(d_rows);
-        MRL_HIP(ctx, e);
-    } else {
-        MRL_HIP(ctx, hipMemcpy(payload.data(), mh.d_texels, (size_t)h.texel_bytes, hipMemcpyDeviceToHost));
-    }
-    if (h.sampling_doubles) MRL_HIP(ctx, hipMemcpy(payload.data() + h.texel_bytes, mh.d_sampling, (size_t)h.sampling_doubles * sizeof(double), hipMemcpyDeviceToHost));
-    if (h.sampling2d_doubles)
-        MRL_HIP(ctx, hipMemcpy(payload.data() + h.texel_bytes + h.sampling_doubles * sizeof(double), mh.d_sampling2d, (size_t)h.sampling2d_doubles * sizeof(double), hipMemcpyDeviceToHost));
-    h.checksum = image_checksum(payload.data(), payload.size(), mrl::kImageChecksumSeed);
-    // written under a private name and renamed into place: a reader never sees half a file
-    const std::string tmp = std::string(path) + ".tmp." + std::to_string((long long)::getpid());
-    FILE *f = std::fopen(tmp.c_str(), "wb");
-    if (!f) return fail(ctx, MRL_ERR_IO, std::string("cannot create ") + tmp);
-    const bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 && (payload.empty() || std::fwrite(payload.data(), 1, payload.size(), f) == payload.size());
-    const bool closed = std::fclose(f) == 0;
-    if (!ok || !closed || std::rename(tmp.c_str(), path) != 0) { (void)std::remove(tmp.c_str()); return fail(ctx, MRL_ERR_IO, std::string("cannot write ") + path); }
-    return MRL_OK;
-}
-
-int mrl_material_load_image(mrl_ctx *ctx, const char *path, int *out_id)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (!path || !out_id) return fail(ctx, MRL_ERR_INVALID, "null argument");
-    FILE *f = std::fopen(path, "rb");
-    if (!f) return fail(ctx, MRL_ERR_IO, std::string("cannot open ") + path);
-    ImageHeader h;
-    auto refuse = [&](const std::string &why) { std::fclose(f); return fail(ctx, MRL_ERR_FORMAT, why + " (" + path + ")"); };
-    if (std::fread(&h, sizeof h, 1, f) != 1) return refuse("not a material image of this library version");
-    if (std::fseek(f, 0, SEEK_END) != 0) return refuse("seek failed");
-    const long long file_bytes = (long long)std::ftell(f);
-    // everything the header implies, computed from its shapes (merl_image_file.hpp: the part that is fuzzed on the CPU)
-    mrl::ImagePlan plan;
-    if (const char *why = mrl::image_plan(h, (unsigned long long)file_bytes, ctx->opts.lookup, ctx->opts.node, ctx->opts.negative, plan)) return refuse(why);
-    if (std::fseek(f, (long)sizeof h, SEEK_SET) != 0) return refuse("seek failed");
-    const bool is_rgl = plan.is_rgl, is_nch = plan.is_nch;
-    const uint64_t texel_bytes = plan.texel_bytes, sampling_doubles = plan.sampling_doubles, sampling2d_doubles = plan.sampling2d_doubles;
-    const size_t payload_bytes = plan.payload_bytes;
-    mrl::RglFields shapes = plan.shapes;
-    const mrl::RglLayout layout = plan.layout;
-    mrl::MaterialDev d;
-    std::memset(&d, 0, sizeof d);
-    d.kind = (int)h.kind;
-    d.n_th = plan.dims[0]; d.n_td = plan.dims[1]; d.n_pd = plan.dims[2];
-    d.n_ch = plan.n_ch; d.param = plan.param;
-    if (!is_rgl) {
-        d.layout = is_nch ? mrl::LAYOUT_BRICK : ctx->table_layout;         // an RGB table becomes what this context holds
-        d.row_td = d.n_pd + 1; d.row_th = (d.n_td + 1) * (d.n_pd + 1);
-    }
-    std::vector<char> payload;
-    try { payload.resize(payload_bytes); } catch (const std::bad_alloc &) { std::fclose(f); return fail(ctx, MRL_ERR_OOM, "image buffer"); }
-    if (payload_bytes && std::fread(payload.data(), 1, payload_bytes, f) != payload_bytes) return refuse("short read");
-    std::fclose(f);
-    if (image_checksum(payload.data(), payload.size(), mrl::kImageChecksumSeed) != h.checksum) return fail(ctx, MRL_ERR_FORMAT, std::string("checksum mismatch (") + path + ")");
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    MaterialHost m;
-    const bool expand = !is_rgl && !is_nch && d.layout == mrl::LAYOUT_BRICK;      // rows on disk, bricks on this context
-    const size_t image_bytes = is_rgl ? ((size_t)texel_bytes + 255) / 256 * 256 : (expand ? texel_image_bytes(d) : (size_t)texel_bytes);
-    m.bytes = image_bytes + (is_rgl ? sizeof(mrl::RglDev) : 0) + (size_t)(sampling_doubles + sampling2d_doubles) * sizeof(double);
-    int rc = budget_check(ctx, m.bytes + (expand ? (size_t)texel_bytes : 0));
-    if (rc != MRL_OK) return rc;
-    hipError_t e;
-    if (is_rgl || is_nch) e = hipMalloc((void **)&m.d_texels, image_bytes + (is_rgl ? sizeof(mrl::RglDev) : 0));
-    else e = table_alloc(ctx, image_bytes, &m.d_texels, &m.in_arena);
-    bool oom = e == hipErrorOutOfMemory;
-    if (e == hipSuccess && expand) {
-        float4 *d_rows = nullptr;
-        e = hipMalloc((void **)&d_rows, (size_t)texel_bytes);
-        oom = oom || e == hipErrorOutOfMemory;
-        if (e == hipSuccess) e = hipMemcpyAsync(d_rows, payload.data(), (size_t)texel_bytes, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = mrl::launch_rows_to_bricks(d_rows, h.dims, m.d_texels, ctx->compute_units, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (d_rows) (void)hipFree(d_rows);
-    } else if (e == hipSuccess) {
-        e = hipMemcpy(m.d_texels, payload.data(), (size_t)texel_bytes, hipMemcpyHostToDevice);
-    }
-    if (e == hipSuccess && is_rgl) {
-        // isotropy and the stored part of the azimuth follow from the phi_i grid, which is the image's first n_phi floats
-        shapes.phi_i = (const float *)payload.data();
-        m.rgl = mrl::rgl_descriptor(shapes, layout, (const float *)m.d_texels);
-        if (m.rgl.reduction != 1 && m.rgl.reduction != 2 && m.rgl.reduction != 4) e = hipErrorInvalidValue;
-        else e = hipMemcpy((char *)m.d_texels + image_bytes, &m.rgl, sizeof m.rgl, hipMemcpyHostToDevice);
-        d.rgl = (const char *)m.d_texels + image_bytes;
-    }
-    if (e == hipSuccess && sampling_doubles) {
-        e = hipMalloc((void **)&m.d_sampling, (size_t)sampling_doubles * sizeof(double));
-        oom = oom || e == hipErrorOutOfMemory;
-        if (e == hipSuccess) e = hipMemcpy(m.d_sampling, payload.data() + texel_bytes, (size_t)sampling_doubles * sizeof(double), hipMemcpyHostToDevice);
-    }
-    if (e == hipSuccess && sampling2d_doubles) {
-        e = hipMalloc((void **)&m.d_sampling2d, (size_t)sampling2d_doubles * sizeof(double));
-        oom = oom || e == hipErrorOutOfMemory;
-        if (e == hipSuccess) e = hipMemcpy(m.d_sampling2d, payload.data() + texel_bytes + sampling_doubles * sizeof(double), (size_t)sampling2d_doubles * sizeof(double), hipMemcpyHostToDevice);
-    }
-    auto drop = [&]() {
-        if (is_rgl || is_nch) { if (m.d_texels) (void)hipFree(m.d_texels); } else table_free(ctx, m.d_texels, m.in_arena);
-        if (m.d_sampling) (void)hipFree(m.d_sampling);
-        if (m.d_sampling2d) (void)hipFree(m.d_sampling2d);
-    };
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        drop();
-        return fail(ctx, oom ? MRL_ERR_OOM : (e == hipErrorInvalidValue ? MRL_ERR_FORMAT : MRL_ERR_HIP), std::string("image upload: ") + hipGetErrorString(e));
-    }
-    d.texels = m.d_texels; d.sampling = m.d_sampling; d.sampling2d = m.d_sampling2d; d.n_ti = sampling2d_doubles ? mrl::kSamplingIncidentBins : 0;
-    m.dev = d;
-    m.rows_lookup = (int)h.lookup; m.rows_node = (int)h.node;
-    rc = place_material(ctx, m, out_id);
-    if (rc != MRL_OK) { drop(); return rc; }
-    return MRL_OK;
-}
-
-} // extern "C"
-
-extern "C" {
-
 int mrl_memory_info(const mrl_ctx *ctx, size_t *material_bytes, size_t *workspace_bytes, size_t *device_free, size_t *device_total)
 {
     if (!ctx) return MRL_ERR_INVALID;
@@ -1604,247 +495,6 @@ int mrl_material_count(const mrl_ctx *ctx)
     if (!ctx) return MRL_ERR_INVALID;
     MRL_GUARD(ctx);
     return (int)ctx->materials.size();
-}
-
-// The host image of a resident RGB table for one-unit calls on the CPU (merl_host_scalar.hip): the device's own Float texel
-// values, re-read from HBM into the rows layout — from a rows-layout table as it is, from bricks by taking corner 0 of
-// every cell (= the texel itself) and re-creating the padding rows — plus the sampling marginal and a snapshot of the
-// context's lookup options.  One D2H copy of the table (24 MB rows / 187 MB bricks for MERL): about 15 ms, once per image.
-int mrl_material_host_table(mrl_ctx *ctx, int id, mrl_host_table **out)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (!out) return fail(ctx, MRL_ERR_INVALID, "null argument");
-    *out = nullptr;
-    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
-    const MaterialHost &mh = ctx->materials[(size_t)id];
-    if (mh.dev.kind != mrl::KIND_MERL && mh.dev.kind != mrl::KIND_TABLE && mh.dev.kind != mrl::KIND_RGL)
-        return fail(ctx, MRL_ERR_MATERIAL, "host images exist for three-channel table materials and RGL materials");
-    if (!__builtin_cpu_supports("fma") || !__builtin_cpu_supports("avx2"))
-        return fail(ctx, MRL_ERR_INVALID, "the host one-unit path needs a CPU with FMA and AVX2");
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    if (mh.dev.kind == mrl::KIND_RGL) {                       // the image is position independent: copy it, move the descriptor's pointers
-        MRL_HIP(ctx, hipSetDevice(ctx->device));
-        mrl_host_table *t = nullptr;
-        try {
-            t = new mrl_host_table;
-            t->rgl_image.resize(mh.bytes / sizeof(float));
-        } catch (const std::bad_alloc &) { delete t; return fail(ctx, MRL_ERR_OOM, "host image"); }
-        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const hipError_t e = hipMemcpy(t->rgl_image.data(), mh.d_texels, mh.bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { (void)hipGetLastError(); delete t; return fail(ctx, MRL_ERR_HIP, std::string("host image: ") + hipGetErrorString(e)); }
-        t->rgl = mh.rgl;
-        const char *from = (const char *)mh.d_texels, *to = (const char *)t->rgl_image.data();
-        mrl::WarpDev *all[5] = { &t->rgl.ndf, &t->rgl.sigma, &t->rgl.vndf, &t->rgl.luminance, &t->rgl.rgb };
-        for (mrl::WarpDev *w : all) {
-            w->cells = (const float4 *)(to + ((const char *)w->cells - from));
-            if (w->cond2) w->cond2 = (const float4 *)(to + ((const char *)w->cond2 - from));
-            if (w->margq) w->margq = (const float4 *)(to + ((const char *)w->margq - from));
-            w->phi = (const float *)(to + ((const char *)w->phi - from)); w->theta = (const float *)(to + ((const char *)w->theta - from));
-        }
-        t->m = mh.dev;
-        t->opts = ctx->opts;
-        *out = t;
-        return MRL_OK;
-    }
-    const int n_th = mh.dev.n_th, n_td = mh.dev.n_td, n_pd = mh.dev.n_pd;
-    const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1, cells = (size_t)n_th * n_td * n_pd;
-    mrl_host_table *t = nullptr;
-    try {
-        t = new mrl_host_table;
-        t->rows.resize(H * D * P);
-        t->marginal.resize(3 * (size_t)n_th + 2);
-        std::vector<float4> bricks;
-        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        hipError_t e = hipSuccess;
-        if (mh.dev.layout == mrl::LAYOUT_ROWS) {
-            e = hipMemcpy(t->rows.data(), mh.d_texels, t->rows.size() * sizeof(float4), hipMemcpyDeviceToHost);
-        } else {
-            bricks.resize(cells * 8);
-            e = hipMemcpy(bricks.data(), mh.d_texels, bricks.size() * sizeof(float4), hipMemcpyDeviceToHost);
-        }
-        if (e == hipSuccess) e = hipMemcpy(t->marginal.data(), mh.d_sampling, t->marginal.size() * sizeof(double), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && mh.d_sampling2d) {
-            t->marginal2d.resize((size_t)mh.dev.n_ti * (2 * (size_t)n_th + 1));
-            e = hipMemcpy(t->marginal2d.data(), mh.d_sampling2d, t->marginal2d.size() * sizeof(double), hipMemcpyDeviceToHost);
-        }
-        if (e != hipSuccess) { (void)hipGetLastError(); delete t; return fail(ctx, MRL_ERR_HIP, std::string("host image: ") + hipGetErrorString(e)); }
-        if (mh.dev.layout != mrl::LAYOUT_ROWS) {
-            const bool periodic = mrl::param_phi_periodic(mh.dev.param);
-            for (size_t ih = 0; ih < H; ++ih)
-                for (size_t idd = 0; idd < D; ++idd)
-                    for (size_t ip = 0; ip < P; ++ip) {
-                        const size_t sh = ih < (size_t)n_th ? ih : n_th - 1, sd = idd < (size_t)n_td ? idd : n_td - 1;
-                        const size_t sp = ip == (size_t)n_pd ? (periodic ? 0 : n_pd - 1) : ip;
-                        const float4 q = bricks[((sh * n_td + sd) * n_pd + sp) * 8];        // corner 0: x y z = the cell's own texel
-                        t->rows[(ih * D + idd) * P + ip] = make_float4(q.x, q.y, q.z, 0.0f);
-                    }
-        }
-    } catch (const std::bad_alloc &) {
-        delete t;
-        return fail(ctx, MRL_ERR_OOM, "host image");
-    }
-    t->m = mh.dev;
-    t->m.texels = t->rows.data();
-    t->m.sampling = t->marginal.data();
-    t->m.sampling2d = t->marginal2d.empty() ? nullptr : t->marginal2d.data();
-    t->m.layout = mrl::LAYOUT_ROWS;
-    t->m.row_td = (int)P;
-    t->m.row_th = (int)(D * P);
-    t->opts = ctx->opts;
-    *out = t;
-    return MRL_OK;
-}
-
-// the conditional sampling table of an RGB table material, as the device built it: n_ti rows of (n_th + 1 cdf | n_th c)
-int mrl_material_sampling2d(mrl_ctx *ctx, int id, int *n_ti, int *n_th, double *out, size_t max_doubles)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
-    const MaterialHost &mh = ctx->materials[(size_t)id];
-    if (!mh.d_sampling2d) return fail(ctx, MRL_ERR_MATERIAL, "the material has no conditional sampling table (RGB table materials do)");
-    const size_t need = (size_t)mh.dev.n_ti * (2 * (size_t)mh.dev.n_th + 1);
-    if (n_ti) *n_ti = mh.dev.n_ti;
-    if (n_th) *n_th = mh.dev.n_th;
-    if (!out) return MRL_OK;
-    if (max_doubles < need) return fail(ctx, MRL_ERR_INVALID, "buffer too small");
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    MRL_HIP(ctx, hipMemcpy(out, mh.d_sampling2d, need * sizeof(double), hipMemcpyDeviceToHost));
-    return MRL_OK;
-}
-
-int mrl_material_info(const mrl_ctx *ctx, int id, int *kind, int dims[3])
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return MRL_ERR_MATERIAL;
-    const mrl::MaterialDev &d = ctx->materials[(size_t)id].dev;
-    if (kind) *kind = d.kind;
-    if (dims) { dims[0] = d.n_th; dims[1] = d.n_td; dims[2] = d.n_pd; }
-    return MRL_OK;
-}
-
-int mrl_eval_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, float *out_rgb)
-{
-    BatchCall c{ 0, wi, wo, nullptr, mat, single_id, n, out_rgb, nullptr, nullptr, nullptr, nullptr };
-    return run_batch(ctx, c);
-}
-
-int mrl_pdf_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, float *out_pdf)
-{
-    BatchCall c{ 1, wi, wo, nullptr, mat, single_id, n, nullptr, out_pdf, nullptr, nullptr, nullptr };
-    return run_batch(ctx, c);
-}
-
-int mrl_sample_batch(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id, size_t n,
-                     float *out_wo, float *out_pdf, float *out_weight)
-{
-    BatchCall c{ 2, wi, nullptr, u, mat, single_id, n, nullptr, nullptr, out_wo, out_pdf, out_weight };
-    return run_batch(ctx, c);
-}
-
-int mrl_eval_sample_batch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u, const int32_t *mat, int32_t single_id,
-                          size_t n, float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
-{
-    BatchCall c{ 3, wi, wo, u, mat, single_id, n, out_rgb, out_pdf, out_wo, out_pdf2, out_weight };
-    return run_batch(ctx, c);
-}
-
-int mrl_eval_pdf_batch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
-                       size_t n, float *out_rgb, float *out_pdf)
-{
-    BatchCall c{ 4, wi, wo, nullptr, mat, single_id, n, out_rgb, out_pdf, nullptr, nullptr, nullptr };
-    return run_batch(ctx, c);
-}
-
-int mrl_partition_by_material(mrl_ctx *ctx, const int32_t *mat, size_t n, uint32_t *queue_out, uint32_t *offsets_out, uint32_t *counts_out)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (!offsets_out || !counts_out || (n > 0 && (!mat || !queue_out))) return fail(ctx, MRL_ERR_INVALID, "null array argument");
-    if (n > ((size_t)1 << 32)) return fail(ctx, MRL_ERR_INVALID, "more than 2^32 slots (queue entries are uint32)");
-    const int K = (int)ctx->materials.size();
-    if (K == 0) return fail(ctx, MRL_ERR_MATERIAL, "no material loaded");
-    if (K > mrl::kMaxPartitionMaterials) return fail(ctx, MRL_ERR_INVALID, "too many materials for the partition kernel");
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    if (common_kind({ mat, queue_out, offsets_out, counts_out }) != 1) return fail(ctx, MRL_ERR_POINTER_MIX, "partition takes device pointers only");
-    if (n == 0) {                                     // nothing to partition: every group is empty
-        MRL_HIP(ctx, hipMemsetAsync(offsets_out, 0, ((size_t)K + 1) * sizeof(uint32_t), ctx->stream));
-        MRL_HIP(ctx, hipMemsetAsync(counts_out, 0, (size_t)K * sizeof(uint32_t), ctx->stream));
-        return MRL_OK;
-    }
-    uint32_t chunks = 0, chunk_len = 0;
-    mrl::material_partition_geometry(n, ctx->compute_units, &chunks, &chunk_len);
-    const size_t need = (size_t)chunks * K + K;
-    if (need > ctx->part_work_cap) {
-        if (ctx->d_part_work) { MRL_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_part_work); ctx->d_part_work = nullptr; ctx->part_work_cap = 0; }
-        MRL_ALLOC(ctx, hipMalloc((void **)&ctx->d_part_work, need * sizeof(uint32_t)));
-        ctx->part_work_cap = need;
-    }
-    MRL_HIP(ctx, mrl::launch_partition_materials(mat, n, K, queue_out, offsets_out, counts_out, ctx->d_part_work, chunks, chunk_len,
-                                                 ctx->compute_units, ctx->stream));
-    return MRL_OK;
-}
-
-int mrl_eval_pdf_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
-                       const uint32_t *queue, const uint32_t *queue_count, size_t capacity, float *out_rgb, float *out_pdf)
-{
-    BatchCall c = { 4, wi, wo, nullptr, mat, single_id, capacity, out_rgb, out_pdf, nullptr, nullptr, nullptr };
-    return run_queue(ctx, c, queue, queue_count);
-}
-
-int mrl_eval_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
-                   const uint32_t *queue, const uint32_t *queue_count, size_t capacity, float *out_rgb)
-{
-    BatchCall c = { 0, wi, wo, nullptr, mat, single_id, capacity, out_rgb, nullptr, nullptr, nullptr, nullptr };
-    return run_queue(ctx, c, queue, queue_count);
-}
-
-int mrl_pdf_queue(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id,
-                  const uint32_t *queue, const uint32_t *queue_count, size_t capacity, float *out_pdf)
-{
-    BatchCall c = { 1, wi, wo, nullptr, mat, single_id, capacity, nullptr, out_pdf, nullptr, nullptr, nullptr };
-    return run_queue(ctx, c, queue, queue_count);
-}
-
-int mrl_sample_queue(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id,
-                     const uint32_t *queue, const uint32_t *queue_count, size_t capacity,
-                     float *out_wo, float *out_pdf, float *out_weight)
-{
-    BatchCall c = { 2, wi, nullptr, u, mat, single_id, capacity, nullptr, nullptr, out_wo, out_pdf, out_weight };
-    return run_queue(ctx, c, queue, queue_count);
-}
-
-int mrl_eval_sample_queue(mrl_ctx *ctx, const float *wi, const float *wo, const float *u,
-                          const int32_t *mat, int32_t single_id,
-                          const uint32_t *queue, const uint32_t *queue_count, size_t capacity,
-                          float *out_rgb, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
-{
-    BatchCall c = { 3, wi, wo, u, mat, single_id, capacity, out_rgb, out_pdf, out_wo, out_pdf2, out_weight };
-    return run_queue(ctx, c, queue, queue_count);
-}
-
-int mrl_generate_pairs(mrl_ctx *ctx, uint64_t seed, uint64_t first_index, size_t n, float *wi, float *wo, float *u)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (!wi || !wo || !u) return fail(ctx, MRL_ERR_INVALID, "null argument");
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    if (common_kind({ wi, wo, u }) != 1) return fail(ctx, MRL_ERR_INVALID, "generator needs device pointers");
-    MRL_HIP(ctx, mrl::launch_generate_pairs(seed, first_index, n, wi, wo, u, ctx->compute_units, ctx->stream));
-    return MRL_OK;
-}
-
-int mrl_generate_materials(mrl_ctx *ctx, uint64_t seed, uint64_t first_index, size_t n, int n_materials, int32_t *mat)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (!mat || n_materials < 1) return fail(ctx, MRL_ERR_INVALID, "bad argument");
-    MRL_HIP(ctx, hipSetDevice(ctx->device));
-    if (pointer_kind(mat) != 1) return fail(ctx, MRL_ERR_INVALID, "generator needs device pointers");
-    MRL_HIP(ctx, mrl::launch_generate_materials(seed, first_index, n, n_materials, mat, ctx->compute_units, ctx->stream));
-    return MRL_OK;
 }
 
 int mrl_device_alloc(mrl_ctx *ctx, size_t bytes, void **out)
@@ -1925,129 +575,6 @@ int mrl_timer_stop(mrl_ctx *ctx, float *elapsed_ms)
     MRL_HIP(ctx, hipEventSynchronize(ctx->ev1));
     MRL_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
     return MRL_OK;
-}
-
-/* ---- n-channel tables ---- */
-int mrl_material_upload_table_nch(mrl_ctx *ctx, const double *planar, const int dims[3], int n_channels, const double *scale, int *out_id)
-{
-    return upload_table_nch(ctx, planar, dims, n_channels, scale, out_id);
-}
-
-// the same upload with the parameterisation named in the call (the context's MRL_OPT_TABLE_PARAM is left as it was)
-int mrl_material_upload_table_param(mrl_ctx *ctx, const double *planar, const int dims[3], int n_channels, const double *scale, int param, int *out_id)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);                                    // recursive: the option cannot be seen half-way by another thread's upload
-    if (param < mrl::PARAM_HALF_DIFF || param > mrl::PARAM_STANDARD_FULL) return fail(ctx, MRL_ERR_INVALID, "unknown parameterisation");
-    const int before = ctx->table_param;
-    ctx->table_param = param;
-    const int rc = upload_table_nch(ctx, planar, dims, n_channels, scale, out_id);
-    ctx->table_param = before;
-    return rc;
-}
-
-int mrl_material_load_table_nch(mrl_ctx *ctx, const char *path, int n_channels, const double *scale, int *out_id)
-{
-    if (!ctx || !out_id) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (n_channels < 1 || n_channels > mrl::kMaxChannels) return fail(ctx, MRL_ERR_INVALID, "channel count must be 1.." + std::to_string(mrl::kMaxChannels));
-    std::vector<double> data; int dims[3];
-    int rc = read_table_file_nch(ctx, path, n_channels, data, dims);
-    if (rc != MRL_OK) return rc;
-    return upload_table_nch(ctx, data.data(), dims, n_channels, scale, out_id);
-}
-
-int mrl_material_channels(const mrl_ctx *ctx, int id, int *n_channels)
-{
-    if (!ctx || !n_channels) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return MRL_ERR_MATERIAL;
-    *n_channels = ctx->materials[(size_t)id].dev.n_ch;
-    return MRL_OK;
-}
-
-int mrl_material_param(const mrl_ctx *ctx, int id, int *param)
-{
-    if (!ctx || !param) return MRL_ERR_INVALID;
-    MRL_GUARD(ctx);
-    if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return MRL_ERR_MATERIAL;
-    const mrl::MaterialDev &d = ctx->materials[(size_t)id].dev;
-    if (d.kind == mrl::KIND_GGX) return MRL_ERR_MATERIAL;
-    *param = d.param;
-    return MRL_OK;
-}
-
-static int nch_call(mrl_ctx *ctx, BatchCall c, int n_channels)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    if (n_channels < 1 || n_channels > mrl::kMaxChannels) return fail(ctx, MRL_ERR_INVALID, "channel count must be 1.." + std::to_string(mrl::kMaxChannels));
-    c.n_ch = n_channels == 3 ? 0 : n_channels;           // three channels: the RGB path, RGB materials
-    return run_batch(ctx, c);
-}
-
-static int nch_queue_call(mrl_ctx *ctx, BatchCall c, int n_channels, const uint32_t *queue, const uint32_t *queue_count)
-{
-    if (!ctx) return MRL_ERR_INVALID;
-    if (n_channels < 1 || n_channels > mrl::kMaxChannels) return fail(ctx, MRL_ERR_INVALID, "channel count must be 1.." + std::to_string(mrl::kMaxChannels));
-    c.n_ch = n_channels == 3 ? 0 : n_channels;
-    return run_queue(ctx, c, queue, queue_count);
-}
-
-int mrl_eval_queue_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, const uint32_t *queue,
-                       const uint32_t *queue_count, size_t capacity, int n_channels, float *out_values)
-{
-    BatchCall c{ 0, wi, wo, nullptr, mat, single_id, capacity, out_values, nullptr, nullptr, nullptr, nullptr };
-    return nch_queue_call(ctx, c, n_channels, queue, queue_count);
-}
-
-int mrl_sample_queue_nch(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id, const uint32_t *queue,
-                         const uint32_t *queue_count, size_t capacity, int n_channels, float *out_wo, float *out_pdf, float *out_weight)
-{
-    BatchCall c{ 2, wi, nullptr, u, mat, single_id, capacity, nullptr, nullptr, out_wo, out_pdf, out_weight };
-    return nch_queue_call(ctx, c, n_channels, queue, queue_count);
-}
-
-int mrl_eval_pdf_queue_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, const uint32_t *queue,
-                           const uint32_t *queue_count, size_t capacity, int n_channels, float *out_values, float *out_pdf)
-{
-    BatchCall c{ 4, wi, wo, nullptr, mat, single_id, capacity, out_values, out_pdf, nullptr, nullptr, nullptr };
-    return nch_queue_call(ctx, c, n_channels, queue, queue_count);
-}
-
-int mrl_eval_sample_queue_nch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u, const int32_t *mat, int32_t single_id,
-                              const uint32_t *queue, const uint32_t *queue_count, size_t capacity, int n_channels,
-                              float *out_values, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
-{
-    BatchCall c{ 3, wi, wo, u, mat, single_id, capacity, out_values, out_pdf, out_wo, out_pdf2, out_weight };
-    return nch_queue_call(ctx, c, n_channels, queue, queue_count);
-}
-
-int mrl_eval_batch_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, int n_channels,
-                       float *out_values)
-{
-    BatchCall c{ 0, wi, wo, nullptr, mat, single_id, n, out_values, nullptr, nullptr, nullptr, nullptr };
-    return nch_call(ctx, c, n_channels);
-}
-
-int mrl_sample_batch_nch(mrl_ctx *ctx, const float *wi, const float *u, const int32_t *mat, int32_t single_id, size_t n, int n_channels,
-                         float *out_wo, float *out_pdf, float *out_weight)
-{
-    BatchCall c{ 2, wi, nullptr, u, mat, single_id, n, nullptr, nullptr, out_wo, out_pdf, out_weight };
-    return nch_call(ctx, c, n_channels);
-}
-
-int mrl_eval_pdf_batch_nch(mrl_ctx *ctx, const float *wi, const float *wo, const int32_t *mat, int32_t single_id, size_t n, int n_channels,
-                           float *out_values, float *out_pdf)
-{
-    BatchCall c{ 4, wi, wo, nullptr, mat, single_id, n, out_values, out_pdf, nullptr, nullptr, nullptr };
-    return nch_call(ctx, c, n_channels);
-}
-
-int mrl_eval_sample_batch_nch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u, const int32_t *mat, int32_t single_id, size_t n,
-                              int n_channels, float *out_values, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight)
-{
-    BatchCall c{ 3, wi, wo, u, mat, single_id, n, out_values, out_pdf, out_wo, out_pdf2, out_weight };
-    return nch_call(ctx, c, n_channels);
 }
 
 } // extern "C"
