@@ -145,7 +145,8 @@ enum mrl_option {
 
 enum mrl_material_kind { MRL_KIND_MERL = 0, MRL_KIND_TABLE = 1, MRL_KIND_GGX = 2, MRL_KIND_RELEASED = 3 /* tombstone, never reported */,
                          MRL_KIND_TABLE_NCH = 4 /* n-channel table: evaluated by the *_nch entry points only */,
-                         MRL_KIND_RGL = 5 /* adaptive-parameterisation measured BSDF (mrl_material_upload_rgl) */ };
+                         MRL_KIND_RGL = 5 /* adaptive-parameterisation measured BSDF (mrl_material_upload_rgl) */,
+                         MRL_KIND_RGL_SPECTRAL = 6 /* the same from a spectral file: evaluated by the mrl_*_spectral_batch entry points */ };
 
 /* ---- context ---- */
 int mrl_init(int device_id, mrl_ctx **out);
@@ -191,8 +192,8 @@ int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float 
  * evaluated by a second launch of the same call, through a descriptor kept behind the image): eval returns f * cos(theta_o);
  * sample() draws from the file's own luminance / vndf warps whatever MRL_OPT_SAMPLING says, and reports eval / pdf AT the Float
  * direction it returns.  The n-channel entry points render its id as zeros; one-unit mrl_scalar_* calls do not take it
- * (MRL_ERR_MATERIAL); mrl_material_host_table does (one-unit calls on the CPU); device groups replicate it like a table.  Spectral files (no "rgb" field) are
- * rejected. */
+ * (MRL_ERR_MATERIAL); mrl_material_host_table does (one-unit calls on the CPU); device groups replicate it like a table.  Spectral files ("spectra" +
+ * "wavelengths" instead of "rgb") become MRL_KIND_RGL_SPECTRAL materials with entry points of their own: see mrl_rgl_spectral_fields below. */
 typedef struct mrl_rgl_fields {
     int n_phi, n_theta;
     const float *phi_i, *theta_i;
@@ -204,6 +205,35 @@ int mrl_material_upload_rgl(mrl_ctx *ctx, const mrl_rgl_fields *fields, int *out
 /* the same from a tensor_file container holding the fields under their RGL names (phi_i, theta_i, ndf, sigma, vndf,
  * luminance, rgb, jacobian); why a file was refused: mrl_tensor_file_last_error(NULL) or mrl_last_error(ctx) */
 int mrl_material_load_rgl(mrl_ctx *ctx, const char *path, int *out_id);
+/* Spectral RGL files ("optional spectral channels"): "spectra" [n_phi][n_theta][n_wavelengths][res[1]][res[0]] over
+ * the strictly ascending grid "wavelengths" [n_wavelengths] where the *_rgb.bsdf variant holds "rgb" (base.rgb is ignored).  Upstream's
+ * `measured` evaluates such a file, in its spectral variants, with the ray's wavelengths as a THIRD interpolated parameter (linear
+ * between the file's nodes, clamped outside them); so do the mrl_*_spectral_batch calls: W values per unit at the wavelengths the caller
+ * passes PER UNIT — wavelengths [n][W], what hero-wavelength rendering carries per ray — or, with wavelengths == NULL, at the file's own
+ * nodes (W must then be n_wavelengths: the n-channel form of the material, channel = node).  out_values / out_weight are [n][W];
+ * pdf and the sampled direction do not depend on the wavelength; sample() reports eval / pdf AT the Float direction it returns, as for
+ * RGB files.  Whole arrays, one material (no material-id array), host or device pointers (host arrays are staged in chunks).
+ * mrl_pdf_batch serves the kind too (the pdf is wavelength-free), mrl_material_load_rgl reads either variant,
+ * mrl_material_save_image / _load_image and mrl_material_host_table take it; the RGB entry points answer MRL_ERR_MATERIAL for a
+ * single_id of this kind and render it as zeros inside a batch with material ids.  PARITY UNPINNED (no spectral file exists offline;
+ * checker: oracle/rgl_oracle.c, rgl_eval_pdf_spectral / rgl_sample_spectral). */
+typedef struct mrl_rgl_spectral_fields {
+    mrl_rgl_fields base;             /* phi_i .. luminance, jacobian as for an RGB file; base.rgb unused */
+    int n_wavelengths;
+    const float *wavelengths;        /* [n_wavelengths], strictly ascending */
+    const float *spectra;            /* [n_phi][n_theta][n_wavelengths][res[1]][res[0]] */
+} mrl_rgl_spectral_fields;
+int mrl_material_upload_rgl_spectral(mrl_ctx *ctx, const mrl_rgl_spectral_fields *fields, int *out_id);
+/* the file's wavelength grid: *n_wavelengths always; the nodes into out when it is not NULL (max_floats >= *n_wavelengths) */
+int mrl_material_wavelengths(mrl_ctx *ctx, int id, int *n_wavelengths, float *out, size_t max_floats);
+int mrl_eval_spectral_batch(mrl_ctx *ctx, const float *wi, const float *wo, const float *wavelengths /* [n][W] or NULL */, int n_wavelengths /* W */,
+                            int32_t id, size_t n, float *out_values /* [n][W] */);
+int mrl_eval_pdf_spectral_batch(mrl_ctx *ctx, const float *wi, const float *wo, const float *wavelengths, int n_wavelengths, int32_t id, size_t n,
+                                float *out_values, float *out_pdf);
+int mrl_sample_spectral_batch(mrl_ctx *ctx, const float *wi, const float *u, const float *wavelengths, int n_wavelengths, int32_t id, size_t n,
+                              float *out_wo, float *out_pdf, float *out_weight /* [n][W] */);
+int mrl_eval_sample_spectral_batch(mrl_ctx *ctx, const float *wi, const float *wo, const float *u, const float *wavelengths, int n_wavelengths, int32_t id,
+                                   size_t n, float *out_values, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight);
 /* On-disk cache of a material's DEVICE image: what is resident for the material — the texels as Float (RGB tables
  * in the compact rows form, 24 MB for a MERL table, whatever the context's layout: a brick context expands them on the device), the
  * sampling marginal, the conditional sampling rows; for an RGL material the cell-brick image with its running integrals — written so that
@@ -286,6 +316,12 @@ int mrl_host_eval_pdf(const mrl_host_table *table, const float wi[3], const floa
 int mrl_host_sample(const mrl_host_table *table, const float wi[3], const float u[2], float out_wo[3], float *out_pdf, float out_weight[3]);
 /* the fused unit: out[11] = rgb[3] pdf wo'[3] pdf' weight'[3], as mrl_scalar_eval_sample lays it out */
 int mrl_host_eval_sample(const mrl_host_table *table, const float wi[3], const float wo[3], const float u[2], float out[11]);
+/* a spectral RGL material (MRL_KIND_RGL_SPECTRAL): W values at wavelengths[0 .. W) (NULL: the file's own nodes); the three calls
+ * above answer MRL_ERR_MATERIAL for it, these two for every other kind */
+int mrl_host_eval_pdf_spectral(const mrl_host_table *table, const float wi[3], const float wo[3], const float *wavelengths, int n_wavelengths,
+                               float *out_values, float *out_pdf /* may be NULL */);
+int mrl_host_sample_spectral(const mrl_host_table *table, const float wi[3], const float u[2], const float *wavelengths, int n_wavelengths,
+                             float out_wo[3], float *out_pdf, float *out_weight);
 
 /* ---- n-channel tables: customized_measurement beyond RGB (monochrome, RGB + alpha, spectral bins; SURVEY.md §8f
  * item 3).  Same MERL parameterisation, same transform and trilinear blend; a texel has n_channels values, 1..32.
@@ -435,7 +471,8 @@ int mrl_group_material_upload_f64(mrl_group *g, const double *planar_rgb, int *o
 int mrl_group_material_upload_table(mrl_group *g, const double *planar_rgb, const int dims[3], const double scale[3], int *out_id);
 int mrl_group_material_ggx(mrl_group *g, float alpha, const float eta[3], const float k[3], int *out_id);
 int mrl_group_material_upload_rgl(mrl_group *g, const mrl_rgl_fields *fields, int *out_id);      /* one image per member, like a table */
-int mrl_group_material_load_rgl(mrl_group *g, const char *path, int *out_id);
+int mrl_group_material_load_rgl(mrl_group *g, const char *path, int *out_id);                      /* RGB or spectral file */
+int mrl_group_material_upload_rgl_spectral(mrl_group *g, const mrl_rgl_spectral_fields *fields, int *out_id);
 int mrl_group_material_release(mrl_group *g, int id);
 /* tile / chunk arithmetic (pure functions; usable without a device) */
 void mrl_tile_bounds(size_t n_total, int world, int rank, size_t *lo, size_t *hi);

@@ -94,6 +94,10 @@ int check_call(mrl_ctx *ctx, const BatchCall &c)
             if (c.n_ch > 0) return fail(ctx, MRL_ERR_MATERIAL, "an RGL material has three channels: use the RGB entry points");
             return MRL_OK;
         }
+        if (d.kind == mrl::KIND_RGL_SPECTRAL) {                // the pdf is wavelength-free: the RGB pdf call serves it
+            if (c.mode == 1 && c.n_ch == 0) return MRL_OK;
+            return fail(ctx, MRL_ERR_MATERIAL, "a spectral RGL material: use the mrl_*_spectral_batch entry points");
+        }
         if (c.n_ch == 0 && c.mode != 1 && !mrl::kind_is_rgb_path(d.kind))               // pdf is channel-free
             return fail(ctx, MRL_ERR_MATERIAL, "material has " + std::to_string(d.n_ch) + " channels: use the *_nch entry points");
         if (c.n_ch > 0 && c.mode != 1 && (d.kind != mrl::KIND_TABLE_NCH || d.n_ch != c.n_ch))
@@ -117,7 +121,7 @@ int launch_device(mrl_ctx *ctx, const BatchCall &c)
 {
     const DeviceCall d = device_call(ctx, c);
     const mrl::BatchArgs &a = d.args;
-    if (!d.multi && a.single.kind == mrl::KIND_RGL) {         // adaptive-parameterisation material: its own kernel
+    if (!d.multi && (a.single.kind == mrl::KIND_RGL || a.single.kind == mrl::KIND_RGL_SPECTRAL)) {     // adaptive-parameterisation material: its own kernel (spectral: pdf only)
         MRL_HIP(ctx, mrl::launch_rgl(c.mode, a, &ctx->materials[(size_t)c.single_id].rgl, false, ctx->rgl_search, ctx->compute_units, ctx->stream));
         return MRL_OK;
     }
@@ -298,7 +302,7 @@ int run_queue(mrl_ctx *ctx, const BatchCall &c, const uint32_t *queue, const uin
     if (call_pointer_kind(c, queue, queue_count) != 1) return fail(ctx, MRL_ERR_POINTER_MIX, "queue calls take device pointers only");
     DeviceCall d = device_call(ctx, c);
     d.args.idx = queue; d.args.idx_count = queue_count;
-    if (!d.multi && d.args.single.kind == mrl::KIND_RGL) {
+    if (!d.multi && (d.args.single.kind == mrl::KIND_RGL || d.args.single.kind == mrl::KIND_RGL_SPECTRAL)) {   // (spectral: pdf only, see check_call)
         MRL_HIP(ctx, mrl::launch_rgl(c.mode, d.args, &ctx->materials[(size_t)c.single_id].rgl, true, ctx->rgl_search, ctx->compute_units, ctx->stream));
         return MRL_OK;
     }

@@ -64,7 +64,8 @@ constexpr float kInvPiF = 0.31830988618379067154f;
 enum Kind : int { KIND_MERL = 0, KIND_TABLE = 1, KIND_GGX = 2,
                   KIND_RELEASED = 3,     // tombstone of mrl_material_release: a valid 1x1x1 zero table, treated like an unknown id
                   KIND_TABLE_NCH = 4,    // n-channel table (merl_nch.hip): only the *_nch entry points evaluate it
-                  KIND_RGL = 5 };        // adaptive-parameterisation measured BSDF (merl_rgl.hip): its own kernel, also behind mixed batches
+                  KIND_RGL = 5,          // adaptive-parameterisation measured BSDF (merl_rgl.hip): its own kernel, also behind mixed batches
+                  KIND_RGL_SPECTRAL = 6 };   // the same from a spectral file: W values per unit at caller-supplied wavelengths (mrl_*_spectral_batch)
 // the RGB kernels evaluate kinds 0..2; anything above renders as an unknown id (every output zero)
 __host__ __device__ constexpr bool kind_is_rgb_path(int kind) { return kind >= KIND_MERL && kind <= KIND_GGX; }
 enum Layout : int { LAYOUT_ROWS = 0, LAYOUT_BRICK = 1 };

@@ -412,6 +412,10 @@ int mrl_group_material_ggx(mrl_group *g, float alpha, const float eta[3], const 
 {
     return replicated_material(g, "mrl_material_ggx", out_id, [&](mrl_ctx *c, int *id) { return mrl_material_ggx(c, alpha, eta, k, id); });
 }
+int mrl_group_material_upload_rgl_spectral(mrl_group *g, const mrl_rgl_spectral_fields *fields, int *out_id)
+{
+    return replicated_material(g, "mrl_material_upload_rgl_spectral", out_id, [&](mrl_ctx *c, int *id) { return mrl_material_upload_rgl_spectral(c, fields, id); });
+}
 int mrl_group_material_upload_rgl(mrl_group *g, const mrl_rgl_fields *fields, int *out_id)
 {
     return replicated_material(g, "mrl_material_upload_rgl", out_id, [&](mrl_ctx *c, int *id) { return mrl_material_upload_rgl(c, fields, id); });

@@ -64,6 +64,7 @@ extern "C" {
 MRL_HOST_FAST int mrl_host_eval_pdf(const mrl_host_table *t, const float wi[3], const float wo[3], float out_rgb[3], float *out_pdf)
 {
     if (!t || !wi || !wo || !out_rgb) return MRL_ERR_INVALID;
+    if (t->m.kind == mrl::KIND_RGL_SPECTRAL) return MRL_ERR_MATERIAL;
     if (t->m.kind == mrl::KIND_RGL) { host_rgl_eval_pdf(t, wi, wo, out_rgb, out_pdf); return MRL_OK; }
     if (t->opts.lookup) host_eval_pdf<1>(t, wi, wo, out_rgb, out_pdf);
     else host_eval_pdf<0>(t, wi, wo, out_rgb, out_pdf);
@@ -73,6 +74,7 @@ MRL_HOST_FAST int mrl_host_eval_pdf(const mrl_host_table *t, const float wi[3], 
 MRL_HOST_FAST int mrl_host_sample(const mrl_host_table *t, const float wi[3], const float u[2], float out_wo[3], float *out_pdf, float out_weight[3])
 {
     if (!t || !wi || !u || !out_wo || !out_pdf || !out_weight) return MRL_ERR_INVALID;
+    if (t->m.kind == mrl::KIND_RGL_SPECTRAL) return MRL_ERR_MATERIAL;
     if (t->m.kind == mrl::KIND_RGL) { mrl::rgl::sample(t->rgl, wi[0], wi[1], wi[2], u[0], u[1], out_wo, *out_pdf, out_weight); return MRL_OK; }
     if (t->opts.lookup) host_sample<1>(t, wi, u, out_wo, out_pdf, out_weight);
     else host_sample<0>(t, wi, u, out_wo, out_pdf, out_weight);
@@ -82,6 +84,7 @@ MRL_HOST_FAST int mrl_host_sample(const mrl_host_table *t, const float wi[3], co
 MRL_HOST_FAST int mrl_host_eval_sample(const mrl_host_table *t, const float wi[3], const float wo[3], const float u[2], float out[11])
 {
     if (!t || !wi || !wo || !u || !out) return MRL_ERR_INVALID;
+    if (t->m.kind == mrl::KIND_RGL_SPECTRAL) return MRL_ERR_MATERIAL;
     if (t->m.kind == mrl::KIND_RGL) {
         host_rgl_eval_pdf(t, wi, wo, out, out + 3);
         mrl::rgl::sample(t->rgl, wi[0], wi[1], wi[2], u[0], u[1], out + 4, out[7], out + 8);
@@ -89,6 +92,28 @@ MRL_HOST_FAST int mrl_host_eval_sample(const mrl_host_table *t, const float wi[3
     }
     if (t->opts.lookup) { host_eval_pdf<1>(t, wi, wo, out, out + 3); host_sample<1>(t, wi, u, out + 4, out + 7, out + 8); }
     else { host_eval_pdf<0>(t, wi, wo, out, out + 3); host_sample<0>(t, wi, u, out + 4, out + 7, out + 8); }
+    return MRL_OK;
+}
+
+// a spectral RGL material: W values at the wavelengths wl[0 .. W) (NULL: the file's own nodes, W = their number)
+MRL_HOST_FAST int mrl_host_eval_pdf_spectral(const mrl_host_table *t, const float wi[3], const float wo[3], const float *wl, int W, float *out_values, float *out_pdf)
+{
+    if (!t || !wi || !wo || !out_values || W < 1) return MRL_ERR_INVALID;
+    if (t->m.kind != mrl::KIND_RGL_SPECTRAL) return MRL_ERR_MATERIAL;
+    if (!wl && W != t->rgl.n_wl) return MRL_ERR_INVALID;
+    float p;
+    if (out_pdf) { mrl::rgl::eval_pdf_spectral<true, true>(t->rgl, wi[0], wi[1], wi[2], wo[0], wo[1], wo[2], wl, W, out_values, p); *out_pdf = p; }
+    else mrl::rgl::eval_pdf_spectral<true, false>(t->rgl, wi[0], wi[1], wi[2], wo[0], wo[1], wo[2], wl, W, out_values, p);
+    return MRL_OK;
+}
+
+MRL_HOST_FAST int mrl_host_sample_spectral(const mrl_host_table *t, const float wi[3], const float u[2], const float *wl, int W, float out_wo[3], float *out_pdf,
+                                           float *out_weight)
+{
+    if (!t || !wi || !u || !out_wo || !out_pdf || !out_weight || W < 1) return MRL_ERR_INVALID;
+    if (t->m.kind != mrl::KIND_RGL_SPECTRAL) return MRL_ERR_MATERIAL;
+    if (!wl && W != t->rgl.n_wl) return MRL_ERR_INVALID;
+    mrl::rgl::sample_spectral(t->rgl, wi[0], wi[1], wi[2], u[0], u[1], wl, W, out_wo, *out_pdf, out_weight);
     return MRL_OK;
 }
 

@@ -46,15 +46,16 @@ int mrl_material_save_image(mrl_ctx *ctx, int id, const char *path)
     h.header_bytes = (uint32_t)sizeof h; h.kind = (uint32_t)d.kind; h.layout = (uint32_t)d.layout; h.n_ch = (uint32_t)d.n_ch; h.param = (uint32_t)d.param;
     // (the conditional rows are stamped with the options they were integrated under — at upload —, not with today's)
     h.lookup = (uint32_t)mh.rows_lookup; h.node = (uint32_t)mh.rows_node; h.n_ti = (uint32_t)d.n_ti;
-    h.negative = d.kind == mrl::KIND_RGL ? 0u : (uint32_t)ctx->opts.negative;
+    const bool rgl_kind = d.kind == mrl::KIND_RGL || d.kind == mrl::KIND_RGL_SPECTRAL;
+    h.negative = rgl_kind ? 0u : (uint32_t)ctx->opts.negative;
     h.dims[0] = d.n_th; h.dims[1] = d.n_td; h.dims[2] = d.n_pd;
-    if (d.kind == mrl::KIND_RGL) {
+    if (rgl_kind) {
         const mrl::RglDev &r = mh.rgl;
         const int32_t shape[8] = { r.vndf.n_phi, r.vndf.n_theta, r.vndf.nx, r.vndf.ny, r.ndf.nx, r.ndf.ny, r.sigma.nx, r.sigma.ny };
         std::memcpy(h.rgl_shape, shape, sizeof shape);
-        h.rgl_flags[0] = r.jacobian;
+        h.rgl_flags[0] = r.jacobian; h.rgl_flags[1] = r.n_wl;
         mrl::RglLayout l;
-        h.texel_bytes = mrl::rgl_plan_layout(rgl_shapes_of(shape, r.jacobian), l) * sizeof(float);
+        h.texel_bytes = mrl::rgl_plan_layout(rgl_shapes_of(shape, r.jacobian, r.n_wl), l) * sizeof(float);
     } else {
         // RGB tables travel in the compact rows form whatever the context's layout (a brick image is 7.8 x larger than the rows image
         // and reads slower than the source file parses); n-channel tables have one layout
@@ -68,7 +69,7 @@ int mrl_material_save_image(mrl_ctx *ctx, int id, const char *path)
     try { payload.resize((size_t)h.texel_bytes + (size_t)(h.sampling_doubles + h.sampling2d_doubles) * sizeof(double)); }
     catch (const std::bad_alloc &) { return fail(ctx, MRL_ERR_OOM, "image buffer"); }
     MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (d.kind != mrl::KIND_RGL && d.kind != mrl::KIND_TABLE_NCH && d.layout == mrl::LAYOUT_BRICK) {
+    if (!rgl_kind && d.kind != mrl::KIND_TABLE_NCH && d.layout == mrl::LAYOUT_BRICK) {
         float4 *d_rows = nullptr;
         MRL_ALLOC(ctx, hipMalloc((void **)&d_rows, (size_t)h.texel_bytes));
         hipError_t e = mrl::launch_bricks_to_rows(mh.d_texels, h.dims, d.param, d_rows, ctx->compute_units, ctx->stream);

@@ -17,8 +17,11 @@ struct RglFields {                   // host arrays, as the file holds them (x f
     int res_ndf[2], res_sigma[2], res[2];
     const float *ndf, *sigma, *vndf, *luminance, *rgb;
     int jacobian;
+    int n_wl;                        // 0: an RGB file (rgb [n_phi][n_theta][3][ny][nx]); else a spectral one: `rgb` holds "spectra"
+    const float *wavelengths;        // [n_phi][n_theta][n_wl][ny][nx] over this ascending grid
 };
-struct RglLayout { size_t phi, theta, cells[5], cond2[5], margq[5]; };   // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
+struct RglLayout { size_t phi, theta, wavelengths, cells[5], cond2[5], margq[5]; };   // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
+inline int rgl_value_channels(const RglFields &f) { return f.n_wl > 0 ? f.n_wl : 3; }
 
 inline const char *rgl_check_shapes(const RglFields &f)
 {
@@ -26,8 +29,9 @@ inline const char *rgl_check_shapes(const RglFields &f)
     for (int k = 0; k < 2; ++k)
         if (f.res_ndf[k] < 2 || f.res_sigma[k] < 2 || f.res[k] < 2 || f.res_ndf[k] > 8192 || f.res_sigma[k] > 8192 || f.res[k] > 8192)
             return "every table needs 2..8192 nodes per axis";
+    if (f.n_wl < 0 || f.n_wl > 4096) return "wavelengths: at most 4096 nodes";
     const size_t slices = (size_t)f.n_phi * (size_t)f.n_theta, per = (size_t)f.res[0] * (size_t)f.res[1];
-    if (slices * per * 3 > ((size_t)1 << 28)) return "tables too large (more than 2^28 values)";
+    if (slices * per * (size_t)rgl_value_channels(f) > ((size_t)1 << 28)) return "tables too large (more than 2^28 values)";
     return nullptr;
 }
 
@@ -52,8 +56,8 @@ inline WarpOffsets plan_warp(size_t &at, int nx, int ny, int n_phi, int n_theta,
 // the image's layout from the shapes alone; returns the image's size in floats
 inline size_t rgl_plan_layout(const RglFields &f, RglLayout &l)
 {
-    size_t at = (size_t)f.n_phi + (size_t)f.n_theta;
-    l.phi = 0; l.theta = (size_t)f.n_phi;
+    size_t at = (size_t)f.n_phi + (size_t)f.n_theta + (size_t)f.n_wl;
+    l.phi = 0; l.theta = (size_t)f.n_phi; l.wavelengths = (size_t)f.n_phi + (size_t)f.n_theta;
     auto put = [&](int which, const int res[2], int n_phi, int n_theta, int n_ch, bool distribution) {
         const WarpOffsets o = plan_warp(at, res[0], res[1], n_phi, n_theta, n_ch, distribution);
         l.cells[which] = o.cells; l.cond2[which] = o.cond2; l.margq[which] = o.margq;
@@ -62,7 +66,7 @@ inline size_t rgl_plan_layout(const RglFields &f, RglLayout &l)
     put(1, f.res_sigma, 1, 1, 1, false);
     put(2, f.res, f.n_phi, f.n_theta, 1, true);
     put(3, f.res, f.n_phi, f.n_theta, 1, true);
-    put(4, f.res, f.n_phi, f.n_theta, 3, false);
+    put(4, f.res, f.n_phi, f.n_theta, rgl_value_channels(f), false);
     return at;
 }
 
@@ -75,14 +79,14 @@ struct ImageHeader {
     uint32_t header_bytes, kind, layout, n_ch, param, lookup, node, n_ti;
     int32_t dims[3];
     int32_t rgl_shape[8];                // n_phi n_theta res_x res_y res_ndf_x res_ndf_y res_sigma_x res_sigma_y
-    int32_t rgl_flags[2];                // jacobian, reserved
+    int32_t rgl_flags[2];                // jacobian, wavelength nodes (0: an RGB file)
     uint32_t negative;                   // MRL_OPT_NEGATIVE the table was built under: 0 = negative values were clamped to 0, 1 / 2 = the image holds them
     uint64_t texel_bytes, sampling_doubles, sampling2d_doubles, checksum;
 };
 constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 2, 0 };
 constexpr uint64_t kImageChecksumSeed = 0xCBF29CE484222325ull;
 // the kinds and layouts an image can name (values of mrl::Kind / mrl::Layout / mrl::Param, repeated here so that this header needs no HIP)
-constexpr uint32_t kImgKindMerl = 0, kImgKindTable = 1, kImgKindNch = 4, kImgKindRgl = 5, kImgLayoutRows = 0, kImgLayoutBrick = 1, kImgParamLast = 2;
+constexpr uint32_t kImgKindMerl = 0, kImgKindTable = 1, kImgKindNch = 4, kImgKindRgl = 5, kImgKindRglSpectral = 6, kImgLayoutRows = 0, kImgLayoutBrick = 1, kImgParamLast = 2;
 constexpr int kImgMaxChannels = 32, kImgIncidentBins = 32;
 
 inline uint64_t image_checksum(const void *p, size_t bytes, uint64_t h)
@@ -94,12 +98,13 @@ inline uint64_t image_checksum(const void *p, size_t bytes, uint64_t h)
     return h;
 }
 
-inline RglFields rgl_shapes_of(const int32_t s[8], int jacobian)
+inline RglFields rgl_shapes_of(const int32_t s[8], int jacobian, int n_wl = 0)
 {
     RglFields f;
     std::memset(&f, 0, sizeof f);
     f.n_phi = s[0]; f.n_theta = s[1]; f.res[0] = s[2]; f.res[1] = s[3]; f.res_ndf[0] = s[4]; f.res_ndf[1] = s[5]; f.res_sigma[0] = s[6]; f.res_sigma[1] = s[7];
     f.jacobian = jacobian;
+    f.n_wl = n_wl;
     return f;
 }
 
@@ -120,13 +125,15 @@ inline const char *image_plan(const ImageHeader &h, unsigned long long file_byte
 {
     if (std::memcmp(h.magic, kImageMagic, 8) != 0 || h.header_bytes != sizeof(ImageHeader)) return "not a material image of this library version";
     p = ImagePlan();
-    p.is_rgl = h.kind == kImgKindRgl; p.is_nch = h.kind == kImgKindNch;
+    p.is_rgl = h.kind == kImgKindRgl || h.kind == kImgKindRglSpectral; p.is_nch = h.kind == kImgKindNch;
     if (!p.is_rgl && !p.is_nch && h.kind != kImgKindMerl && h.kind != kImgKindTable) return "unknown material kind";
     if (p.is_rgl) {
-        p.shapes = rgl_shapes_of(h.rgl_shape, h.rgl_flags[0] != 0);
+        if ((h.kind == kImgKindRglSpectral) != (h.rgl_flags[1] > 0)) return "kind and wavelength count disagree";
+        if (h.rgl_flags[1] < 0 || h.rgl_flags[1] > 4096) return "bad wavelength count";
+        p.shapes = rgl_shapes_of(h.rgl_shape, h.rgl_flags[0] != 0, h.rgl_flags[1]);
         if (const char *why = rgl_check_shapes(p.shapes)) return why;
         p.texel_bytes = (uint64_t)rgl_plan_layout(p.shapes, p.layout) * sizeof(float);
-        p.n_ch = 3; p.dims[0] = p.shapes.n_phi; p.dims[1] = p.shapes.n_theta; p.dims[2] = p.shapes.res[0];
+        p.n_ch = rgl_value_channels(p.shapes); p.dims[0] = p.shapes.n_phi; p.dims[1] = p.shapes.n_theta; p.dims[2] = p.shapes.res[0];
     } else {
         for (int k = 0; k < 3; ++k)
             if (h.dims[k] < 1 || h.dims[k] > (1 << 28)) return "table dims out of range";           // each one first: the product below must not overflow

@@ -81,6 +81,9 @@ RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base)
 // search (MRL_OPT_RGL_SEARCH): 0 = a single-material launch reads the distributions' search tables from a copy in LDS when they fit
 // a CU's LDS, 1 = always from memory (the results are the same bits)
 hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev *r, bool indexed, int search, int compute_units, hipStream_t stream);
+// a spectral RGL material: a.out_rgb / a.out_weight hold n x W values at the per-unit wavelengths wl [n][W] (nullptr: the file's own
+// wavelength nodes, W = their number); single material, whole arrays
+hipError_t launch_rgl_spectral(int mode, const BatchArgs &a, const RglDev &r, const float *wl, int W, int search, int compute_units, hipStream_t stream);
 // ---- one-unit calls (merl_scalar.hip): a bounded-lifetime service kernel answers requests posted in pinned host memory ----
 struct ScalarBoard;
 struct ScalarArgs {

@@ -353,7 +353,7 @@ int mrl_material_ggx(mrl_ctx *ctx, float alpha, const float eta[3], const float 
 
 // The adaptive-parameterisation measured BSDF (RGL *.bsdf fields): the host normalises the two distributions and forms
 // their running integrals (f64, once), the image goes to HBM as one allocation.  PARITY UNPINNED (merl_rgl.hpp).
-int mrl_material_upload_rgl(mrl_ctx *ctx, const mrl_rgl_fields *f, int *out_id)
+static int upload_rgl_fields(mrl_ctx *ctx, const mrl_rgl_fields *f, int n_wl, const float *wavelengths, const float *values, int *out_id)
 {
     if (!ctx) return MRL_ERR_INVALID;
     MRL_GUARD(ctx);
@@ -361,8 +361,9 @@ int mrl_material_upload_rgl(mrl_ctx *ctx, const mrl_rgl_fields *f, int *out_id)
     mrl::RglFields h;
     h.n_phi = f->n_phi; h.n_theta = f->n_theta; h.phi_i = f->phi_i; h.theta_i = f->theta_i;
     for (int k = 0; k < 2; ++k) { h.res_ndf[k] = f->res_ndf[k]; h.res_sigma[k] = f->res_sigma[k]; h.res[k] = f->res[k]; }
-    h.ndf = f->ndf; h.sigma = f->sigma; h.vndf = f->vndf; h.luminance = f->luminance; h.rgb = f->rgb;
+    h.ndf = f->ndf; h.sigma = f->sigma; h.vndf = f->vndf; h.luminance = f->luminance; h.rgb = values;
     h.jacobian = f->jacobian;
+    h.n_wl = n_wl; h.wavelengths = wavelengths;
     if (const char *why = mrl::rgl_check_fields(h)) return fail(ctx, MRL_ERR_INVALID, std::string("RGL fields: ") + why);
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<float> blob;
@@ -386,13 +387,26 @@ int mrl_material_upload_rgl(mrl_ctx *ctx, const mrl_rgl_fields *f, int *out_id)
         return fail(ctx, oom ? MRL_ERR_OOM : MRL_ERR_HIP, std::string("RGL upload: ") + hipGetErrorString(e));
     }
     std::memset(&m.dev, 0, sizeof m.dev);
-    m.dev.kind = mrl::KIND_RGL;
+    m.dev.kind = n_wl > 0 ? mrl::KIND_RGL_SPECTRAL : mrl::KIND_RGL;
     m.dev.rgl = (const char *)m.d_texels + image_bytes;
-    m.dev.n_ch = 3;
+    m.dev.n_ch = n_wl > 0 ? n_wl : 3;
     m.dev.n_th = h.n_phi; m.dev.n_td = h.n_theta; m.dev.n_pd = h.res[0];     // what mrl_material_info reports
     rc = place_material(ctx, m, out_id);
     if (rc != MRL_OK) { (void)hipFree(m.d_texels); return rc; }
     return MRL_OK;
+}
+
+int mrl_material_upload_rgl(mrl_ctx *ctx, const mrl_rgl_fields *f, int *out_id)
+{
+    return upload_rgl_fields(ctx, f, 0, nullptr, f ? f->rgb : nullptr, out_id);
+}
+
+// a spectral file: "spectra" over "wavelengths" instead of "rgb" (merl_rgl_spectral.hip holds the calls)
+int mrl_material_upload_rgl_spectral(mrl_ctx *ctx, const mrl_rgl_spectral_fields *f, int *out_id)
+{
+    if (!ctx) return MRL_ERR_INVALID;
+    if (!f || f->n_wavelengths < 1 || !f->wavelengths || !f->spectra) { MRL_GUARD(ctx); return fail(ctx, MRL_ERR_INVALID, "a spectral RGL material needs spectra over at least one wavelength"); }
+    return upload_rgl_fields(ctx, &f->base, f->n_wavelengths, f->wavelengths, f->spectra, out_id);
 }
 
 int mrl_material_release(mrl_ctx *ctx, int id)
@@ -433,12 +447,12 @@ int mrl_material_host_table(mrl_ctx *ctx, int id, mrl_host_table **out)
     *out = nullptr;
     if (id < 0 || (size_t)id >= ctx->materials.size() || ctx->materials[(size_t)id].released) return fail(ctx, MRL_ERR_MATERIAL, "unknown material id");
     const MaterialHost &mh = ctx->materials[(size_t)id];
-    if (mh.dev.kind != mrl::KIND_MERL && mh.dev.kind != mrl::KIND_TABLE && mh.dev.kind != mrl::KIND_RGL)
+    if (mh.dev.kind != mrl::KIND_MERL && mh.dev.kind != mrl::KIND_TABLE && mh.dev.kind != mrl::KIND_RGL && mh.dev.kind != mrl::KIND_RGL_SPECTRAL)
         return fail(ctx, MRL_ERR_MATERIAL, "host images exist for three-channel table materials and RGL materials");
     if (!__builtin_cpu_supports("fma") || !__builtin_cpu_supports("avx2"))
         return fail(ctx, MRL_ERR_INVALID, "the host one-unit path needs a CPU with FMA and AVX2");
     MRL_HIP(ctx, hipSetDevice(ctx->device));
-    if (mh.dev.kind == mrl::KIND_RGL) {                       // the image is position independent: copy it, move the descriptor's pointers
+    if (mh.dev.kind == mrl::KIND_RGL || mh.dev.kind == mrl::KIND_RGL_SPECTRAL) {      // the image is position independent: copy it, move the descriptor's pointers
         MRL_HIP(ctx, hipSetDevice(ctx->device));
         mrl_host_table *t = nullptr;
         try {
@@ -457,6 +471,7 @@ int mrl_material_host_table(mrl_ctx *ctx, int id, mrl_host_table **out)
             if (w->margq) w->margq = (const float4 *)(to + ((const char *)w->margq - from));
             w->phi = (const float *)(to + ((const char *)w->phi - from)); w->theta = (const float *)(to + ((const char *)w->theta - from));
         }
+        if (t->rgl.wavelengths) t->rgl.wavelengths = (const float *)(to + ((const char *)t->rgl.wavelengths - from));
         t->m = mh.dev;
         t->opts = ctx->opts;
         *out = t;

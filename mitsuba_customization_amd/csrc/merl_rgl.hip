@@ -164,6 +164,52 @@ __global__ __launch_bounds__(rgl_lds_block(MODE)) void k_rgl_lds(BatchArgs a, Rg
     }
 }
 
+// ---- spectral files: W values per unit at the wavelengths wl[i * W .. ) (nullptr: the file's own nodes) ----
+// a.out_rgb / a.out_weight hold n x W values.  Same structure as rgl_unit: what depends on wi alone is formed once.
+template <int MODE, class Search>
+__device__ __forceinline__ void rgl_unit_spectral(const BatchArgs &a, const RglDev &r, const Search &tv, const Search &tl, size_t i, const float *wl_all, int W)
+{
+    constexpr bool has_eval = MODE == 0 || MODE == 3 || MODE == 4, has_pdf = MODE == 1 || MODE == 3 || MODE == 4,
+                   has_sample = MODE == 2 || MODE == 3;
+    const float wix = a.wi[3 * i], wiy = a.wi[3 * i + 1], wiz = a.wi[3 * i + 2];
+    const float *wl = wl_all ? wl_all + i * (size_t)W : nullptr;
+    rgl::Incident in;
+    const bool up = wiz > 0.0f && rgl::incident<has_eval || has_sample>(r, wix, wiy, wiz, in);
+    if constexpr (has_eval || has_pdf) {
+        const float wox = a.wo[3 * i], woy = a.wo[3 * i + 1], woz = a.wo[3 * i + 2];
+        float *values = has_eval ? a.out_rgb + i * (size_t)W : nullptr;
+        float pdf = 0.0f;
+        if (up) rgl::eval_pdf_spectral_at<has_eval, has_pdf>(r, tv, in, wox, woy, woz, wl, W, values, pdf);
+        else if constexpr (has_eval) for (int k = 0; k < W; ++k) values[k] = 0.0f;
+        if constexpr (has_pdf) a.out_pdf[i] = pdf;
+    }
+    if constexpr (has_sample) {
+        float wo2[3] = { 0.0f, 0.0f, 0.0f }, pdf2 = 0.0f;
+        float *weight = a.out_weight + i * (size_t)W;
+        if (up) rgl::sample_spectral_at(r, tv, tl, in, a.u[2 * i], a.u[2 * i + 1], wl, W, wo2, pdf2, weight);
+        else for (int k = 0; k < W; ++k) weight[k] = 0.0f;
+        a.out_wo[3 * i] = wo2[0]; a.out_wo[3 * i + 1] = wo2[1]; a.out_wo[3 * i + 2] = wo2[2];
+        a.out_pdf2[i] = pdf2;
+    }
+}
+
+template <int MODE, bool LDS>
+__global__ __launch_bounds__(LDS ? rgl_lds_block(MODE) : kRglBlock) void k_rgl_spectral(BatchArgs a, RglDev r, const float *wl, int W)
+{
+    constexpr int kBlockThreads = LDS ? rgl_lds_block(MODE) : kRglBlock;
+    const size_t stride = (size_t)gridDim.x * kBlockThreads;
+    if constexpr (LDS) {
+        unsigned at = 0;
+        const SearchLds tv = stage_search(r.vndf, at, kBlockThreads);
+        const SearchLds tl = stage_search(r.luminance, at, kBlockThreads);
+        __syncthreads();
+        for (size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride) rgl_unit_spectral<MODE>(a, r, tv, tl, i, wl, W);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride)
+            rgl_unit_spectral<MODE>(a, r, rgl::SearchMem(r.vndf), rgl::SearchMem(r.luminance), i, wl, W);
+    }
+}
+
 int lds_limit()
 {
     static const int limit = [] {
@@ -300,19 +346,21 @@ int rgl_reduction(const RglFields &f)
 {
     if (f.n_phi <= 2) return 1;
     const double span = (double)f.phi_i[f.n_phi - 1] - (double)f.phi_i[0];
-    return span > 0.0 ? (int)std::floor(2.0 * kPi / span + 0.5) : 0;
+    const double q = span > 0.0 ? 2.0 * kPi / span : 0.0;                 // (a denormal span gives inf: no cast of that)
+    return (q >= 0.5 && q < 4.5) ? (int)std::floor(q + 0.5) : 0;
 }
 
 const char *rgl_check_fields(const RglFields &f)
 {
     if (const char *why = rgl_check_shapes(f)) return why;
-    if (!f.phi_i || !f.theta_i || !f.ndf || !f.sigma || !f.vndf || !f.luminance || !f.rgb) return "null field";
+    if (!f.phi_i || !f.theta_i || !f.ndf || !f.sigma || !f.vndf || !f.luminance || !f.rgb || (f.n_wl > 0 && !f.wavelengths)) return "null field";
     const size_t slices = (size_t)f.n_phi * (size_t)f.n_theta, per = (size_t)f.res[0] * (size_t)f.res[1];
     if (!all_finite(f.phi_i, (size_t)f.n_phi) || !all_finite(f.theta_i, (size_t)f.n_theta) || !ascending(f.phi_i, f.n_phi) || !ascending(f.theta_i, f.n_theta))
         return "phi_i / theta_i must be finite and strictly ascending";
     if (!all_finite(f.ndf, (size_t)f.res_ndf[0] * f.res_ndf[1]) || !all_finite(f.sigma, (size_t)f.res_sigma[0] * f.res_sigma[1]) ||
-        !all_finite(f.vndf, slices * per) || !all_finite(f.luminance, slices * per) || !all_finite(f.rgb, slices * per * 3))
+        !all_finite(f.vndf, slices * per) || !all_finite(f.luminance, slices * per) || !all_finite(f.rgb, slices * per * (size_t)rgl_value_channels(f)))
         return "non-finite table value";
+    if (f.n_wl > 0 && (!all_finite(f.wavelengths, (size_t)f.n_wl) || !ascending(f.wavelengths, f.n_wl))) return "wavelengths must be finite and strictly ascending";
     for (size_t k = 0; k < slices * per; ++k)
         if (f.vndf[k] < 0.0f || f.luminance[k] < 0.0f) return "vndf / luminance must be non-negative (they are densities)";
     // an anisotropic file covers the whole azimuth, or the half / quarter a sample with a point symmetry / two mirror planes needs
@@ -330,6 +378,8 @@ RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob)
     l.phi = 0; l.theta = (size_t)f.n_phi;
     blob.insert(blob.end(), f.phi_i, f.phi_i + f.n_phi);
     blob.insert(blob.end(), f.theta_i, f.theta_i + f.n_theta);
+    l.wavelengths = blob.size();
+    if (f.n_wl > 0) blob.insert(blob.end(), f.wavelengths, f.wavelengths + f.n_wl);
     auto put = [&](int which, const float *src, const int res[2], int n_phi, int n_theta, int n_ch, bool distribution) {
         const WarpOffsets o = append_warp(blob, src, res[0], res[1], n_phi, n_theta, n_ch, distribution);
         l.cells[which] = o.cells; l.cond2[which] = o.cond2; l.margq[which] = o.margq;
@@ -338,7 +388,7 @@ RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob)
     put(1, f.sigma, f.res_sigma, 1, 1, 1, false);
     put(2, f.vndf, f.res, f.n_phi, f.n_theta, 1, true);
     put(3, f.luminance, f.res, f.n_phi, f.n_theta, 1, true);
-    put(4, f.rgb, f.res, f.n_phi, f.n_theta, 3, false);
+    put(4, f.rgb, f.res, f.n_phi, f.n_theta, rgl_value_channels(f), false);
     return l;
 }
 
@@ -360,11 +410,50 @@ RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base)
     r.sigma = warp(1, f.res_sigma, 1, 1, 1, false);
     r.vndf = warp(2, f.res, f.n_phi, f.n_theta, 1, true);
     r.luminance = warp(3, f.res, f.n_phi, f.n_theta, 1, true);
-    r.rgb = warp(4, f.res, f.n_phi, f.n_theta, 3, false);
+    r.rgb = warp(4, f.res, f.n_phi, f.n_theta, rgl_value_channels(f), false);
+    r.wavelengths = f.n_wl > 0 ? base + l.wavelengths : nullptr;
+    r.n_wl = f.n_wl;
     r.isotropic = f.n_phi <= 2;
     r.jacobian = f.jacobian ? 1 : 0;
     r.reduction = rgl_reduction(f);
     return r;
+}
+
+namespace {
+template <int MODE>
+hipError_t launch_spectral_mode(const BatchArgs &a, const RglDev &r, const float *wl, int W, int search, int compute_units, hipStream_t stream)
+{
+    if (search == 0 && a.n >= (size_t)1 << 15) {
+        const size_t need = lds_bytes_of(r);
+        if (need <= (size_t)lds_limit()) {
+            constexpr int kThreads = rgl_lds_block(MODE);
+            size_t blocks = (a.n + kThreads - 1) / kThreads;
+            if (blocks > (size_t)compute_units) blocks = (size_t)compute_units;
+            (void)hipFuncSetAttribute((const void *)k_rgl_spectral<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            hipLaunchKernelGGL((k_rgl_spectral<MODE, true>), dim3((unsigned)blocks), dim3(kThreads), need, stream, a, r, wl, W);
+            return hipGetLastError();
+        }
+    }
+    size_t blocks = (a.n + kRglBlock - 1) / kRglBlock;
+    const size_t cap = (size_t)compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_rgl_spectral<MODE, false>), dim3((unsigned)blocks), dim3(kRglBlock), 0, stream, a, r, wl, W);
+    return hipGetLastError();
+}
+} // namespace
+
+hipError_t launch_rgl_spectral(int mode, const BatchArgs &a, const RglDev &r, const float *wl, int W, int search, int compute_units, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    switch (mode) {
+        case 0: return launch_spectral_mode<0>(a, r, wl, W, search, compute_units, stream);
+        case 1: return launch_spectral_mode<1>(a, r, wl, W, search, compute_units, stream);
+        case 2: return launch_spectral_mode<2>(a, r, wl, W, search, compute_units, stream);
+        case 3: return launch_spectral_mode<3>(a, r, wl, W, search, compute_units, stream);
+        case 4: return launch_spectral_mode<4>(a, r, wl, W, search, compute_units, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev *r, bool indexed, int search, int compute_units, hipStream_t stream)

@@ -59,6 +59,10 @@ struct RglDev {
     int isotropic;          // n_phi <= 2: phi_m is measured relative to phi_i
     int jacobian;           // the file's flag: multiply the spectrum by ndf / (4 sigma)
     int reduction;          // anisotropic: 2 pi / (span of phi_i) — 1 the whole azimuth, 2 [-pi, 0] (point symmetry), 4 [-pi, -pi/2] (+ two mirror planes)
+    // spectral files ("spectra" + "wavelengths" instead of "rgb"): `rgb` then holds the spectra, one channel per wavelength node
+    // (rgb.n_ch = n_wl), and a value is interpolated linearly between the nodes around the wavelength asked for
+    const float *wavelengths;   // [n_wl], ascending; nullptr for an RGB file
+    int n_wl;                   // 0: an RGB file
 };
 
 namespace rgl {
@@ -351,54 +355,78 @@ MRL_HD bool incident(const RglDev &b, float wix, float wiy, float wiz, Incident 
     return true;
 }
 
+// What eval and pdf share about a pair: the half vector's warp coordinates, their pre-image (sx, sy) under the vndf warp with the
+// warp's density there, and the two geometric factors of the pdf.  ok = false: the pair evaluates to zero.
+struct Half { bool ok; double u_m_x, u_m_y, sx, sy, vndf_pdf, sin_theta_m, wi_dot_m; };
+
+// tv: where vndf's search tables are read; fv (may be null): the cell of vndf a sample() has just visited
+template <class Search>
+MRL_HD Half half_lookup(const RglDev &b, const Search &tv, const Incident &in, float wox, float woy, float woz, const Found *fv)
+{
+#pragma clang fp contract(off)
+    Half h;
+    h.ok = false;
+    if (!(woz > 0.0f)) return h;
+    const Vec3d &wi = in.wi;
+    Vec3d wo = { (double)(wox * in.fx), (double)(woy * in.fy), (double)woz };
+    if (!unit3(wo)) return h;
+    Vec3d m = { wi.x + wo.x, wi.y + wo.y, wi.z + wo.z };
+    if (!unit3(m)) return h;
+    const double theta_m = elevation(m), phi_m = azimuth(m.y, m.x);
+    h.u_m_x = theta2u(theta_m);
+    h.u_m_y = phi2u(b.isotropic ? phi_m - in.phi_i : phi_m);
+    h.u_m_y -= floor(h.u_m_y);
+    h.vndf_pdf = warp_invert(b.vndf, tv, in.sv, h.u_m_x, h.u_m_y, h.sx, h.sy, fv);
+    h.sin_theta_m = fast::sqrt_fast(__builtin_fma(m.x, m.x, m.y * m.y));
+    h.wi_dot_m = __builtin_fma(wi.x, m.x, __builtin_fma(wi.y, m.y, wi.z * m.z));
+    h.ok = true;
+    return h;
+}
+
+// the jacobian's factor ndf(u_m) / (4 sigma(u_wi)) of the measured values (1 when the file's flag is off)
+MRL_HD double value_scale(const RglDev &b, const Incident &in, const Half &h)
+{
+    return b.jacobian ? fast::div_fast(warp_eval(b.ndf, single_slice(), h.u_m_x, h.u_m_y), in.sigma4) : 1.0;
+}
+
+// fl (may be null): the cell of luminance a sample() has just visited
+MRL_HD float pdf_of(const RglDev &b, const Incident &in, const Half &h, const Found *fl)
+{
+#pragma clang fp contract(off)
+    const double lum_pdf = warp_eval(b.luminance, in.sv, h.sx, h.sy, 0, fl);
+    const double jac = fmax(2.0 * kPi * kPi * h.u_m_x * h.sin_theta_m, 1e-6) * 4.0 * h.wi_dot_m;
+    return (float)fast::div_fast(h.vndf_pdf * lum_pdf, jac);
+}
+
 // eval (f cos theta_o, RGB) and / or pdf for an incident direction that is above the horizon; wo as the caller holds it.
-// tv: where vndf's search tables are read; fv / fl (may be null): the cells of vndf / luminance a sample() has just visited.
 template <bool WANT_RGB, bool WANT_PDF, class Search>
 MRL_HD void eval_pdf_at(const RglDev &b, const Search &tv, const Incident &in, float wox, float woy, float woz, float rgb[3], float &pdf,
                         const Found *fv = nullptr, const Found *fl = nullptr)
 {
 #pragma clang fp contract(off)
     rgb[0] = rgb[1] = rgb[2] = 0.0f; pdf = 0.0f;
-    if (!(woz > 0.0f)) return;
-    const Vec3d &wi = in.wi;
-    Vec3d wo = { (double)(wox * in.fx), (double)(woy * in.fy), (double)woz };
-    if (!unit3(wo)) return;
-    Vec3d m = { wi.x + wo.x, wi.y + wo.y, wi.z + wo.z };
-    if (!unit3(m)) return;
-    const double theta_m = elevation(m), phi_m = azimuth(m.y, m.x);
-    const double u_m_x = theta2u(theta_m);
-    double u_m_y = phi2u(b.isotropic ? phi_m - in.phi_i : phi_m);
-    u_m_y -= floor(u_m_y);
-    double sx, sy;
-    const double vndf_pdf = warp_invert(b.vndf, tv, in.sv, u_m_x, u_m_y, sx, sy, fv);
+    const Half h = half_lookup(b, tv, in, wox, woy, woz, fv);
+    if (!h.ok) return;
     if constexpr (WANT_RGB) {
-        double scale = 1.0;
-        if (b.jacobian) scale = fast::div_fast(warp_eval(b.ndf, single_slice(), u_m_x, u_m_y), in.sigma4);
+        const double scale = value_scale(b, in, h);
         for (int c = 0; c < 3; ++c) {
-            double v = warp_eval(b.rgb, in.sv, sx, sy, c);
+            double v = warp_eval(b.rgb, in.sv, h.sx, h.sy, c);
             v = v < 0.0 ? 0.0 : v;
             rgb[c] = (float)(v * scale);
         }
     }
-    if constexpr (WANT_PDF) {
-        const double lum_pdf = warp_eval(b.luminance, in.sv, sx, sy, 0, fl);
-        const double sin_theta_m = fast::sqrt_fast(__builtin_fma(m.x, m.x, m.y * m.y));
-        const double jac = fmax(2.0 * kPi * kPi * u_m_x * sin_theta_m, 1e-6) * 4.0 * __builtin_fma(wi.x, m.x, __builtin_fma(wi.y, m.y, wi.z * m.z));
-        pdf = (float)fast::div_fast(vndf_pdf * lum_pdf, jac);
-    }
+    if constexpr (WANT_PDF) pdf = pdf_of(b, in, h, fl);
 }
 
-// sample() for an incident direction that is above the horizon
+// sample()'s direction for an incident direction that is above the horizon: false when the draw is rejected (reflected below the
+// horizon); fl / fv receive the cells the two forward warps ended in
 template <class Search>
-MRL_HD void sample_at(const RglDev &b, const Search &tv, const Search &tl, const Incident &in, float u0, float u1,
-                      float wo_out[3], float &pdf_out, float weight[3])
+MRL_HD bool sample_direction(const RglDev &b, const Search &tv, const Search &tl, const Incident &in, float u0, float u1, float wof[3], Found &fl, Found &fv)
 {
 #pragma clang fp contract(off)
-    wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
     const Vec3d &wi = in.wi;
     const float fx = in.fx, fy = in.fy;
     double sx, sy, umx, umy;
-    Found fl, fv;
     (void)warp_sample(b.luminance, tl, in.sv, (double)u1, (double)u0, sx, sy, fl);
     (void)warp_sample(b.vndf, tv, in.sv, sx, sy, umx, umy, fv);
     // m = (theta_m, phi_m) with theta_m = umx^2 pi/2 and phi_m = (2 umy - 1) pi [+ phi_i]: sin / cos of 2 pi (umx^2 / 4) and
@@ -417,15 +445,91 @@ MRL_HD void sample_at(const RglDev &b, const Search &tv, const Search &tl, const
     const Vec3d m = { cp * st, sp * st, ct };
     const double c = __builtin_fma(wi.x, m.x, __builtin_fma(wi.y, m.y, wi.z * m.z));
     // (the direction drawn in the stored part of the azimuth goes back through the same sign flips)
-    const float wof[3] = { (float)(__builtin_fma(2.0 * c, m.x, -wi.x) * (double)fx), (float)(__builtin_fma(2.0 * c, m.y, -wi.y) * (double)fy),
-                           (float)__builtin_fma(2.0 * c, m.z, -wi.z) };
-    if (!(wof[2] > 0.0f) || !(c > 0.0)) return;
+    wof[0] = (float)(__builtin_fma(2.0 * c, m.x, -wi.x) * (double)fx);
+    wof[1] = (float)(__builtin_fma(2.0 * c, m.y, -wi.y) * (double)fy);
+    wof[2] = (float)__builtin_fma(2.0 * c, m.z, -wi.z);
+    return wof[2] > 0.0f && c > 0.0;
+}
+
+// sample() for an incident direction that is above the horizon
+template <class Search>
+MRL_HD void sample_at(const RglDev &b, const Search &tv, const Search &tl, const Incident &in, float u0, float u1,
+                      float wo_out[3], float &pdf_out, float weight[3])
+{
+    wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
+    float wof[3];
+    Found fl, fv;
+    if (!sample_direction(b, tv, tl, in, u0, u1, wof, fl, fv)) return;
     float f[3], p;
     eval_pdf_at<true, true>(b, tv, in, wof[0], wof[1], wof[2], f, p, &fv, &fl);          // at the Float direction that is returned
     if (!(p > 0.0f)) return;
     wo_out[0] = wof[0]; wo_out[1] = wof[1]; wo_out[2] = wof[2];
     pdf_out = p;
     weight[0] = f[0] / p; weight[1] = f[1] / p; weight[2] = f[2] / p;
+}
+
+// ---- spectral files: W values per unit, at the wavelengths wl[0 .. W) (wl == nullptr: at the file's own nodes, W = n_wl) ----
+// the measured spectrum at warp position (sx, sy): linear between the file's wavelength nodes, clamped outside them — the
+// wavelength as the third interpolated parameter, as upstream's spectral variants evaluate `spectra`
+MRL_HD double spectrum_at(const RglDev &b, const Slices &sv, double sx, double sy, const float *wl, int k)
+{
+#pragma clang fp contract(off)
+    double v;
+    if (!wl) {
+        v = warp_eval(b.rgb, sv, sx, sy, k);
+    } else {
+        int c0 = 0;
+        double t = 0.0;
+        if (b.n_wl > 1) bracket(b.wavelengths, b.n_wl, (double)wl[k], c0, t);
+        v = warp_eval(b.rgb, sv, sx, sy, c0);
+        if (b.n_wl > 1) v = lerp(t, v, warp_eval(b.rgb, sv, sx, sy, c0 + 1));
+    }
+    return v < 0.0 ? 0.0 : v;
+}
+
+// values[0 .. W) and / or pdf; values is the caller's row (written once per wavelength, no register array)
+template <bool WANT_VALUES, bool WANT_PDF, class Search>
+MRL_HD void eval_pdf_spectral_at(const RglDev &b, const Search &tv, const Incident &in, float wox, float woy, float woz, const float *wl, int W,
+                                 float *values, float &pdf, const Found *fv = nullptr, const Found *fl = nullptr)
+{
+#pragma clang fp contract(off)
+    pdf = 0.0f;
+    const Half h = half_lookup(b, tv, in, wox, woy, woz, fv);
+    if (!h.ok) {
+        if constexpr (WANT_VALUES) for (int k = 0; k < W; ++k) values[k] = 0.0f;
+        return;
+    }
+    if constexpr (WANT_VALUES) {
+        const double scale = value_scale(b, in, h);
+        for (int k = 0; k < W; ++k) values[k] = (float)(spectrum_at(b, in.sv, h.sx, h.sy, wl, k) * scale);
+    }
+    if constexpr (WANT_PDF) pdf = pdf_of(b, in, h, fl);
+}
+
+template <class Search>
+MRL_HD void sample_spectral_at(const RglDev &b, const Search &tv, const Search &tl, const Incident &in, float u0, float u1, const float *wl, int W,
+                               float wo_out[3], float &pdf_out, float *weight)
+{
+#pragma clang fp contract(off)
+    wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f;
+    float wof[3];
+    Found fl, fv;
+    bool live = sample_direction(b, tv, tl, in, u0, u1, wof, fl, fv);
+    Half h;
+    float p = 0.0f;
+    if (live) {
+        h = half_lookup(b, tv, in, wof[0], wof[1], wof[2], &fv);                  // at the Float direction that is returned
+        live = h.ok;
+        if (live) { p = pdf_of(b, in, h, &fl); live = p > 0.0f; }
+    }
+    if (!live) { for (int k = 0; k < W; ++k) weight[k] = 0.0f; return; }
+    wo_out[0] = wof[0]; wo_out[1] = wof[1]; wo_out[2] = wof[2];
+    pdf_out = p;
+    const double scale = value_scale(b, in, h);
+    for (int k = 0; k < W; ++k) {
+        const float f = (float)(spectrum_at(b, in.sv, h.sx, h.sy, wl, k) * scale);
+        weight[k] = f / p;
+    }
 }
 
 // ---- one unit through the image in memory (host images: mrl_host_*; tests/rgl_host_harness.hip) ----
@@ -445,6 +549,28 @@ MRL_HD void sample(const RglDev &b, float wix, float wiy, float wiz, float u0, f
     Incident in;
     if (!(wiz > 0.0f) || !incident<true>(b, wix, wiy, wiz, in)) return;
     sample_at(b, SearchMem(b.vndf), SearchMem(b.luminance), in, u0, u1, wo_out, pdf_out, weight);
+}
+
+// a spectral file, one unit through the image in memory
+template <bool WANT_VALUES, bool WANT_PDF>
+MRL_HD void eval_pdf_spectral(const RglDev &b, float wix, float wiy, float wiz, float wox, float woy, float woz, const float *wl, int W, float *values, float &pdf)
+{
+    pdf = 0.0f;
+    Incident in;
+    if (!(wiz > 0.0f) || !(woz > 0.0f) || !incident<WANT_VALUES>(b, wix, wiy, wiz, in)) {
+        if constexpr (WANT_VALUES) for (int k = 0; k < W; ++k) values[k] = 0.0f;
+        return;
+    }
+    eval_pdf_spectral_at<WANT_VALUES, WANT_PDF>(b, SearchMem(b.vndf), in, wox, woy, woz, wl, W, values, pdf);
+}
+
+MRL_HD void sample_spectral(const RglDev &b, float wix, float wiy, float wiz, float u0, float u1, const float *wl, int W,
+                            float wo_out[3], float &pdf_out, float *weight)
+{
+    wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f;
+    Incident in;
+    if (!(wiz > 0.0f) || !incident<true>(b, wix, wiy, wiz, in)) { for (int k = 0; k < W; ++k) weight[k] = 0.0f; return; }
+    sample_spectral_at(b, SearchMem(b.vndf), SearchMem(b.luminance), in, u0, u1, wl, W, wo_out, pdf_out, weight);
 }
 
 } // namespace rgl

@@ -262,20 +262,22 @@ int mrl_material_load_rgl(mrl_ctx *ctx, const char *path, int *out_id)
         for (uint64_t d : fd.shape) if (d < 1 || d > 8192) { why = std::string("field \"") + name + "\": every axis must have 1..8192 entries"; return nullptr; }
         return &fd;
     };
-    if (mrl_tensor_file_find(f, "rgb") < 0 && mrl_tensor_file_find(f, "spectra") >= 0)
-        return refuse("a spectral RGL file (\"spectra\" without \"rgb\"): only the *_rgb.bsdf variant is evaluated");
+    // a spectral file holds "spectra" [n_phi, n_theta, n_wavelengths, res, res] + "wavelengths" instead of "rgb"
+    const bool spectral = mrl_tensor_file_find(f, "rgb") < 0 && mrl_tensor_file_find(f, "spectra") >= 0;
     const Field *phi = floats("phi_i", 1);
     const Field *theta = phi ? floats("theta_i", 1) : nullptr;
     const Field *ndf = theta ? floats("ndf", 2) : nullptr;
     const Field *sigma = ndf ? floats("sigma", 2) : nullptr;
     const Field *vndf = sigma ? floats("vndf", 4) : nullptr;
     const Field *lum = vndf ? floats("luminance", 4) : nullptr;
-    const Field *rgb = lum ? floats("rgb", 5) : nullptr;
-    if (!rgb) return refuse(why);
-    const uint64_t n_phi = phi->shape[0], n_theta = theta->shape[0];
+    const Field *rgb = lum ? floats(spectral ? "spectra" : "rgb", 5) : nullptr;
+    const Field *wavelengths = (rgb && spectral) ? floats("wavelengths", 1) : nullptr;
+    if (!rgb || (spectral && !wavelengths)) return refuse(why);
+    const uint64_t n_phi = phi->shape[0], n_theta = theta->shape[0], n_values = spectral ? wavelengths->shape[0] : 3;
     if (vndf->shape[0] != n_phi || vndf->shape[1] != n_theta || lum->shape != vndf->shape || rgb->shape[0] != n_phi || rgb->shape[1] != n_theta ||
-        rgb->shape[2] != 3 || rgb->shape[3] != vndf->shape[2] || rgb->shape[4] != vndf->shape[3])
-        return refuse("vndf / luminance must be [n_phi, n_theta, res, res] and rgb [n_phi, n_theta, 3, res, res]");
+        rgb->shape[2] != n_values || rgb->shape[3] != vndf->shape[2] || rgb->shape[4] != vndf->shape[3])
+        return refuse(spectral ? "vndf / luminance must be [n_phi, n_theta, res, res] and spectra [n_phi, n_theta, n_wavelengths, res, res]"
+                               : "vndf / luminance must be [n_phi, n_theta, res, res] and rgb [n_phi, n_theta, 3, res, res]");
     int jacobian = 0;
     const int jf = mrl_tensor_file_find(f, "jacobian");
     if (jf >= 0) {
@@ -292,7 +294,15 @@ int mrl_material_load_rgl(mrl_ctx *ctx, const char *path, int *out_id)
     r.res[0] = (int)vndf->shape[3]; r.res[1] = (int)vndf->shape[2];
     r.ndf = data(ndf); r.sigma = data(sigma); r.vndf = data(vndf); r.luminance = data(lum); r.rgb = data(rgb);
     r.jacobian = jacobian;
-    rc = mrl_material_upload_rgl(ctx, &r, out_id);
+    if (spectral) {
+        mrl_rgl_spectral_fields sp;
+        sp.base = r;
+        sp.base.rgb = nullptr;
+        sp.n_wavelengths = (int)n_values; sp.wavelengths = data(wavelengths); sp.spectra = data(rgb);
+        rc = mrl_material_upload_rgl_spectral(ctx, &sp, out_id);
+    } else {
+        rc = mrl_material_upload_rgl(ctx, &r, out_id);
+    }
     mrl_tensor_file_close(f);
     return rc;
 }

@@ -29,6 +29,7 @@ LOOKUP_NEAREST, LOOKUP_TRILINEAR = 0, 1
 KIND_MERL, KIND_TABLE, KIND_GGX = 0, 1, 2
 KIND_TABLE_NCH = 4
 KIND_RGL = 5
+KIND_RGL_SPECTRAL = 6
 ERR_INVALID, ERR_HIP, ERR_IO, ERR_FORMAT, ERR_OOM, ERR_MATERIAL, ERR_POINTER_MIX, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7, -8
 
 # every symbol include/merl_hip.h declares (tests check the library exports all of them)
@@ -56,6 +57,9 @@ ABI_SYMBOLS = (
     "mrl_group_last_timing", "mrl_group_plan", "mrl_group_link_test",
     "mrl_material_sampling2d", "mrl_material_host_table", "mrl_host_table_retain", "mrl_host_table_release", "mrl_host_table_info",
     "mrl_host_eval_pdf", "mrl_host_sample", "mrl_host_eval_sample",
+    "mrl_material_upload_rgl_spectral", "mrl_material_wavelengths", "mrl_eval_spectral_batch", "mrl_eval_pdf_spectral_batch",
+    "mrl_sample_spectral_batch", "mrl_eval_sample_spectral_batch", "mrl_host_eval_pdf_spectral", "mrl_host_sample_spectral",
+    "mrl_group_material_upload_rgl_spectral",
 )
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_PEER_COPY = 0, 1, 2
 ERR_COMM = -9
@@ -94,6 +98,19 @@ class HostTable:
             raise MerlHipError(rc, "mrl_host_eval_sample")
         return np.frombuffer(out, dtype=np.float32).copy()
 
+    def eval_sample_spectral(self, wi, wo, u, wavelengths) -> tuple:
+        """ONE unit of a spectral RGL material on this thread at `wavelengths` [W]: (values [W], pdf, wo' [3], pdf', weight' [W])."""
+        a = (C.c_float * 3)(*[float(x) for x in wi]); b = (C.c_float * 3)(*[float(x) for x in wo]); c = (C.c_float * 2)(*[float(x) for x in u])
+        W = len(wavelengths)
+        wl = (C.c_float * W)(*[float(x) for x in wavelengths])
+        val = (C.c_float * W)(); pdf = C.c_float(); wo2 = (C.c_float * 3)(); pdf2 = C.c_float(); w = (C.c_float * W)()
+        rc = self._lib.mrl_host_eval_pdf_spectral(self._h, a, b, wl, W, val, C.byref(pdf))
+        if rc == 0:
+            rc = self._lib.mrl_host_sample_spectral(self._h, a, c, wl, W, wo2, C.byref(pdf2), w)
+        if rc != 0:
+            raise MerlHipError(rc, "mrl_host_*_spectral")
+        return (np.array(val[:], np.float32), np.float32(pdf.value), np.array(wo2[:], np.float32), np.float32(pdf2.value), np.array(w[:], np.float32))
+
 
 class RglFields(C.Structure):
     """struct mrl_rgl_fields"""
@@ -103,18 +120,31 @@ class RglFields(C.Structure):
                 ("luminance", C.POINTER(C.c_float)), ("rgb", C.POINTER(C.c_float)), ("jacobian", C.c_int)]
 
 
+class RglSpectralFields(C.Structure):
+    """struct mrl_rgl_spectral_fields"""
+    _fields_ = [("base", RglFields), ("n_wavelengths", C.c_int), ("wavelengths", C.POINTER(C.c_float)), ("spectra", C.POINTER(C.c_float))]
+
+
 def rgl_fields_struct(fields: dict):
-    """(struct mrl_rgl_fields, the arrays it points into) from a dict of RGL field arrays."""
-    a = {k: np.ascontiguousarray(fields[k], np.float32) for k in ("phi_i", "theta_i", "ndf", "sigma", "vndf", "luminance", "rgb")}
+    """(struct mrl_rgl_fields — or mrl_rgl_spectral_fields for a dict with "spectra" + "wavelengths" instead of "rgb" —, the arrays it
+    points into) from a dict of RGL field arrays."""
+    spectral = "spectra" in fields and "rgb" not in fields
+    names = ("phi_i", "theta_i", "ndf", "sigma", "vndf", "luminance") + (("spectra", "wavelengths") if spectral else ("rgb",))
+    a = {k: np.ascontiguousarray(fields[k], np.float32) for k in names}
     vn = a["vndf"].shape
-    if len(vn) != 4 or a["luminance"].shape != vn or a["rgb"].shape != (vn[0], vn[1], 3, vn[2], vn[3]) or a["ndf"].ndim != 2 or a["sigma"].ndim != 2 \
-            or a["phi_i"].shape != (vn[0],) or a["theta_i"].shape != (vn[1],):
-        raise ValueError("RGL fields: vndf / luminance [n_phi, n_theta, res, res], rgb [n_phi, n_theta, 3, res, res], ndf / sigma 2-D")
+    values = a["spectra" if spectral else "rgb"]
+    n_values = a["wavelengths"].shape[0] if spectral else 3
+    if len(vn) != 4 or a["luminance"].shape != vn or values.shape != (vn[0], vn[1], n_values, vn[2], vn[3]) or a["ndf"].ndim != 2 or a["sigma"].ndim != 2 \
+            or a["phi_i"].shape != (vn[0],) or a["theta_i"].shape != (vn[1],) or (spectral and a["wavelengths"].ndim != 1):
+        raise ValueError("RGL fields: vndf / luminance [n_phi, n_theta, res, res], rgb [n_phi, n_theta, 3, res, res] "
+                         "(or spectra [n_phi, n_theta, n_wavelengths, res, res] + wavelengths), ndf / sigma 2-D")
     fp = C.POINTER(C.c_float)
     p = lambda k: a[k].ctypes.data_as(fp)
     r = RglFields(vn[0], vn[1], p("phi_i"), p("theta_i"), (C.c_int * 2)(a["ndf"].shape[1], a["ndf"].shape[0]),
                   (C.c_int * 2)(a["sigma"].shape[1], a["sigma"].shape[0]), (C.c_int * 2)(vn[3], vn[2]),
-                  p("ndf"), p("sigma"), p("vndf"), p("luminance"), p("rgb"), int(np.asarray(fields.get("jacobian", 1)).reshape(-1)[0]))
+                  p("ndf"), p("sigma"), p("vndf"), p("luminance"), None if spectral else p("rgb"), int(np.asarray(fields.get("jacobian", 1)).reshape(-1)[0]))
+    if spectral:
+        return RglSpectralFields(r, int(n_values), p("wavelengths"), p("spectra")), a
     return r, a
 
 
@@ -228,6 +258,15 @@ def load_library(path: Optional[str] = None):
     L.mrl_tensor_file_read_f64.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.mrl_material_load_tensor_table.argtypes = [vp, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mrl_material_upload_rgl.argtypes = [vp, C.POINTER(RglFields), C.POINTER(C.c_int)]
+    L.mrl_material_upload_rgl_spectral.argtypes = [vp, C.POINTER(RglSpectralFields), C.POINTER(C.c_int)]
+    L.mrl_material_wavelengths.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_size_t]
+    L.mrl_eval_spectral_batch.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int32, C.c_size_t, fp]
+    L.mrl_eval_pdf_spectral_batch.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int32, C.c_size_t, fp, fp]
+    L.mrl_sample_spectral_batch.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int32, C.c_size_t, fp, fp, fp]
+    L.mrl_eval_sample_spectral_batch.argtypes = [vp, fp, fp, fp, fp, C.c_int, C.c_int32, C.c_size_t, fp, fp, fp, fp, fp]
+    cfp = C.POINTER(C.c_float)
+    L.mrl_host_eval_pdf_spectral.argtypes = [vp, cfp, cfp, cfp, C.c_int, cfp, cfp]
+    L.mrl_host_sample_spectral.argtypes = [vp, cfp, cfp, cfp, C.c_int, cfp, cfp, cfp]
     L.mrl_material_load_rgl.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     L.mrl_material_save_image.argtypes = [vp, C.c_int, C.c_char_p]
     L.mrl_material_load_image.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
@@ -392,8 +431,55 @@ class MerlHip:
         ndf, sigma, vndf, luminance, rgb[, jacobian]).  Single-material calls evaluate it (mrl_material_upload_rgl)."""
         r, keep = rgl_fields_struct(fields)
         mid = C.c_int()
-        self._check(self._lib.mrl_material_upload_rgl(self._ctx, C.byref(r), C.byref(mid)), "mrl_material_upload_rgl")
+        if isinstance(r, RglSpectralFields):       # "spectra" + "wavelengths": a spectral material (the *_spectral calls evaluate it)
+            self._check(self._lib.mrl_material_upload_rgl_spectral(self._ctx, C.byref(r), C.byref(mid)), "mrl_material_upload_rgl_spectral")
+        else:
+            self._check(self._lib.mrl_material_upload_rgl(self._ctx, C.byref(r), C.byref(mid)), "mrl_material_upload_rgl")
         return mid.value
+
+    def wavelengths(self, mid: int) -> np.ndarray:
+        """the wavelength grid of a spectral RGL material"""
+        n = C.c_int()
+        self._check(self._lib.mrl_material_wavelengths(self._ctx, mid, C.byref(n), None, 0), "mrl_material_wavelengths")
+        out = np.empty(n.value, np.float32)
+        self._check(self._lib.mrl_material_wavelengths(self._ctx, mid, C.byref(n), out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "mrl_material_wavelengths")
+        return out
+
+    def eval_sample_spectral(self, wi, wo, u, wavelengths, material: int, n_wavelengths: Optional[int] = None):
+        """A spectral RGL material at per-unit wavelengths [n, W] (None: the file's own nodes, n_wavelengths = their number):
+        (values [n, W], pdf, wo', pdf', weight' [n, W])."""
+        n = int(wi.shape[0]); self._prep(wi)
+        W = int(wavelengths.shape[1]) if wavelengths is not None else int(n_wavelengths)
+        out = (self._empty(wi, (n, W)), self._empty(wi, (n,)), self._empty(wi, (n, 3)), self._empty(wi, (n,)), self._empty(wi, (n, W)))
+        val, pdf, wo2, pdf2, w = out
+        self._check(self._lib.mrl_eval_sample_spectral_batch(
+            self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"), _addr(u, np.float32, 2, n, "u"),
+            _addr(wavelengths, np.float32, W, n, "wavelengths"), W, material, n,
+            _addr(val, np.float32, W, n, "out_values"), _addr(pdf, np.float32, None, n, "out_pdf"), _addr(wo2, np.float32, 3, n, "out_wo"),
+            _addr(pdf2, np.float32, None, n, "out_pdf2"), _addr(w, np.float32, W, n, "out_weight")), "mrl_eval_sample_spectral_batch")
+        return out
+
+    def eval_spectral(self, wi, wo, wavelengths, material: int, n_wavelengths: Optional[int] = None, with_pdf: bool = False):
+        n = int(wi.shape[0]); self._prep(wi)
+        W = int(wavelengths.shape[1]) if wavelengths is not None else int(n_wavelengths)
+        val = self._empty(wi, (n, W))
+        args = (self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(wo, np.float32, 3, n, "wo"), _addr(wavelengths, np.float32, W, n, "wavelengths"), W, material, n,
+                _addr(val, np.float32, W, n, "out_values"))
+        if with_pdf:
+            pdf = self._empty(wi, (n,))
+            self._check(self._lib.mrl_eval_pdf_spectral_batch(*args, _addr(pdf, np.float32, None, n, "out_pdf")), "mrl_eval_pdf_spectral_batch")
+            return val, pdf
+        self._check(self._lib.mrl_eval_spectral_batch(*args), "mrl_eval_spectral_batch")
+        return val
+
+    def sample_spectral(self, wi, u, wavelengths, material: int, n_wavelengths: Optional[int] = None):
+        n = int(wi.shape[0]); self._prep(wi)
+        W = int(wavelengths.shape[1]) if wavelengths is not None else int(n_wavelengths)
+        wo2, pdf2, w = self._empty(wi, (n, 3)), self._empty(wi, (n,)), self._empty(wi, (n, W))
+        self._check(self._lib.mrl_sample_spectral_batch(
+            self._ctx, _addr(wi, np.float32, 3, n, "wi"), _addr(u, np.float32, 2, n, "u"), _addr(wavelengths, np.float32, W, n, "wavelengths"), W, material, n,
+            _addr(wo2, np.float32, 3, n, "out_wo"), _addr(pdf2, np.float32, None, n, "out_pdf"), _addr(w, np.float32, W, n, "out_weight")), "mrl_sample_spectral_batch")
+        return wo2, pdf2, w
 
     def load_rgl(self, path: str) -> int:
         """An RGL *.bsdf file (tensor_file container with the RGL field names; the *_rgb variant)."""
@@ -904,7 +990,10 @@ class MerlGroup:
     def upload_rgl(self, fields: dict) -> int:
         r, keep = rgl_fields_struct(fields)
         mid = C.c_int()
-        self._check(self._lib.mrl_group_material_upload_rgl(self._g, C.byref(r), C.byref(mid)), "mrl_group_material_upload_rgl")
+        if isinstance(r, RglSpectralFields):
+            self._check(self._lib.mrl_group_material_upload_rgl_spectral(self._g, C.byref(r), C.byref(mid)), "mrl_group_material_upload_rgl_spectral")
+        else:
+            self._check(self._lib.mrl_group_material_upload_rgl(self._g, C.byref(r), C.byref(mid)), "mrl_group_material_upload_rgl")
         return mid.value
 
     def upload_table(self, planar: np.ndarray, scale: Sequence[float] = (1.0, 1.0, 1.0)) -> int:

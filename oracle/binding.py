@@ -399,7 +399,7 @@ class RglWarp(C.Structure):
 
 
 class RglBsdf(C.Structure):
-    _fields_ = [("isotropic", C.c_int), ("jacobian", C.c_int), ("reduction", C.c_int), ("ndf", RglWarp), ("sigma", RglWarp), ("vndf", RglWarp), ("luminance", RglWarp), ("rgb", RglWarp)]
+    _fields_ = [("isotropic", C.c_int), ("jacobian", C.c_int), ("reduction", C.c_int), ("n_wavelengths", C.c_int), ("ndf", RglWarp), ("sigma", RglWarp), ("vndf", RglWarp), ("luminance", RglWarp), ("rgb", RglWarp)]
 
 
 def _rgl_lib():
@@ -415,6 +415,9 @@ def _rgl_lib():
         L.rgl_bsdf_free.argtypes = [C.POINTER(RglBsdf)]
         L.rgl_eval_pdf_batch.argtypes = [C.POINTER(RglBsdf), fp, fp, C.c_size_t, fp, fp]
         L.rgl_sample_batch.argtypes = [C.POINTER(RglBsdf), fp, fp, C.c_size_t, fp, fp, fp]
+        L.rgl_bsdf_init_spectral.argtypes = [C.POINTER(RglBsdf), C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, C.c_int, fp, fp, C.c_int]
+        L.rgl_eval_pdf_spectral_batch.argtypes = [C.POINTER(RglBsdf), fp, fp, fp, C.c_int, C.c_size_t, fp, fp]
+        L.rgl_sample_spectral_batch.argtypes = [C.POINTER(RglBsdf), fp, fp, fp, C.c_int, C.c_size_t, fp, fp, fp]
         L.rgl_half_vector.argtypes = [C.POINTER(RglBsdf), fp, fp, dp, dp]; L.rgl_half_vector.restype = C.c_int
         L.rgl_eval_pdf_half.argtypes = [C.POINTER(RglBsdf), dp, dp, fp, fp]
         L._rgl_ready = True
@@ -463,18 +466,55 @@ class OracleRgl:
     """The BSDF over the fields of an RGL *.bsdf file (dict of arrays: phi_i, theta_i, ndf, sigma, vndf, luminance, rgb[, jacobian])."""
 
     def __init__(self, fields):
+        """A spectral file holds "spectra" [n_phi, n_theta, n_wavelengths, res, res] and "wavelengths" instead of "rgb"."""
         L = _rgl_lib()
         f32 = lambda k: np.ascontiguousarray(fields[k], np.float32)
-        self.f = {k: f32(k) for k in ("phi_i", "theta_i", "ndf", "sigma", "vndf", "luminance", "rgb")}
+        self.spectral = "spectra" in fields
+        names = ("phi_i", "theta_i", "ndf", "sigma", "vndf", "luminance") + (("spectra", "wavelengths") if self.spectral else ("rgb",))
+        self.f = {k: f32(k) for k in names}
         fp = C.POINTER(C.c_float)
         p = lambda k: self.f[k].ctypes.data_as(fp)
         vn = self.f["vndf"].shape
-        assert self.f["rgb"].shape == (vn[0], vn[1], 3, vn[2], vn[3]) and self.f["luminance"].shape == vn
         jac = int(np.asarray(fields.get("jacobian", 1)).reshape(-1)[0])
         self.c = RglBsdf()
-        rc = L.rgl_bsdf_init(C.byref(self.c), vn[0], vn[1], p("phi_i"), p("theta_i"), self.f["ndf"].shape[1], self.f["ndf"].shape[0], p("ndf"),
-                             self.f["sigma"].shape[1], self.f["sigma"].shape[0], p("sigma"), vn[3], vn[2], p("vndf"), p("luminance"), p("rgb"), jac)
+        if self.spectral:
+            self.n_wavelengths = int(self.f["wavelengths"].shape[0])
+            assert self.f["spectra"].shape == (vn[0], vn[1], self.n_wavelengths, vn[2], vn[3]) and self.f["luminance"].shape == vn
+            rc = L.rgl_bsdf_init_spectral(C.byref(self.c), vn[0], vn[1], p("phi_i"), p("theta_i"), self.f["ndf"].shape[1], self.f["ndf"].shape[0], p("ndf"),
+                                          self.f["sigma"].shape[1], self.f["sigma"].shape[0], p("sigma"), vn[3], vn[2], p("vndf"), p("luminance"),
+                                          self.n_wavelengths, p("wavelengths"), p("spectra"), jac)
+        else:
+            assert self.f["rgb"].shape == (vn[0], vn[1], 3, vn[2], vn[3]) and self.f["luminance"].shape == vn
+            rc = L.rgl_bsdf_init(C.byref(self.c), vn[0], vn[1], p("phi_i"), p("theta_i"), self.f["ndf"].shape[1], self.f["ndf"].shape[0], p("ndf"),
+                                 self.f["sigma"].shape[1], self.f["sigma"].shape[0], p("sigma"), vn[3], vn[2], p("vndf"), p("luminance"), p("rgb"), jac)
         assert rc == 0, rc
+
+    def _wl(self, wl, n):
+        """(pointer or None, W): per-unit wavelengths [n, W], or None = the file's own nodes"""
+        if wl is None:
+            return None, None, self.n_wavelengths
+        w = np.ascontiguousarray(wl, np.float32)
+        assert w.ndim == 2 and w.shape[0] == n
+        return w, w.ctypes.data_as(C.POINTER(C.c_float)), int(w.shape[1])
+
+    def eval_pdf_spectral(self, wi, wo, wl=None):
+        """values [n, W], pdf [n] of a spectral file at per-unit wavelengths wl [n, W] (None: the file's wavelength nodes)"""
+        wi, pwi = _f32(wi); wo, pwo = _f32(wo)
+        n = wi.shape[0]
+        keep, pwl, W = self._wl(wl, n)
+        fp = C.POINTER(C.c_float)
+        val = np.empty((n, W), np.float32); pdf = np.empty(n, np.float32)
+        _rgl_lib().rgl_eval_pdf_spectral_batch(C.byref(self.c), pwi, pwo, pwl, W, n, val.ctypes.data_as(fp), pdf.ctypes.data_as(fp))
+        return val, pdf
+
+    def sample_spectral(self, wi, u, wl=None):
+        wi, pwi = _f32(wi); u, pu = _f32(u)
+        n = wi.shape[0]
+        keep, pwl, W = self._wl(wl, n)
+        fp = C.POINTER(C.c_float)
+        wo = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32); w = np.empty((n, W), np.float32)
+        _rgl_lib().rgl_sample_spectral_batch(C.byref(self.c), pwi, pu, pwl, W, n, wo.ctypes.data_as(fp), pdf.ctypes.data_as(fp), w.ctypes.data_as(fp))
+        return wo, pdf, w
 
     def eval_pdf(self, wi, wo):
         wi, pwi = _f32(wi); wo, pwo = _f32(wo)

@@ -233,12 +233,15 @@ static int unit3(double v[3])
     return 1;
 }
 
-static void spectrum(const rgl_bsdf *b, const double sample[2], double phi_i, double theta_i, double rgb[3])
+/* the measured values at `n` settings of the third parameter: the channel number 0, 1, 2 of an RGB file (third == NULL), or n
+ * wavelengths of a spectral file — interpolated linearly between the file's wavelength nodes, clamped outside them, as upstream's
+ * spectral variants evaluate `spectra` with the wavelength as the third interpolated parameter */
+static void spectrum(const rgl_bsdf *b, const double sample[2], double phi_i, double theta_i, int n, const float *third, double *out)
 {
-    for (int c = 0; c < 3; ++c) {
-        const double p[3] = { phi_i, theta_i, (double)c };
-        rgb[c] = rgl_warp_eval(&b->rgb, sample, p);
-        if (rgb[c] < 0.0) rgb[c] = 0.0;
+    for (int c = 0; c < n; ++c) {
+        const double p[3] = { phi_i, theta_i, third ? (double)third[c] : (double)c };
+        out[c] = rgl_warp_eval(&b->rgb, sample, p);
+        if (out[c] < 0.0) out[c] = 0.0;
     }
 }
 
@@ -261,12 +264,14 @@ static void reduce_pair(const rgl_bsdf *b, double wi[3], double wo[3], double fl
  * m = wi + wo.  rgl_eval_pdf below is this after its prelude; the tests call it directly to measure conditioning: for a
  * near-mirror pair m's transverse part is the difference of two normalisations and carries their rounding errors (a few 1e-16
  * absolute on a length that can be 1e-9), so they evaluate it over the box of half vectors the f64 arithmetic can land on. */
-void rgl_eval_pdf_half(const rgl_bsdf *b, const double wi[3], const double m_in[3], float rgb[3], float *pdf_out)
+#define RGL_MAX_VALUES 4096
+/* n values (third == NULL: n = 3 RGB channels; else n wavelengths) and / or the pdf */
+static void eval_pdf_half_n(const rgl_bsdf *b, const double wi[3], const double m_in[3], int n, const float *third, float *values, float *pdf_out)
 {
-    rgb[0] = rgb[1] = rgb[2] = 0.0f;
+    for (int c = 0; c < n; ++c) values[c] = 0.0f;
     if (pdf_out) *pdf_out = 0.0f;
     double m[3] = { m_in[0], m_in[1], m_in[2] };
-    if (!unit3(m)) return;
+    if (!unit3(m) || n > RGL_MAX_VALUES) return;
     const double theta_i = elevation(wi), phi_i = atan2(wi[1], wi[0]);
     const double theta_m = elevation(m), phi_m = atan2(m[1], m[0]);
     const double params[2] = { phi_i, theta_i };
@@ -275,19 +280,26 @@ void rgl_eval_pdf_half(const rgl_bsdf *b, const double wi[3], const double m_in[
     u_m[1] -= floor(u_m[1]);
     double sample[2], vndf_pdf;
     rgl_warp_invert(&b->vndf, u_m, params, sample, &vndf_pdf);
-    double spec[3];
-    spectrum(b, sample, phi_i, theta_i, spec);
-    if (b->jacobian) {
-        const double scale = rgl_warp_eval(&b->ndf, u_m, params) / (4.0 * rgl_warp_eval(&b->sigma, u_wi, params));
-        spec[0] *= scale; spec[1] *= scale; spec[2] *= scale;
-    }
-    rgb[0] = (float)spec[0]; rgb[1] = (float)spec[1]; rgb[2] = (float)spec[2];
+    double spec[RGL_MAX_VALUES];
+    spectrum(b, sample, phi_i, theta_i, n, third, spec);
+    double scale = 1.0;
+    if (b->jacobian) scale = rgl_warp_eval(&b->ndf, u_m, params) / (4.0 * rgl_warp_eval(&b->sigma, u_wi, params));
+    for (int c = 0; c < n; ++c) values[c] = (float)(spec[c] * scale);
     if (pdf_out) {
         const double lum_pdf = rgl_warp_eval(&b->luminance, sample, params);
         const double sin_theta_m = sqrt(m[0] * m[0] + m[1] * m[1]);
         const double jac = fmax(2.0 * M_PI * M_PI * u_m[0] * sin_theta_m, 1e-6) * 4.0 * (wi[0] * m[0] + wi[1] * m[1] + wi[2] * m[2]);
         *pdf_out = (float)(vndf_pdf * lum_pdf / jac);
     }
+}
+
+/* eval / pdf from the normalised incident direction (already in the stored part of the azimuth) and the UNNORMALISED half vector
+ * m = wi + wo.  rgl_eval_pdf below is this after its prelude; the tests call it directly to measure conditioning: for a
+ * near-mirror pair m's transverse part is the difference of two normalisations and carries their rounding errors (a few 1e-16
+ * absolute on a length that can be 1e-9), so they evaluate it over the box of half vectors the f64 arithmetic can land on. */
+void rgl_eval_pdf_half(const rgl_bsdf *b, const double wi[3], const double m_in[3], float rgb[3], float *pdf_out)
+{
+    eval_pdf_half_n(b, wi, m_in, 3, NULL, rgb, pdf_out);
 }
 
 /* the prelude alone: wi, wo in the stored part of the azimuth and normalised, m = wi + wo; 0 when the pair evaluates to zero */
@@ -311,9 +323,33 @@ void rgl_eval_pdf(const rgl_bsdf *b, const float wi_f[3], const float wo_f[3], f
     rgl_eval_pdf_half(b, wi, m, rgb, pdf_out);
 }
 
+/* a spectral file: the values at W wavelengths (wl == NULL: at the file's own wavelength nodes, W = their number) */
+void rgl_eval_pdf_spectral(const rgl_bsdf *b, const float wi_f[3], const float wo_f[3], const float *wl, int W, float *values, float *pdf_out)
+{
+    for (int c = 0; c < W; ++c) values[c] = 0.0f;
+    if (pdf_out) *pdf_out = 0.0f;
+    double wi[3], m[3];
+    if (!rgl_half_vector(b, wi_f, wo_f, wi, m)) return;
+    eval_pdf_half_n(b, wi, m, W, wl ? wl : b->rgb.par[2], values, pdf_out);
+}
+
+static void sample_n(const rgl_bsdf *b, const float wi_f[3], const float u[2], int n, const float *third, float wo_out[3], float *pdf_out, float *weight);
+
+void rgl_sample_spectral(const rgl_bsdf *b, const float wi_f[3], const float u[2], const float *wl, int W, float wo_out[3], float *pdf_out, float *weight)
+{
+    sample_n(b, wi_f, u, W, wl ? wl : b->rgb.par[2], wo_out, pdf_out, weight);
+}
+
 void rgl_sample(const rgl_bsdf *b, const float wi_f[3], const float u[2], float wo_out[3], float *pdf_out, float weight[3])
 {
-    wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; *pdf_out = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
+    sample_n(b, wi_f, u, 3, NULL, wo_out, pdf_out, weight);
+}
+
+static void sample_n(const rgl_bsdf *b, const float wi_f[3], const float u[2], int n, const float *third, float wo_out[3], float *pdf_out, float *weight)
+{
+    wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; *pdf_out = 0.0f;
+    for (int c = 0; c < n; ++c) weight[c] = 0.0f;
+    if (n > RGL_MAX_VALUES) return;
     if (!(wi_f[2] > 0.0f)) return;
     double wi[3] = { wi_f[0], wi_f[1], wi_f[2] };
     double unused[3] = { 0.0, 0.0, 1.0 }, flip[2];
@@ -337,13 +373,27 @@ void rgl_sample(const rgl_bsdf *b, const float wi_f[3], const float u[2], float 
     const float wof[3] = { (float)wo[0], (float)wo[1], (float)wo[2] };
     if (!(wof[2] > 0.0f) || !(c > 0.0)) return;
     /* report what eval / pdf say AT the Float direction returned, so that pdf(wi, sample.wo) == sample.pdf and weight == eval / pdf */
-    float f[3], p;
-    rgl_eval_pdf(b, wi_f, wof, f, &p);
+    float f[RGL_MAX_VALUES], p;
+    {
+        double wi_d[3], m_d[3];
+        for (int c = 0; c < n; ++c) f[c] = 0.0f;
+        p = 0.0f;
+        if (rgl_half_vector(b, wi_f, wof, wi_d, m_d)) eval_pdf_half_n(b, wi_d, m_d, n, third, f, &p);       /* = rgl_eval_pdf(b, wi_f, wof, ...) */
+    }
     (void)u_wi; (void)lum_pdf; (void)ndf_pdf;
     if (!(p > 0.0f)) return;
     wo_out[0] = wof[0]; wo_out[1] = wof[1]; wo_out[2] = wof[2];
     *pdf_out = p;
-    weight[0] = f[0] / p; weight[1] = f[1] / p; weight[2] = f[2] / p;
+    for (int c = 0; c < n; ++c) weight[c] = f[c] / p;
+}
+
+void rgl_eval_pdf_spectral_batch(const rgl_bsdf *b, const float *wi, const float *wo, const float *wl, int W, size_t n, float *values, float *pdf)
+{
+    for (size_t i = 0; i < n; ++i) rgl_eval_pdf_spectral(b, wi + 3 * i, wo + 3 * i, wl ? wl + (size_t)W * i : NULL, W, values + (size_t)W * i, pdf ? pdf + i : NULL);
+}
+void rgl_sample_spectral_batch(const rgl_bsdf *b, const float *wi, const float *u, const float *wl, int W, size_t n, float *wo, float *pdf, float *weight)
+{
+    for (size_t i = 0; i < n; ++i) rgl_sample_spectral(b, wi + 3 * i, u + 2 * i, wl ? wl + (size_t)W * i : NULL, W, wo + 3 * i, pdf + i, weight + (size_t)W * i);
 }
 
 void rgl_eval_pdf_batch(const rgl_bsdf *b, const float *wi, const float *wo, size_t n, float *rgb, float *pdf)
@@ -359,6 +409,16 @@ int rgl_bsdf_init(rgl_bsdf *b, int n_phi, int n_theta, const float *phi_i, const
                   int res_sigma_x, int res_sigma_y, const float *sigma, int res_x, int res_y, const float *vndf, const float *luminance,
                   const float *rgb, int jacobian)
 {
+    return rgl_bsdf_init_spectral(b, n_phi, n_theta, phi_i, theta_i, res_ndf_x, res_ndf_y, ndf, res_sigma_x, res_sigma_y, sigma, res_x, res_y, vndf, luminance,
+                                  0, NULL, rgb, jacobian);
+}
+
+/* n_wavelengths == 0: an RGB file (values [n_phi][n_theta][3][res_y][res_x]); else a spectral one: `spectra`
+ * [n_phi][n_theta][n_wavelengths][res_y][res_x] over the ascending grid `wavelengths` */
+int rgl_bsdf_init_spectral(rgl_bsdf *b, int n_phi, int n_theta, const float *phi_i, const float *theta_i, int res_ndf_x, int res_ndf_y, const float *ndf,
+                           int res_sigma_x, int res_sigma_y, const float *sigma, int res_x, int res_y, const float *vndf, const float *luminance,
+                           int n_wavelengths, const float *wavelengths, const float *rgb, int jacobian)
+{
     memset(b, 0, sizeof *b);
     b->isotropic = n_phi <= 2;
     b->jacobian = jacobian;
@@ -371,8 +431,9 @@ int rgl_bsdf_init(rgl_bsdf *b, int n_phi, int n_theta, const float *phi_i, const
     const int np2[2] = { n_phi, n_theta };
     const float *par2[2] = { phi_i, theta_i };
     const float chan[3] = { 0.f, 1.f, 2.f };
-    const int np3[3] = { n_phi, n_theta, 3 };
-    const float *par3[3] = { phi_i, theta_i, chan };
+    const int np3[3] = { n_phi, n_theta, n_wavelengths > 0 ? n_wavelengths : 3 };
+    const float *par3[3] = { phi_i, theta_i, n_wavelengths > 0 ? wavelengths : chan };
+    b->n_wavelengths = n_wavelengths > 0 ? n_wavelengths : 0;
     int rc = rgl_warp_init(&b->ndf, res_ndf_x, res_ndf_y, 0, NULL, NULL, ndf, 0, 0);
     if (!rc) rc = rgl_warp_init(&b->sigma, res_sigma_x, res_sigma_y, 0, NULL, NULL, sigma, 0, 0);
     if (!rc) rc = rgl_warp_init(&b->vndf, res_x, res_y, 2, np2, par2, vndf, 1, 1);

@@ -25,6 +25,7 @@ void   rgl_warp_invert(const rgl_warp *w, const double pos[2], const double *par
 typedef struct rgl_bsdf {
     int isotropic, jacobian;
     int reduction;              /* anisotropic files: 2 pi / (span of phi_i), rounded: 1 full azimuth, 2 half (point symmetry), 4 quarter */
+    int n_wavelengths;          /* 0: an RGB file; else `rgb` holds the spectra, its third parameter grid the wavelengths */
     rgl_warp ndf, sigma, vndf, luminance, rgb;
 } rgl_bsdf;
 
@@ -33,7 +34,17 @@ typedef struct rgl_bsdf {
 int  rgl_bsdf_init(rgl_bsdf *b, int n_phi, int n_theta, const float *phi_i, const float *theta_i, int res_ndf_x, int res_ndf_y, const float *ndf,
                    int res_sigma_x, int res_sigma_y, const float *sigma, int res_x, int res_y, const float *vndf, const float *luminance,
                    const float *rgb, int jacobian);
+/* spectral files ("spectra" [n_phi][n_theta][n_wavelengths][res_y][res_x] + "wavelengths" instead of "rgb"); n_wavelengths == 0: as above */
+int  rgl_bsdf_init_spectral(rgl_bsdf *b, int n_phi, int n_theta, const float *phi_i, const float *theta_i, int res_ndf_x, int res_ndf_y, const float *ndf,
+                            int res_sigma_x, int res_sigma_y, const float *sigma, int res_x, int res_y, const float *vndf, const float *luminance,
+                            int n_wavelengths, const float *wavelengths, const float *spectra, int jacobian);
 void rgl_bsdf_free(rgl_bsdf *b);
+/* a spectral file evaluated at W wavelengths per unit — wl [W] (NULL: the file's own nodes, W = n_wavelengths): the wavelength is
+ * the third interpolated parameter of `spectra` (linear between nodes, clamped outside); pdf and sampled direction are wavelength-free */
+void rgl_eval_pdf_spectral(const rgl_bsdf *b, const float wi[3], const float wo[3], const float *wl, int W, float *values, float *pdf_out);
+void rgl_sample_spectral(const rgl_bsdf *b, const float wi[3], const float u[2], const float *wl, int W, float wo[3], float *pdf, float *weight);
+void rgl_eval_pdf_spectral_batch(const rgl_bsdf *b, const float *wi, const float *wo, const float *wl /* [n][W] or NULL */, int W, size_t n, float *values, float *pdf);
+void rgl_sample_spectral_batch(const rgl_bsdf *b, const float *wi, const float *u, const float *wl, int W, size_t n, float *wo, float *pdf, float *weight);
 /* eval: f cos(theta_o) (RGB); pdf_out may be NULL */
 void rgl_eval_pdf(const rgl_bsdf *b, const float wi[3], const float wo[3], float rgb[3], float *pdf_out);
 /* rgl_eval_pdf in its two steps (for the tests' conditioning range): the prelude — both directions into the stored part of the

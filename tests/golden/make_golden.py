@@ -65,6 +65,21 @@ def rgl_cases():
                             wi=wi, wo=wo, u=u, rgb=rgb, pdf=pdf, wo2=wo2, pdf2=pdf2, weight=w)
 
 
+def spectral_cases():
+    """A spectral RGL file (real field names: "spectra" + "wavelengths" instead of "rgb") in the real container + what the oracle says
+    about it at four per-unit wavelengths (some outside the file's grid: clamped)."""
+    name, shape = "rgl_spectral", dict(seed=23, n_phi=1, n_theta=4, res=8, res_ndf=8, res_sigma=6, n_wavelengths=9)
+    fields = synth.make_rgl_fields(**shape)
+    synth.write_tensor_file(os.path.join(HERE, name + "_spec.bsdf"), fields)
+    B = ob.OracleRgl(fields)
+    wi, wo, u = ob.generate_pairs(0x5EED, 220_000, N)
+    wl = np.random.default_rng(23).uniform(330.0, 1030.0, (N, 4)).astype(np.float32)
+    val, pdf = B.eval_pdf_spectral(wi, wo, wl)
+    wo2, pdf2, w = B.sample_spectral(wi, u, wl)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), table_kind="rgl_spectral", table_seed=shape["seed"], bsdf_file=name + "_spec.bsdf",
+                        wi=wi, wo=wo, u=u, wavelengths=wl, rgb=val, pdf=pdf, wo2=wo2, pdf2=pdf2, weight=w)
+
+
 def option_cases():
     """SURVEY.md Appendix B 2 and 4 as options (MRL_OPT_COSINE_FACTOR, MRL_OPT_NEGATIVE): one fixture per non-default value.  Both
     synthetic tables carry MERL's -1 markers (24 % of the GGX-shaped table's texels — the below-horizon configurations —, 2 % of the
@@ -93,7 +108,10 @@ def option_cases():
 
 
 def main():
-    if "--options-only" in sys.argv:                   # the older fixtures stay byte-identical in git
+    if "--spectral-only" in sys.argv:                  # the older fixtures stay byte-identical in git
+        return spectral_cases()
+    spectral_cases()
+    if "--options-only" in sys.argv:
         return option_cases()
     option_cases()
     if "--rgl-only" in sys.argv:                       # the older fixtures stay byte-identical in git

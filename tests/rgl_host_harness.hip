@@ -8,9 +8,53 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+
+// --spectral <fields.bin> <pairs.bin> <out.bin>: fields.bin has a seventh int (n_wavelengths) and holds spectra + wavelengths in place
+// of rgb; pairs.bin: uint64 n, int32 W, wi wo u, then wavelengths [n][W]; out.bin: n x (values[W] pdf | wo'[3] pdf' weight'[W])
+static int spectral_main(char **argv)
+{
+    FILE *f = std::fopen(argv[0], "rb");
+    if (!f) return 3;
+    int h[7];
+    if (std::fread(h, 4, 7, f) != 7) return 3;
+    mrl::RglFields F;
+    F.n_phi = h[0]; F.n_theta = h[1]; F.res[0] = F.res[1] = h[2]; F.res_ndf[0] = F.res_ndf[1] = h[3]; F.res_sigma[0] = F.res_sigma[1] = h[4]; F.jacobian = h[5];
+    F.n_wl = h[6];
+    std::vector<std::vector<float>> keep;
+    auto rd = [&](size_t n) { keep.emplace_back(n); if (std::fread(keep.back().data(), 4, n, f) != n) std::exit(3); return keep.back().data(); };
+    const size_t per = (size_t)h[2] * h[2], sl = (size_t)h[0] * h[1];
+    F.phi_i = rd(h[0]); F.theta_i = rd(h[1]); F.ndf = rd((size_t)h[3] * h[3]); F.sigma = rd((size_t)h[4] * h[4]);
+    F.vndf = rd(sl * per); F.luminance = rd(sl * per); F.rgb = rd(sl * per * h[6]); F.wavelengths = rd(h[6]);
+    std::fclose(f);
+    if (const char *why = mrl::rgl_check_fields(F)) { std::fprintf(stderr, "%s\n", why); return 4; }
+    std::vector<float> blob;
+    const mrl::RglLayout L = mrl::rgl_build_image(F, blob);
+    const mrl::RglDev r = mrl::rgl_descriptor(F, L, blob.data());
+    f = std::fopen(argv[1], "rb");
+    if (!f) return 3;
+    unsigned long long n = 0;
+    int W = 0;
+    if (std::fread(&n, 8, 1, f) != 1 || std::fread(&W, 4, 1, f) != 1 || W < 1) return 3;
+    std::vector<float> wi(3 * n), wo(3 * n), u(2 * n), wl((size_t)W * n), out((size_t)(2 * W + 5) * n);
+    if (std::fread(wi.data(), 4, 3 * n, f) != 3 * n || std::fread(wo.data(), 4, 3 * n, f) != 3 * n || std::fread(u.data(), 4, 2 * n, f) != 2 * n ||
+        std::fread(wl.data(), 4, (size_t)W * n, f) != (size_t)W * n) return 3;
+    std::fclose(f);
+    for (size_t i = 0; i < n; ++i) {
+        float *o = &out[(size_t)(2 * W + 5) * i];
+        mrl::rgl::eval_pdf_spectral<true, true>(r, wi[3 * i], wi[3 * i + 1], wi[3 * i + 2], wo[3 * i], wo[3 * i + 1], wo[3 * i + 2], &wl[(size_t)W * i], W, o, o[W]);
+        mrl::rgl::sample_spectral(r, wi[3 * i], wi[3 * i + 1], wi[3 * i + 2], u[2 * i], u[2 * i + 1], &wl[(size_t)W * i], W, o + W + 1, o[W + 4], o + W + 5);
+    }
+    f = std::fopen(argv[2], "wb");
+    if (!f || std::fwrite(out.data(), 4, out.size(), f) != out.size()) return 5;
+    std::fclose(f);
+    std::printf("rgl host harness ok (spectral): %llu units x %d wavelengths\n", n, W);
+    return 0;
+}
 
 int main(int argc, char **argv)
 {
+    if (argc >= 5 && std::strcmp(argv[1], "--spectral") == 0) return spectral_main(argv + 2);
     if (argc < 4) return 2;
     FILE *f = std::fopen(argv[1], "rb");
     if (!f) return 3;
@@ -18,6 +62,7 @@ int main(int argc, char **argv)
     if (std::fread(h, 4, 6, f) != 6) return 3;
     mrl::RglFields F;
     F.n_phi = h[0]; F.n_theta = h[1]; F.res[0] = F.res[1] = h[2]; F.res_ndf[0] = F.res_ndf[1] = h[3]; F.res_sigma[0] = F.res_sigma[1] = h[4]; F.jacobian = h[5];
+    F.n_wl = 0; F.wavelengths = nullptr;
     std::vector<std::vector<float>> keep;
     auto rd = [&](size_t n) { keep.emplace_back(n); if (std::fread(keep.back().data(), 4, n, f) != n) std::exit(3); return keep.back().data(); };
     const size_t per = (size_t)h[2] * h[2], sl = (size_t)h[0] * h[1];

@@ -325,7 +325,7 @@ def test_golden_fixtures(tables, oracle):
     assert len(files) >= 8, "golden fixtures missing"
     for f in files:
         z = np.load(f)
-        if "n_ch" in z or str(z["table_kind"]) == "rgl":
+        if "n_ch" in z or str(z["table_kind"]) in ("rgl", "rgl_spectral"):
             continue                                     # n-channel fixtures: tests/test_gpu_nch.py::test_nch_golden_fixtures; RGL: test_gpu_rgl.py
         kind, seed = str(z["table_kind"]), int(z["table_seed"])
         sampling = int(z["sampling"]) if "sampling" in z else 0
