@@ -199,7 +199,7 @@ def test_load_from_a_tensor_file_and_refusals(tmp_path):
             assert g.material_count() == count
 
         refused(lambda f: f.pop("vndf"), "vndf")
-        refused(lambda f: (f.pop("rgb"), f.__setitem__("spectra", np.zeros((1, 4, 5, 8, 8), np.float32))), "spectral")
+        refused(lambda f: (f.pop("rgb"), f.__setitem__("spectra", np.zeros((1, 4, 5, 8, 8), np.float32))), "wavelengths")   # a spectral file needs its grid (test_gpu_rgl_spectral.py)
         refused(lambda f: f.__setitem__("rgb", f["rgb"][:, :, :2]), "rgb")
         refused(lambda f: f.__setitem__("theta_i", f["theta_i"][::-1].copy()), "ascending")
         refused(lambda f: f.__setitem__("vndf", -f["vndf"]), "non-negative")
