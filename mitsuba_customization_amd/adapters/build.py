@@ -51,6 +51,12 @@ def build_all(force: bool = False):
         if force or _stale(drv, deps + [drv_src, os.path.join(HERE, "tests", "driver_common.hpp")]):
             subprocess.check_call([CXX] + [f for f in CXXFLAGS if f != "-fvisibility=hidden"] + inc + ["-o", drv, drv_src, "-ldl", "-lpthread"])
         outs.append(drv)
+        if host == "mitsuba3":                      # the scalar_spectral variant's driver (an RGL *_spec.bsdf file through `measured`)
+            sp_src = os.path.join(HERE, "tests", "driver3_spectral.cpp")
+            sp = os.path.join(LIBDIR, "driver3_spectral")
+            if force or _stale(sp, deps + [sp_src, os.path.join(HERE, "tests", "driver_common.hpp")]):
+                subprocess.check_call([CXX] + [f for f in CXXFLAGS if f != "-fvisibility=hidden"] + inc + ["-o", sp, sp_src, "-ldl", "-lpthread"])
+            outs.append(sp)
     # the C ABI from plain C99 (examples/abi_example.c): also proves include/merl_hip.h is a C header
     ex_src = os.path.join(os.path.dirname(PKG), "examples", "abi_example.c")
     ex = os.path.join(LIBDIR, "abi_example")

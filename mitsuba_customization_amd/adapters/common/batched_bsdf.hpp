@@ -4,6 +4,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <stdexcept>
 
 class BatchedBSDF {
 public:
@@ -24,6 +25,13 @@ public:
     virtual void evalSampleQueue(const float *wi, const float *wo, const float *u,
                                  const uint32_t *queue, const uint32_t *count, size_t capacity,
                                  float *rgb, float *pdf, float *wo2, float *pdf2, float *weight) const = 0;
+    // spectral materials (an RGL *_spec.bsdf file under a spectral variant): the fused unit at W wavelengths per unit,
+    // wavelengths [n][W] in nm, values / weight [n][W] (include/merl_hip.h, mrl_eval_sample_spectral_batch)
+    virtual void evalSampleSpectralBatch(const float *, const float *, const float *, const float *, int, size_t,
+                                         float *, float *, float *, float *, float *) const
+    {
+        throw std::runtime_error("this BSDF holds no spectral material");
+    }
     // device-pointer calls are asynchronous: wait for them
     virtual void synchronize() const = 0;
 };

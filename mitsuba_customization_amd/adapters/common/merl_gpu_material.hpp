@@ -301,6 +301,14 @@ public:
                                 }, "mrl_material_load_rgl");
         return Material(ctx, res);
     }
+    // is the resident material a spectral RGL file (MRL_KIND_RGL_SPECTRAL)?
+    bool spectral() const
+    {
+        int kind = -1, dims[3];
+        std::lock_guard<std::mutex> lock(m_ctx->mutex());
+        check(ctx(), mrl_material_info(ctx(), m_id, &kind, dims), "mrl_material_info");
+        return kind == MRL_KIND_RGL_SPECTRAL;
+    }
     static bool is_tensor_file(const std::string &path)
     {
         return path.size() > 5 && path.compare(path.size() - 5, 5, ".bsdf") == 0;
@@ -345,6 +353,23 @@ public:
     {
         if (m_host) check(nullptr, mrl_host_sample(m_host, wi, u, wo, &pdf, weight), "mrl_host_sample");
         else m_ctx->scalar_sample(m_id, wi, u, wo, pdf, weight);
+    }
+    // ---- spectral materials: W values at the ray's wavelengths; one-unit calls on the calling thread over the host image ----
+    void eval_pdf_spectral1(const float wi[3], const float wo[3], const float *wl, int W, float *values, float &pdf) const
+    {
+        if (!m_host) throw Error(MRL_ERR_INVALID, "spectral one-unit calls evaluate on the CPU (scalar = \"cpu\")");
+        check(nullptr, mrl_host_eval_pdf_spectral(m_host, wi, wo, wl, W, values, &pdf), "mrl_host_eval_pdf_spectral");
+    }
+    void sample_spectral1(const float wi[3], const float u[2], const float *wl, int W, float wo[3], float &pdf, float *weight) const
+    {
+        if (!m_host) throw Error(MRL_ERR_INVALID, "spectral one-unit calls evaluate on the CPU (scalar = \"cpu\")");
+        check(nullptr, mrl_host_sample_spectral(m_host, wi, u, wl, W, wo, &pdf, weight), "mrl_host_sample_spectral");
+    }
+    void eval_sample_spectral_batch(const float *wi, const float *wo, const float *u, const float *wl, int W, size_t n,
+                                    float *values, float *pdf, float *wo2, float *pdf2, float *weight) const
+    {
+        std::lock_guard<std::mutex> lock(m_ctx->mutex());
+        check(ctx(), mrl_eval_sample_spectral_batch(ctx(), wi, wo, u, wl, W, m_id, n, values, pdf, wo2, pdf2, weight), "mrl_eval_sample_spectral_batch");
     }
     // ---- batch / wavefront calls: host or device arrays, n units (see include/merl_hip.h) ----
     void eval_batch(const float *wi, const float *wo, size_t n, float *rgb) const

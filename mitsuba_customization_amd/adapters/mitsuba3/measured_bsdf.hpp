@@ -37,9 +37,7 @@ public:
     // variants (llvm_*, cuda_*) are Dr.Jit traces, which this build replaces by the BatchedBSDF entry points.
     static_assert(std::is_floating_point<Float>::value,
                   "merl / customized_measurement: scalar_rgb variants only; array variants go through BatchedBSDF");
-#ifdef MERL_USE_REAL_MITSUBA
-    static_assert(is_rgb_v<Spectrum>, "merl / customized_measurement return RGB coefficients: build an *_rgb variant");
-#endif
+    // (an RGB variant evaluates RGB materials, a spectral variant spectral RGL files: finish_load() checks the pairing at load time)
 
     explicit MeasuredBSDFBase(const Properties &props) : Base(props)
     {
@@ -58,37 +56,64 @@ public:
         this->m_components.push_back(this->m_flags);
     }
 
+    // Spectral variants (Spectrum = four wavelength samples, si.wavelengths in nm): the material must be a spectral RGL file; its
+    // values are interpolated at the ray's own wavelengths (include/merl_hip.h, mrl_rgl_spectral_fields).  RGB variants: three floats.
+    static constexpr bool kSpectral = is_spectral_v<Spectrum>;
+    static constexpr int kValues = kSpectral ? 4 : 3;
+    static Spectrum make_spectrum(const float *v)
+    {
+        if constexpr (kSpectral) return Spectrum(v[0], v[1], v[2], v[3]);
+        else return Spectrum(v[0], v[1], v[2]);
+    }
+
     std::pair<BSDFSample3f, Spectrum> sample(const BSDFContext &ctx, const SurfaceInteraction3f &si, Float /*sample1*/,
                                              const Point2f &sample2, Mask active) const override
     {
         BSDFSample3f bs;
         if (!active || !ctx.is_enabled(BSDFFlags::GlossyReflection)) return { bs, Spectrum(0.f) };
         const float wi[3] = { si.wi.x(), si.wi.y(), si.wi.z() }, u[2] = { sample2.x(), sample2.y() };
-        float wo[3], pdf, w[3];
-        m_material.sample1(wi, u, wo, pdf, w);
+        float wo[3], pdf, w[4];
+        if constexpr (kSpectral) {
+            const float wl[4] = { si.wavelengths[0], si.wavelengths[1], si.wavelengths[2], si.wavelengths[3] };
+            m_material.sample_spectral1(wi, u, wl, 4, wo, pdf, w);
+        } else {
+            m_material.sample1(wi, u, wo, pdf, w);
+        }
         if (!(pdf > 0.f)) return { bs, Spectrum(0.f) };
         bs.wo = Vector3f(wo[0], wo[1], wo[2]);
         bs.pdf = pdf;
         bs.eta = 1.f;
         bs.sampled_type = +BSDFFlags::GlossyReflection;
         bs.sampled_component = 0;
-        return { bs, Spectrum(w[0], w[1], w[2]) };
+        return { bs, make_spectrum(w) };
     }
 
     Spectrum eval(const BSDFContext &ctx, const SurfaceInteraction3f &si, const Vector3f &wo_, Mask active) const override
     {
         if (!active || !ctx.is_enabled(BSDFFlags::GlossyReflection)) return Spectrum(0.f);
         const float wi[3] = { si.wi.x(), si.wi.y(), si.wi.z() }, wo[3] = { wo_.x(), wo_.y(), wo_.z() };
-        float rgb[3];
-        m_material.eval1(wi, wo, rgb);
-        return Spectrum(rgb[0], rgb[1], rgb[2]);
+        float rgb[4], pdf;
+        if constexpr (kSpectral) {
+            const float wl[4] = { si.wavelengths[0], si.wavelengths[1], si.wavelengths[2], si.wavelengths[3] };
+            m_material.eval_pdf_spectral1(wi, wo, wl, 4, rgb, pdf);
+        } else {
+            m_material.eval1(wi, wo, rgb);
+        }
+        return make_spectrum(rgb);
     }
 
     Float pdf(const BSDFContext &ctx, const SurfaceInteraction3f &si, const Vector3f &wo_, Mask active) const override
     {
         if (!active || !ctx.is_enabled(BSDFFlags::GlossyReflection)) return 0.f;
         const float wi[3] = { si.wi.x(), si.wi.y(), si.wi.z() }, wo[3] = { wo_.x(), wo_.y(), wo_.z() };
-        return m_material.pdf1(wi, wo);
+        if constexpr (kSpectral) {                       // the pdf is wavelength-free
+            const float wl[4] = { si.wavelengths[0], si.wavelengths[1], si.wavelengths[2], si.wavelengths[3] };
+            float v[4], pdf;
+            m_material.eval_pdf_spectral1(wi, wo, wl, 4, v, pdf);
+            return pdf;
+        } else {
+            return m_material.pdf1(wi, wo);
+        }
     }
 
     std::pair<Spectrum, Float> eval_pdf(const BSDFContext &ctx, const SurfaceInteraction3f &si, const Vector3f &wo_,
@@ -96,9 +121,14 @@ public:
     {
         if (!active || !ctx.is_enabled(BSDFFlags::GlossyReflection)) return { Spectrum(0.f), 0.f };
         const float wi[3] = { si.wi.x(), si.wi.y(), si.wi.z() }, wo[3] = { wo_.x(), wo_.y(), wo_.z() };
-        float rgb[3], pdf;
-        m_material.eval_pdf1(wi, wo, rgb, pdf);
-        return { Spectrum(rgb[0], rgb[1], rgb[2]), pdf };
+        float rgb[4], pdf;
+        if constexpr (kSpectral) {
+            const float wl[4] = { si.wavelengths[0], si.wavelengths[1], si.wavelengths[2], si.wavelengths[3] };
+            m_material.eval_pdf_spectral1(wi, wo, wl, 4, rgb, pdf);
+        } else {
+            m_material.eval_pdf1(wi, wo, rgb, pdf);
+        }
+        return { make_spectrum(rgb), pdf };
     }
 
     // ---- BatchedBSDF: the wavefront entry that stands in for upstream's Dr.Jit array variants ----
@@ -123,6 +153,11 @@ public:
     {
         m_material.eval_sample_queue(wi, wo, u, queue, count, capacity, rgb, pdf, wo2, pdf2, weight);
     }
+    void evalSampleSpectralBatch(const float *wi, const float *wo, const float *u, const float *wavelengths, int n_wavelengths, size_t n,
+                                 float *values, float *pdf, float *wo2, float *pdf2, float *weight) const override
+    {
+        m_material.eval_sample_spectral_batch(wi, wo, u, wavelengths, n_wavelengths, n, values, pdf, wo2, pdf2, weight);
+    }
     void synchronize() const override { m_material.synchronize(); }
 
     std::string to_string() const override
@@ -139,7 +174,15 @@ public:
 
 protected:
     virtual const char *plugin_class() const = 0;
-    void finish_load() { if (m_cpu_scalar) m_material.use_cpu_scalar(); }      // after the subclass has loaded m_material
+    // after the subclass has loaded m_material: an RGB variant evaluates RGB materials, a spectral variant spectral files (upstream
+    // upsamples RGB data to spectra there: not this path's job)
+    void finish_load()
+    {
+        if (m_material.spectral() != kSpectral)
+            throw merl_gpu::Error(MRL_ERR_MATERIAL, kSpectral ? std::string(plugin_class()) + ": a spectral variant needs a spectral file (\"spectra\" + \"wavelengths\"; RGL *_spec.bsdf)"
+                                                               : std::string(plugin_class()) + ": an RGB variant needs RGB data (a spectral file belongs to a *_spectral variant)");
+        if (m_cpu_scalar) m_material.use_cpu_scalar();
+    }
     std::string m_filename;
     bool m_cpu_scalar = true;
     merl_gpu::ContextKey m_key;

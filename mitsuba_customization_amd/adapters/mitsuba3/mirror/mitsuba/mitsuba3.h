@@ -49,6 +49,21 @@ struct Color3f {
     float &operator[](int i) { return v[i]; }
 };
 
+// the spectral variants' Spectrum: four wavelength samples per ray (upstream: Spectrum<Float, 4>), and the traits a plugin tells
+// the variants apart with
+struct Spectrum4f {
+    float v[4];
+    Spectrum4f() { v[0] = v[1] = v[2] = v[3] = 0; }
+    explicit Spectrum4f(float a) { v[0] = v[1] = v[2] = v[3] = a; }
+    Spectrum4f(float a, float b, float c, float d) { v[0] = a; v[1] = b; v[2] = c; v[3] = d; }
+    float operator[](int i) const { return v[i]; }
+    float &operator[](int i) { return v[i]; }
+    static constexpr int Size = 4;
+};
+template <typename T> constexpr bool is_spectral_v = false;
+template <> inline constexpr bool is_spectral_v<Spectrum4f> = true;
+template <typename T> constexpr bool is_rgb_v = !is_spectral_v<T>;
+
 struct Frame3f {
     static float cos_theta(const Vector3f &v) { return v.z(); }
 };
@@ -75,6 +90,7 @@ struct BSDFContext {
 
 template <typename Float, typename Spectrum> struct SurfaceInteraction {
     Vector3f wi;     // incident direction, local shading frame
+    Spectrum wavelengths;   // the ray's wavelengths in nm (spectral variants; unused in the RGB ones — upstream: an empty Color0f there)
 };
 
 template <typename Float, typename Spectrum> struct BSDFSample3 {
@@ -209,5 +225,9 @@ NAMESPACE_END(mitsuba)
     MI_EXPORT void *plugin_create_scalar_rgb(const mitsuba::Properties &props)                            \
     {                                                                                                     \
         return new mitsuba::Name<float, mitsuba::Color3f>(props);                                         \
+    }                                                                                                     \
+    MI_EXPORT void *plugin_create_scalar_spectral(const mitsuba::Properties &props)                       \
+    {                                                                                                     \
+        return new mitsuba::Name<float, mitsuba::Spectrum4f>(props);                                      \
     }                                                                                                     \
     }
