@@ -7,7 +7,7 @@
 //
 //   g++ -std=c++17 -O2 -I include examples/group_host.cpp -L mitsuba_customization_amd/lib -lmerl_hip -o group_host
 //   group_host --devices 0,1,2,3 [--transport auto|rccl|copy] [--units-per-device N] [--chunk C] [--tables T]
-//              [--steps K] [--warmup W] [--table file.binary] [--check] [--root R] [--selftest] [--no-fallback]
+//              [--steps K] [--warmup W] [--table file.binary] [--check] [--root R] [--selftest] [--no-fallback] [--reserve-cus K]
 //   (a device may repeat, e.g. --devices 0,0,0: rehearsal on a 1-GPU box, transport = device copies)
 // --selftest: before the pipeline, every peer -> root link on its own (mrl_group_link_test: 1 / 4 / 16 / 64 MB, timed and
 //   bit-checked, RCCL and device copies), reported per link.
@@ -108,6 +108,7 @@ int main(int argc, char **argv)
     int transport = MRL_TRANSPORT_AUTO, tables = 1, steps = 5, warmup = 2, root = 0;
     size_t units_per_device = (size_t)8 << 20, chunk = (size_t)2 << 20;
     bool check = false, selftest = false, child = false, fallback = true;
+    int reserve_cus = 0;
     std::string table_file, fallback_from;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -135,6 +136,7 @@ int main(int argc, char **argv)
         else if (a == "--check") check = true;
         else if (a == "--selftest") selftest = true;
         else if (a == "--no-fallback") fallback = false;
+        else if (a == "--reserve-cus") reserve_cus = std::atoi(next());
         else if (a == "--child") child = true;
         else if (a == "--fallback-from") fallback_from = next();
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -161,11 +163,18 @@ int main(int argc, char **argv)
         if (rc != MRL_OK) { std::fprintf(stderr, "mrl_group_init -> %s (%s)\n", mrl_strerror(rc), mrl_group_last_error(nullptr)); return 1; }
     }
     const int used_transport = mrl_group_transport(group);
+    // CUs the compute grids leave to the transfer kernels (RCCL's send / receive are kernels): MRL_OPT_RESERVED_CUS on every member
+    if (reserve_cus > 0) GCHECK(mrl_group_set_option(group, MRL_OPT_RESERVED_CUS, reserve_cus));
     std::vector<int> ids;
+    std::vector<std::vector<double>> synthetic(16);                    // 100 resident tables cycle through 16 distinct ones
     for (int t = 0; t < tables; ++t) {
         int id = -1;
         if (!table_file.empty()) GCHECK(mrl_group_material_load_merl(group, table_file.c_str(), &id));
-        else { const std::vector<double> tab = synthetic_table(t % 16); GCHECK(mrl_group_material_upload_f64(group, tab.data(), &id)); }
+        else {
+            std::vector<double> &tab = synthetic[(size_t)(t % 16)];
+            if (tab.empty()) tab = synthetic_table(t % 16);
+            GCHECK(mrl_group_material_upload_f64(group, tab.data(), &id));
+        }
         ids.push_back(id);
     }
     const size_t n_total = units_per_device * (size_t)G;
@@ -191,8 +200,18 @@ int main(int argc, char **argv)
             const size_t sizes[4] = { (size_t)1 << 20, (size_t)4 << 20, (size_t)16 << 20, (size_t)64 << 20 };
             for (int k = 0; k < 4; ++k) {
                 std::vector<mrl_link_report> rep((size_t)G);
-                GCHECK(mrl_group_link_test(group, sizes[k], mode, root, rep.data()));       // wrong data or a failed call: exit non-zero
-                GCHECK(mrl_group_link_test(group, sizes[k], mode, root, rep.data()));       // second pass: timed warm
+                // a failed link test is REPORTED, it does not end the run: the pipeline below is the measurement, and its --check
+                // compares every gathered value (a selftest bug must not hide the transport behind the fallback)
+                int rc_link = mrl_group_link_test(group, sizes[k], mode, root, rep.data());
+                if (rc_link == MRL_OK) rc_link = mrl_group_link_test(group, sizes[k], mode, root, rep.data());       // second pass: timed warm
+                if (rc_link != MRL_OK) {
+                    std::string why = mrl_group_last_error(group) ? mrl_group_last_error(group) : "";
+                    for (char &c : why) if (c == '"' || c == '\\' || c == '\n') c = ' ';
+                    selftest_json += std::string(k ? ", " : "") + "{\"bytes\": " + std::to_string(sizes[k]) + ", \"failed\": \"" + mrl_strerror(rc_link) + ": " + why + "\"}";
+                    std::fprintf(stderr, "group_host: link selftest (%s, %zu bytes) failed: %s (%s)\n", mode == MRL_TRANSPORT_RCCL ? "rccl" : "peer_copy", sizes[k],
+                                 mrl_strerror(rc_link), why.c_str());
+                    break;
+                }
                 selftest_json += std::string(k ? ", " : "") + "{\"bytes\": " + std::to_string(sizes[k]) + ", \"GBps_per_peer\": [";
                 bool first_peer = true;
                 for (int r = 0; r < G; ++r) {
@@ -306,7 +325,7 @@ int main(int argc, char **argv)
                 bytes_into_root, gathered_ms > 0 ? bytes_into_root / gathered_ms / 1e6 : 0.0, bytes_into_root * 12.0 / 44.0,
                 rgb_gathered_ms > 0 ? bytes_into_root * 12.0 / 44.0 / rgb_gathered_ms / 1e6 : 0.0, mismatches,
                 fallback_from.empty() ? "" : "\"", fallback_from.empty() ? "null" : fallback_from.c_str(), fallback_from.empty() ? "" : "\"",
-                selftest_json.c_str());
+                reserve_cus, selftest_json.c_str());
     for (int r = 0; r < G; ++r) (void)mrl_device_free(ctxs[(size_t)r], local[(size_t)r]);
     (void)mrl_device_free(rctx, out);
     GCHECK(mrl_group_destroy(group));

@@ -7,6 +7,20 @@ namespace mrlabi {
 
 
 
+hipError_t create_compute_stream(int device_cus, int reserved, hipStream_t *out)
+{
+    if (reserved <= 0) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    const int words = (device_cus + 31) / 32;
+    std::vector<uint32_t> mask((size_t)words, 0u);
+    for (int i = 0; i < device_cus; ++i) mask[(size_t)(i >> 5)] |= 1u << (i & 31);
+    // clear `reserved` bits at even spacing, starting in the middle of the first interval
+    for (int k = 0; k < reserved; ++k) {
+        const int bit = (int)(((long long)(2 * k + 1) * device_cus) / (2 * reserved));
+        mask[(size_t)(bit >> 5)] &= ~(1u << (bit & 31));
+    }
+    return hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask.data());
+}
+
 int fail(mrl_ctx *ctx, int status, const std::string &msg)
 {
     if (ctx) ctx->last_error = msg;
@@ -307,6 +321,7 @@ int mrl_init(int device_id, mrl_ctx **out)
     if (!ctx) return MRL_ERR_OOM;
     ctx->device = device_id;
     ctx->compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->device_cus = ctx->compute_units;
     ctx->device_name = prop.name;
     ctx->total_mem = prop.totalGlobalMem;
     if (hipSetDevice(device_id) != hipSuccess ||
@@ -347,6 +362,7 @@ int mrl_destroy(mrl_ctx *ctx)
     if (ctx->d_part_work) (void)hipFree(ctx->d_part_work);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->masked_stream) (void)hipStreamDestroy(ctx->masked_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MRL_OK;
@@ -388,6 +404,23 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
         case MRL_OPT_BLOCK_MAP: if (value < 0 || value > 1) break; ctx->block_map = value; return MRL_OK;
         case MRL_OPT_RGL_SEARCH: if (value < 0 || value > 1) break; ctx->rgl_search = value; return MRL_OK;
         case MRL_OPT_COSINE_FACTOR: if (value < 0 || value > 1) break; ctx->opts.cosine = value; return MRL_OK;
+        case MRL_OPT_RESERVED_CUS: {
+            if (value < 0 || value > ctx->device_cus / 2) break;
+            MRL_HIP(ctx, hipSetDevice(ctx->device));
+            const ScalarPause quiet(ctx);
+            MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            hipStream_t fresh = nullptr;
+            if (value > 0) MRL_HIP(ctx, create_compute_stream(ctx->device_cus, value, &fresh));
+            // the context's own stream changes hands; a caller's stream (mrl_set_stream) stays the caller's business — a device
+            // group re-creates its compute streams with the same mask (mrl_group_set_option)
+            const bool on_own = ctx->stream == ctx->own_stream || (ctx->masked_stream && ctx->stream == ctx->masked_stream);
+            if (ctx->masked_stream) (void)hipStreamDestroy(ctx->masked_stream);
+            ctx->masked_stream = fresh;
+            if (on_own) ctx->stream = fresh ? fresh : ctx->own_stream;
+            ctx->reserved_cus = value;
+            ctx->compute_units = ctx->device_cus - value;
+            return MRL_OK;
+        }
         case MRL_OPT_NEGATIVE: {
             if (value < 0 || value > 2) break;
             // the policy decides what a table's image holds (clamped or raw values): context-wide, like the layout
@@ -429,6 +462,7 @@ int mrl_get_option(const mrl_ctx *ctx, int option, int *value)
         case MRL_OPT_BLOCK_MAP: *value = ctx->block_map; return MRL_OK;
         case MRL_OPT_RGL_SEARCH: *value = ctx->rgl_search; return MRL_OK;
         case MRL_OPT_COSINE_FACTOR: *value = ctx->opts.cosine; return MRL_OK;
+        case MRL_OPT_RESERVED_CUS: *value = ctx->reserved_cus; return MRL_OK;
         case MRL_OPT_NEGATIVE: *value = ctx->opts.negative; return MRL_OK;
         case MRL_OPT_HOST_CHUNK: *value = (int)ctx->host_chunk; return MRL_OK;
         case MRL_OPT_TABLE_PARAM: *value = ctx->table_param; return MRL_OK;
@@ -449,7 +483,7 @@ int mrl_reset_stream(mrl_ctx *ctx)
 {
     if (!ctx) return MRL_ERR_INVALID;
     MRL_GUARD(ctx);
-    ctx->stream = ctx->own_stream;
+    ctx->stream = ctx->masked_stream ? ctx->masked_stream : ctx->own_stream;
     return MRL_OK;
 }
 

@@ -175,6 +175,9 @@ struct mrl_ctx {
     size_t host_chunk = (size_t)1 << 22;
     int block_map = 0;               // MRL_OPT_BLOCK_MAP
     int rgl_search = 0;              // MRL_OPT_RGL_SEARCH
+    int device_cus = 256;            // the device's compute units (compute_units = device_cus - reserved_cus sizes the persistent grids)
+    int reserved_cus = 0;            // MRL_OPT_RESERVED_CUS
+    hipStream_t masked_stream = nullptr;     // own stream restricted to the unreserved CUs (created by MRL_OPT_RESERVED_CUS > 0)
     int host_threads = 4;            // MRL_OPT_HOST_THREADS: copy threads of the pipelined host-array path; 0 = staged hipMemcpy path
     HostPipe pipe;
     void *d_stage = nullptr;
@@ -216,6 +219,10 @@ namespace mrlabi {
 inline constexpr size_t kMaxSegments = 256 * 8 + 64;     // partition_geometry caps segments at 8 per CU
 
 // ---- merl_abi.hip ----
+// a non-blocking stream whose kernels may use all but `reserved` of the device's `device_cus` compute units (reserved = 0: a plain
+// stream).  The reserved CUs are spread evenly over the mask (one per XCD for 8): what a communication library's kernels — RCCL's
+// send / receive — run on while a persistent compute grid owns the rest (include/merl_hip.h, MRL_OPT_RESERVED_CUS).
+hipError_t create_compute_stream(int device_cus, int reserved, hipStream_t *out);
 int fail(mrl_ctx *ctx, int status, const std::string &msg);
 int pointer_kind(const void *p);                                  // 1 = the device can dereference it, 0 = plain host
 int common_kind(std::initializer_list<const void *> ptrs);        // 0 / 1, or -1 on a mix

@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+namespace mrlabi { hipError_t create_compute_stream(int device_cus, int reserved, hipStream_t *out); }     // merl_abi.hip
+
 #include <algorithm>
 #include <cstring>
 #include <new>
@@ -392,6 +394,23 @@ int mrl_group_context(mrl_group *g, int rank, mrl_ctx **out)
 int mrl_group_set_option(mrl_group *g, int option, int value)
 {
     if (!g) return MRL_ERR_INVALID;
+    if (option == MRL_OPT_RESERVED_CUS) {
+        // every member's COMPUTE stream gets the CU mask (the group owns those streams); the transfer streams — where RCCL's
+        // send / receive kernels run — stay unrestricted, so the reserved CUs are theirs while the persistent grids run
+        return for_each_member(g, "mrl_set_option(reserved CUs)", [&](Member &m, int) {
+            int rc = mrl_set_option(m.ctx, option, value);                       // validates the value, sizes the grids
+            if (rc != MRL_OK) return rc;
+            int name_cus = 0;
+            rc = mrl_device_info(m.ctx, nullptr, 0, &name_cus, nullptr);
+            if (rc != MRL_OK) return rc;
+            if (hipSetDevice(m.device) != hipSuccess || hipStreamSynchronize(m.compute) != hipSuccess) { (void)hipGetLastError(); return (int)MRL_ERR_HIP; }
+            hipStream_t fresh = nullptr;
+            if (mrlabi::create_compute_stream(name_cus + value, value, &fresh) != hipSuccess)      // (mrl_device_info reports the CUs left to the grids) { (void)hipGetLastError(); return (int)MRL_ERR_HIP; }
+            (void)hipStreamDestroy(m.compute);
+            m.compute = fresh;
+            return mrl_set_stream(m.ctx, (void *)m.compute);
+        });
+    }
     return for_each_member(g, "mrl_set_option", [&](Member &m, int) { return mrl_set_option(m.ctx, option, value); });
 }
 

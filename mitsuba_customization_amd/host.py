@@ -20,6 +20,7 @@ OPT_TABLE_PARAM = 10
 OPT_TABLE_ARENA_MB = 11
 OPT_RGL_SEARCH = 12           # 0: RGL search tables from LDS when they fit (default), 1: always from memory
 OPT_COSINE_FACTOR = 13        # 0: eval() = f cos(theta_o) (default), 1: eval() = f            
+OPT_RESERVED_CUS = 15          # compute units the batch kernels leave to communication kernels (CU-masked stream)
 OPT_NEGATIVE = 14             # negative stored values: 0 clamp (default), 1 keep, 2 skip and renormalise   
 NEGATIVE_CLAMP, NEGATIVE_KEEP, NEGATIVE_RENORMALISE = 0, 1, 2
 PARAM_HALF_DIFF, PARAM_STANDARD, PARAM_STANDARD_FULL = 0, 1, 2          # enum mrl_param
