@@ -136,13 +136,14 @@ enum mrl_option {
                                   (MRL_OPT_SAMPLING) are built from clamped values under every setting.  With 2 the batch calls run the
                                   generic kernel for nearest lookups and rows-layout tables and the LDS-DMA kernel for trilinear lookups
                                   on bricks, whatever MRL_OPT_KERNEL says. */
-    MRL_OPT_RESERVED_CUS = 15, /* compute units the batch kernels leave alone (0 .. half the device; default 0).  The kernels are
+    MRL_OPT_RESERVED_CUS = 15, /* compute units the batch kernels leave alone (0 .. 16; default 0).  The kernels are
                                   persistent grids sized to fill every CU; a communication library whose transfers are KERNELS (RCCL's
                                   ncclSend / ncclRecv) then finds no CU to run on until a grid drains.  With k > 0 the context's stream
                                   becomes a stream with a CU mask (hipExtStreamCreateWithCUMask: k CUs, spread evenly, are excluded)
                                   and the grids are sized for the rest.  mrl_group_set_option applies it to every member's compute
-                                  stream; the transfer streams stay unrestricted.  Results do not depend on it.  Cost on one
-                                  device: DESIGN.md §7 (profiles/r04_reserved_cus.json). */
+                                  stream; the transfer streams stay unrestricted.  Results do not depend on it.  Verified with hardware
+                                  ids: k = 1, 8, 16 idle exactly k CUs; larger masks are dropped by the driver, hence the range
+                                  (profiles/r04_cu_mask_probe.json).  Cost on one device: DESIGN.md §7 (profiles/r04_reserved_cus.json). */
     MRL_OPT_MEMORY_LIMIT_MB = 7 /* budget for the context's resident material data (tables + sampling marginals), in MiB;
                                   0 (default) = no budget, the device's free memory is the limit.  An upload that would
                                   exceed the budget — or the device — fails with MRL_ERR_OOM and leaves the context as it

@@ -405,7 +405,9 @@ int mrl_set_option(mrl_ctx *ctx, int option, int value)
         case MRL_OPT_RGL_SEARCH: if (value < 0 || value > 1) break; ctx->rgl_search = value; return MRL_OK;
         case MRL_OPT_COSINE_FACTOR: if (value < 0 || value > 1) break; ctx->opts.cosine = value; return MRL_OK;
         case MRL_OPT_RESERVED_CUS: {
-            if (value < 0 || value > ctx->device_cus / 2) break;
+            // 0 .. 16: the range in which the mask is verified to idle exactly `value` CUs (profiles/r04_cu_mask_probe.json: with 32 or more
+            // bits cleared the driver runs the stream on all CUs again)
+            if (value < 0 || value > 16 || value > ctx->device_cus / 2) break;
             MRL_HIP(ctx, hipSetDevice(ctx->device));
             const ScalarPause quiet(ctx);
             MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
