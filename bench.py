@@ -107,7 +107,7 @@ def parse(argv=None):
     p.add_argument("--arena-mb", type=int, default=-1,
                    help="MRL_OPT_TABLE_ARENA_MB: place the tables back to back in one device allocation of this size; -1 (default): 20 GB for "
                         "--config resident100 and 4 GB for mixed16_256m (address translation bounds those launches; one arena removes the slow mode "
-                        "of the process-to-process spread and is worth 5 %: profiles/r03_arena_ab.txt), none otherwise; 0: one allocation per table")
+                        "of the process-to-process spread and is worth 5 %%: profiles/r03_arena_ab.txt), none otherwise; 0: one allocation per table")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-reps", type=int, default=5, help="repetitions of each CPU baseline leg (median is reported)")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the separately reported RCCL gather leg")
@@ -126,6 +126,13 @@ def parse(argv=None):
                    help="N>1: skip the separately reported run of the native C++ host (lib/group_host: one process, mrl_group over the N GPUs, RCCL gather)")
     p.add_argument("--native-units", type=int, default=8 << 20, help="N>1: units per device of the native C++ host's run")
     p.add_argument("--native-deadline", type=float, default=90.0, help="N>1: seconds before the native C++ host is killed")
+    p.add_argument("--no-configs4", action="store_true",
+                   help="N>1: skip the full-shape BASELINE configs[4] block (100 resident tables, --configs4-units pairs over the N devices, "
+                        "compute-only / rgb-only gather / full gather for both transports, native C++ host)")
+    p.add_argument("--configs4-units", type=int, default=10**9, help="N>1: total units of the configs[4] block (BASELINE: 1B pairs)")
+    p.add_argument("--configs4-deadline", type=float, default=420.0, help="N>1: seconds before one leg of the configs[4] block is killed")
+    p.add_argument("--configs4-reserve-cus", type=int, default=8,
+                   help="N>1: compute units per device that the second run of each transport leaves to the transfer kernels (MRL_OPT_RESERVED_CUS)")
     return p.parse_args(argv)
 
 
@@ -216,6 +223,52 @@ def native_group_leg(n_gpus: int, share_gpu: bool, units: int, deadline: float) 
     out = json.loads(line[-1])
     out["cmd"] = " ".join(cmd)
     return out
+
+
+def configs4_block(n_gpus: int, share_gpu: bool, total_units: int, deadline: float, reserve_cus: int) -> dict:
+    """BASELINE configs[4] at its full shape, beside `value` (never in it): ALL 100 tables resident on every device, `total_units`
+    pairs (1e9) in N index tiles, the chunk-pipelined gather of every result to device 0 — through lib/group_host (plain C++ over
+    mrl_group_*; one process, one RCCL communicator per device).  One leg per (transport, reserved CUs): each a fresh process under its
+    own deadline, so that a transport that hangs or dies costs its leg, not the others.  Per leg (DESIGN.md §7 has the schema):
+    compute_only_Meval_s (nothing crosses a link), rgb_gathered_Meval_s (eval alone: 12 B/unit to the root), gathered_Meval_s (the fused
+    unit: 44 B/unit), root_ingress_GBps, check_mismatches (the gathered arrays against one device evaluating the whole range: must be 0),
+    selftest (per-link GB/s, bit-checked; a failure is reported, not fatal).  reserved_cus > 0 answers what nobody could test on one
+    GPU: RCCL's send / receive are KERNELS and the compute grids are persistent — do the transfers of chunk k overlap the compute of
+    chunk k + 1, or wait for a grid to drain?  The second run of a transport keeps `reserve_cus` CUs per device free for them
+    (MRL_OPT_RESERVED_CUS: a CU-masked compute stream, verified with hardware ids in profiles/r04_cu_mask_probe.json)."""
+    import subprocess
+    exe = os.path.join(ROOT, "mitsuba_customization_amd", "lib", "group_host")
+    if not os.path.exists(exe):
+        return {"skipped": "lib/group_host is not built"}
+    devices = ",".join("0" if share_gpu else str(i) for i in range(n_gpus))
+    per_device = (total_units + n_gpus - 1) // n_gpus
+    chunk = max(1, min(8 << 20, per_device // 4))
+    transports = ["copy"] if share_gpu else ["rccl", "copy"]       # RCCL refuses two ranks on one device: the rehearsal runs copies only
+    legs = []
+    for transport in transports:
+        for reserve in ((0, reserve_cus) if reserve_cus > 0 else (0,)):
+            cmd = [exe, "--devices", devices, "--transport", transport, "--no-fallback", "--tables", "100", "--units-per-device", str(per_device),
+                   "--chunk", str(chunk), "--steps", "2", "--warmup", "1", "--check", "--selftest", "--reserve-cus", str(reserve)]
+            leg = {"transport_asked": transport, "reserved_cus": reserve, "cmd": " ".join(cmd)}
+            t0 = time.time()
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=deadline)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if r.returncode != 0 or not line:
+                    leg["failed"] = f"exit code {r.returncode}"
+                    leg["stderr"] = r.stderr[-600:]
+                else:
+                    leg.update(json.loads(line[-1]))
+            except subprocess.TimeoutExpired:
+                leg["failed"] = f"did not finish within {deadline} s and was killed"
+            except Exception as e:
+                leg["failed"] = repr(e)
+            leg["wall_s"] = round(time.time() - t0, 1)
+            legs.append(leg)
+    ok = [g for g in legs if "failed" not in g]
+    return {"workload": f"BASELINE configs[4]: 100 MERL tables resident per device, {total_units} pairs tile-sharded over {n_gpus} device(s), "
+                        "results gathered to device 0 in pipelined chunks", "total_units": total_units, "units_per_device": per_device,
+            "chunk_units": chunk, "legs": legs, "legs_ok": len(ok), "all_legs_failed": not ok}
 
 
 def scalar_calls_leg(deadline: float = 60.0) -> dict:
@@ -605,10 +658,16 @@ def main():
         del wi, wo, u, out, mat
         torch.cuda.empty_cache()
         result["native_group"] = native_group_leg(world, args.share_gpu, args.native_units, args.native_deadline)
+        if not args.no_configs4:
+            result["configs4"] = configs4_block(world, args.share_gpu, args.configs4_units, args.configs4_deadline, args.configs4_reserve_cus)
+            configs4_dead = bool(result["configs4"].get("all_legs_failed"))
     # ---- N=1: the per-ray plugin path (one-unit calls), beside `value`, never in it ----
     if world == 1 and args.config == "merl64m" and not args.no_scalar_calls and not args.no_cpu_baseline:
         result["scalar_calls"] = scalar_calls_leg()
     emit()
+    if rank == 0 and world > 1 and locals().get("configs4_dead"):
+        sys.stderr.write("bench.py: every leg of the configs[4] block failed\n")
+        sys.exit(EXIT_GATHER_FAILED)                             # the line above is complete; the exit code says the block is not
 
 
 if __name__ == "__main__":

@@ -58,7 +58,7 @@ def test_self_launch_two_ranks_share_gpu():
     """Plain `python bench.py --gpus 2` end to end on the 1-GPU box: two ranks share GPU 0 for the compute, gloo is the
     control plane and carries the gather leg; one JSON line, n_gpus 2, twice one rank's units."""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--share-gpu", "--units", str(1 << 20),
-                        "--steps", "3", "--warmup", "1", "--gather-units", str(1 << 18)],
+                        "--steps", "3", "--warmup", "1", "--gather-units", str(1 << 18), "--configs4-units", str(6 << 20)],
                        capture_output=True, text=True, timeout=900, env=_clean_env())
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -72,6 +72,28 @@ def test_self_launch_two_ranks_share_gpu():
     assert "cpu_baseline" not in out                                 # N=1 only
     ng = out["native_group"]                                          # the C++ host over the same "GPUs" (here: GPU 0 twice)
     assert ng["check_mismatches"] == 0 and ng["devices"] == [0, 0] and ng["transport"] == "peer_copy", ng
+    # the full-shape configs[4] block, rehearsed at reduced units: 100 resident tables, both CU reservations, every leg checked
+    c4 = out["configs4"]
+    assert c4["total_units"] == 6 << 20 and c4["units_per_device"] == 3 << 20 and not c4["all_legs_failed"], c4
+    assert [(g["transport_asked"], g["reserved_cus"]) for g in c4["legs"]] == [("copy", 0), ("copy", 8)]
+    for g in c4["legs"]:
+        assert "failed" not in g, g
+        assert g["tables_resident"] == 100 and g["check_mismatches"] == 0 and g["transport"] == "peer_copy"
+        assert g["compute_only_Meval_s"] > 0 and g["rgb_gathered_Meval_s"] > 0 and g["gathered_Meval_s"] > 0
+        assert "peer_copy" in g["selftest"]
+
+
+@pytest.mark.gpu
+def test_resident100_two_ranks_share_gpu():
+    """BASELINE configs[4]'s per-device share through the Python ranks: `--config resident100 --gpus 2 --share-gpu` (100 resident
+    tables per rank, material ids in the batch: 80 B/unit), without the native legs."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--share-gpu", "--config", "resident100", "--units", str(1 << 20),
+                        "--steps", "2", "--warmup", "1", "--gather-units", str(1 << 18), "--no-native-group"],
+                       capture_output=True, text=True, timeout=900, env=_clean_env())
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["config"]["materials_resident"] == 100 and out["roofline"]["bytes_per_unit"] == 80
+    assert out["parity"]["max_rel_err_vs_oracle"] <= 1e-6 and "ms" in out["gather"]
 
 
 @pytest.mark.gpu
