@@ -318,7 +318,7 @@ int main(int argc, char **argv)
                 "\"compute_only_ms\": %.4f, \"compute_only_Meval_s\": %.1f, \"rgb_gathered_ms\": %.4f, \"rgb_gathered_Meval_s\": %.1f, "
                 "\"gathered_ms\": %.4f, \"gathered_Meval_s\": %.1f, "
                 "\"slowest_member_device_ms\": %.4f, \"bytes_into_root\": %.0f, \"root_ingress_GBps\": %.2f, \"rgb_bytes_into_root\": %.0f, "
-                "\"rgb_root_ingress_GBps\": %.2f, \"check_mismatches\": %lld, \"fallback_from\": %s%s%s, \"selftest\": %s}\n",
+                "\"rgb_root_ingress_GBps\": %.2f, \"check_mismatches\": %lld, \"fallback_from\": %s%s%s, \"reserved_cus\": %d, \"selftest\": %s}\n",
                 used_transport == MRL_TRANSPORT_RCCL ? "rccl" : "peer_copy", units_per_device, chunk, tables, steps,
                 compute_ms, (double)n_total / compute_ms / 1e3, rgb_gathered_ms, (double)n_total / rgb_gathered_ms / 1e3,
                 gathered_ms, (double)n_total / gathered_ms / 1e3, slowest,
