@@ -273,3 +273,51 @@ def test_one_wide_table_beyond_four_gigabytes(oracle):
     ok = np.abs(got[0].astype(np.float64) - want[0]) <= 1e-6 * np.abs(want[0]) + 1e-30
     assert ok[well].all(), int((~ok[well]).sum())
     assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+
+
+def test_64m_ggx_rough_conductor(gpu, batch64, oracle):
+    """BASELINE configs[2] at its size: GGX rough conductor alpha = 0.1, analytic eval + visible-normal sample over all 64M units —
+    tile invariance (one launch == ragged launches, bit for bit), a strided sample against the oracle, the fused entry point against
+    the separate ones, and the size-independent properties of the model over ALL units: reciprocity of f = eval / cos(theta_o)
+    (the microfacet BRDF is symmetric), the pdf of a sampled direction re-evaluated by pdf(), energy bounds of the weight
+    (F G1 <= 1 per channel), unit-length directions above the horizon."""
+    import torch
+    eta, k = (0.143, 0.375, 1.442), (3.983, 2.386, 1.603)
+    mid = gpu.ggx(0.1, eta, k)
+    wi, wo, u = batch64
+    one = gpu.eval_sample(wi, wo, u, material=mid)
+    cuts = [0, 7_000_001, 7_000_002, 33_554_432, 63_999_999, N64]
+    parts = [gpu.eval_sample(wi[a:b], wo[a:b], u[a:b], material=mid) for a, b in zip(cuts, cuts[1:])]
+    for q in range(5):
+        assert torch.equal(one[q], torch.cat([p[q] for p in parts])), f"output {q} depends on the launch tiling"
+    del parts
+    rgb, pdf, wo2, pdf2, w = one
+    # the separate entry points give the fused call's bits
+    assert torch.equal(gpu.eval(wi, wo, material=mid), rgb) and torch.equal(gpu.pdf(wi, wo, material=mid), pdf)
+    s_wo, s_pdf, s_w = gpu.sample(wi, u, material=mid)
+    assert torch.equal(s_wo, wo2) and torch.equal(s_pdf, pdf2) and torch.equal(s_w, w)
+    del s_wo, s_pdf, s_w
+    # a strided sample against the oracle (tolerances of tests/test_gpu_parity.py::test_ggx_matches_oracle)
+    idx = _spot(N64)
+    G = oracle.OracleGgx(np.float32(0.1).item(), [np.float32(x).item() for x in eta], [np.float32(x).item() for x in k])
+    hwi, hwo, hu = wi[idx].cpu().numpy(), wo[idx].cpu().numpy(), u[idx].cpu().numpy()
+    assert _rel_ok(rgb[idx].cpu().numpy(), G.eval(hwi, hwo)) and _rel_ok(pdf[idx].cpu().numpy(), G.pdf(hwi, hwo))
+    c_wo, c_pdf, c_w = G.sample(hwi, hu)
+    assert float(np.abs(wo2[idx].cpu().numpy().astype(np.float64) - c_wo).max()) <= 1.2e-7
+    assert _rel_ok(pdf2[idx].cpu().numpy(), c_pdf, rel=2e-6) and _rel_ok(w[idx].cpu().numpy(), c_w)
+    # reciprocity of the BRDF over all units: eval(wi, wo) / wo.z == eval(wo, wi) / wi.z  (f64 results rounded once to Float)
+    f_oi = gpu.eval(wo, wi, material=mid)
+    a = rgb.double() / wo[:, 2:3].double()
+    b = f_oi.double() / wi[:, 2:3].double()
+    assert bool(((a - b).abs() <= 4e-7 * a.abs() + 1e-30).all()), "f(wi, wo) != f(wo, wi)"
+    del a, b, f_oi
+    # sample(): accepted directions are unit vectors above the horizon, their pdf is what pdf() says there, the weight F G1 is bounded
+    live = pdf2 > 0
+    assert 0.5 < float(live.float().mean()) <= 1.0
+    assert bool((wo2[live][:, 2] > 0).all()) and bool(((wo2[live].double().norm(dim=1) - 1).abs() < 3e-7).all())
+    back = gpu.pdf(wi, wo2, material=mid)
+    rel = ((back[live].double() - pdf2[live].double()).abs() / pdf2[live].double())
+    # (the device forms the pdf at the f64 direction, pdf() at its Float rounding: 1e-7 of direction error against a lobe of width alpha)
+    assert float(rel.max()) < 2e-4 and float((rel > 3e-6).float().mean()) < 1e-3
+    assert bool((w[live] >= 0).all()) and bool((w[live] <= 1.0 + 1e-6).all())
+    assert bool((w[~live] == 0).all()) and bool((wo2[~live] == 0).all())
