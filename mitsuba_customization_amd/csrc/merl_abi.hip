@@ -109,14 +109,17 @@ mrl::MaterialDev tombstone_dev(const mrl_ctx *ctx)
 
 
 // MRL_ERR_OOM when `need` more bytes of material data would exceed the context's budget or the device's free memory
-int budget_check(mrl_ctx *ctx, size_t need)
+// in_arena: that many of the `need` bytes will be placed in the context's table arena, which is allocated already (they count
+// against the budget, not against the device's free memory)
+int budget_check(mrl_ctx *ctx, size_t need, size_t in_arena)
 {
     if (ctx->memory_limit && ctx->material_bytes + need > ctx->memory_limit)
         return fail(ctx, MRL_ERR_OOM, "material needs " + std::to_string(need >> 20) + " MiB: over the context's budget (" +
                                       std::to_string(ctx->material_bytes >> 20) + " of " + std::to_string(ctx->memory_limit >> 20) + " MiB in use)");
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b)
-        return fail(ctx, MRL_ERR_OOM, "material needs " + std::to_string(need >> 20) + " MiB, the device has " + std::to_string(free_b >> 20) + " MiB free");
+    const size_t fresh = need > in_arena ? need - in_arena : 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && fresh > free_b)
+        return fail(ctx, MRL_ERR_OOM, "material needs " + std::to_string(fresh >> 20) + " MiB, the device has " + std::to_string(free_b >> 20) + " MiB free");
     (void)hipGetLastError();
     return MRL_OK;
 }
@@ -144,6 +147,13 @@ int place_material(mrl_ctx *ctx, const MaterialHost &m, int *out_id)
 
 // Table storage: a slice of the context's arena while it has room (back to back, 2 MiB aligned: one mapping with the
 // largest page fragments the driver grants, instead of one mapping per table), else an allocation of its own.
+bool arena_has_room(const mrl_ctx *ctx, size_t bytes)
+{
+    const size_t align = (size_t)2 << 20;
+    const size_t at = (ctx->arena_used + align - 1) / align * align;
+    return ctx->arena && at + bytes <= ctx->arena_bytes;
+}
+
 hipError_t table_alloc(mrl_ctx *ctx, size_t bytes, float4 **out, bool *in_arena)
 {
     const size_t align = (size_t)2 << 20;
@@ -514,7 +524,8 @@ int mrl_memory_info(const mrl_ctx *ctx, size_t *material_bytes, size_t *workspac
     MRL_GUARD(ctx);
     if (material_bytes) *material_bytes = ctx->material_bytes;
     if (workspace_bytes)
-        *workspace_bytes = ctx->d_stage_bytes + (ctx->queue_cap ? (2 * ctx->queue_cap + 4 * kMaxSegments + 2) * sizeof(uint32_t) : 0) +
+        // (the table arena is workspace for as far as no table lives in it: tables placed there are counted as material bytes)
+        *workspace_bytes = (ctx->arena_bytes > ctx->arena_used ? ctx->arena_bytes - ctx->arena_used : 0) + ctx->d_stage_bytes + (ctx->queue_cap ? (2 * ctx->queue_cap + 4 * kMaxSegments + 2) * sizeof(uint32_t) : 0) +
                            ctx->part_work_cap * sizeof(uint32_t) + ctx->d_materials_cap * sizeof(mrl::MaterialDev) +
                            (ctx->d_dummy ? 256 + 5 * sizeof(double) : 0);
     if (device_free || device_total) {

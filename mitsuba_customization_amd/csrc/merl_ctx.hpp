@@ -229,7 +229,8 @@ int common_kind(std::initializer_list<const void *> ptrs);        // 0 / 1, or -
 int sync_material_array(mrl_ctx *ctx);
 int ensure_dummy(mrl_ctx *ctx);
 mrl::MaterialDev tombstone_dev(const mrl_ctx *ctx);
-int budget_check(mrl_ctx *ctx, size_t need);
+int budget_check(mrl_ctx *ctx, size_t need, size_t in_arena = 0);
+bool arena_has_room(const mrl_ctx *ctx, size_t bytes);           // would table_alloc place `bytes` in the context's arena?
 int place_material(mrl_ctx *ctx, const MaterialHost &m, int *out_id);
 hipError_t table_alloc(mrl_ctx *ctx, size_t bytes, float4 **out, bool *in_arena);
 void table_free(mrl_ctx *ctx, float4 *p, bool in_arena);

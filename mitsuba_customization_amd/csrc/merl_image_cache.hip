@@ -129,6 +129,8 @@ int mrl_material_load_image(mrl_ctx *ctx, const char *path, int *out_id)
     if (payload_bytes && std::fread(payload.data(), 1, payload_bytes, f) != payload_bytes) return refuse("short read");
     std::fclose(f);
     if (image_checksum(payload.data(), payload.size(), mrl::kImageChecksumSeed) != h.checksum) return fail(ctx, MRL_ERR_FORMAT, std::string("checksum mismatch (") + path + ")");
+    // the checksum is unkeyed: what a foreign writer could have put there is checked for being evaluable
+    if (const char *why = mrl::image_content_check(plan, payload.data())) return fail(ctx, MRL_ERR_FORMAT, std::string(why) + " (" + path + ")");
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     MaterialHost m;
     const bool expand = !is_rgl && !is_nch && d.layout == mrl::LAYOUT_BRICK;      // rows on disk, bricks on this context

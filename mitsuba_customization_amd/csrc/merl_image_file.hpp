@@ -165,4 +165,45 @@ inline const char *image_plan(const ImageHeader &h, unsigned long long file_byte
     return nullptr;
 }
 
+// What the checksum cannot say (it is unkeyed: it catches corruption, not a foreign writer): is the CONTENT something the kernels can
+// evaluate?  Every value finite; an RGL image's parameter grids (and wavelength grid) strictly ascending, its two distributions and their
+// running integrals non-negative; a table image's sampling rows monotone cdfs in [0, 1] with non-negative densities.  Searches are
+// index-bounded either way (memory-safe); this keeps a crafted or foreign image from evaluating to NaN / garbage with MRL_OK.
+// payload: plan.payload_bytes bytes.  nullptr, or what is wrong.
+inline const char *image_content_check(const ImagePlan &p, const void *payload)
+{
+    auto finite = [](double v) { return v == v && v - v == 0.0; };
+    const float *f = (const float *)payload;
+    const size_t n_floats = (size_t)(p.texel_bytes / 4);
+    for (size_t i = 0; i < n_floats; ++i) if (!finite((double)f[i])) return "non-finite value in the image";
+    if (p.is_rgl) {
+        const RglFields &s = p.shapes;
+        auto ascending = [&](size_t at, int n) { for (int i = 1; i < n; ++i) if (!(f[at + i] > f[at + i - 1])) return false; return true; };
+        if (!ascending(p.layout.phi, s.n_phi) || !ascending(p.layout.theta, s.n_theta) || (s.n_wl > 0 && !ascending(p.layout.wavelengths, s.n_wl)))
+            return "phi_i / theta_i / wavelengths must be strictly ascending";
+        const size_t cells = (size_t)(s.res[0] - 1) * (size_t)(s.res[1] - 1), slices = (size_t)s.n_phi * (size_t)s.n_theta;
+        const size_t tb = rgl_theta_brackets(s.n_theta), pb = rgl_phi_brackets(s.n_phi);
+        for (int w = 2; w <= 3; ++w) {                       // vndf, luminance: densities and their integrals
+            const size_t spans[3][2] = { { p.layout.cells[w], cells * 4 * slices }, { p.layout.cond2[w], cells * 4 * (size_t)s.n_phi * tb },
+                                         { p.layout.margq[w], (size_t)(s.res[1] - 1) * 4 * pb * tb } };
+            for (const auto &sp : spans)
+                for (size_t i = 0; i < sp[1]; ++i) if (f[sp[0] + i] < 0.0f) return "negative value in a distribution of the image";
+        }
+    } else {
+        const double *d = (const double *)((const char *)payload + p.texel_bytes);
+        const size_t n_th = (size_t)p.dims[0];
+        for (size_t i = 0; i < (size_t)(p.sampling_doubles + p.sampling2d_doubles); ++i) if (!finite(d[i])) return "non-finite value in the image's sampling rows";
+        auto row_ok = [&](const double *cdf, const double *c) {
+            for (size_t i = 0; i <= n_th; ++i) if (cdf[i] < 0.0 || cdf[i] > 1.0 + 1e-9 || (i && cdf[i] < cdf[i - 1])) return false;
+            for (size_t i = 0; i < n_th; ++i) if (c[i] < 0.0) return false;
+            return true;
+        };
+        if (p.sampling_doubles && !row_ok(d + (n_th + 1), d + 2 * (n_th + 1))) return "the image's sampling marginal is not a distribution";
+        const double *r = d + p.sampling_doubles;
+        for (int i = 0; p.sampling2d_doubles && i < kImgIncidentBins; ++i, r += 2 * n_th + 1)
+            if (!row_ok(r, r + (n_th + 1))) return "a conditional sampling row of the image is not a distribution";
+    }
+    return nullptr;
+}
+
 } // namespace mrl

@@ -67,7 +67,9 @@ int upload_table(mrl_ctx *ctx, const double *planar, const int dims[3], const do
     MaterialHost m;
     m.bytes = out_texels * sizeof(float4) + sampling_doubles * sizeof(double);
     // budget first: the resident image plus the transient planar copy the re-layout kernel reads
-    int rc = budget_check(ctx, m.bytes + 3 * plane * sizeof(double));
+    // (a table that will land in the already-allocated arena needs no free device memory of its own)
+    const size_t table_bytes = out_texels * sizeof(float4);
+    int rc = budget_check(ctx, m.bytes + 3 * plane * sizeof(double), arena_has_room(ctx, table_bytes) ? table_bytes : 0);
     if (rc != MRL_OK) return rc;
     // the file payload goes to the device as it is; a kernel scales, clamps and re-lays it out
     double *d_planar = nullptr;
@@ -454,12 +456,12 @@ int mrl_material_host_table(mrl_ctx *ctx, int id, mrl_host_table **out)
     MRL_HIP(ctx, hipSetDevice(ctx->device));
     if (mh.dev.kind == mrl::KIND_RGL || mh.dev.kind == mrl::KIND_RGL_SPECTRAL) {      // the image is position independent: copy it, move the descriptor's pointers
         MRL_HIP(ctx, hipSetDevice(ctx->device));
+        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));            // before anything is allocated: an early return leaks nothing
         mrl_host_table *t = nullptr;
         try {
             t = new mrl_host_table;
             t->rgl_image.resize(mh.bytes / sizeof(float));
         } catch (const std::bad_alloc &) { delete t; return fail(ctx, MRL_ERR_OOM, "host image"); }
-        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const hipError_t e = hipMemcpy(t->rgl_image.data(), mh.d_texels, mh.bytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { (void)hipGetLastError(); delete t; return fail(ctx, MRL_ERR_HIP, std::string("host image: ") + hipGetErrorString(e)); }
         t->rgl = mh.rgl;
@@ -479,13 +481,13 @@ int mrl_material_host_table(mrl_ctx *ctx, int id, mrl_host_table **out)
     }
     const int n_th = mh.dev.n_th, n_td = mh.dev.n_td, n_pd = mh.dev.n_pd;
     const size_t H = n_th + 1, D = n_td + 1, P = n_pd + 1, cells = (size_t)n_th * n_td * n_pd;
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));                // before anything is allocated: an early return leaks nothing
     mrl_host_table *t = nullptr;
     try {
         t = new mrl_host_table;
         t->rows.resize(H * D * P);
         t->marginal.resize(3 * (size_t)n_th + 2);
         std::vector<float4> bricks;
-        MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         hipError_t e = hipSuccess;
         if (mh.dev.layout == mrl::LAYOUT_ROWS) {
             e = hipMemcpy(t->rows.data(), mh.d_texels, t->rows.size() * sizeof(float4), hipMemcpyDeviceToHost);

@@ -108,6 +108,22 @@ def test_altered_truncated_and_mismatched_images_are_refused(tables, tmp_path):
         assert struct.unpack_from("<4i", raw_rgl, off_shape) == (1, 3, 5, 5)
         grown = bytearray(raw_rgl); struct.pack_into("<i", grown, off_shape + 8, 500)
         refused(bytes(grown), "sizes do not follow")
+        # a FOREIGN writer: structurally perfect, checksum and all, but with content no kernel can evaluate (the checksum is unkeyed)
+        def resealed(data):
+            h, mask = 0xCBF29CE484222325, (1 << 64) - 1
+            body = bytes(data[128:])
+            for k in range(0, len(body) - len(body) % 8, 8):
+                h = ((h ^ struct.unpack_from("<Q", body, k)[0]) * 0x9E3779B97F4A7C15) & mask
+                h ^= h >> 29
+            for b in body[len(body) - len(body) % 8:]:
+                h = ((h ^ b) * 0x100000001B3) & mask
+            out = bytearray(data); struct.pack_into("<Q", out, 120, h)
+            return bytes(out)
+        assert resealed(raw) == raw and resealed(raw_rgl) == raw_rgl               # the header is 128 bytes, the checksum its last word
+        nan = bytearray(raw); struct.pack_into("<f", nan, 128 + 16 * 7, float("nan"))
+        refused(resealed(nan), "non-finite")
+        desc = bytearray(raw_rgl); struct.pack_into("<f", desc, 128 + 4 * 2, -9.0)     # theta_i[1] below theta_i[0] (n_phi = 1: floats 1..3)
+        refused(resealed(desc), "ascending")
         huge = bytearray(raw_rgl); struct.pack_into("<i", huge, off_shape + 8, 50000)
         refused(bytes(huge), "nodes per axis")
         with pytest.raises(host.MerlHipError) as e:
