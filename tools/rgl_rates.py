@@ -37,6 +37,23 @@ with host.MerlHip(0) as g:
         g.set_option(host.OPT_RGL_SEARCH, 0)
         res[name] = row
         g.release_material(mid)
+    # a spectral file of the isotropic shape (195 wavelength nodes would be the database's; 32 here), four wavelengths per unit
+    mid = g.upload_rgl(synth.make_rgl_fields(seed=9, n_phi=1, n_theta=8, res=32, res_ndf=128, res_sigma=64, n_wavelengths=32))
+    wl = torch.rand(n, 4, device="cuda") * 640.0 + 360.0
+    row = {"image_bytes": g.memory_info()["table_bytes"], "wavelengths_per_unit": 4}
+    for what, call in (("eval", lambda: g.eval_spectral(wi, wo, wl, mid)), ("sample", lambda: g.sample_spectral(wi, u, wl, mid)),
+                       ("eval_sample", lambda: g.eval_sample_spectral(wi, wo, u, wl, mid))):
+        for _ in range(2):
+            out = call()
+        torch.cuda.synchronize()
+        g.timer_start()
+        for _ in range(5):
+            out = call()
+        ms = g.timer_stop() / 5
+        row[what] = {"ms": round(ms, 3), "G_units_per_s": round(n / ms / 1e6, 3)}
+    res["spectral_isotropic_8x32x32_32wl"] = row
+    g.release_material(mid)
+    del wl
     # a batch with material ids: a MERL-sized table, an analytic material and two RGL files, one quarter of the units each
     tab = g.upload_merl(synth.make_table("ggx_tab", 0))
     ggx = g.ggx(0.1, (0.143, 0.375, 1.442), (3.983, 2.386, 1.603))
