@@ -57,6 +57,47 @@ struct SearchLds {
     }
 };
 
+// The partial form for files whose conditional integrals do not fit (an anisotropic 16 x 8 x 32 x 32 file: 1.7 MB per
+// distribution): the MARGINAL rows alone, in their bracket form (one ds_read_b128 per row-search step: 52 KB per distribution for
+// that file), the conditional integrals from memory.  Takes the row searches — 5 of the ~21 dependent reads of a forward warp,
+// and the `before` read of an inverse warp — off the texture addresser.
+struct SearchLdsMarg {
+    const float4 *cond2;
+    unsigned marg_at;                   // float4 index of the table's first quad in rgl_lds
+    int per_c, per_r;
+    __device__ __forceinline__ rgl::D2 cond(const rgl::Slices &s, int cell) const
+    {
+        const float4 a = cond2[s.pair[0] * (unsigned)per_c + (unsigned)cell];
+        float4 b = a;
+        if (s.mask & 2) b = cond2[s.pair[1] * (unsigned)per_c + (unsigned)cell];
+        return rgl::blend_pairs(s, a, b);
+    }
+    __device__ __forceinline__ double marg(const rgl::Slices &s, int row) const
+    {
+        return rgl::blend_quad(s, rgl_lds[marg_at + s.quad * (unsigned)per_r + (unsigned)row]);
+    }
+};
+
+size_t lds_marg_bytes_of(const RglDev &r)
+{
+    const WarpDev &w = r.vndf;
+    const size_t tb = w.n_theta > 1 ? w.n_theta - 1 : 1, pb = w.n_phi > 1 ? w.n_phi - 1 : 1;
+    return 2 * pb * tb * (size_t)(w.ny - 1) * sizeof(float4);
+}
+
+__device__ __forceinline__ SearchLdsMarg stage_marg(const WarpDev &w, unsigned &at_float4, int block)
+{
+    const int per_r = w.ny - 1;
+    const int tb = w.n_theta > 1 ? w.n_theta - 1 : 1, pb = w.n_phi > 1 ? w.n_phi - 1 : 1;
+    SearchLdsMarg t;
+    t.cond2 = w.cond2; t.per_c = (w.nx - 1) * (w.ny - 1); t.per_r = per_r;
+    t.marg_at = at_float4;
+    const int n = pb * tb * per_r;
+    for (int k = threadIdx.x; k < n; k += block) rgl_lds[at_float4 + (unsigned)k] = w.margq[k];
+    at_float4 += (unsigned)n;
+    return t;
+}
+
 // bytes of LDS the two distributions' search tables take, slice by slice (16-B aligned pieces)
 size_t lds_bytes_of(const RglDev &r)
 {
@@ -147,20 +188,25 @@ __global__ __launch_bounds__(kRglBlock) void k_rgl(BatchArgs a, RglDev r)
 
 // The single-material launch when the file's search tables fit a CU's LDS: one workgroup per CU copies them in (once: the grid is
 // persistent) and every search step of every unit is a ds_read.  Same functions, same sums, same bits as k_rgl.
-template <int MODE, bool INDEXED>
+// MARG_ONLY: the partial form (SearchLdsMarg) for files whose conditional integrals do not fit
+template <int MODE, bool INDEXED, bool MARG_ONLY = false>
 __global__ __launch_bounds__(rgl_lds_block(MODE)) void k_rgl_lds(BatchArgs a, RglDev r)
 {
     constexpr int kRglLdsBlock = rgl_lds_block(MODE);
-    unsigned at = 0;
-    const SearchLds tv = stage_search(r.vndf, at, kRglLdsBlock);
-    const SearchLds tl = stage_search(r.luminance, at, kRglLdsBlock);
-    __syncthreads();
     const size_t stride = (size_t)gridDim.x * kRglLdsBlock;
     size_t n_items = a.n;
     if constexpr (INDEXED) { const size_t c = (size_t)*a.idx_count; n_items = c < a.n ? c : a.n; }
-    for (size_t j = (size_t)blockIdx.x * kRglLdsBlock + threadIdx.x; j < n_items; j += stride) {
-        const size_t i = INDEXED ? (size_t)a.idx[j] : j;
-        rgl_unit<MODE>(a, r, tv, tl, i);
+    unsigned at = 0;
+    if constexpr (MARG_ONLY) {
+        const SearchLdsMarg tv = stage_marg(r.vndf, at, kRglLdsBlock);
+        const SearchLdsMarg tl = stage_marg(r.luminance, at, kRglLdsBlock);
+        __syncthreads();
+        for (size_t j = (size_t)blockIdx.x * kRglLdsBlock + threadIdx.x; j < n_items; j += stride) rgl_unit<MODE>(a, r, tv, tl, INDEXED ? (size_t)a.idx[j] : j);
+    } else {
+        const SearchLds tv = stage_search(r.vndf, at, kRglLdsBlock);
+        const SearchLds tl = stage_search(r.luminance, at, kRglLdsBlock);
+        __syncthreads();
+        for (size_t j = (size_t)blockIdx.x * kRglLdsBlock + threadIdx.x; j < n_items; j += stride) rgl_unit<MODE>(a, r, tv, tl, INDEXED ? (size_t)a.idx[j] : j);
     }
 }
 
@@ -225,18 +271,29 @@ hipError_t launch_mode(const BatchArgs &a, const RglDev *r, bool indexed, int se
 {
     // LDS variant: a single-material launch large enough to pay for the copy (one image of the search tables per CU)
     if (r && search == 0 && a.n >= (size_t)1 << 15) {
-        const size_t need = lds_bytes_of(*r);
+        constexpr int kRglLdsBlock = rgl_lds_block(MODE);
+        size_t blocks = (a.n + kRglLdsBlock - 1) / kRglLdsBlock;
+        if (blocks > (size_t)compute_units) blocks = (size_t)compute_units;
+        const dim3 grid((unsigned)blocks), block(kRglLdsBlock);
+        const size_t need = lds_bytes_of(*r), need_marg = lds_marg_bytes_of(*r);
         if (need <= (size_t)lds_limit()) {
-            constexpr int kRglLdsBlock = rgl_lds_block(MODE);
-            size_t blocks = (a.n + kRglLdsBlock - 1) / kRglLdsBlock;
-            if (blocks > (size_t)compute_units) blocks = (size_t)compute_units;
-            const dim3 grid((unsigned)blocks), block(kRglLdsBlock);
             if (indexed) {
                 (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
                 hipLaunchKernelGGL((k_rgl_lds<MODE, true>), grid, block, need, stream, a, *r);
             } else {
                 (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
                 hipLaunchKernelGGL((k_rgl_lds<MODE, false>), grid, block, need, stream, a, *r);
+            }
+            return hipGetLastError();
+        }
+        // the marginal rows alone (sample modes only: eval / pdf read one marginal value per unit, not worth a copy per CU)
+        if (MODE >= 2 && MODE != 4 && need_marg <= (size_t)lds_limit()) {
+            if (indexed) {
+                (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_marg);
+                hipLaunchKernelGGL((k_rgl_lds<MODE, true, true>), grid, block, need_marg, stream, a, *r);
+            } else {
+                (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_marg);
+                hipLaunchKernelGGL((k_rgl_lds<MODE, false, true>), grid, block, need_marg, stream, a, *r);
             }
             return hipGetLastError();
         }

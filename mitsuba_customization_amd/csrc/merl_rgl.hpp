@@ -133,8 +133,29 @@ MRL_HD D4 fetch4(const Slices &s, const float4 *base, int per_slice, int index, 
     return v;
 }
 
+// the blends of the bracket vectors, in slice order (the same sums, in the same order, as a slice-by-slice read):
+// a / b: cond2 of the theta bracket at phi node ip / ip + 1 (b unused without an upper phi neighbour)
+MRL_HD D2 blend_pairs(const Slices &s, const float4 &a, const float4 &b)
+{
+#pragma clang fp contract(off)
+    D2 v = { s.w[0] * (double)a.x, s.w[0] * (double)a.y };
+    if (s.mask & 2) { v.x = __builtin_fma(s.w[1], (double)b.x, v.x); v.y = __builtin_fma(s.w[1], (double)b.y, v.y); }
+    if (s.mask & 4) { v.x = __builtin_fma(s.w[2], (double)a.z, v.x); v.y = __builtin_fma(s.w[2], (double)a.w, v.y); }
+    if (s.mask & 8) { v.x = __builtin_fma(s.w[3], (double)b.z, v.x); v.y = __builtin_fma(s.w[3], (double)b.w, v.y); }
+    return v;
+}
+MRL_HD double blend_quad(const Slices &s, const float4 &q)
+{
+#pragma clang fp contract(off)
+    double v = s.w[0] * (double)q.x;
+    if (s.mask & 2) v = __builtin_fma(s.w[1], (double)q.y, v);
+    if (s.mask & 4) v = __builtin_fma(s.w[2], (double)q.z, v);
+    if (s.mask & 8) v = __builtin_fma(s.w[3], (double)q.w, v);
+    return v;
+}
+
 // The search tables of one distribution read from memory: one load serves the two theta slices of a bracket (cond2) or all
-// four slices (margq).  The same sums, in the same order, as a slice-by-slice read.
+// four slices (margq).
 struct SearchMem {
     const float4 *cond2, *margq;
     int per_c, per_r;
@@ -142,29 +163,13 @@ struct SearchMem {
     // the conditional running integrals of node rows (row, row + 1) up to node col + 1, cell = row (nx - 1) + col
     MRL_HD D2 cond(const Slices &s, int cell) const
     {
-#pragma clang fp contract(off)
         const float4 a = cond2[s.pair[0] * (unsigned)per_c + (unsigned)cell];
-        D2 v = { s.w[0] * (double)a.x, s.w[0] * (double)a.y };
         float4 b = a;
-        if (s.mask & 2) {
-            b = cond2[s.pair[1] * (unsigned)per_c + (unsigned)cell];
-            v.x = __builtin_fma(s.w[1], (double)b.x, v.x); v.y = __builtin_fma(s.w[1], (double)b.y, v.y);
-        }
-        if (s.mask & 4) { v.x = __builtin_fma(s.w[2], (double)a.z, v.x); v.y = __builtin_fma(s.w[2], (double)a.w, v.y); }
-        if (s.mask & 8) { v.x = __builtin_fma(s.w[3], (double)b.z, v.x); v.y = __builtin_fma(s.w[3], (double)b.w, v.y); }
-        return v;
+        if (s.mask & 2) b = cond2[s.pair[1] * (unsigned)per_c + (unsigned)cell];
+        return blend_pairs(s, a, b);
     }
     // the marginal cdf after cell row `row`
-    MRL_HD double marg(const Slices &s, int row) const
-    {
-#pragma clang fp contract(off)
-        const float4 q = margq[s.quad * (unsigned)per_r + (unsigned)row];
-        double v = s.w[0] * (double)q.x;
-        if (s.mask & 2) v = __builtin_fma(s.w[1], (double)q.y, v);
-        if (s.mask & 4) v = __builtin_fma(s.w[2], (double)q.z, v);
-        if (s.mask & 8) v = __builtin_fma(s.w[3], (double)q.w, v);
-        return v;
-    }
+    MRL_HD double marg(const Slices &s, int row) const { return blend_quad(s, margq[s.quad * (unsigned)per_r + (unsigned)row]); }
 };
 
 MRL_HD int clamp_cell(double p, int last)
