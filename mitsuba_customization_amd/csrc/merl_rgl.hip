@@ -165,8 +165,11 @@ __device__ __forceinline__ void rgl_unit(const BatchArgs &a, const RglDev &r, co
 // MULTI: a batch with a material id per unit — the lanes whose id names an RGL material evaluate it through the descriptor
 // stored behind that material's image (read on demand: a few more cache-resident loads per lookup) and overwrite the zeros
 // the table / GGX kernel of the same call left there; every other lane skips.  Launched after that kernel, on the same stream.
+// (three blocks per CU = three waves per SIMD: the sample modes sit at 169-172 VGPRs, one register over the 168 that a third wave
+// allows — the bound makes the compiler find it; the kernel waits on memory, a third wave is worth more than the register;
+// eval + pdf: four waves, 128 VGPRs)
 template <int MODE, bool INDEXED, bool MULTI>
-__global__ __launch_bounds__(kRglBlock) void k_rgl(BatchArgs a, RglDev r)
+__global__ __launch_bounds__(kRglBlock, (MODE == 2 || MODE == 3) ? 3 : 4) void k_rgl(BatchArgs a, RglDev r)
 {
     const size_t stride = (size_t)gridDim.x * kRglBlock;
     size_t n_items = a.n;
@@ -286,8 +289,9 @@ hipError_t launch_mode(const BatchArgs &a, const RglDev *r, bool indexed, int se
             }
             return hipGetLastError();
         }
-        // the marginal rows alone (sample modes only: eval / pdf read one marginal value per unit, not worth a copy per CU)
-        if (MODE >= 2 && MODE != 4 && need_marg <= (size_t)lds_limit()) {
+        // the marginal rows alone — sample() alone: eval / pdf read one marginal value per unit (not worth a copy per CU), and the fused
+        // unit of such a file is issued as two launches (launch_rgl)
+        if (MODE == 2 && need_marg <= (size_t)lds_limit()) {
             if (indexed) {
                 (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_marg);
                 hipLaunchKernelGGL((k_rgl_lds<MODE, true, true>), grid, block, need_marg, stream, a, *r);
@@ -516,6 +520,15 @@ hipError_t launch_rgl_spectral(int mode, const BatchArgs &a, const RglDev &r, co
 hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev *r, bool indexed, int search, int compute_units, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
+    // The fused unit of a file whose search tables do not fit a CU's LDS (an anisotropic file: its lookups blend four slices of a
+    // 14 MB image, the launch waits on L2 / memory): eval + pdf and sample() as TWO launches on the stream.  The fused kernel carries
+    // sample()'s 170 VGPRs through its eval as well (2-3 waves per SIMD); apart, eval + pdf runs at 5 waves per SIMD and sample()
+    // with its marginal rows in LDS — 16M units: 7.1 ms fused, 6.2 ms apart (profiles/r04_rgl_rates.json); the 12 B per unit of wi
+    // read twice do not show.  Same functions, same bits (the separate entry points are bit-compared with the fused one).
+    if (mode == 3 && r && search == 0 && a.n >= (size_t)1 << 15 && lds_bytes_of(*r) > (size_t)lds_limit()) {
+        const hipError_t e = launch_mode<4>(a, r, indexed, search, compute_units, stream);
+        return e != hipSuccess ? e : launch_mode<2>(a, r, indexed, search, compute_units, stream);
+    }
     switch (mode) {
         case 0: return launch_mode<0>(a, r, indexed, search, compute_units, stream);
         case 1: return launch_mode<1>(a, r, indexed, search, compute_units, stream);

@@ -24,6 +24,7 @@ with host.MerlHip(0) as g:
             g.set_option(host.OPT_RGL_SEARCH, search)
             sub = {}
             for what, call in (("eval", lambda: g.eval(wi, wo, material=mid)), ("pdf", lambda: g.pdf(wi, wo, material=mid)),
+                               ("eval_pdf", lambda: g.eval_pdf(wi, wo, material=mid)),
                                ("sample", lambda: g.sample(wi, u, material=mid)), ("eval_sample", lambda: g.eval_sample(wi, wo, u, material=mid))):
                 for _ in range(2):
                     out = call()
