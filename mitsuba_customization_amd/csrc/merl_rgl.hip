@@ -165,11 +165,16 @@ __device__ __forceinline__ void rgl_unit(const BatchArgs &a, const RglDev &r, co
 // MULTI: a batch with a material id per unit — the lanes whose id names an RGL material evaluate it through the descriptor
 // stored behind that material's image (read on demand: a few more cache-resident loads per lookup) and overwrite the zeros
 // the table / GGX kernel of the same call left there; every other lane skips.  Launched after that kernel, on the same stream.
-// (three blocks per CU = three waves per SIMD: the sample modes sit at 169-172 VGPRs, one register over the 168 that a third wave
-// allows — the bound makes the compiler find it; the kernel waits on memory, a third wave is worth more than the register;
-// eval + pdf: four waves, 128 VGPRs)
+// Blocks per CU the compiler is asked to make room for (= waves per SIMD): the kernel waits on memory, a wave more is worth a
+// register or two.  sample() alone sits at 167 VGPRs: 3; eval + pdf at 131: 4 (128 VGPRs, 3 dwords of scratch); the fused unit inside
+// a batch with ids at 172: 3 (168, no spill: 3.75 -> 3.32 ms on the mixed batch of tools/rgl_rates.py) — but the fused
+// single-material kernel spills at 168 and LOSES (7.06 -> 8.14 ms on the anisotropic file): 2, as it was.
+#ifndef MRL_RGL_EVALPDF_BLOCKS
+#define MRL_RGL_EVALPDF_BLOCKS 4
+#endif
+constexpr int rgl_min_blocks(int mode, bool multi) { return mode == 3 ? (multi ? 3 : 2) : (mode == 2 ? 3 : (mode == 4 ? MRL_RGL_EVALPDF_BLOCKS : 4)); }
 template <int MODE, bool INDEXED, bool MULTI>
-__global__ __launch_bounds__(kRglBlock, (MODE == 2 || MODE == 3) ? 3 : 4) void k_rgl(BatchArgs a, RglDev r)
+__global__ __launch_bounds__(kRglBlock, rgl_min_blocks(MODE, MULTI)) void k_rgl(BatchArgs a, RglDev r)
 {
     const size_t stride = (size_t)gridDim.x * kRglBlock;
     size_t n_items = a.n;
