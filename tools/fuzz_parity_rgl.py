@@ -28,7 +28,33 @@ def outside_range(B, what, got, wi, wo):
     return not B.in_conditioning_range(kind, got, wi, wo)
 
 
+def spectral_round(r, rng, shape, worst, beyond, n):
+    """every fifth round also builds the SPECTRAL file of the same shape (1..24 wavelength nodes) and checks values / weights at four
+    per-unit wavelengths (some outside the grid) — counted under "spectral_values" / "spectral_weights" (1e-6 relative, no exemptions:
+    random pairs; a near-mirror unit would show up here as a count)"""
+    sp = dict(shape); sp["n_wavelengths"] = int(rng.integers(1, 25))
+    fields = synth.make_rgl_fields(**sp)
+    B = ob.OracleRgl(fields)
+    m = n // 4
+    wi, wo, u = ob.generate_pairs(0xBEEF + r, r * 104729, m)
+    lo, hi = float(fields["wavelengths"][0]), float(fields["wavelengths"][-1])
+    wl = rng.uniform(lo - 50.0, hi + 50.0, (m, 4)).astype(np.float32)
+    with host.MerlHip(0) as g:
+        g.set_option(host.OPT_RGL_SEARCH, r % 2)
+        mid = g.upload_rgl(fields)
+        val, pdf, wo2, pdf2, w = [np.asarray(t) for t in g.eval_sample_spectral(wi, wo, u, wl, mid)]
+    o_val, o_pdf = B.eval_pdf_spectral(wi, wo, wl)
+    live = pdf2 > 0
+    c_val, c_pdf = B.eval_pdf_spectral(wi[live], wo2[live], wl[live])
+    for k, e in (("spectral_values", rel(val, o_val)), ("spectral_weights", rel(w[live], c_val / c_pdf[:, None]))):
+        if e.size:
+            worst[k] = max(worst.get(k, 0.0), float(e.max()))
+            beyond[k] = beyond.get(k, 0) + int(np.count_nonzero(e > 1e-6))
+    return m
+
+
 def soak(rounds, n):
+    spectral_units = 0
     worst = {"eval": 0.0, "pdf": 0.0, "sample_pdf": 0.0, "sample_weight": 0.0, "direction_abs": 0.0}
     beyond = {k: 0 for k in worst}
     outside = {k: 0 for k in worst if k != "direction_abs"}
@@ -67,6 +93,8 @@ def soak(rounds, n):
                     sel = queue.long().cpu().numpy()
                     got = [t[queue.long()].cpu().numpy() for t in out]
                     wi, wo, u = wi[sel], wo[sel], u[sel]
+        if r % 5 == 4:
+            spectral_units += spectral_round(r, rng, shape, worst, beyond, n)
         rgb, pdf, wo2, pdf2, w = got
         o_rgb, o_pdf = B.eval_pdf(wi, wo)
         o_wo2, o_pdf2, _ = B.sample(wi, u)
@@ -89,11 +117,11 @@ def soak(rounds, n):
                 worst[k] = max(worst[k], float(e.max()))
                 over = e > (5e-7 if k == "direction_abs" else 1e-6)
                 beyond[k] += int(np.count_nonzero(over))
-                if k != "direction_abs":
+                if k != "direction_abs" and k in outside:
                     for j in np.nonzero(over.reshape(over.shape[0], -1).any(axis=1))[0]:
                         outside[k] += int(outside_range(B, k, val[j], a_in[j], a_out[j]))
         total += wi.shape[0]
-    return {"rounds": rounds, "units": total, "files": shapes, "worst": {k: float(f"{v:.3g}") for k, v in worst.items()},
+    return {"rounds": rounds, "units": total, "spectral_units": spectral_units, "files": shapes, "worst": {k: float(f"{v:.3g}") for k, v in worst.items()},
             "beyond_1e-6 (direction: 5e-7 absolute)": beyond, "outside_the_oracles_rounding_range": outside,
             "sampled_above_horizon_mismatches": live_mismatch, "worst_sample_pdf_unit": worst_case,
             "error_measure": "|gpu - oracle| / |oracle| for every value (floor 1e-30); sample pdf / weight against the oracle AT the device's direction; "
