@@ -17,18 +17,23 @@ with host.MerlHip(0) as g:
     tab = g.upload_merl(synth.make_table("ggx_tab", 0))
     ggx = g.ggx(0.1, (0.143, 0.375, 1.442), (3.983, 2.386, 1.603))
     wi, wo, u = g.generate_pairs(0x5EED, 0, n)
+    # the 100-table set of BASELINE configs[4] (translation-bound): material ids per unit
+    g.set_option(host.OPT_TABLE_ARENA_MB, 20480)
+    many = [g.upload_merl(synth.make_table("ggx_tab", s % 16)) for s in range(100)]
+    mat = g.generate_materials(0x5EED, 0, n, 100) + many[0]
     ref = {}
     for k in (0, 4, 8, 16, 0):
         # (the context's own stream carries the mask: no use_torch_stream here)
         g.set_option(host.OPT_RESERVED_CUS, k)
         row = {"reserved_cus": k, "compute_units_for_grids": g.compute_units - k}
-        for name, mid in (("merl64m", tab), ("ggx64m", ggx)):
+        for name, mid in (("merl64m", tab), ("ggx64m", ggx), ("resident100_64m", None)):
+            call = (lambda: g.eval_sample(wi, wo, u, mat=mat)) if mid is None else (lambda: g.eval_sample(wi, wo, u, material=mid))
             for _ in range(3):
-                out = g.eval_sample(wi, wo, u, material=mid)
+                out = call()
             g.synchronize()
             g.timer_start()
             for _ in range(10):
-                out = g.eval_sample(wi, wo, u, material=mid)
+                out = call()
             ms = g.timer_stop() / 10
             g.synchronize()
             same = True
