@@ -130,7 +130,7 @@ def parse(argv=None):
                    help="N>1: skip the full-shape BASELINE configs[4] block (100 resident tables, --configs4-units pairs over the N devices, "
                         "compute-only / rgb-only gather / full gather for both transports, native C++ host)")
     p.add_argument("--configs4-units", type=int, default=10**9, help="N>1: total units of the configs[4] block (BASELINE: 1B pairs)")
-    p.add_argument("--configs4-deadline", type=float, default=420.0, help="N>1: seconds before one leg of the configs[4] block is killed")
+    p.add_argument("--configs4-deadline", type=float, default=240.0, help="N>1: seconds before one leg of the configs[4] block is killed")
     p.add_argument("--configs4-reserve-cus", type=int, default=8,
                    help="N>1: compute units per device that the second run of each transport leaves to the transfer kernels (MRL_OPT_RESERVED_CUS)")
     return p.parse_args(argv)
