@@ -48,6 +48,24 @@ extern "C" int mrl_material_upload_rgl(mrl_ctx *, const mrl_rgl_fields *f, int *
     return MRL_OK;
 }
 
+// ... and of a spectral file: spectra [n_phi][n_theta][n_wavelengths][res][res] over wavelengths [n_wavelengths]
+static int g_spectral_uploads = 0;
+extern "C" int mrl_material_upload_rgl_spectral(mrl_ctx *, const mrl_rgl_spectral_fields *sp, int *out_id)
+{
+    const mrl_rgl_fields *f = &sp->base;
+    double sum = 0.0;
+    auto eat = [&](const float *p, size_t n) { for (size_t i = 0; i < n; ++i) sum += p[i]; };
+    const size_t slices = (size_t)f->n_phi * (size_t)f->n_theta, per = (size_t)f->res[0] * (size_t)f->res[1];
+    if (f->rgb || sp->n_wavelengths < 1) std::abort();
+    eat(f->phi_i, (size_t)f->n_phi); eat(f->theta_i, (size_t)f->n_theta);
+    eat(f->ndf, (size_t)f->res_ndf[0] * f->res_ndf[1]); eat(f->sigma, (size_t)f->res_sigma[0] * f->res_sigma[1]);
+    eat(f->vndf, slices * per); eat(f->luminance, slices * per);
+    eat(sp->wavelengths, (size_t)sp->n_wavelengths); eat(sp->spectra, slices * per * (size_t)sp->n_wavelengths);
+    *out_id = sum == 12345.0 ? 1 : 0;
+    ++g_spectral_uploads;
+    return MRL_OK;
+}
+
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
 
@@ -83,15 +101,16 @@ static std::vector<unsigned char> good_file(const double *param_as_f64 = nullptr
 }
 
 // a well-formed file with the RGL field names: n_phi = 1, n_theta = 2, 3 x 2 warps, 2 x 2 ndf, 3 x 2 sigma
-static std::vector<unsigned char> good_rgl_file()
+static std::vector<unsigned char> good_rgl_file(bool spectral = false)
 {
     std::vector<unsigned char> b;
     put(b, "tensor_file", 12);
     const uint8_t ver[2] = { 1, 0 }; put(b, ver, 2);
     struct F { const char *name; uint8_t dtype; std::vector<uint64_t> shape; };
     const std::vector<F> fs = { { "phi_i", 10, { 1 } }, { "theta_i", 10, { 2 } }, { "ndf", 10, { 2, 2 } }, { "sigma", 10, { 2, 3 } },
-                                { "vndf", 10, { 1, 2, 2, 3 } }, { "luminance", 10, { 1, 2, 2, 3 } }, { "rgb", 10, { 1, 2, 3, 2, 3 } },
-                                { "jacobian", 1, { 1 } } };
+                                { "vndf", 10, { 1, 2, 2, 3 } }, { "luminance", 10, { 1, 2, 2, 3 } },
+                                spectral ? F{ "spectra", 10, { 1, 2, 5, 2, 3 } } : F{ "rgb", 10, { 1, 2, 3, 2, 3 } },
+                                spectral ? F{ "wavelengths", 10, { 5 } } : F{ "jacobian", 1, { 1 } } };
     const uint32_t nf = (uint32_t)fs.size(); put(b, &nf, 4);
     size_t head = b.size();
     for (const F &f : fs) head += 2 + std::strlen(f.name) + 2 + 1 + 8 + 8 * f.shape.size();
@@ -191,6 +210,20 @@ int main(int argc, char **argv)
             if (rc == MRL_OK) ++opened; else ++refused;
         }
         std::printf("rgl files handed on: %d\n", g_rgl_uploads);
+        // the spectral variant of the file ("spectra" + "wavelengths" instead of "rgb")
+        const std::vector<unsigned char> spec = good_rgl_file(true);
+        if (probe(path, spec) != MRL_OK || g_spectral_uploads != 1) { std::fprintf(stderr, "the well-formed spectral RGL file was rejected: %s\n", mrl_tensor_file_last_error(nullptr)); return 1; }
+        for (int round = 0; round < 4000; ++round) {
+            std::vector<unsigned char> b = spec;
+            const int kind = (int)(rnd() % 4);
+            if (kind == 0) { for (int k = 0, m = 1 + (int)(rnd() % 4); k < m; ++k) b[rnd() % 340] ^= (unsigned char)(1u << (rnd() % 8)); }
+            else if (kind == 1) b.resize(rnd() % b.size());
+            else if (kind == 2) { const uint64_t v = (rnd() % 2) ? ~0ull >> (rnd() % 40) : rnd() % 64; std::memcpy(&b[18 + rnd() % 300], &v, 8); }
+            else b[rnd() % b.size()] = (unsigned char)rnd();
+            const int rc = probe(path, b);
+            if (rc == MRL_OK) ++opened; else ++refused;
+        }
+        std::printf("spectral rgl files handed on: %d\n", g_spectral_uploads);
     }
     // a float-typed "parameterization": only 0.0, 1.0, 2.0 are values of enum mrl_param; NaN, infinities and magnitudes
     // beyond the integer range must be refused BEFORE any float -> integer conversion (-fsanitize=float-cast-overflow)
