@@ -528,7 +528,7 @@ hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev *r, bool indexe
     // The fused unit of a file whose search tables do not fit a CU's LDS (an anisotropic file: its lookups blend four slices of a
     // 14 MB image, the launch waits on L2 / memory): eval + pdf and sample() as TWO launches on the stream.  The fused kernel carries
     // sample()'s 170 VGPRs through its eval as well (2-3 waves per SIMD); apart, eval + pdf runs at 5 waves per SIMD and sample()
-    // with its marginal rows in LDS — 16M units: 7.1 ms fused, 6.2 ms apart (profiles/r04_rgl_rates.json); the 12 B per unit of wi
+    // with its marginal rows in LDS — 16M units: 7.03 ms fused, 6.63 ms apart on one box (profiles/r04_rgl_rates.json); the 12 B per unit of wi
     // read twice do not show.  Same functions, same bits (the separate entry points are bit-compared with the fused one).
     if (mode == 3 && r && search == 0 && a.n >= (size_t)1 << 15 && lds_bytes_of(*r) > (size_t)lds_limit()) {
         const hipError_t e = launch_mode<4>(a, r, indexed, search, compute_units, stream);
