@@ -51,7 +51,7 @@ int mrl_material_save_image(mrl_ctx *ctx, int id, const char *path)
     h.dims[0] = d.n_th; h.dims[1] = d.n_td; h.dims[2] = d.n_pd;
     if (rgl_kind) {
         const mrl::RglDev &r = mh.rgl;
-        const int32_t shape[8] = { r.vndf.n_phi, r.vndf.n_theta, r.vndf.nx, r.vndf.ny, r.ndf.nx, r.ndf.ny, r.sigma.nx, r.sigma.ny };
+        const int32_t shape[8] = { r.n_phi, r.n_theta, r.nx, r.ny, r.ndf_nx, r.ndf_ny, r.sigma_nx, r.sigma_ny };
         std::memcpy(h.rgl_shape, shape, sizeof shape);
         h.rgl_flags[0] = r.jacobian; h.rgl_flags[1] = r.n_wl;
         mrl::RglLayout l;

@@ -466,14 +466,7 @@ int mrl_material_host_table(mrl_ctx *ctx, int id, mrl_host_table **out)
         if (e != hipSuccess) { (void)hipGetLastError(); delete t; return fail(ctx, MRL_ERR_HIP, std::string("host image: ") + hipGetErrorString(e)); }
         t->rgl = mh.rgl;
         const char *from = (const char *)mh.d_texels, *to = (const char *)t->rgl_image.data();
-        mrl::WarpDev *all[5] = { &t->rgl.ndf, &t->rgl.sigma, &t->rgl.vndf, &t->rgl.luminance, &t->rgl.rgb };
-        for (mrl::WarpDev *w : all) {
-            w->cells = (const float4 *)(to + ((const char *)w->cells - from));
-            if (w->cond2) w->cond2 = (const float4 *)(to + ((const char *)w->cond2 - from));
-            if (w->margq) w->margq = (const float4 *)(to + ((const char *)w->margq - from));
-            w->phi = (const float *)(to + ((const char *)w->phi - from)); w->theta = (const float *)(to + ((const char *)w->theta - from));
-        }
-        if (t->rgl.wavelengths) t->rgl.wavelengths = (const float *)(to + ((const char *)t->rgl.wavelengths - from));
+        t->rgl.rebase(from, to);
         t->m = mh.dev;
         t->opts = ctx->opts;
         *out = t;

@@ -30,17 +30,16 @@ extern __shared__ float4 rgl_lds[];
 
 struct SearchLds {
     unsigned cond_at, marg_at;          // float2 / float index of the table's first element in rgl_lds
-    int per_c, per_r;
     __device__ __forceinline__ rgl::D2 cond(const rgl::Slices &s, int cell) const
     {
 #pragma clang fp contract(off)
         const float2 *t = (const float2 *)rgl_lds + cond_at;
-        const float2 q0 = t[s.s[0] * (unsigned)per_c + (unsigned)cell];
+        const float2 q0 = t[s.soff[0] + (unsigned)cell];
         rgl::D2 v = { s.w[0] * (double)q0.x, s.w[0] * (double)q0.y };
 #pragma unroll
         for (int k = 1; k < 4; ++k)
             if ((s.mask >> k) & 1) {
-                const float2 q = t[s.s[k] * (unsigned)per_c + (unsigned)cell];
+                const float2 q = t[s.soff[k] + (unsigned)cell];
                 v.x = __builtin_fma(s.w[k], (double)q.x, v.x); v.y = __builtin_fma(s.w[k], (double)q.y, v.y);
             }
         return v;
@@ -49,10 +48,10 @@ struct SearchLds {
     {
 #pragma clang fp contract(off)
         const float *t = (const float *)rgl_lds + marg_at;
-        double v = s.w[0] * (double)t[s.s[0] * (unsigned)per_r + (unsigned)row];
+        double v = s.w[0] * (double)t[s.roff[0] + (unsigned)row];
 #pragma unroll
         for (int k = 1; k < 4; ++k)
-            if ((s.mask >> k) & 1) v = __builtin_fma(s.w[k], (double)t[s.s[k] * (unsigned)per_r + (unsigned)row], v);
+            if ((s.mask >> k) & 1) v = __builtin_fma(s.w[k], (double)t[s.roff[k] + (unsigned)row], v);
         return v;
     }
 };
@@ -64,23 +63,22 @@ struct SearchLds {
 struct SearchLdsMarg {
     const float4 *cond2;
     unsigned marg_at;                   // float4 index of the table's first quad in rgl_lds
-    int per_c, per_r;
     __device__ __forceinline__ rgl::D2 cond(const rgl::Slices &s, int cell) const
     {
-        const float4 a = cond2[s.pair[0] * (unsigned)per_c + (unsigned)cell];
+        const float4 a = cond2[s.pair[0] + (unsigned)cell];
         float4 b = a;
-        if (s.mask & 2) b = cond2[s.pair[1] * (unsigned)per_c + (unsigned)cell];
+        if (s.mask & 2) b = cond2[s.pair[1] + (unsigned)cell];
         return rgl::blend_pairs(s, a, b);
     }
     __device__ __forceinline__ double marg(const rgl::Slices &s, int row) const
     {
-        return rgl::blend_quad(s, rgl_lds[marg_at + s.quad * (unsigned)per_r + (unsigned)row]);
+        return rgl::blend_quad(s, rgl_lds[marg_at + s.quad + (unsigned)row]);
     }
 };
 
 size_t lds_marg_bytes_of(const RglDev &r)
 {
-    const WarpDev &w = r.vndf;
+    const WarpDev w = r.vndf();
     const size_t tb = w.n_theta > 1 ? w.n_theta - 1 : 1, pb = w.n_phi > 1 ? w.n_phi - 1 : 1;
     return 2 * pb * tb * (size_t)(w.ny - 1) * sizeof(float4);
 }
@@ -90,7 +88,7 @@ __device__ __forceinline__ SearchLdsMarg stage_marg(const WarpDev &w, unsigned &
     const int per_r = w.ny - 1;
     const int tb = w.n_theta > 1 ? w.n_theta - 1 : 1, pb = w.n_phi > 1 ? w.n_phi - 1 : 1;
     SearchLdsMarg t;
-    t.cond2 = w.cond2; t.per_c = (w.nx - 1) * (w.ny - 1); t.per_r = per_r;
+    t.cond2 = w.cond2;
     t.marg_at = at_float4;
     const int n = pb * tb * per_r;
     for (int k = threadIdx.x; k < n; k += block) rgl_lds[at_float4 + (unsigned)k] = w.margq[k];
@@ -101,7 +99,7 @@ __device__ __forceinline__ SearchLdsMarg stage_marg(const WarpDev &w, unsigned &
 // bytes of LDS the two distributions' search tables take, slice by slice (16-B aligned pieces)
 size_t lds_bytes_of(const RglDev &r)
 {
-    const WarpDev &w = r.vndf;
+    const WarpDev w = r.vndf();
     const size_t slices = (size_t)w.n_phi * (size_t)w.n_theta, per_c = (size_t)(w.nx - 1) * (size_t)(w.ny - 1), per_r = (size_t)(w.ny - 1);
     const size_t cond = (slices * per_c * 8 + 15) / 16 * 16, marg = (slices * per_r * 4 + 15) / 16 * 16;
     return 2 * (cond + marg);
@@ -113,7 +111,6 @@ __device__ __forceinline__ SearchLds stage_search(const WarpDev &w, unsigned &at
     const int per_c = (w.nx - 1) * (w.ny - 1), per_r = w.ny - 1, slices = w.n_phi * w.n_theta;
     const int tb = w.n_theta > 1 ? w.n_theta - 1 : 1, pb = w.n_phi > 1 ? w.n_phi - 1 : 1;
     SearchLds t;
-    t.per_c = per_c; t.per_r = per_r;
     t.cond_at = at_float4 * 2;                                   // in float2
     at_float4 += (unsigned)((slices * per_c + 1) / 2);
     t.marg_at = at_float4 * 4;                                   // in float
@@ -187,9 +184,9 @@ __global__ __launch_bounds__(kRglBlock, rgl_min_blocks(MODE, MULTI)) void k_rgl(
             const MaterialDev &m = a.materials[id];
             if (m.kind != KIND_RGL) continue;
             const RglDev &rm = *(const RglDev *)m.rgl;
-            rgl_unit<MODE>(a, rm, rgl::SearchMem(rm.vndf), rgl::SearchMem(rm.luminance), i);
+            rgl_unit<MODE>(a, rm, rgl::SearchMem(rm.vndf()), rgl::SearchMem(rm.luminance()), i);
         } else {
-            rgl_unit<MODE>(a, r, rgl::SearchMem(r.vndf), rgl::SearchMem(r.luminance), i);
+            rgl_unit<MODE>(a, r, rgl::SearchMem(r.vndf()), rgl::SearchMem(r.luminance()), i);
         }
     }
 }
@@ -206,13 +203,13 @@ __global__ __launch_bounds__(rgl_lds_block(MODE)) void k_rgl_lds(BatchArgs a, Rg
     if constexpr (INDEXED) { const size_t c = (size_t)*a.idx_count; n_items = c < a.n ? c : a.n; }
     unsigned at = 0;
     if constexpr (MARG_ONLY) {
-        const SearchLdsMarg tv = stage_marg(r.vndf, at, kRglLdsBlock);
-        const SearchLdsMarg tl = stage_marg(r.luminance, at, kRglLdsBlock);
+        const SearchLdsMarg tv = stage_marg(r.vndf(), at, kRglLdsBlock);
+        const SearchLdsMarg tl = stage_marg(r.luminance(), at, kRglLdsBlock);
         __syncthreads();
         for (size_t j = (size_t)blockIdx.x * kRglLdsBlock + threadIdx.x; j < n_items; j += stride) rgl_unit<MODE>(a, r, tv, tl, INDEXED ? (size_t)a.idx[j] : j);
     } else {
-        const SearchLds tv = stage_search(r.vndf, at, kRglLdsBlock);
-        const SearchLds tl = stage_search(r.luminance, at, kRglLdsBlock);
+        const SearchLds tv = stage_search(r.vndf(), at, kRglLdsBlock);
+        const SearchLds tl = stage_search(r.luminance(), at, kRglLdsBlock);
         __syncthreads();
         for (size_t j = (size_t)blockIdx.x * kRglLdsBlock + threadIdx.x; j < n_items; j += stride) rgl_unit<MODE>(a, r, tv, tl, INDEXED ? (size_t)a.idx[j] : j);
     }
@@ -254,13 +251,13 @@ __global__ __launch_bounds__(LDS ? rgl_lds_block(MODE) : kRglBlock) void k_rgl_s
     const size_t stride = (size_t)gridDim.x * kBlockThreads;
     if constexpr (LDS) {
         unsigned at = 0;
-        const SearchLds tv = stage_search(r.vndf, at, kBlockThreads);
-        const SearchLds tl = stage_search(r.luminance, at, kBlockThreads);
+        const SearchLds tv = stage_search(r.vndf(), at, kBlockThreads);
+        const SearchLds tl = stage_search(r.luminance(), at, kBlockThreads);
         __syncthreads();
         for (size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride) rgl_unit_spectral<MODE>(a, r, tv, tl, i, wl, W);
     } else {
         for (size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride)
-            rgl_unit_spectral<MODE>(a, r, rgl::SearchMem(r.vndf), rgl::SearchMem(r.luminance), i, wl, W);
+            rgl_unit_spectral<MODE>(a, r, rgl::SearchMem(r.vndf()), rgl::SearchMem(r.luminance()), i, wl, W);
     }
 }
 
@@ -461,22 +458,14 @@ RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob)
 // base: 16-B aligned
 RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base)
 {
-    auto warp = [&](int which, const int res[2], int n_phi, int n_theta, int n_ch, bool distribution) {
-        WarpDev w;
-        w.cells = (const float4 *)(base + l.cells[which]);
-        w.cond2 = distribution ? (const float4 *)(base + l.cond2[which]) : nullptr;
-        w.margq = distribution ? (const float4 *)(base + l.margq[which]) : nullptr;
-        w.phi = base + l.phi; w.theta = base + l.theta;
-        w.nx = res[0]; w.ny = res[1]; w.n_phi = n_phi; w.n_theta = n_theta; w.n_ch = n_ch;
-        w.normalized = distribution ? 1 : 0;
-        return w;
-    };
+    auto at = [&](size_t off) { return (const float4 *)(base + off); };
     RglDev r;
-    r.ndf = warp(0, f.res_ndf, 1, 1, 1, false);
-    r.sigma = warp(1, f.res_sigma, 1, 1, 1, false);
-    r.vndf = warp(2, f.res, f.n_phi, f.n_theta, 1, true);
-    r.luminance = warp(3, f.res, f.n_phi, f.n_theta, 1, true);
-    r.rgb = warp(4, f.res, f.n_phi, f.n_theta, rgl_value_channels(f), false);
+    r.ndf_cells = at(l.cells[0]); r.sigma_cells = at(l.cells[1]); r.vndf_cells = at(l.cells[2]); r.lum_cells = at(l.cells[3]); r.rgb_cells = at(l.cells[4]);
+    r.vndf_cond2 = at(l.cond2[2]); r.vndf_margq = at(l.margq[2]); r.lum_cond2 = at(l.cond2[3]); r.lum_margq = at(l.margq[3]);
+    r.phi = base + l.phi; r.theta = base + l.theta;
+    r.ndf_nx = f.res_ndf[0]; r.ndf_ny = f.res_ndf[1]; r.sigma_nx = f.res_sigma[0]; r.sigma_ny = f.res_sigma[1];
+    r.nx = f.res[0]; r.ny = f.res[1]; r.n_phi = f.n_phi; r.n_theta = f.n_theta;
+    r.n_values = rgl_value_channels(f);
     r.wavelengths = f.n_wl > 0 ? base + l.wavelengths : nullptr;
     r.n_wl = f.n_wl;
     r.isotropic = f.n_phi <= 2;

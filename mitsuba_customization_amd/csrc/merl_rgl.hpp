@@ -54,15 +54,35 @@ struct WarpDev {
     int normalized;
 };
 
+// The material's descriptor, compact: it travels to the kernels by value in SGPRs (12 pointers + 13 integers; five full WarpDev
+// records — 90 SGPRs — made the compiler park scalars in VGPR lanes inside the unit loop).  vndf, luminance and the measured values
+// share the parameter grids and the resolution; the five functions are handed out as WarpDev views.
 struct RglDev {
-    WarpDev ndf, sigma, vndf, luminance, rgb;
+    const float4 *ndf_cells, *sigma_cells, *vndf_cells, *lum_cells, *rgb_cells;
+    const float4 *vndf_cond2, *vndf_margq, *lum_cond2, *lum_margq;
+    const float *phi, *theta;   // ascending parameter grids of vndf / luminance / rgb
+    // spectral files ("spectra" + "wavelengths" instead of "rgb"): `rgb_cells` then holds the spectra, one channel per wavelength
+    // node (n_values = n_wl), and a value is interpolated linearly between the nodes around the wavelength asked for
+    const float *wavelengths;   // [n_wl], ascending; nullptr for an RGB file
+    int ndf_nx, ndf_ny, sigma_nx, sigma_ny, nx, ny, n_phi, n_theta;
+    int n_values;           // channels of the measured values: 3 (RGB) or n_wl
     int isotropic;          // n_phi <= 2: phi_m is measured relative to phi_i
     int jacobian;           // the file's flag: multiply the spectrum by ndf / (4 sigma)
     int reduction;          // anisotropic: 2 pi / (span of phi_i) — 1 the whole azimuth, 2 [-pi, 0] (point symmetry), 4 [-pi, -pi/2] (+ two mirror planes)
-    // spectral files ("spectra" + "wavelengths" instead of "rgb"): `rgb` then holds the spectra, one channel per wavelength node
-    // (rgb.n_ch = n_wl), and a value is interpolated linearly between the nodes around the wavelength asked for
-    const float *wavelengths;   // [n_wl], ascending; nullptr for an RGB file
-    int n_wl;                   // 0: an RGB file
+    int n_wl;               // 0: an RGB file
+    // the same descriptor over a copy of the image at another address (the host table: merl_materials.hip)
+    void rebase(const char *from, const char *to)
+    {
+        const float4 **q[9] = { &ndf_cells, &sigma_cells, &vndf_cells, &lum_cells, &rgb_cells, &vndf_cond2, &vndf_margq, &lum_cond2, &lum_margq };
+        for (const float4 **x : q) *x = (const float4 *)(to + ((const char *)*x - from));
+        const float **g[3] = { &phi, &theta, &wavelengths };
+        for (const float **x : g) if (*x) *x = (const float *)(to + ((const char *)*x - from));
+    }
+    MRL_HD WarpDev ndf() const { return { ndf_cells, nullptr, nullptr, nullptr, nullptr, ndf_nx, ndf_ny, 1, 1, 1, 0 }; }
+    MRL_HD WarpDev sigma() const { return { sigma_cells, nullptr, nullptr, nullptr, nullptr, sigma_nx, sigma_ny, 1, 1, 1, 0 }; }
+    MRL_HD WarpDev vndf() const { return { vndf_cells, vndf_cond2, vndf_margq, phi, theta, nx, ny, n_phi, n_theta, 1, 1 }; }
+    MRL_HD WarpDev luminance() const { return { lum_cells, lum_cond2, lum_margq, phi, theta, nx, ny, n_phi, n_theta, 1, 1 }; }
+    MRL_HD WarpDev rgb() const { return { rgb_cells, nullptr, nullptr, phi, theta, nx, ny, n_phi, n_theta, n_values, 0 }; }
 };
 
 namespace rgl {
@@ -71,7 +91,9 @@ namespace rgl {
 // says which entries exist (a grid of one node has no upper neighbour) — uniform over a launch, so the tests on it are
 // scalar branches and the arrays stay in registers.  pair[]: the theta bracket's index in cond2 for phi node ip / ip + 1;
 // quad: the (phi, theta) bracket's index in margq.
-struct Slices { unsigned s[4]; double w[4]; int mask; unsigned pair[2], quad; };
+// Offsets instead of indices (formed once per unit: a 32-bit multiply costs what an f64 FMA costs): soff[k] = slice k x cells of a
+// slice (into the per-slice tables), roff[k] = slice k x cell rows, pair[] / quad already multiplied by their row lengths.
+struct Slices { unsigned soff[4], roff[4]; double w[4]; int mask; unsigned pair[2], quad; };
 
 MRL_HD void bracket(const float *grid, int n, double p, int &i, double &t)
 {
@@ -94,39 +116,40 @@ MRL_HD Slices find_slices(const WarpDev &w, double phi_i, double theta_i)
     if (w.n_theta > 1) bracket(w.theta, w.n_theta, theta_i, it, tt);
     const int ip1 = w.n_phi > 1 ? ip + 1 : ip, it1 = w.n_theta > 1 ? it + 1 : it;
     const int tb = w.n_theta > 1 ? w.n_theta - 1 : 1;
+    const unsigned per_c = (unsigned)((w.nx - 1) * (w.ny - 1)), per_r = (unsigned)(w.ny - 1);
+    const unsigned sl[4] = { (unsigned)(ip * w.n_theta + it), (unsigned)(ip1 * w.n_theta + it), (unsigned)(ip * w.n_theta + it1), (unsigned)(ip1 * w.n_theta + it1) };
     Slices out;
-    out.s[0] = (unsigned)(ip * w.n_theta + it);  out.w[0] = (1.0 - tp) * (1.0 - tt);
-    out.s[1] = (unsigned)(ip1 * w.n_theta + it); out.w[1] = tp * (1.0 - tt);
-    out.s[2] = (unsigned)(ip * w.n_theta + it1); out.w[2] = (1.0 - tp) * tt;
-    out.s[3] = (unsigned)(ip1 * w.n_theta + it1); out.w[3] = tp * tt;
+    for (int k = 0; k < 4; ++k) { out.soff[k] = sl[k] * per_c; out.roff[k] = sl[k] * per_r; }
+    out.w[0] = (1.0 - tp) * (1.0 - tt); out.w[1] = tp * (1.0 - tt); out.w[2] = (1.0 - tp) * tt; out.w[3] = tp * tt;
     out.mask = 1 | (w.n_phi > 1 ? 2 : 0) | (w.n_theta > 1 ? 4 : 0) | (w.n_phi > 1 && w.n_theta > 1 ? 8 : 0);
-    out.pair[0] = (unsigned)(ip * tb + it); out.pair[1] = (unsigned)(ip1 * tb + it);
-    out.quad = (unsigned)(ip * tb + it);
+    out.pair[0] = (unsigned)(ip * tb + it) * per_c; out.pair[1] = (unsigned)(ip1 * tb + it) * per_c;
+    out.quad = (unsigned)(ip * tb + it) * per_r;
     return out;
 }
 
 MRL_HD Slices single_slice()
 {
     Slices out;
-    for (int k = 0; k < 4; ++k) { out.s[k] = 0u; out.w[k] = 0.0; }
+    for (int k = 0; k < 4; ++k) { out.soff[k] = out.roff[k] = 0u; out.w[k] = 0.0; }
     out.w[0] = 1.0; out.mask = 1;
     out.pair[0] = out.pair[1] = out.quad = 0u;
     return out;
 }
 
 // weighted sums over the parameter slices, component by component in slice order (what the oracle's scalar loop does; the
-// first term is a product, every later one an explicit FMA); 32-bit offsets: a function's tables hold at most 2^28 values
+// first term is a product, every later one an explicit FMA); 32-bit offsets: a function's tables hold at most 2^28 values;
+// index: the cell inside a slice (ndf / sigma: single_slice(), whose offsets are zero)
 struct D4 { double x, y, z, w; };
 struct D2 { double x, y; };
-MRL_HD D4 fetch4(const Slices &s, const float4 *base, int per_slice, int index, int stride = 1, int offset = 0)
+MRL_HD D4 fetch4(const Slices &s, const float4 *base, int index, int stride = 1, int offset = 0)
 {
 #pragma clang fp contract(off)
-    const float4 q0 = base[(s.s[0] * (unsigned)per_slice + (unsigned)index) * (unsigned)stride + (unsigned)offset];
+    const float4 q0 = base[(s.soff[0] + (unsigned)index) * (unsigned)stride + (unsigned)offset];
     D4 v = { s.w[0] * (double)q0.x, s.w[0] * (double)q0.y, s.w[0] * (double)q0.z, s.w[0] * (double)q0.w };
 #pragma unroll
     for (int k = 1; k < 4; ++k)
         if ((s.mask >> k) & 1) {
-            const float4 q = base[(s.s[k] * (unsigned)per_slice + (unsigned)index) * (unsigned)stride + (unsigned)offset];
+            const float4 q = base[(s.soff[k] + (unsigned)index) * (unsigned)stride + (unsigned)offset];
             v.x = __builtin_fma(s.w[k], (double)q.x, v.x); v.y = __builtin_fma(s.w[k], (double)q.y, v.y);
             v.z = __builtin_fma(s.w[k], (double)q.z, v.z); v.w = __builtin_fma(s.w[k], (double)q.w, v.w);
         }
@@ -158,18 +181,17 @@ MRL_HD double blend_quad(const Slices &s, const float4 &q)
 // four slices (margq).
 struct SearchMem {
     const float4 *cond2, *margq;
-    int per_c, per_r;
-    MRL_HD explicit SearchMem(const WarpDev &w) : cond2(w.cond2), margq(w.margq), per_c((w.nx - 1) * (w.ny - 1)), per_r(w.ny - 1) {}
+    MRL_HD explicit SearchMem(const WarpDev &w) : cond2(w.cond2), margq(w.margq) {}
     // the conditional running integrals of node rows (row, row + 1) up to node col + 1, cell = row (nx - 1) + col
     MRL_HD D2 cond(const Slices &s, int cell) const
     {
-        const float4 a = cond2[s.pair[0] * (unsigned)per_c + (unsigned)cell];
+        const float4 a = cond2[s.pair[0] + (unsigned)cell];
         float4 b = a;
-        if (s.mask & 2) b = cond2[s.pair[1] * (unsigned)per_c + (unsigned)cell];
+        if (s.mask & 2) b = cond2[s.pair[1] + (unsigned)cell];
         return blend_pairs(s, a, b);
     }
     // the marginal cdf after cell row `row`
-    MRL_HD double marg(const Slices &s, int row) const { return blend_quad(s, margq[s.quad * (unsigned)per_r + (unsigned)row]); }
+    MRL_HD double marg(const Slices &s, int row) const { return blend_quad(s, margq[s.quad + (unsigned)row]); }
 };
 
 MRL_HD int clamp_cell(double p, int last)
@@ -204,7 +226,7 @@ MRL_HD double warp_eval(const WarpDev &w, const Slices &s, double x_in, double y
     const double fx = px - (double)ox, fy = py - (double)oy;
     D4 q;
     if (known && known->row == oy && known->col == ox) q = known->q;
-    else q = fetch4(s, w.cells, (w.nx - 1) * (w.ny - 1), oy * (w.nx - 1) + ox, w.n_ch, channel);
+    else q = fetch4(s, w.cells, oy * (w.nx - 1) + ox, w.n_ch, channel);
     const double v = bilinear(q, fx, fy);
     return w.normalized ? v * (double)(w.nx - 1) * (double)(w.ny - 1) : v;
 }
@@ -252,7 +274,7 @@ MRL_HD double warp_sample(const WarpDev &w, const Search &t, const Slices &s, do
     }
     const int col = lo;
     ux -= lerp(y, left.x, left.y);
-    const D4 q = fetch4(s, w.cells, per_c, row * (nx - 1) + col);
+    const D4 q = fetch4(s, w.cells, row * (nx - 1) + col);
     const double c0 = lerp(y, q.x, q.z), c1 = lerp(y, q.y, q.w);
     const double x = clamp01(invert_linear(c0, c1, ux));
     x_out = fast::div_fast((double)col + x, (double)(nx - 1));
@@ -279,7 +301,7 @@ MRL_HD double warp_invert(const WarpDev &w, const Search &t, const Slices &s, do
     if (known && known->row == row && known->col == col) {
         q = known->q; left = known->left; before = known->before; r0 = known->r0; r1 = known->r1;
     } else {
-        q = fetch4(s, w.cells, per_c, row * (nx - 1) + col);
+        q = fetch4(s, w.cells, row * (nx - 1) + col);
         if (col > 0) left = t.cond(s, row * (nx - 1) + col - 1);
         const D2 tot = t.cond(s, row * (nx - 1) + nx - 2);
         r0 = tot.x; r1 = tot.y;
@@ -353,10 +375,10 @@ MRL_HD bool incident(const RglDev &b, float wix, float wiy, float wiz, Incident 
     in.wi = { (double)(wix * in.fx), (double)(wiy * in.fy), (double)wiz };
     if (!unit3(in.wi)) return false;
     in.theta_i = elevation(in.wi); in.phi_i = azimuth(in.wi.y, in.wi.x);
-    in.sv = find_slices(b.vndf, in.phi_i, in.theta_i);
+    in.sv = find_slices(b.vndf(), in.phi_i, in.theta_i);
     in.sigma4 = 1.0;
     if constexpr (WANT_SIGMA)
-        if (b.jacobian) in.sigma4 = 4.0 * warp_eval(b.sigma, single_slice(), theta2u(in.theta_i), phi2u(in.phi_i));
+        if (b.jacobian) in.sigma4 = 4.0 * warp_eval(b.sigma(), single_slice(), theta2u(in.theta_i), phi2u(in.phi_i));
     return true;
 }
 
@@ -381,7 +403,7 @@ MRL_HD Half half_lookup(const RglDev &b, const Search &tv, const Incident &in, f
     h.u_m_x = theta2u(theta_m);
     h.u_m_y = phi2u(b.isotropic ? phi_m - in.phi_i : phi_m);
     h.u_m_y -= floor(h.u_m_y);
-    h.vndf_pdf = warp_invert(b.vndf, tv, in.sv, h.u_m_x, h.u_m_y, h.sx, h.sy, fv);
+    h.vndf_pdf = warp_invert(b.vndf(), tv, in.sv, h.u_m_x, h.u_m_y, h.sx, h.sy, fv);
     h.sin_theta_m = fast::sqrt_fast(__builtin_fma(m.x, m.x, m.y * m.y));
     h.wi_dot_m = __builtin_fma(wi.x, m.x, __builtin_fma(wi.y, m.y, wi.z * m.z));
     h.ok = true;
@@ -391,14 +413,14 @@ MRL_HD Half half_lookup(const RglDev &b, const Search &tv, const Incident &in, f
 // the jacobian's factor ndf(u_m) / (4 sigma(u_wi)) of the measured values (1 when the file's flag is off)
 MRL_HD double value_scale(const RglDev &b, const Incident &in, const Half &h)
 {
-    return b.jacobian ? fast::div_fast(warp_eval(b.ndf, single_slice(), h.u_m_x, h.u_m_y), in.sigma4) : 1.0;
+    return b.jacobian ? fast::div_fast(warp_eval(b.ndf(), single_slice(), h.u_m_x, h.u_m_y), in.sigma4) : 1.0;
 }
 
 // fl (may be null): the cell of luminance a sample() has just visited
 MRL_HD float pdf_of(const RglDev &b, const Incident &in, const Half &h, const Found *fl)
 {
 #pragma clang fp contract(off)
-    const double lum_pdf = warp_eval(b.luminance, in.sv, h.sx, h.sy, 0, fl);
+    const double lum_pdf = warp_eval(b.luminance(), in.sv, h.sx, h.sy, 0, fl);
     const double jac = fmax(2.0 * kPi * kPi * h.u_m_x * h.sin_theta_m, 1e-6) * 4.0 * h.wi_dot_m;
     return (float)fast::div_fast(h.vndf_pdf * lum_pdf, jac);
 }
@@ -415,7 +437,7 @@ MRL_HD void eval_pdf_at(const RglDev &b, const Search &tv, const Incident &in, f
     if constexpr (WANT_RGB) {
         const double scale = value_scale(b, in, h);
         for (int c = 0; c < 3; ++c) {
-            double v = warp_eval(b.rgb, in.sv, h.sx, h.sy, c);
+            double v = warp_eval(b.rgb(), in.sv, h.sx, h.sy, c);
             v = v < 0.0 ? 0.0 : v;
             rgb[c] = (float)(v * scale);
         }
@@ -432,8 +454,8 @@ MRL_HD bool sample_direction(const RglDev &b, const Search &tv, const Search &tl
     const Vec3d &wi = in.wi;
     const float fx = in.fx, fy = in.fy;
     double sx, sy, umx, umy;
-    (void)warp_sample(b.luminance, tl, in.sv, (double)u1, (double)u0, sx, sy, fl);
-    (void)warp_sample(b.vndf, tv, in.sv, sx, sy, umx, umy, fv);
+    (void)warp_sample(b.luminance(), tl, in.sv, (double)u1, (double)u0, sx, sy, fl);
+    (void)warp_sample(b.vndf(), tv, in.sv, sx, sy, umx, umy, fv);
     // m = (theta_m, phi_m) with theta_m = umx^2 pi/2 and phi_m = (2 umy - 1) pi [+ phi_i]: sin / cos of 2 pi (umx^2 / 4) and
     // of 2 pi umy - pi; the isotropic offset is a rotation by wi's own azimuth (cos, sin = wi_xy / |wi_xy|), no second sincos
     double st, ct, sp, cp;
@@ -481,13 +503,13 @@ MRL_HD double spectrum_at(const RglDev &b, const Slices &sv, double sx, double s
 #pragma clang fp contract(off)
     double v;
     if (!wl) {
-        v = warp_eval(b.rgb, sv, sx, sy, k);
+        v = warp_eval(b.rgb(), sv, sx, sy, k);
     } else {
         int c0 = 0;
         double t = 0.0;
         if (b.n_wl > 1) bracket(b.wavelengths, b.n_wl, (double)wl[k], c0, t);
-        v = warp_eval(b.rgb, sv, sx, sy, c0);
-        if (b.n_wl > 1) v = lerp(t, v, warp_eval(b.rgb, sv, sx, sy, c0 + 1));
+        v = warp_eval(b.rgb(), sv, sx, sy, c0);
+        if (b.n_wl > 1) v = lerp(t, v, warp_eval(b.rgb(), sv, sx, sy, c0 + 1));
     }
     return v < 0.0 ? 0.0 : v;
 }
@@ -545,7 +567,7 @@ MRL_HD void eval_pdf(const RglDev &b, float wix, float wiy, float wiz, float wox
     rgb[0] = rgb[1] = rgb[2] = 0.0f; pdf = 0.0f;
     Incident in;
     if (!(wiz > 0.0f) || !(woz > 0.0f) || !incident<WANT_RGB>(b, wix, wiy, wiz, in)) return;
-    eval_pdf_at<WANT_RGB, WANT_PDF>(b, SearchMem(b.vndf), in, wox, woy, woz, rgb, pdf);
+    eval_pdf_at<WANT_RGB, WANT_PDF>(b, SearchMem(b.vndf()), in, wox, woy, woz, rgb, pdf);
 }
 
 MRL_HD void sample(const RglDev &b, float wix, float wiy, float wiz, float u0, float u1, float wo_out[3], float &pdf_out, float weight[3])
@@ -553,7 +575,7 @@ MRL_HD void sample(const RglDev &b, float wix, float wiy, float wiz, float u0, f
     wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
     Incident in;
     if (!(wiz > 0.0f) || !incident<true>(b, wix, wiy, wiz, in)) return;
-    sample_at(b, SearchMem(b.vndf), SearchMem(b.luminance), in, u0, u1, wo_out, pdf_out, weight);
+    sample_at(b, SearchMem(b.vndf()), SearchMem(b.luminance()), in, u0, u1, wo_out, pdf_out, weight);
 }
 
 // a spectral file, one unit through the image in memory
@@ -566,7 +588,7 @@ MRL_HD void eval_pdf_spectral(const RglDev &b, float wix, float wiy, float wiz, 
         if constexpr (WANT_VALUES) for (int k = 0; k < W; ++k) values[k] = 0.0f;
         return;
     }
-    eval_pdf_spectral_at<WANT_VALUES, WANT_PDF>(b, SearchMem(b.vndf), in, wox, woy, woz, wl, W, values, pdf);
+    eval_pdf_spectral_at<WANT_VALUES, WANT_PDF>(b, SearchMem(b.vndf()), in, wox, woy, woz, wl, W, values, pdf);
 }
 
 MRL_HD void sample_spectral(const RglDev &b, float wix, float wiy, float wiz, float u0, float u1, const float *wl, int W,
@@ -575,7 +597,7 @@ MRL_HD void sample_spectral(const RglDev &b, float wix, float wiy, float wiz, fl
     wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f;
     Incident in;
     if (!(wiz > 0.0f) || !incident<true>(b, wix, wiy, wiz, in)) { for (int k = 0; k < W; ++k) weight[k] = 0.0f; return; }
-    sample_spectral_at(b, SearchMem(b.vndf), SearchMem(b.luminance), in, u0, u1, wl, W, wo_out, pdf_out, weight);
+    sample_spectral_at(b, SearchMem(b.vndf()), SearchMem(b.luminance()), in, u0, u1, wl, W, wo_out, pdf_out, weight);
 }
 
 } // namespace rgl
