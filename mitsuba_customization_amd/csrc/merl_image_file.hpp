@@ -32,6 +32,9 @@ inline const char *rgl_check_shapes(const RglFields &f)
     if (f.n_wl < 0 || f.n_wl > 4096) return "wavelengths: at most 4096 nodes";
     const size_t slices = (size_t)f.n_phi * (size_t)f.n_theta, per = (size_t)f.res[0] * (size_t)f.res[1];
     if (slices * per * (size_t)rgl_value_channels(f) > ((size_t)1 << 28)) return "tables too large (more than 2^28 values)";
+    // the image stores a slice's cells once per parameter bracket it bounds (up to 4 x): 32-bit float4 offsets must still reach
+    const size_t pb = f.n_phi > 1 ? (size_t)f.n_phi - 1 : 1, tb = f.n_theta > 1 ? (size_t)f.n_theta - 1 : 1, in_bracket = (f.n_phi > 1 ? 2 : 1) * (f.n_theta > 1 ? 2 : 1);
+    if (pb * tb * in_bracket * per * (size_t)rgl_value_channels(f) > ((size_t)1 << 30)) return "tables too large (more than 2^30 cell vectors in the image)";
     return nullptr;
 }
 
@@ -39,13 +42,16 @@ struct WarpOffsets { size_t cells = 0, cond2 = 0, margq = 0; };
 // the search tables of a distribution are stored per parameter BRACKET (merl_rgl.hpp, WarpDev): brackets along theta / phi
 inline size_t rgl_theta_brackets(int n_theta) { return n_theta > 1 ? (size_t)n_theta - 1 : 1; }
 inline size_t rgl_phi_brackets(int n_phi) { return n_phi > 1 ? (size_t)n_phi - 1 : 1; }
+// ... and so are the cells: the 1 / 2 / 4 slices of a bracket side by side, one copy of a slice per bracket it bounds
+inline size_t rgl_bracket_slices(int n_phi, int n_theta) { return (size_t)(n_phi > 1 ? 2 : 1) * (size_t)(n_theta > 1 ? 2 : 1); }
+inline size_t rgl_cell_copies(int n_phi, int n_theta) { return rgl_phi_brackets(n_phi) * rgl_theta_brackets(n_theta) * rgl_bracket_slices(n_phi, n_theta); }
 // where one function's tables go: `at` is the running size of the image in floats (every table starts on a 16-byte boundary)
 inline WarpOffsets plan_warp(size_t &at, int nx, int ny, int n_phi, int n_theta, int n_ch, bool distribution)
 {
-    const size_t cells = (size_t)(nx - 1) * (size_t)(ny - 1), slices = (size_t)n_phi * (size_t)n_theta;
+    const size_t cells = (size_t)(nx - 1) * (size_t)(ny - 1);
     auto grow = [&](size_t floats) { const size_t off = (at + 3) / 4 * 4; at = off + floats; return off; };
     WarpOffsets off;
-    off.cells = grow(cells * 4 * (size_t)n_ch * slices);
+    off.cells = grow(cells * 4 * (size_t)n_ch * rgl_cell_copies(n_phi, n_theta));
     if (distribution) {
         off.cond2 = grow(cells * 4 * (size_t)n_phi * rgl_theta_brackets(n_theta));
         off.margq = grow((size_t)(ny - 1) * 4 * rgl_phi_brackets(n_phi) * rgl_theta_brackets(n_theta));
@@ -75,7 +81,7 @@ inline size_t nch_brick_float4s(int n_ch) { return n_ch == 1 ? 2 : n_ch == 2 ? 4
 
 // ---- the file ----
 struct ImageHeader {
-    char magic[8];                       // "MRLIMG\2\0" (2: RGL search tables in the bracket form)
+    char magic[8];                       // "MRLIMG\3\0" (2: RGL search tables in the bracket form; 3: the cells too)
     uint32_t header_bytes, kind, layout, n_ch, param, lookup, node, n_ti;
     int32_t dims[3];
     int32_t rgl_shape[8];                // n_phi n_theta res_x res_y res_ndf_x res_ndf_y res_sigma_x res_sigma_y
@@ -83,7 +89,7 @@ struct ImageHeader {
     uint32_t negative;                   // MRL_OPT_NEGATIVE the table was built under: 0 = negative values were clamped to 0, 1 / 2 = the image holds them
     uint64_t texel_bytes, sampling_doubles, sampling2d_doubles, checksum;
 };
-constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 2, 0 };
+constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 3, 0 };
 constexpr uint64_t kImageChecksumSeed = 0xCBF29CE484222325ull;
 // the kinds and layouts an image can name (values of mrl::Kind / mrl::Layout / mrl::Param, repeated here so that this header needs no HIP)
 constexpr uint32_t kImgKindMerl = 0, kImgKindTable = 1, kImgKindNch = 4, kImgKindRgl = 5, kImgKindRglSpectral = 6, kImgLayoutRows = 0, kImgLayoutBrick = 1, kImgParamLast = 2;
@@ -181,10 +187,10 @@ inline const char *image_content_check(const ImagePlan &p, const void *payload)
         auto ascending = [&](size_t at, int n) { for (int i = 1; i < n; ++i) if (!(f[at + i] > f[at + i - 1])) return false; return true; };
         if (!ascending(p.layout.phi, s.n_phi) || !ascending(p.layout.theta, s.n_theta) || (s.n_wl > 0 && !ascending(p.layout.wavelengths, s.n_wl)))
             return "phi_i / theta_i / wavelengths must be strictly ascending";
-        const size_t cells = (size_t)(s.res[0] - 1) * (size_t)(s.res[1] - 1), slices = (size_t)s.n_phi * (size_t)s.n_theta;
+        const size_t cells = (size_t)(s.res[0] - 1) * (size_t)(s.res[1] - 1);
         const size_t tb = rgl_theta_brackets(s.n_theta), pb = rgl_phi_brackets(s.n_phi);
         for (int w = 2; w <= 3; ++w) {                       // vndf, luminance: densities and their integrals
-            const size_t spans[3][2] = { { p.layout.cells[w], cells * 4 * slices }, { p.layout.cond2[w], cells * 4 * (size_t)s.n_phi * tb },
+            const size_t spans[3][2] = { { p.layout.cells[w], cells * 4 * rgl_cell_copies(s.n_phi, s.n_theta) }, { p.layout.cond2[w], cells * 4 * (size_t)s.n_phi * tb },
                                          { p.layout.margq[w], (size_t)(s.res[1] - 1) * 4 * pb * tb } };
             for (const auto &sp : spans)
                 for (size_t i = 0; i < sp[1]; ++i) if (f[sp[0] + i] < 0.0f) return "negative value in a distribution of the image";

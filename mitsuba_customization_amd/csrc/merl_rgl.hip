@@ -20,7 +20,16 @@ namespace {
 constexpr int kRglBlock = 256;
 // the LDS variant: ONE workgroup per CU holds the file's search tables (up to 160 KB) — 4 waves per SIMD for eval and for pdf alone, 3 for the fused modes and the
 // modes with a sample() (which carries two visited cells through its eval: 130 - 170 VGPRs)
-constexpr int rgl_lds_block(int mode) { return mode >= 2 ? 768 : 1024; }
+#ifndef MRL_RGL_LDS_BLOCK_SAMPLE
+#define MRL_RGL_LDS_BLOCK_SAMPLE 768
+#endif
+#ifndef MRL_RGL_LDS_BLOCK_EVAL
+#define MRL_RGL_LDS_BLOCK_EVAL 1024
+#endif
+#ifndef MRL_RGL_LDS_BLOCK_SAMPLE15
+#define MRL_RGL_LDS_BLOCK_SAMPLE15 512
+#endif
+constexpr int rgl_lds_block(int mode, int mask = 0) { return mode >= 2 ? (mask == 15 ? MRL_RGL_LDS_BLOCK_SAMPLE15 : MRL_RGL_LDS_BLOCK_SAMPLE) : MRL_RGL_LDS_BLOCK_EVAL; }
 
 // ---- the search tables in LDS ----
 // Slice by slice (a bracket's float4 taken apart while it is copied): cond [slices][cell] float2, marg [slices][ny - 1] float, for vndf
@@ -28,32 +37,69 @@ constexpr int rgl_lds_block(int mode) { return mode >= 2 ? 768 : 1024; }
 // and these are the reads sample() is made of: 2 x (log2 ny + log2 nx) dependent steps per unit and slice.
 extern __shared__ float4 rgl_lds[];
 
+// ---- the parameter grids in LDS (every single-material kernel): phi_i then theta_i at the start of the block's LDS ----
+struct GridLds {
+    unsigned theta_at_;                 // float index of theta_i's first node in rgl_lds (phi_i starts at 0)
+    __device__ __forceinline__ float phi_at(int k) const { return ((const float *)rgl_lds)[k]; }
+    __device__ __forceinline__ float theta_at(int k) const { return ((const float *)rgl_lds)[theta_at_ + (unsigned)k]; }
+};
+size_t grid_bytes_of(const RglDev &r) { return ((size_t)(r.n_phi + r.n_theta) * sizeof(float) + 15) / 16 * 16; }
+__device__ __forceinline__ GridLds stage_grids(const RglDev &r, unsigned &at_float4, int block)
+{
+    float *g = (float *)rgl_lds;
+    for (int k = threadIdx.x; k < r.n_phi; k += block) g[k] = r.phi[k];
+    for (int k = threadIdx.x; k < r.n_theta; k += block) g[r.n_phi + k] = r.theta[k];
+    at_float4 += (unsigned)((r.n_phi + r.n_theta + 3) / 4);
+    return GridLds{ (unsigned)r.n_phi };
+}
+
 struct SearchLds {
     unsigned cond_at, marg_at;          // float2 / float index of the table's first element in rgl_lds
-    __device__ __forceinline__ rgl::D2 cond(const rgl::Slices &s, int cell) const
+    // reads, then sums (rgl::fetch_raw), slice by slice
+    struct CondRaw { float2 q0, q1, q2, q3; };
+    struct MargRaw { float m0, m1, m2, m3; };
+    __device__ __forceinline__ CondRaw cond_raw(const rgl::Slices &s, int cell) const
+    {
+        const float2 *t = (const float2 *)rgl_lds + cond_at + (unsigned)cell;
+        CondRaw r;
+        r.q1 = r.q2 = r.q3 = make_float2(0.0f, 0.0f);
+        r.q0 = t[s.soff[0]];
+        if (s.mask & 2) r.q1 = t[s.soff[1]];
+        if (s.mask & 4) r.q2 = t[s.soff[2]];
+        if (s.mask & 8) r.q3 = t[s.soff[3]];
+        return r;
+    }
+    __device__ __forceinline__ rgl::D2 cond_blend(const rgl::Slices &s, const CondRaw &r) const
     {
 #pragma clang fp contract(off)
-        const float2 *t = (const float2 *)rgl_lds + cond_at;
-        const float2 q0 = t[s.soff[0] + (unsigned)cell];
-        rgl::D2 v = { s.w[0] * (double)q0.x, s.w[0] * (double)q0.y };
-#pragma unroll
-        for (int k = 1; k < 4; ++k)
-            if ((s.mask >> k) & 1) {
-                const float2 q = t[s.soff[k] + (unsigned)cell];
-                v.x = __builtin_fma(s.w[k], (double)q.x, v.x); v.y = __builtin_fma(s.w[k], (double)q.y, v.y);
-            }
+        rgl::D2 v = { s.w[0] * (double)r.q0.x, s.w[0] * (double)r.q0.y };
+        if (s.mask & 2) { v.x = __builtin_fma(s.w[1], (double)r.q1.x, v.x); v.y = __builtin_fma(s.w[1], (double)r.q1.y, v.y); }
+        if (s.mask & 4) { v.x = __builtin_fma(s.w[2], (double)r.q2.x, v.x); v.y = __builtin_fma(s.w[2], (double)r.q2.y, v.y); }
+        if (s.mask & 8) { v.x = __builtin_fma(s.w[3], (double)r.q3.x, v.x); v.y = __builtin_fma(s.w[3], (double)r.q3.y, v.y); }
         return v;
     }
-    __device__ __forceinline__ double marg(const rgl::Slices &s, int row) const
+    __device__ __forceinline__ MargRaw marg_raw(const rgl::Slices &s, int row) const
+    {
+        const float *t = (const float *)rgl_lds + marg_at + (unsigned)row;
+        MargRaw r;
+        r.m1 = r.m2 = r.m3 = 0.0f;
+        r.m0 = t[s.roff[0]];
+        if (s.mask & 2) r.m1 = t[s.roff[1]];
+        if (s.mask & 4) r.m2 = t[s.roff[2]];
+        if (s.mask & 8) r.m3 = t[s.roff[3]];
+        return r;
+    }
+    __device__ __forceinline__ double marg_blend(const rgl::Slices &s, const MargRaw &r) const
     {
 #pragma clang fp contract(off)
-        const float *t = (const float *)rgl_lds + marg_at;
-        double v = s.w[0] * (double)t[s.roff[0] + (unsigned)row];
-#pragma unroll
-        for (int k = 1; k < 4; ++k)
-            if ((s.mask >> k) & 1) v = __builtin_fma(s.w[k], (double)t[s.roff[k] + (unsigned)row], v);
+        double v = s.w[0] * (double)r.m0;
+        if (s.mask & 2) v = __builtin_fma(s.w[1], (double)r.m1, v);
+        if (s.mask & 4) v = __builtin_fma(s.w[2], (double)r.m2, v);
+        if (s.mask & 8) v = __builtin_fma(s.w[3], (double)r.m3, v);
         return v;
     }
+    __device__ __forceinline__ rgl::D2 cond(const rgl::Slices &s, int cell) const { return cond_blend(s, cond_raw(s, cell)); }
+    __device__ __forceinline__ double marg(const rgl::Slices &s, int row) const { return marg_blend(s, marg_raw(s, row)); }
 };
 
 // The partial form for files whose conditional integrals do not fit (an anisotropic 16 x 8 x 32 x 32 file: 1.7 MB per
@@ -63,24 +109,28 @@ struct SearchLds {
 struct SearchLdsMarg {
     const float4 *cond2;
     unsigned marg_at;                   // float4 index of the table's first quad in rgl_lds
-    __device__ __forceinline__ rgl::D2 cond(const rgl::Slices &s, int cell) const
+    struct CondRaw { float4 a, b; };
+    typedef float4 MargRaw;
+    __device__ __forceinline__ CondRaw cond_raw(const rgl::Slices &s, int cell) const
     {
-        const float4 a = cond2[s.pair[0] + (unsigned)cell];
-        float4 b = a;
-        if (s.mask & 2) b = cond2[s.pair[1] + (unsigned)cell];
-        return rgl::blend_pairs(s, a, b);
+        CondRaw r;
+        r.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        r.a = cond2[s.pair[0] + (unsigned)cell];
+        if (s.mask & 2) r.b = cond2[s.pair[1] + (unsigned)cell];
+        return r;
     }
-    __device__ __forceinline__ double marg(const rgl::Slices &s, int row) const
-    {
-        return rgl::blend_quad(s, rgl_lds[marg_at + s.quad + (unsigned)row]);
-    }
+    __device__ __forceinline__ rgl::D2 cond_blend(const rgl::Slices &s, const CondRaw &r) const { return rgl::blend_pairs(s, r.a, r.b); }
+    __device__ __forceinline__ MargRaw marg_raw(const rgl::Slices &s, int row) const { return rgl_lds[marg_at + s.quad + (unsigned)row]; }
+    __device__ __forceinline__ double marg_blend(const rgl::Slices &s, const MargRaw &q) const { return rgl::blend_quad(s, q); }
+    __device__ __forceinline__ rgl::D2 cond(const rgl::Slices &s, int cell) const { return cond_blend(s, cond_raw(s, cell)); }
+    __device__ __forceinline__ double marg(const rgl::Slices &s, int row) const { return marg_blend(s, marg_raw(s, row)); }
 };
 
 size_t lds_marg_bytes_of(const RglDev &r)
 {
     const WarpDev w = r.vndf();
     const size_t tb = w.n_theta > 1 ? w.n_theta - 1 : 1, pb = w.n_phi > 1 ? w.n_phi - 1 : 1;
-    return 2 * pb * tb * (size_t)(w.ny - 1) * sizeof(float4);
+    return grid_bytes_of(r) + 2 * pb * tb * (size_t)(w.ny - 1) * sizeof(float4);
 }
 
 __device__ __forceinline__ SearchLdsMarg stage_marg(const WarpDev &w, unsigned &at_float4, int block)
@@ -102,7 +152,7 @@ size_t lds_bytes_of(const RglDev &r)
     const WarpDev w = r.vndf();
     const size_t slices = (size_t)w.n_phi * (size_t)w.n_theta, per_c = (size_t)(w.nx - 1) * (size_t)(w.ny - 1), per_r = (size_t)(w.ny - 1);
     const size_t cond = (slices * per_c * 8 + 15) / 16 * 16, marg = (slices * per_r * 4 + 15) / 16 * 16;
-    return 2 * (cond + marg);
+    return grid_bytes_of(r) + 2 * (cond + marg);
 }
 
 // one distribution's tables: memory (bracket form) -> LDS (slice form); every thread of the block takes part
@@ -135,16 +185,23 @@ __device__ __forceinline__ SearchLds stage_search(const WarpDev &w, unsigned &at
 
 // One unit.  What depends on the incident direction alone — its angles, the parameter bracket, the projected area — is formed once
 // and serves the eval, the pdf and the sample of the unit.
-template <int MODE, class Search>
-__device__ __forceinline__ void rgl_unit(const BatchArgs &a, const RglDev &r, const Search &tv, const Search &tl, size_t i)
+// g: where the parameter grids are read (GridLds: the launch's one material; rgl::GridMem: a batch with ids)
+// MASK: which slices a parameter bracket of the launch's file has, known when the kernel is compiled (5: isotropic — theta_i alone;
+// 15: anisotropic; 0: decided per launch) — every test on it then folds, and the reads of a lookup are straight-line code
+template <int MODE, int MASK, class Grids, class Search>
+__device__ __forceinline__ void rgl_unit(const BatchArgs &a, const RglDev &r, const Grids &g, const Search &tv, const Search &tl, size_t i)
 {
     constexpr bool has_eval = MODE == 0 || MODE == 3 || MODE == 4, has_pdf = MODE == 1 || MODE == 3 || MODE == 4,
                    has_sample = MODE == 2 || MODE == 3;
     const float wix = a.wi[3 * i], wiy = a.wi[3 * i + 1], wiz = a.wi[3 * i + 2];
+    // (the unit's other stream reads are issued before the incident-only work waits for its own)
+    float wox = 0.0f, woy = 0.0f, woz = 0.0f, u0 = 0.0f, u1 = 0.0f;
+    if constexpr (has_eval || has_pdf) { wox = a.wo[3 * i]; woy = a.wo[3 * i + 1]; woz = a.wo[3 * i + 2]; }
+    if constexpr (has_sample) { u0 = a.u[2 * i]; u1 = a.u[2 * i + 1]; }
     rgl::Incident in;
-    const bool up = wiz > 0.0f && rgl::incident<has_eval || has_sample>(r, wix, wiy, wiz, in);
+    const bool up = wiz > 0.0f && rgl::incident<has_eval || has_sample>(r, g, wix, wiy, wiz, in);
+    if constexpr (MASK != 0) in.sv.mask = MASK;
     if constexpr (has_eval || has_pdf) {
-        const float wox = a.wo[3 * i], woy = a.wo[3 * i + 1], woz = a.wo[3 * i + 2];
         float rgb[3] = { 0.0f, 0.0f, 0.0f }, pdf = 0.0f;
         if (up) rgl::eval_pdf_at<has_eval, has_pdf>(r, tv, in, wox, woy, woz, rgb, pdf);
         if constexpr (has_eval) { a.out_rgb[3 * i] = rgb[0]; a.out_rgb[3 * i + 1] = rgb[1]; a.out_rgb[3 * i + 2] = rgb[2]; }
@@ -152,7 +209,7 @@ __device__ __forceinline__ void rgl_unit(const BatchArgs &a, const RglDev &r, co
     }
     if constexpr (has_sample) {
         float wo2[3] = { 0.0f, 0.0f, 0.0f }, pdf2 = 0.0f, w[3] = { 0.0f, 0.0f, 0.0f };
-        if (up) rgl::sample_at(r, tv, tl, in, a.u[2 * i], a.u[2 * i + 1], wo2, pdf2, w);
+        if (up) rgl::sample_at(r, tv, tl, in, u0, u1, wo2, pdf2, w);
         a.out_wo[3 * i] = wo2[0]; a.out_wo[3 * i + 1] = wo2[1]; a.out_wo[3 * i + 2] = wo2[2];
         a.out_pdf2[i] = pdf2;
         a.out_weight[3 * i] = w[0]; a.out_weight[3 * i + 1] = w[1]; a.out_weight[3 * i + 2] = w[2];
@@ -169,13 +226,37 @@ __device__ __forceinline__ void rgl_unit(const BatchArgs &a, const RglDev &r, co
 #ifndef MRL_RGL_EVALPDF_BLOCKS
 #define MRL_RGL_EVALPDF_BLOCKS 4
 #endif
-constexpr int rgl_min_blocks(int mode, bool multi) { return mode == 3 ? (multi ? 3 : 2) : (mode == 2 ? 3 : (mode == 4 ? MRL_RGL_EVALPDF_BLOCKS : 4)); }
-template <int MODE, bool INDEXED, bool MULTI>
-__global__ __launch_bounds__(kRglBlock, rgl_min_blocks(MODE, MULTI)) void k_rgl(BatchArgs a, RglDev r)
+#ifndef MRL_RGL_SAMPLE_BLOCKS
+#define MRL_RGL_SAMPLE_BLOCKS 3
+#endif
+#ifndef MRL_RGL_EVAL_BLOCKS
+#define MRL_RGL_EVAL_BLOCKS 4
+#endif
+#ifndef MRL_RGL_BLOCKS15
+#define MRL_RGL_BLOCKS15 3, 4, 2, 2, 3          // eval, pdf, sample, fused, eval + pdf of the anisotropic shape (four slices in flight per lookup)
+#endif
+#ifndef MRL_RGL_BLOCKS5
+#define MRL_RGL_BLOCKS5 4, 4, 3, 3, 4
+#endif
+constexpr int rgl_min_blocks(int mode, bool multi, int mask)
+{
+    constexpr int b15[5] = { MRL_RGL_BLOCKS15 }, b5[5] = { MRL_RGL_BLOCKS5 };
+    if (mask == 15) return b15[mode];
+    if (mask == 5) return b5[mode];
+    return mode == 3 ? (multi ? 3 : 2) : (mode == 2 ? MRL_RGL_SAMPLE_BLOCKS : (mode == 4 ? MRL_RGL_EVALPDF_BLOCKS : MRL_RGL_EVAL_BLOCKS));
+}
+template <int MODE, bool INDEXED, bool MULTI, int MASK = 0>
+__global__ __launch_bounds__(kRglBlock, rgl_min_blocks(MODE, MULTI, MASK)) void k_rgl(BatchArgs a, RglDev r)
 {
     const size_t stride = (size_t)gridDim.x * kRglBlock;
     size_t n_items = a.n;
     if constexpr (INDEXED) { const size_t c = (size_t)*a.idx_count; n_items = c < a.n ? c : a.n; }
+    GridLds grids{ 0u };
+    if constexpr (!MULTI) {
+        unsigned at = 0;
+        grids = stage_grids(r, at, kRglBlock);
+        __syncthreads();
+    }
     for (size_t j = (size_t)blockIdx.x * kRglBlock + threadIdx.x; j < n_items; j += stride) {
         const size_t i = INDEXED ? (size_t)a.idx[j] : j;
         if constexpr (MULTI) {
@@ -184,9 +265,9 @@ __global__ __launch_bounds__(kRglBlock, rgl_min_blocks(MODE, MULTI)) void k_rgl(
             const MaterialDev &m = a.materials[id];
             if (m.kind != KIND_RGL) continue;
             const RglDev &rm = *(const RglDev *)m.rgl;
-            rgl_unit<MODE>(a, rm, rgl::SearchMem(rm.vndf()), rgl::SearchMem(rm.luminance()), i);
+            rgl_unit<MODE, 0>(a, rm, rgl::GridMem{ rm.phi, rm.theta }, rgl::SearchMem(rm.vndf()), rgl::SearchMem(rm.luminance()), i);
         } else {
-            rgl_unit<MODE>(a, r, rgl::SearchMem(r.vndf()), rgl::SearchMem(r.luminance()), i);
+            rgl_unit<MODE, MASK>(a, r, grids, rgl::SearchMem(r.vndf()), rgl::SearchMem(r.luminance()), i);
         }
     }
 }
@@ -194,38 +275,39 @@ __global__ __launch_bounds__(kRglBlock, rgl_min_blocks(MODE, MULTI)) void k_rgl(
 // The single-material launch when the file's search tables fit a CU's LDS: one workgroup per CU copies them in (once: the grid is
 // persistent) and every search step of every unit is a ds_read.  Same functions, same sums, same bits as k_rgl.
 // MARG_ONLY: the partial form (SearchLdsMarg) for files whose conditional integrals do not fit
-template <int MODE, bool INDEXED, bool MARG_ONLY = false>
-__global__ __launch_bounds__(rgl_lds_block(MODE)) void k_rgl_lds(BatchArgs a, RglDev r)
+template <int MODE, bool INDEXED, bool MARG_ONLY = false, int MASK = 0>
+__global__ __launch_bounds__(rgl_lds_block(MODE, MASK)) void k_rgl_lds(BatchArgs a, RglDev r)
 {
-    constexpr int kRglLdsBlock = rgl_lds_block(MODE);
+    constexpr int kRglLdsBlock = rgl_lds_block(MODE, MASK);
     const size_t stride = (size_t)gridDim.x * kRglLdsBlock;
     size_t n_items = a.n;
     if constexpr (INDEXED) { const size_t c = (size_t)*a.idx_count; n_items = c < a.n ? c : a.n; }
     unsigned at = 0;
+    const GridLds grids = stage_grids(r, at, kRglLdsBlock);
     if constexpr (MARG_ONLY) {
         const SearchLdsMarg tv = stage_marg(r.vndf(), at, kRglLdsBlock);
         const SearchLdsMarg tl = stage_marg(r.luminance(), at, kRglLdsBlock);
         __syncthreads();
-        for (size_t j = (size_t)blockIdx.x * kRglLdsBlock + threadIdx.x; j < n_items; j += stride) rgl_unit<MODE>(a, r, tv, tl, INDEXED ? (size_t)a.idx[j] : j);
+        for (size_t j = (size_t)blockIdx.x * kRglLdsBlock + threadIdx.x; j < n_items; j += stride) rgl_unit<MODE, MASK>(a, r, grids, tv, tl, INDEXED ? (size_t)a.idx[j] : j);
     } else {
         const SearchLds tv = stage_search(r.vndf(), at, kRglLdsBlock);
         const SearchLds tl = stage_search(r.luminance(), at, kRglLdsBlock);
         __syncthreads();
-        for (size_t j = (size_t)blockIdx.x * kRglLdsBlock + threadIdx.x; j < n_items; j += stride) rgl_unit<MODE>(a, r, tv, tl, INDEXED ? (size_t)a.idx[j] : j);
+        for (size_t j = (size_t)blockIdx.x * kRglLdsBlock + threadIdx.x; j < n_items; j += stride) rgl_unit<MODE, MASK>(a, r, grids, tv, tl, INDEXED ? (size_t)a.idx[j] : j);
     }
 }
 
 // ---- spectral files: W values per unit at the wavelengths wl[i * W .. ) (nullptr: the file's own nodes) ----
 // a.out_rgb / a.out_weight hold n x W values.  Same structure as rgl_unit: what depends on wi alone is formed once.
 template <int MODE, class Search>
-__device__ __forceinline__ void rgl_unit_spectral(const BatchArgs &a, const RglDev &r, const Search &tv, const Search &tl, size_t i, const float *wl_all, int W)
+__device__ __forceinline__ void rgl_unit_spectral(const BatchArgs &a, const RglDev &r, const GridLds &g, const Search &tv, const Search &tl, size_t i, const float *wl_all, int W)
 {
     constexpr bool has_eval = MODE == 0 || MODE == 3 || MODE == 4, has_pdf = MODE == 1 || MODE == 3 || MODE == 4,
                    has_sample = MODE == 2 || MODE == 3;
     const float wix = a.wi[3 * i], wiy = a.wi[3 * i + 1], wiz = a.wi[3 * i + 2];
     const float *wl = wl_all ? wl_all + i * (size_t)W : nullptr;
     rgl::Incident in;
-    const bool up = wiz > 0.0f && rgl::incident<has_eval || has_sample>(r, wix, wiy, wiz, in);
+    const bool up = wiz > 0.0f && rgl::incident<has_eval || has_sample>(r, g, wix, wiy, wiz, in);
     if constexpr (has_eval || has_pdf) {
         const float wox = a.wo[3 * i], woy = a.wo[3 * i + 1], woz = a.wo[3 * i + 2];
         float *values = has_eval ? a.out_rgb + i * (size_t)W : nullptr;
@@ -249,15 +331,17 @@ __global__ __launch_bounds__(LDS ? rgl_lds_block(MODE) : kRglBlock) void k_rgl_s
 {
     constexpr int kBlockThreads = LDS ? rgl_lds_block(MODE) : kRglBlock;
     const size_t stride = (size_t)gridDim.x * kBlockThreads;
+    unsigned at = 0;
+    const GridLds grids = stage_grids(r, at, kBlockThreads);
     if constexpr (LDS) {
-        unsigned at = 0;
         const SearchLds tv = stage_search(r.vndf(), at, kBlockThreads);
         const SearchLds tl = stage_search(r.luminance(), at, kBlockThreads);
         __syncthreads();
-        for (size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride) rgl_unit_spectral<MODE>(a, r, tv, tl, i, wl, W);
+        for (size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride) rgl_unit_spectral<MODE>(a, r, grids, tv, tl, i, wl, W);
     } else {
+        __syncthreads();
         for (size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride)
-            rgl_unit_spectral<MODE>(a, r, rgl::SearchMem(r.vndf()), rgl::SearchMem(r.luminance()), i, wl, W);
+            rgl_unit_spectral<MODE>(a, r, grids, rgl::SearchMem(r.vndf()), rgl::SearchMem(r.luminance()), i, wl, W);
     }
 }
 
@@ -271,37 +355,42 @@ int lds_limit()
     return limit;
 }
 
-template <int MODE>
-hipError_t launch_mode(const BatchArgs &a, const RglDev *r, bool indexed, int search, int compute_units, hipStream_t stream)
+template <int MODE, int MASK>
+hipError_t launch_masked(const BatchArgs &a, const RglDev *r, bool indexed, int search, int compute_units, hipStream_t stream)
 {
+    // (kernels compiled for a bracket shape: the full LDS form for isotropic files — anisotropic ones rarely fit —, the marginal-rows
+    // form for anisotropic ones; the other combinations take the kernel that tests the shape at run time)
+    constexpr int kLdsMask = MASK == 5 ? 5 : 0, kMargMask = MASK == 15 ? 15 : 0;
     // LDS variant: a single-material launch large enough to pay for the copy (one image of the search tables per CU)
-    if (r && search == 0 && a.n >= (size_t)1 << 15) {
-        constexpr int kRglLdsBlock = rgl_lds_block(MODE);
-        size_t blocks = (a.n + kRglLdsBlock - 1) / kRglLdsBlock;
-        if (blocks > (size_t)compute_units) blocks = (size_t)compute_units;
-        const dim3 grid((unsigned)blocks), block(kRglLdsBlock);
+    if (search == 0 && a.n >= (size_t)1 << 15) {
+        // one workgroup per CU
+        auto grid_of = [&](int threads) { size_t blocks = (a.n + (size_t)threads - 1) / (size_t)threads; return dim3((unsigned)(blocks > (size_t)compute_units ? (size_t)compute_units : blocks)); };
         const size_t need = lds_bytes_of(*r), need_marg = lds_marg_bytes_of(*r);
         if (need <= (size_t)lds_limit()) {
+            constexpr int kThreads = rgl_lds_block(MODE, kLdsMask);
             if (indexed) {
-                (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-                hipLaunchKernelGGL((k_rgl_lds<MODE, true>), grid, block, need, stream, a, *r);
+                (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, true, false, kLdsMask>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+                hipLaunchKernelGGL((k_rgl_lds<MODE, true, false, kLdsMask>), grid_of(kThreads), dim3(kThreads), need, stream, a, *r);
             } else {
-                (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-                hipLaunchKernelGGL((k_rgl_lds<MODE, false>), grid, block, need, stream, a, *r);
+                (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, false, false, kLdsMask>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+                hipLaunchKernelGGL((k_rgl_lds<MODE, false, false, kLdsMask>), grid_of(kThreads), dim3(kThreads), need, stream, a, *r);
             }
             return hipGetLastError();
         }
         // the marginal rows alone — sample() alone: eval / pdf read one marginal value per unit (not worth a copy per CU), and the fused
         // unit of such a file is issued as two launches (launch_rgl)
-        if (MODE == 2 && need_marg <= (size_t)lds_limit()) {
-            if (indexed) {
-                (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_marg);
-                hipLaunchKernelGGL((k_rgl_lds<MODE, true, true>), grid, block, need_marg, stream, a, *r);
-            } else {
-                (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_marg);
-                hipLaunchKernelGGL((k_rgl_lds<MODE, false, true>), grid, block, need_marg, stream, a, *r);
+        if constexpr (MODE == 2) {
+            if (need_marg <= (size_t)lds_limit()) {
+                constexpr int kThreads = rgl_lds_block(MODE, kMargMask);
+                if (indexed) {
+                    (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, true, true, kMargMask>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_marg);
+                    hipLaunchKernelGGL((k_rgl_lds<MODE, true, true, kMargMask>), grid_of(kThreads), dim3(kThreads), need_marg, stream, a, *r);
+                } else {
+                    (void)hipFuncSetAttribute((const void *)k_rgl_lds<MODE, false, true, kMargMask>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_marg);
+                    hipLaunchKernelGGL((k_rgl_lds<MODE, false, true, kMargMask>), grid_of(kThreads), dim3(kThreads), need_marg, stream, a, *r);
+                }
+                return hipGetLastError();
             }
-            return hipGetLastError();
         }
     }
     size_t blocks = (a.n + kRglBlock - 1) / kRglBlock;
@@ -309,15 +398,29 @@ hipError_t launch_mode(const BatchArgs &a, const RglDev *r, bool indexed, int se
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     const dim3 grid((unsigned)blocks), block(kRglBlock);
+    const size_t grids = grid_bytes_of(*r);                     // (at most 32 KB: 4,096 nodes per grid)
+    if (indexed) hipLaunchKernelGGL((k_rgl<MODE, true, false, MASK>), grid, block, grids, stream, a, *r);
+    else hipLaunchKernelGGL((k_rgl<MODE, false, false, MASK>), grid, block, grids, stream, a, *r);
+    return hipGetLastError();
+}
+
+template <int MODE>
+hipError_t launch_mode(const BatchArgs &a, const RglDev *r, bool indexed, int search, int compute_units, hipStream_t stream)
+{
     if (!r) {                                                   // a batch with material ids: descriptors come from the material array
+        size_t blocks = (a.n + kRglBlock - 1) / kRglBlock;
+        const size_t cap = (size_t)compute_units * 8;
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        const dim3 grid((unsigned)blocks), block(kRglBlock);
         const RglDev none{};
         if (indexed) hipLaunchKernelGGL((k_rgl<MODE, true, true>), grid, block, 0, stream, a, none);
         else hipLaunchKernelGGL((k_rgl<MODE, false, true>), grid, block, 0, stream, a, none);
-    } else {
-        if (indexed) hipLaunchKernelGGL((k_rgl<MODE, true, false>), grid, block, 0, stream, a, *r);
-        else hipLaunchKernelGGL((k_rgl<MODE, false, false>), grid, block, 0, stream, a, *r);
+        return hipGetLastError();
     }
-    return hipGetLastError();
+    if (r->n_phi == 1 && r->n_theta > 1) return launch_masked<MODE, 5>(a, r, indexed, search, compute_units, stream);
+    if (r->n_phi > 1 && r->n_theta > 1) return launch_masked<MODE, 15>(a, r, indexed, search, compute_units, stream);
+    return launch_masked<MODE, 0>(a, r, indexed, search, compute_units, stream);
 }
 
 bool all_finite(const float *p, size_t n)
@@ -333,7 +436,7 @@ bool ascending(const float *p, int n)
 }
 
 // appends one function's tables to the image (offsets in floats, each a multiple of 4 so that the vectors are 16-B aligned):
-// the corner bricks (normalised if a distribution) and, for distributions, the running integrals in the BRACKET form the
+// the corner bricks (normalised if a distribution; per parameter bracket like the search tables) and, for distributions, the running integrals in the BRACKET form the
 // kernels search — `cond2` (along x, node rows row / row + 1, the two theta slices of a bracket side by side) and `margq` (the
 // marginal cdf after the cell row, the four slices of a (phi, theta) bracket side by side) — all rounded to Float once from
 // f64 sums, in the oracle's loop order.  src: [n_phi][n_theta][n_ch][ny][nx].
@@ -368,12 +471,22 @@ WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, 
                 for (size_t k = 0; k < per_marg; ++k) margf[s * per_marg + k] = (float)(marg[k] * norm);
             }
             for (size_t k = 0; k < per; ++k) node[k] = (float)((double)src[k] * norm);
-            for (int y = 0; y < ny - 1; ++y)
-                for (int x = 0; x < nx - 1; ++x) {
-                    const size_t cell = (size_t)y * (size_t)(nx - 1) + (size_t)x;
-                    float *q = &blob[off.cells + ((s * cells + cell) * (size_t)n_ch + (size_t)ch) * 4];
-                    q[0] = node[(size_t)y * nx + x]; q[1] = node[(size_t)y * nx + x + 1];
-                    q[2] = node[(size_t)(y + 1) * nx + x]; q[3] = node[(size_t)(y + 1) * nx + x + 1];
+            // a slice's corner bricks go to every bracket the slice bounds: [bracket][cell][channel][slice of the bracket, phi fastest]
+            const int ip = (int)(s / (size_t)n_theta), it = (int)(s % (size_t)n_theta);
+            const int tb = n_theta > 1 ? n_theta - 1 : 1, pb = n_phi > 1 ? n_phi - 1 : 1;
+            const size_t in_bracket = rgl_bracket_slices(n_phi, n_theta);
+            for (int dp = 0; dp < (n_phi > 1 ? 2 : 1); ++dp)
+                for (int dt = 0; dt < (n_theta > 1 ? 2 : 1); ++dt) {
+                    const int ipb = ip - dp, itb = it - dt;          // the bracket in which this slice is the (dp, dt) corner
+                    if (ipb < 0 || ipb >= pb || itb < 0 || itb >= tb) continue;
+                    const size_t slot = n_phi > 1 ? (size_t)dp + 2 * (size_t)dt : (size_t)dt, first = ((size_t)ipb * tb + itb) * cells;
+                    for (int y = 0; y < ny - 1; ++y)
+                        for (int x = 0; x < nx - 1; ++x) {
+                            const size_t cell = (size_t)y * (size_t)(nx - 1) + (size_t)x;
+                            float *q = &blob[off.cells + (((first + cell) * (size_t)n_ch + (size_t)ch) * in_bracket + slot) * 4];
+                            q[0] = node[(size_t)y * nx + x]; q[1] = node[(size_t)y * nx + x + 1];
+                            q[2] = node[(size_t)(y + 1) * nx + x]; q[3] = node[(size_t)(y + 1) * nx + x + 1];
+                        }
                 }
         }
     if (distribution) {
@@ -493,7 +606,7 @@ hipError_t launch_spectral_mode(const BatchArgs &a, const RglDev &r, const float
     const size_t cap = (size_t)compute_units * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_rgl_spectral<MODE, false>), dim3((unsigned)blocks), dim3(kRglBlock), 0, stream, a, r, wl, W);
+    hipLaunchKernelGGL((k_rgl_spectral<MODE, false>), dim3((unsigned)blocks), dim3(kRglBlock), grid_bytes_of(r), stream, a, r, wl, W);
     return hipGetLastError();
 }
 } // namespace

@@ -22,7 +22,9 @@
 // What bounds the kernel and what this file does about it (profiles/r03_rgl_pmc.json, r04_rgl_pmc.json): the
 // cost is the number of SCATTERED lane-addresses the CU's texture addresser resolves (one load instruction of 64 lanes that
 // touch ~50 lines costs ~80 cycles of a CU whatever its width), not bytes and not arithmetic.  Hence
-//   * cell bricks: what a lookup needs about a cell sits in ONE aligned 16-B vector per table and parameter slice;
+//   * cell bricks: what a lookup needs about a cell sits in ONE aligned 16-B vector per table and parameter slice, and the
+//     vectors of the 2 / 4 slices of a parameter BRACKET lie side by side (32 / 64 B: one cache line where slice-major tables
+//     cost one line per slice — the L1 hit rate of eval was 16 - 40 %, its miss path the busiest unit);
 //   * the SEARCH tables (conditional and marginal running integrals — ten dependent reads per sample() and slice in the
 //     textbook form) are stored for the BRACKET, not the slice: the two theta_i slices of a bracket side by side in one
 //     float4 (`cond2`), the four slices of a (phi_i, theta_i) bracket's marginal in one float4 (`margq`) — one load where
@@ -44,8 +46,9 @@ namespace mrl {
 
 // One piecewise-bilinear function.  Slices are row-major in (phi, theta); a slice is (ny - 1) x (nx - 1) cells, x fastest.
 struct WarpDev {
-    const float4 *cells;    // [slices][cell][n_ch]  the cell's four corner values (v00, v10, v01, v11), normalised if a distribution
-    // distributions only — the search tables, per parameter BRACKET (tb = max(n_theta - 1, 1), pb = max(n_phi - 1, 1)):
+    // per parameter BRACKET (tb = max(n_theta - 1, 1), pb = max(n_phi - 1, 1); a bracket has 1 / 2 / 4 slices, phi fastest):
+    const float4 *cells;    // [pb][tb][cell][n_ch][slice of the bracket]  the cell's four corner values (v00, v10, v01, v11), normalised if a distribution
+    // distributions only — the search tables:
     const float4 *cond2;    // [n_phi][tb][cell]   running integrals along x, up to node col + 1, of node rows (row, row + 1):
                             //                     .xy of slice (ip, it), .zw of slice (ip, it + 1) (of (ip, it) again when n_theta = 1)
     const float4 *margq;    // [pb][tb][ny - 1]    marginal cdf after the cell row, of slices (ip, it) (ip+1, it) (ip, it+1) (ip+1, it+1)
@@ -87,6 +90,10 @@ struct RglDev {
 
 namespace rgl {
 
+#ifndef MRL_RGL_SAMPLE_BATCH
+#define MRL_RGL_SAMPLE_BATCH true
+#endif
+
 // the four parameter slices around (phi_i, theta_i) and their weights, phi fastest (the order the oracle sums in); `mask`
 // says which entries exist (a grid of one node has no upper neighbour) — uniform over a launch, so the tests on it are
 // scalar branches and the arrays stay in registers.  pair[]: the theta bracket's index in cond2 for phi node ip / ip + 1;
@@ -95,25 +102,40 @@ namespace rgl {
 // slice (into the per-slice tables), roff[k] = slice k x cell rows, pair[] / quad already multiplied by their row lengths.
 struct Slices { unsigned soff[4], roff[4]; double w[4]; int mask; unsigned pair[2], quad; };
 
-MRL_HD void bracket(const float *grid, int n, double p, int &i, double &t)
+// largest i in [0, n - 2] with node(i) <= p, and p's position in that bracket; node(k): the ascending grid's k-th value
+template <class Node>
+MRL_HD void bracket_by(const Node &node, int n, double p, int &i, double &t)
 {
 #pragma clang fp contract(off)
-    // largest i in [0, n - 2] with grid[i] <= p
     int lo = 0, hi = n - 1;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((double)grid[mid] <= p) lo = mid; else hi = mid; }
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((double)node(mid) <= p) lo = mid; else hi = mid; }
     i = lo;
-    const double p0 = grid[lo], p1 = grid[lo + 1];
+    const double p0 = node(lo), p1 = node(lo + 1);
     t = fast::div_fast(p - p0, p1 - p0);
     t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
 }
+MRL_HD void bracket(const float *grid, int n, double p, int &i, double &t)
+{
+    bracket_by([grid](int k) { return grid[k]; }, n, p, i, t);
+}
 
-MRL_HD Slices find_slices(const WarpDev &w, double phi_i, double theta_i)
+// Where the two parameter grids are read: from the image (host code, batches with material ids) or from the copy a single-material
+// kernel keeps in LDS (merl_rgl.hip: GridLds) — the bracket search is 3 - 4 dependent reads per grid and unit, a third of an
+// anisotropic eval while each was a round trip through the vector memory pipe.
+struct GridMem {
+    const float *phi, *theta;
+    MRL_HD float phi_at(int k) const { return phi[k]; }
+    MRL_HD float theta_at(int k) const { return theta[k]; }
+};
+
+template <class Grids>
+MRL_HD Slices find_slices(const WarpDev &w, const Grids &g, double phi_i, double theta_i)
 {
 #pragma clang fp contract(off)
     int ip = 0, it = 0;
     double tp = 0.0, tt = 0.0;
-    if (w.n_phi > 1) bracket(w.phi, w.n_phi, phi_i, ip, tp);
-    if (w.n_theta > 1) bracket(w.theta, w.n_theta, theta_i, it, tt);
+    if (w.n_phi > 1) bracket_by([&g](int k) { return g.phi_at(k); }, w.n_phi, phi_i, ip, tp);
+    if (w.n_theta > 1) bracket_by([&g](int k) { return g.theta_at(k); }, w.n_theta, theta_i, it, tt);
     const int ip1 = w.n_phi > 1 ? ip + 1 : ip, it1 = w.n_theta > 1 ? it + 1 : it;
     const int tb = w.n_theta > 1 ? w.n_theta - 1 : 1;
     const unsigned per_c = (unsigned)((w.nx - 1) * (w.ny - 1)), per_r = (unsigned)(w.ny - 1);
@@ -138,22 +160,47 @@ MRL_HD Slices single_slice()
 
 // weighted sums over the parameter slices, component by component in slice order (what the oracle's scalar loop does; the
 // first term is a product, every later one an explicit FMA); 32-bit offsets: a function's tables hold at most 2^28 values;
-// index: the cell inside a slice (ndf / sigma: single_slice(), whose offsets are zero)
+// index: the cell inside a slice (ndf / sigma: single_slice(), whose offsets are zero); the cells are stored per (phi, theta)
+// BRACKET — pair[0] is the bracket's first cell —, [cell][channel][slice of the bracket]
 struct D4 { double x, y, z, w; };
 struct D2 { double x, y; };
-MRL_HD D4 fetch4(const Slices &s, const float4 *base, int index, int stride = 1, int offset = 0)
+// A lookup in two steps, so that the loads of everything a stage needs are in flight together: the compiler waits for a load where
+// its value is first used, and a load inside a conditional block next to its use is a round trip of its own — 25 serial round
+// trips per anisotropic eval was what bounded the kernel, not the addresser and not the lines fetched.
+//   fetch_raw: the corner vectors of one cell (and channel), one per slice of the bracket — loads only;
+//   blend4:    their weighted sum.
+struct Raw4 { float4 q0, q1, q2, q3; };      // q1: the phi neighbour, q2: the theta neighbour, q3: both
+MRL_HD unsigned bracket_slices(const Slices &s) { return (unsigned)((s.mask & 1) + ((s.mask >> 1) & 1) + ((s.mask >> 2) & 1) + ((s.mask >> 3) & 1)); }
+MRL_HD Raw4 fetch_raw(const Slices &s, const float4 *base, int index, int n_ch = 1, int channel = 0)
+{
+    // the bracket's slices lie side by side (16 / 32 / 64 B per cell and channel), phi fastest
+    const float4 *p = base + ((s.pair[0] + (unsigned)index) * (unsigned)n_ch + (unsigned)channel) * bracket_slices(s);
+    Raw4 r;
+    // absent slices: zeros (never summed).  Defined values on purpose: left undefined, the compiler merges each conditional read with the
+    // conditional sum that uses it — the load next to its use again, one round trip per slice (measured: 1.49 -> 1.97 ms)
+    r.q1 = r.q2 = r.q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    r.q0 = p[0];
+    if (s.mask & 2) r.q1 = p[1];
+    if (s.mask & 4) r.q2 = p[(s.mask & 2) ? 2 : 1];
+    if (s.mask & 8) r.q3 = p[3];
+    return r;
+}
+MRL_HD D4 blend4(const Slices &s, const Raw4 &r)
 {
 #pragma clang fp contract(off)
-    const float4 q0 = base[(s.soff[0] + (unsigned)index) * (unsigned)stride + (unsigned)offset];
-    D4 v = { s.w[0] * (double)q0.x, s.w[0] * (double)q0.y, s.w[0] * (double)q0.z, s.w[0] * (double)q0.w };
-#pragma unroll
-    for (int k = 1; k < 4; ++k)
-        if ((s.mask >> k) & 1) {
-            const float4 q = base[(s.soff[k] + (unsigned)index) * (unsigned)stride + (unsigned)offset];
-            v.x = __builtin_fma(s.w[k], (double)q.x, v.x); v.y = __builtin_fma(s.w[k], (double)q.y, v.y);
-            v.z = __builtin_fma(s.w[k], (double)q.z, v.z); v.w = __builtin_fma(s.w[k], (double)q.w, v.w);
-        }
+    D4 v = { s.w[0] * (double)r.q0.x, s.w[0] * (double)r.q0.y, s.w[0] * (double)r.q0.z, s.w[0] * (double)r.q0.w };
+    auto add = [&](double w, const float4 &q) {
+        v.x = __builtin_fma(w, (double)q.x, v.x); v.y = __builtin_fma(w, (double)q.y, v.y);
+        v.z = __builtin_fma(w, (double)q.z, v.z); v.w = __builtin_fma(w, (double)q.w, v.w);
+    };
+    if (s.mask & 2) add(s.w[1], r.q1);
+    if (s.mask & 4) add(s.w[2], r.q2);
+    if (s.mask & 8) add(s.w[3], r.q3);
     return v;
+}
+MRL_HD D4 fetch4(const Slices &s, const float4 *base, int index, int n_ch = 1, int channel = 0)
+{
+    return blend4(s, fetch_raw(s, base, index, n_ch, channel));
 }
 
 // the blends of the bracket vectors, in slice order (the same sums, in the same order, as a slice-by-slice read):
@@ -183,15 +230,23 @@ struct SearchMem {
     const float4 *cond2, *margq;
     MRL_HD explicit SearchMem(const WarpDev &w) : cond2(w.cond2), margq(w.margq) {}
     // the conditional running integrals of node rows (row, row + 1) up to node col + 1, cell = row (nx - 1) + col
-    MRL_HD D2 cond(const Slices &s, int cell) const
-    {
-        const float4 a = cond2[s.pair[0] + (unsigned)cell];
-        float4 b = a;
-        if (s.mask & 2) b = cond2[s.pair[1] + (unsigned)cell];
-        return blend_pairs(s, a, b);
-    }
+    MRL_HD D2 cond(const Slices &s, int cell) const { return cond_blend(s, cond_raw(s, cell)); }
     // the marginal cdf after cell row `row`
-    MRL_HD double marg(const Slices &s, int row) const { return blend_quad(s, margq[s.quad + (unsigned)row]); }
+    MRL_HD double marg(const Slices &s, int row) const { return marg_blend(s, marg_raw(s, row)); }
+    // the same in two steps (loads, then sums: see fetch_raw)
+    struct CondRaw { float4 a, b; };
+    typedef float4 MargRaw;
+    MRL_HD CondRaw cond_raw(const Slices &s, int cell) const
+    {
+        CondRaw r;
+        r.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        r.a = cond2[s.pair[0] + (unsigned)cell];
+        if (s.mask & 2) r.b = cond2[s.pair[1] + (unsigned)cell];
+        return r;
+    }
+    MRL_HD D2 cond_blend(const Slices &s, const CondRaw &r) const { return blend_pairs(s, r.a, r.b); }
+    MRL_HD MargRaw marg_raw(const Slices &s, int row) const { return margq[s.quad + (unsigned)row]; }
+    MRL_HD double marg_blend(const Slices &s, const MargRaw &q) const { return blend_quad(s, q); }
 };
 
 MRL_HD int clamp_cell(double p, int last)
@@ -217,18 +272,34 @@ MRL_HD double bilinear(const D4 &q, double fx, double fy)
     return lerp(fy, lerp(fx, q.x, q.y), lerp(fx, q.z, q.w));
 }
 
-// a plain lookup; `known` (may be null): a cell of this table whose corner values are already held
-MRL_HD double warp_eval(const WarpDev &w, const Slices &s, double x_in, double y_in, int channel = 0, const Found *known = nullptr)
+// the cell of a table a position falls in, and the position inside the cell
+struct Cell { int ox, oy, index; double fx, fy; };
+MRL_HD Cell locate(const WarpDev &w, double x_in, double y_in)
 {
 #pragma clang fp contract(off)
     const double px = x_in * (double)(w.nx - 1), py = y_in * (double)(w.ny - 1);
-    const int ox = clamp_cell(px, w.nx - 2), oy = clamp_cell(py, w.ny - 2);
-    const double fx = px - (double)ox, fy = py - (double)oy;
-    D4 q;
-    if (known && known->row == oy && known->col == ox) q = known->q;
-    else q = fetch4(s, w.cells, oy * (w.nx - 1) + ox, w.n_ch, channel);
-    const double v = bilinear(q, fx, fy);
+    Cell c;
+    c.ox = clamp_cell(px, w.nx - 2); c.oy = clamp_cell(py, w.ny - 2);
+    c.fx = px - (double)c.ox; c.fy = py - (double)c.oy;
+    c.index = c.oy * (w.nx - 1) + c.ox;
+    return c;
+}
+// the value at the position from the cell's blended corners
+MRL_HD double cell_value(const WarpDev &w, const Cell &c, const D4 &q)
+{
+#pragma clang fp contract(off)
+    const double v = bilinear(q, c.fx, c.fy);
     return w.normalized ? v * (double)(w.nx - 1) * (double)(w.ny - 1) : v;
+}
+
+// a plain lookup; `known` (may be null): a cell of this table whose corner values are already held
+MRL_HD double warp_eval(const WarpDev &w, const Slices &s, double x_in, double y_in, int channel = 0, const Found *known = nullptr)
+{
+    const Cell c = locate(w, x_in, y_in);
+    D4 q;
+    if (known && known->row == c.oy && known->col == c.ox) q = known->q;
+    else q = fetch4(s, w.cells, c.index, w.n_ch, channel);
+    return cell_value(w, c, q);
 }
 
 MRL_HD double safe_sqrt(double x) { return x > 0.0 ? fast::sqrt_fast(x) : 0.0; }
@@ -250,7 +321,6 @@ MRL_HD double warp_sample(const WarpDev &w, const Search &t, const Slices &s, do
 {
 #pragma clang fp contract(off)
     const int nx = w.nx, ny = w.ny;
-    const int per_c = (ny - 1) * (nx - 1);
     ux = clamp01(ux); uy = clamp01(uy);
     int lo = 0, hi = ny - 2;
     double before = 0.0;                                     // the marginal cdf below row lo: every step that raises lo has just read it
@@ -291,7 +361,6 @@ MRL_HD double warp_invert(const WarpDev &w, const Search &t, const Slices &s, do
 {
 #pragma clang fp contract(off)
     const int nx = w.nx, ny = w.ny;
-    const int per_c = (ny - 1) * (nx - 1);
     const double px = x_in * (double)(nx - 1), py = y_in * (double)(ny - 1);
     const int col = clamp_cell(px, nx - 2), row = clamp_cell(py, ny - 2);
     const double x = px - (double)col, y = py - (double)row;
@@ -301,11 +370,18 @@ MRL_HD double warp_invert(const WarpDev &w, const Search &t, const Slices &s, do
     if (known && known->row == row && known->col == col) {
         q = known->q; left = known->left; before = known->before; r0 = known->r0; r1 = known->r1;
     } else {
-        q = fetch4(s, w.cells, row * (nx - 1) + col);
-        if (col > 0) left = t.cond(s, row * (nx - 1) + col - 1);
-        const D2 tot = t.cond(s, row * (nx - 1) + nx - 2);
+        // everything the cell needs is read before anything is summed: one round trip (the reads left of column 0 / below row 0
+        // are issued at a clamped index and dropped)
+        const Raw4 qr = fetch_raw(s, w.cells, row * (nx - 1) + col);
+        const auto lr = t.cond_raw(s, row * (nx - 1) + (col > 0 ? col - 1 : 0));
+        const auto tr = t.cond_raw(s, row * (nx - 1) + nx - 2);
+        const auto br = t.marg_raw(s, row > 0 ? row - 1 : 0);
+        q = blend4(s, qr);
+        const D2 l = t.cond_blend(s, lr), tot = t.cond_blend(s, tr);
+        if (col > 0) left = l;
         r0 = tot.x; r1 = tot.y;
-        if (row > 0) before = t.marg(s, row - 1);
+        const double bf = t.marg_blend(s, br);
+        if (row > 0) before = bf;
     }
     const double c0 = lerp(y, q.x, q.z), c1 = lerp(y, q.y, q.w);
     const double pdf = lerp(x, c0, c1) * (double)(nx - 1) * (double)(ny - 1);
@@ -367,15 +443,15 @@ MRL_HD void reduce_signs(int reduction, float wix, float wiy, float &sx, float &
 // jacobian's denominator: a function of wi alone)
 struct Incident { Vec3d wi; float fx, fy; double theta_i, phi_i, sigma4; Slices sv; };
 
-template <bool WANT_SIGMA>
-MRL_HD bool incident(const RglDev &b, float wix, float wiy, float wiz, Incident &in)
+template <bool WANT_SIGMA, class Grids>
+MRL_HD bool incident(const RglDev &b, const Grids &g, float wix, float wiy, float wiz, Incident &in)
 {
 #pragma clang fp contract(off)
     reduce_signs(b.reduction, wix, wiy, in.fx, in.fy);
     in.wi = { (double)(wix * in.fx), (double)(wiy * in.fy), (double)wiz };
     if (!unit3(in.wi)) return false;
     in.theta_i = elevation(in.wi); in.phi_i = azimuth(in.wi.y, in.wi.x);
-    in.sv = find_slices(b.vndf(), in.phi_i, in.theta_i);
+    in.sv = find_slices(b.vndf(), g, in.phi_i, in.theta_i);
     in.sigma4 = 1.0;
     if constexpr (WANT_SIGMA)
         if (b.jacobian) in.sigma4 = 4.0 * warp_eval(b.sigma(), single_slice(), theta2u(in.theta_i), phi2u(in.phi_i));
@@ -416,17 +492,22 @@ MRL_HD double value_scale(const RglDev &b, const Incident &in, const Half &h)
     return b.jacobian ? fast::div_fast(warp_eval(b.ndf(), single_slice(), h.u_m_x, h.u_m_y), in.sigma4) : 1.0;
 }
 
-// fl (may be null): the cell of luminance a sample() has just visited
-MRL_HD float pdf_of(const RglDev &b, const Incident &in, const Half &h, const Found *fl)
+MRL_HD float pdf_from(const Incident &in, const Half &h, double lum_pdf)
 {
 #pragma clang fp contract(off)
-    const double lum_pdf = warp_eval(b.luminance(), in.sv, h.sx, h.sy, 0, fl);
     const double jac = fmax(2.0 * kPi * kPi * h.u_m_x * h.sin_theta_m, 1e-6) * 4.0 * h.wi_dot_m;
     return (float)fast::div_fast(h.vndf_pdf * lum_pdf, jac);
 }
+// fl (may be null): the cell of luminance a sample() has just visited
+MRL_HD float pdf_of(const RglDev &b, const Incident &in, const Half &h, const Found *fl)
+{
+    return pdf_from(in, h, warp_eval(b.luminance(), in.sv, h.sx, h.sy, 0, fl));
+}
 
 // eval (f cos theta_o, RGB) and / or pdf for an incident direction that is above the horizon; wo as the caller holds it.
-template <bool WANT_RGB, bool WANT_PDF, class Search>
+// BATCH: the three channels' reads in flight together (12 vectors for an anisotropic file: 48 registers) — or channel by channel,
+// for the callers that are short of registers (sample(): it carries two visited cells)
+template <bool WANT_RGB, bool WANT_PDF, bool BATCH = true, class Search>
 MRL_HD void eval_pdf_at(const RglDev &b, const Search &tv, const Incident &in, float wox, float woy, float woz, float rgb[3], float &pdf,
                         const Found *fv = nullptr, const Found *fl = nullptr)
 {
@@ -434,15 +515,29 @@ MRL_HD void eval_pdf_at(const RglDev &b, const Search &tv, const Incident &in, f
     rgb[0] = rgb[1] = rgb[2] = 0.0f; pdf = 0.0f;
     const Half h = half_lookup(b, tv, in, wox, woy, woz, fv);
     if (!h.ok) return;
+    // the luminance cell (pdf) and the three channels' cells lie at the same position of tables of one shape: located once, read together
+    const WarpDev wr = b.rgb(), wl = b.luminance();
+    const Cell c = locate(wr, h.sx, h.sy);
+    Raw4 raw[BATCH ? 3 : 1], rawl{};
+    const bool have_l = fl && fl->row == c.oy && fl->col == c.ox;
+    if constexpr (WANT_RGB && BATCH)
+        for (int k = 0; k < 3; ++k) raw[k] = fetch_raw(in.sv, wr.cells, c.index, wr.n_ch, k);
+    if constexpr (WANT_PDF)
+        if (!have_l) rawl = fetch_raw(in.sv, wl.cells, c.index);
     if constexpr (WANT_RGB) {
         const double scale = value_scale(b, in, h);
-        for (int c = 0; c < 3; ++c) {
-            double v = warp_eval(b.rgb(), in.sv, h.sx, h.sy, c);
+        for (int k = 0; k < 3; ++k) {
+            if constexpr (!BATCH) raw[0] = fetch_raw(in.sv, wr.cells, c.index, wr.n_ch, k);
+            double v = cell_value(wr, c, blend4(in.sv, raw[BATCH ? k : 0]));
             v = v < 0.0 ? 0.0 : v;
-            rgb[c] = (float)(v * scale);
+            rgb[k] = (float)(v * scale);
         }
     }
-    if constexpr (WANT_PDF) pdf = pdf_of(b, in, h, fl);
+    if constexpr (WANT_PDF) {
+        D4 ql;
+        if (have_l) ql = fl->q; else ql = blend4(in.sv, rawl);
+        pdf = pdf_from(in, h, cell_value(wl, c, ql));
+    }
 }
 
 // sample()'s direction for an incident direction that is above the horizon: false when the draw is rejected (reflected below the
@@ -488,7 +583,7 @@ MRL_HD void sample_at(const RglDev &b, const Search &tv, const Search &tl, const
     Found fl, fv;
     if (!sample_direction(b, tv, tl, in, u0, u1, wof, fl, fv)) return;
     float f[3], p;
-    eval_pdf_at<true, true>(b, tv, in, wof[0], wof[1], wof[2], f, p, &fv, &fl);          // at the Float direction that is returned
+    eval_pdf_at<true, true, MRL_RGL_SAMPLE_BATCH>(b, tv, in, wof[0], wof[1], wof[2], f, p, &fv, &fl);    // at the Float direction that is returned
     if (!(p > 0.0f)) return;
     wo_out[0] = wof[0]; wo_out[1] = wof[1]; wo_out[2] = wof[2];
     pdf_out = p;
@@ -566,7 +661,7 @@ MRL_HD void eval_pdf(const RglDev &b, float wix, float wiy, float wiz, float wox
 {
     rgb[0] = rgb[1] = rgb[2] = 0.0f; pdf = 0.0f;
     Incident in;
-    if (!(wiz > 0.0f) || !(woz > 0.0f) || !incident<WANT_RGB>(b, wix, wiy, wiz, in)) return;
+    if (!(wiz > 0.0f) || !(woz > 0.0f) || !incident<WANT_RGB>(b, GridMem{ b.phi, b.theta }, wix, wiy, wiz, in)) return;
     eval_pdf_at<WANT_RGB, WANT_PDF>(b, SearchMem(b.vndf()), in, wox, woy, woz, rgb, pdf);
 }
 
@@ -574,7 +669,7 @@ MRL_HD void sample(const RglDev &b, float wix, float wiy, float wiz, float u0, f
 {
     wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f; weight[0] = weight[1] = weight[2] = 0.0f;
     Incident in;
-    if (!(wiz > 0.0f) || !incident<true>(b, wix, wiy, wiz, in)) return;
+    if (!(wiz > 0.0f) || !incident<true>(b, GridMem{ b.phi, b.theta }, wix, wiy, wiz, in)) return;
     sample_at(b, SearchMem(b.vndf()), SearchMem(b.luminance()), in, u0, u1, wo_out, pdf_out, weight);
 }
 
@@ -584,7 +679,7 @@ MRL_HD void eval_pdf_spectral(const RglDev &b, float wix, float wiy, float wiz, 
 {
     pdf = 0.0f;
     Incident in;
-    if (!(wiz > 0.0f) || !(woz > 0.0f) || !incident<WANT_VALUES>(b, wix, wiy, wiz, in)) {
+    if (!(wiz > 0.0f) || !(woz > 0.0f) || !incident<WANT_VALUES>(b, GridMem{ b.phi, b.theta }, wix, wiy, wiz, in)) {
         if constexpr (WANT_VALUES) for (int k = 0; k < W; ++k) values[k] = 0.0f;
         return;
     }
@@ -596,7 +691,7 @@ MRL_HD void sample_spectral(const RglDev &b, float wix, float wiy, float wiz, fl
 {
     wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f;
     Incident in;
-    if (!(wiz > 0.0f) || !incident<true>(b, wix, wiy, wiz, in)) { for (int k = 0; k < W; ++k) weight[k] = 0.0f; return; }
+    if (!(wiz > 0.0f) || !incident<true>(b, GridMem{ b.phi, b.theta }, wix, wiy, wiz, in)) { for (int k = 0; k < W; ++k) weight[k] = 0.0f; return; }
     sample_spectral_at(b, SearchMem(b.vndf()), SearchMem(b.luminance()), in, u0, u1, wl, W, wo_out, pdf_out, weight);
 }
 

@@ -55,10 +55,12 @@ static bool consistent(const ImageHeader &h, unsigned long long file_bytes, cons
     if (p.texel_bytes != h.texel_bytes) return false;
     if (p.is_rgl) {
         const RglFields &f = p.shapes;
-        const uint64_t floats = p.texel_bytes / 4, slices = (uint64_t)f.n_phi * f.n_theta;
+        // the cells are stored per parameter bracket, the bracket's 1 / 2 / 4 slices side by side
+        const uint64_t floats = p.texel_bytes / 4;
+        const uint64_t copies = (uint64_t)(f.n_phi > 1 ? f.n_phi - 1 : 1) * (f.n_theta > 1 ? f.n_theta - 1 : 1) * (f.n_phi > 1 ? 2 : 1) * (f.n_theta > 1 ? 2 : 1);
         const uint64_t cells[5] = { (uint64_t)(f.res_ndf[0] - 1) * (f.res_ndf[1] - 1), (uint64_t)(f.res_sigma[0] - 1) * (f.res_sigma[1] - 1),
-                                    (uint64_t)(f.res[0] - 1) * (f.res[1] - 1) * slices, (uint64_t)(f.res[0] - 1) * (f.res[1] - 1) * slices,
-                                    (uint64_t)(f.res[0] - 1) * (f.res[1] - 1) * slices * 3 };
+                                    (uint64_t)(f.res[0] - 1) * (f.res[1] - 1) * copies, (uint64_t)(f.res[0] - 1) * (f.res[1] - 1) * copies,
+                                    (uint64_t)(f.res[0] - 1) * (f.res[1] - 1) * copies * 3 };
         for (int w = 0; w < 5; ++w) {
             if (p.layout.cells[w] % 4 != 0 || p.layout.cells[w] + cells[w] * 4 > floats) return false;
             if (w == 2 || w == 3) {

@@ -12,13 +12,15 @@ from collections import defaultdict
 
 out = sys.argv[1]
 UNITS = 16 << 20
-MODES = {"0": "eval", "1": "pdf", "2": "sample", "3": "eval_sample"}
+MODES = {"0": "eval", "1": "pdf", "2": "sample", "3": "eval_sample", "4": "eval_pdf"}
 res = {"what": "rocprofv3 --kernel-trace --pmc passes over tools/rgl_pmc_driver.py (tools/pmc_rgl.sh): mean per launch, 16M random units per launch; "
                "GRBM_GUI_ACTIVE is summed over 8 XCDs, TA / TCP counters over 256 CUs. Round 3's kernel for comparison: profiles/r03_rgl_pmc.json "
-               "(vmem loads per unit 33.5 / 25.5 / 126 / 159.5 for eval / pdf / sample / eval_sample, mean of the two files)."}
+               "(vmem loads per unit 33.5 / 25.5 / 126 / 159.5 for eval / pdf / sample / eval_sample, mean of the two files). "
+               "anisotropic_lds: the default for a file whose conditional integrals do not fit a CU's LDS — marginal rows in LDS for sample(), and "
+               "the fused call runs as the eval_pdf kernel followed by the sample kernel (no eval_sample row)."}
 for cfg in sorted(os.listdir(out)):
     d = os.path.join(out, cfg)
-    if not os.path.isdir(d):
+    if not os.path.isdir(d) or cfg.startswith("stats_"):
         continue
     acc = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):

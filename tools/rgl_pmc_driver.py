@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One RGL material, one search mode, the four entry points three times each over 16M random units: the process tools/pmc_rgl.sh
+"""One RGL material, one search mode, the five entry points three times each over 16M random units: the process tools/pmc_rgl.sh
 profiles (kernel names then tell the entry points apart; file shape and search mode are the run's).
     python tools/rgl_pmc_driver.py isotropic|anisotropic lds|memory"""
 import os
@@ -20,6 +20,6 @@ with host.MerlHip(0) as g:
     wi, wo, u = g.generate_pairs(0x5EED, 0, n)
     mid = g.upload_rgl(synth.make_rgl_fields(seed=9, **shape))
     for _ in range(3):
-        g.eval(wi, wo, material=mid); g.pdf(wi, wo, material=mid); g.sample(wi, u, material=mid); g.eval_sample(wi, wo, u, material=mid)
+        g.eval(wi, wo, material=mid); g.pdf(wi, wo, material=mid); g.eval_pdf(wi, wo, material=mid); g.sample(wi, u, material=mid); g.eval_sample(wi, wo, u, material=mid)
     torch.cuda.synchronize()
 print("ok")
