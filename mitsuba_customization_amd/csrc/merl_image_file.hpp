@@ -20,7 +20,7 @@ struct RglFields {                   // host arrays, as the file holds them (x f
     int n_wl;                        // 0: an RGB file (rgb [n_phi][n_theta][3][ny][nx]); else a spectral one: `rgb` holds "spectra"
     const float *wavelengths;        // [n_phi][n_theta][n_wl][ny][nx] over this ascending grid
 };
-struct RglLayout { size_t phi, theta, wavelengths, cells[5], cond2[5], margq[5]; };   // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
+struct RglLayout { size_t phi, theta, wavelengths, cells[5], margq[5]; };   // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
 inline int rgl_value_channels(const RglFields &f) { return f.n_wl > 0 ? f.n_wl : 3; }
 
 inline const char *rgl_check_shapes(const RglFields &f)
@@ -34,27 +34,33 @@ inline const char *rgl_check_shapes(const RglFields &f)
     if (slices * per * (size_t)rgl_value_channels(f) > ((size_t)1 << 28)) return "tables too large (more than 2^28 values)";
     // the image stores a slice's cells once per parameter bracket it bounds (up to 4 x): 32-bit float4 offsets must still reach
     const size_t pb = f.n_phi > 1 ? (size_t)f.n_phi - 1 : 1, tb = f.n_theta > 1 ? (size_t)f.n_theta - 1 : 1, in_bracket = (f.n_phi > 1 ? 2 : 1) * (f.n_theta > 1 ? 2 : 1);
-    if (pb * tb * in_bracket * per * (size_t)rgl_value_channels(f) > ((size_t)1 << 30)) return "tables too large (more than 2^30 cell vectors in the image)";
+    const size_t widest = in_bracket * (size_t)rgl_value_channels(f) > 2 * (size_t)(f.n_phi > 1 ? 2 : 1) + in_bracket ? in_bracket * (size_t)rgl_value_channels(f) : 2 * (size_t)(f.n_phi > 1 ? 2 : 1) + in_bracket;
+    if (pb * tb * per * widest > ((size_t)1 << 30)) return "tables too large (more than 2^30 cell vectors in the image)";
     return nullptr;
 }
 
-struct WarpOffsets { size_t cells = 0, cond2 = 0, margq = 0; };
-// the search tables of a distribution are stored per parameter BRACKET (merl_rgl.hpp, WarpDev): brackets along theta / phi
+struct WarpOffsets { size_t cells = 0, margq = 0; };
+// Everything is stored per parameter BRACKET (merl_rgl.hpp, WarpDev): brackets along theta / phi, the 1 / 2 / 4 slices of a bracket
+// side by side, one copy of a slice per bracket it bounds
 inline size_t rgl_theta_brackets(int n_theta) { return n_theta > 1 ? (size_t)n_theta - 1 : 1; }
 inline size_t rgl_phi_brackets(int n_phi) { return n_phi > 1 ? (size_t)n_phi - 1 : 1; }
-// ... and so are the cells: the 1 / 2 / 4 slices of a bracket side by side, one copy of a slice per bracket it bounds
 inline size_t rgl_bracket_slices(int n_phi, int n_theta) { return (size_t)(n_phi > 1 ? 2 : 1) * (size_t)(n_theta > 1 ? 2 : 1); }
-inline size_t rgl_cell_copies(int n_phi, int n_theta) { return rgl_phi_brackets(n_phi) * rgl_theta_brackets(n_theta) * rgl_bracket_slices(n_phi, n_theta); }
-// where one function's tables go: `at` is the running size of the image in floats (every table starts on a 16-byte boundary)
+inline size_t rgl_brackets(int n_phi, int n_theta) { return rgl_phi_brackets(n_phi) * rgl_theta_brackets(n_theta); }
+// float4s per cell of a DISTRIBUTION's record: the running integrals left of the cell (one float4 per phi node of the bracket), the
+// corner values (one per slice), the totals of the cell's two node rows (per phi node): 64 B isotropic, 128 B — one line — anisotropic
+inline size_t rgl_record_float4s(int n_phi, int n_theta) { return 2 * (size_t)(n_phi > 1 ? 2 : 1) + rgl_bracket_slices(n_phi, n_theta); }
+// where one function's tables go: `at` is the running size of the image in floats (every table starts on a 128-byte boundary, a cache
+// line: records and the value vectors of a cell then never straddle one more line than their size asks for)
 inline WarpOffsets plan_warp(size_t &at, int nx, int ny, int n_phi, int n_theta, int n_ch, bool distribution)
 {
-    const size_t cells = (size_t)(nx - 1) * (size_t)(ny - 1);
-    auto grow = [&](size_t floats) { const size_t off = (at + 3) / 4 * 4; at = off + floats; return off; };
+    const size_t cells = (size_t)(nx - 1) * (size_t)(ny - 1), brackets = rgl_brackets(n_phi, n_theta);
+    auto grow = [&](size_t floats) { const size_t off = (at + 31) / 32 * 32; at = off + floats; return off; };
     WarpOffsets off;
-    off.cells = grow(cells * 4 * (size_t)n_ch * rgl_cell_copies(n_phi, n_theta));
     if (distribution) {
-        off.cond2 = grow(cells * 4 * (size_t)n_phi * rgl_theta_brackets(n_theta));
-        off.margq = grow((size_t)(ny - 1) * 4 * rgl_phi_brackets(n_phi) * rgl_theta_brackets(n_theta));
+        off.cells = grow(cells * 4 * brackets * rgl_record_float4s(n_phi, n_theta));
+        off.margq = grow((size_t)(ny - 1) * 4 * brackets);
+    } else {
+        off.cells = grow(cells * 4 * (size_t)n_ch * brackets * rgl_bracket_slices(n_phi, n_theta));
     }
     return off;
 }
@@ -66,7 +72,7 @@ inline size_t rgl_plan_layout(const RglFields &f, RglLayout &l)
     l.phi = 0; l.theta = (size_t)f.n_phi; l.wavelengths = (size_t)f.n_phi + (size_t)f.n_theta;
     auto put = [&](int which, const int res[2], int n_phi, int n_theta, int n_ch, bool distribution) {
         const WarpOffsets o = plan_warp(at, res[0], res[1], n_phi, n_theta, n_ch, distribution);
-        l.cells[which] = o.cells; l.cond2[which] = o.cond2; l.margq[which] = o.margq;
+        l.cells[which] = o.cells; l.margq[which] = o.margq;
     };
     put(0, f.res_ndf, 1, 1, 1, false);
     put(1, f.res_sigma, 1, 1, 1, false);
@@ -81,7 +87,7 @@ inline size_t nch_brick_float4s(int n_ch) { return n_ch == 1 ? 2 : n_ch == 2 ? 4
 
 // ---- the file ----
 struct ImageHeader {
-    char magic[8];                       // "MRLIMG\3\0" (2: RGL search tables in the bracket form; 3: the cells too)
+    char magic[8];                       // "MRLIMG\4\0" (2: RGL search tables in the bracket form; 3: the cells too; 4: one record per cell of a distribution)
     uint32_t header_bytes, kind, layout, n_ch, param, lookup, node, n_ti;
     int32_t dims[3];
     int32_t rgl_shape[8];                // n_phi n_theta res_x res_y res_ndf_x res_ndf_y res_sigma_x res_sigma_y
@@ -89,7 +95,7 @@ struct ImageHeader {
     uint32_t negative;                   // MRL_OPT_NEGATIVE the table was built under: 0 = negative values were clamped to 0, 1 / 2 = the image holds them
     uint64_t texel_bytes, sampling_doubles, sampling2d_doubles, checksum;
 };
-constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 3, 0 };
+constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 4, 0 };
 constexpr uint64_t kImageChecksumSeed = 0xCBF29CE484222325ull;
 // the kinds and layouts an image can name (values of mrl::Kind / mrl::Layout / mrl::Param, repeated here so that this header needs no HIP)
 constexpr uint32_t kImgKindMerl = 0, kImgKindTable = 1, kImgKindNch = 4, kImgKindRgl = 5, kImgKindRglSpectral = 6, kImgLayoutRows = 0, kImgLayoutBrick = 1, kImgParamLast = 2;
@@ -188,10 +194,10 @@ inline const char *image_content_check(const ImagePlan &p, const void *payload)
         if (!ascending(p.layout.phi, s.n_phi) || !ascending(p.layout.theta, s.n_theta) || (s.n_wl > 0 && !ascending(p.layout.wavelengths, s.n_wl)))
             return "phi_i / theta_i / wavelengths must be strictly ascending";
         const size_t cells = (size_t)(s.res[0] - 1) * (size_t)(s.res[1] - 1);
-        const size_t tb = rgl_theta_brackets(s.n_theta), pb = rgl_phi_brackets(s.n_phi);
-        for (int w = 2; w <= 3; ++w) {                       // vndf, luminance: densities and their integrals
-            const size_t spans[3][2] = { { p.layout.cells[w], cells * 4 * rgl_cell_copies(s.n_phi, s.n_theta) }, { p.layout.cond2[w], cells * 4 * (size_t)s.n_phi * tb },
-                                         { p.layout.margq[w], (size_t)(s.res[1] - 1) * 4 * pb * tb } };
+        const size_t brackets = rgl_brackets(s.n_phi, s.n_theta);
+        for (int w = 2; w <= 3; ++w) {                       // vndf, luminance: densities and their integrals (the records, the marginals)
+            const size_t spans[2][2] = { { p.layout.cells[w], cells * 4 * brackets * rgl_record_float4s(s.n_phi, s.n_theta) },
+                                         { p.layout.margq[w], (size_t)(s.res[1] - 1) * 4 * brackets } };
             for (const auto &sp : spans)
                 for (size_t i = 0; i < sp[1]; ++i) if (f[sp[0] + i] < 0.0f) return "negative value in a distribution of the image";
         }

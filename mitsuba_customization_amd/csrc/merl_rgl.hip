@@ -29,7 +29,14 @@ constexpr int kRglBlock = 256;
 #ifndef MRL_RGL_LDS_BLOCK_SAMPLE15
 #define MRL_RGL_LDS_BLOCK_SAMPLE15 512
 #endif
-constexpr int rgl_lds_block(int mode, int mask = 0) { return mode >= 2 ? (mask == 15 ? MRL_RGL_LDS_BLOCK_SAMPLE15 : MRL_RGL_LDS_BLOCK_SAMPLE) : MRL_RGL_LDS_BLOCK_EVAL; }
+#ifndef MRL_RGL_LDS_BLOCK_EVALPDF5
+#define MRL_RGL_LDS_BLOCK_EVALPDF5 768
+#endif
+constexpr int rgl_lds_block(int mode, int mask = 0)
+{
+    if (mode == 4 && mask == 5) return MRL_RGL_LDS_BLOCK_EVALPDF5;
+    return mode >= 2 ? (mask == 15 ? MRL_RGL_LDS_BLOCK_SAMPLE15 : MRL_RGL_LDS_BLOCK_SAMPLE) : MRL_RGL_LDS_BLOCK_EVAL;
+}
 
 // ---- the search tables in LDS ----
 // Slice by slice (a bracket's float4 taken apart while it is copied): cond [slices][cell] float2, marg [slices][ny - 1] float, for vndf
@@ -53,23 +60,27 @@ __device__ __forceinline__ GridLds stage_grids(const RglDev &r, unsigned &at_flo
     return GridLds{ (unsigned)r.n_phi };
 }
 
+// Slice by slice, taken out of the records while they are copied: left [slices][cell] float2 (node rows row / row + 1, up to node col),
+// total [slices][ny - 1] float2, marg [slices][ny - 1] float — for vndf and then luminance.
 struct SearchLds {
-    unsigned cond_at, marg_at;          // float2 / float index of the table's first element in rgl_lds
+    unsigned left_at, total_at, marg_at;    // float2 / float2 / float index of the table's first element in rgl_lds
+    unsigned per_row;
     // reads, then sums (rgl::fetch_raw), slice by slice
-    struct CondRaw { float2 q0, q1, q2, q3; };
+    struct PairRaw { float2 q0, q1, q2, q3; };
     struct MargRaw { float m0, m1, m2, m3; };
-    __device__ __forceinline__ CondRaw cond_raw(const rgl::Slices &s, int cell) const
+    __device__ __forceinline__ PairRaw pair_at(const rgl::Slices &s, const float2 *t, const unsigned (&off)[4]) const
     {
-        const float2 *t = (const float2 *)rgl_lds + cond_at + (unsigned)cell;
-        CondRaw r;
+        PairRaw r;
         r.q1 = r.q2 = r.q3 = make_float2(0.0f, 0.0f);
-        r.q0 = t[s.soff[0]];
-        if (s.mask & 2) r.q1 = t[s.soff[1]];
-        if (s.mask & 4) r.q2 = t[s.soff[2]];
-        if (s.mask & 8) r.q3 = t[s.soff[3]];
+        r.q0 = t[off[0]];
+        if (s.mask & 2) r.q1 = t[off[1]];
+        if (s.mask & 4) r.q2 = t[off[2]];
+        if (s.mask & 8) r.q3 = t[off[3]];
         return r;
     }
-    __device__ __forceinline__ rgl::D2 cond_blend(const rgl::Slices &s, const CondRaw &r) const
+    __device__ __forceinline__ PairRaw left_raw(const rgl::Slices &s, int cell) const { return pair_at(s, (const float2 *)rgl_lds + left_at + (unsigned)cell, s.soff); }
+    __device__ __forceinline__ PairRaw total_raw(const rgl::Slices &s, int row) const { return pair_at(s, (const float2 *)rgl_lds + total_at + (unsigned)row, s.roff); }
+    __device__ __forceinline__ rgl::D2 pair_blend(const rgl::Slices &s, const PairRaw &r) const
     {
 #pragma clang fp contract(off)
         rgl::D2 v = { s.w[0] * (double)r.q0.x, s.w[0] * (double)r.q0.y };
@@ -98,31 +109,19 @@ struct SearchLds {
         if (s.mask & 8) v = __builtin_fma(s.w[3], (double)r.m3, v);
         return v;
     }
-    __device__ __forceinline__ rgl::D2 cond(const rgl::Slices &s, int cell) const { return cond_blend(s, cond_raw(s, cell)); }
+    __device__ __forceinline__ rgl::D2 left(const rgl::Slices &s, int cell) const { return pair_blend(s, left_raw(s, cell)); }
+    __device__ __forceinline__ rgl::D2 total(const rgl::Slices &s, int row) const { return pair_blend(s, total_raw(s, row)); }
     __device__ __forceinline__ double marg(const rgl::Slices &s, int row) const { return marg_blend(s, marg_raw(s, row)); }
 };
 
-// The partial form for files whose conditional integrals do not fit (an anisotropic 16 x 8 x 32 x 32 file: 1.7 MB per
-// distribution): the MARGINAL rows alone, in their bracket form (one ds_read_b128 per row-search step: 52 KB per distribution for
-// that file), the conditional integrals from memory.  Takes the row searches — 5 of the ~21 dependent reads of a forward warp,
-// and the `before` read of an inverse warp — off the texture addresser.
-struct SearchLdsMarg {
-    const float4 *cond2;
+// The partial form for files whose records do not fit (an anisotropic 16 x 8 x 32 x 32 file: 12.9 MB per distribution): the
+// MARGINAL rows alone, in their bracket form (one ds_read_b128 per row-search step: 52 KB per distribution for that file), the
+// conditional integrals from the records in memory.  Takes the row searches — 5 of the ~21 dependent reads of a forward warp — off
+// the vector memory pipe.
+struct SearchLdsMarg : rgl::SearchMem {
     unsigned marg_at;                   // float4 index of the table's first quad in rgl_lds
-    struct CondRaw { float4 a, b; };
-    typedef float4 MargRaw;
-    __device__ __forceinline__ CondRaw cond_raw(const rgl::Slices &s, int cell) const
-    {
-        CondRaw r;
-        r.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        r.a = cond2[s.pair[0] + (unsigned)cell];
-        if (s.mask & 2) r.b = cond2[s.pair[1] + (unsigned)cell];
-        return r;
-    }
-    __device__ __forceinline__ rgl::D2 cond_blend(const rgl::Slices &s, const CondRaw &r) const { return rgl::blend_pairs(s, r.a, r.b); }
+    __device__ __forceinline__ SearchLdsMarg(const WarpDev &w, unsigned at) : rgl::SearchMem(w), marg_at(at) {}
     __device__ __forceinline__ MargRaw marg_raw(const rgl::Slices &s, int row) const { return rgl_lds[marg_at + s.quad + (unsigned)row]; }
-    __device__ __forceinline__ double marg_blend(const rgl::Slices &s, const MargRaw &q) const { return rgl::blend_quad(s, q); }
-    __device__ __forceinline__ rgl::D2 cond(const rgl::Slices &s, int cell) const { return cond_blend(s, cond_raw(s, cell)); }
     __device__ __forceinline__ double marg(const rgl::Slices &s, int row) const { return marg_blend(s, marg_raw(s, row)); }
 };
 
@@ -137,9 +136,7 @@ __device__ __forceinline__ SearchLdsMarg stage_marg(const WarpDev &w, unsigned &
 {
     const int per_r = w.ny - 1;
     const int tb = w.n_theta > 1 ? w.n_theta - 1 : 1, pb = w.n_phi > 1 ? w.n_phi - 1 : 1;
-    SearchLdsMarg t;
-    t.cond2 = w.cond2;
-    t.marg_at = at_float4;
+    const SearchLdsMarg t(w, at_float4);
     const int n = pb * tb * per_r;
     for (int k = threadIdx.x; k < n; k += block) rgl_lds[at_float4 + (unsigned)k] = w.margq[k];
     at_float4 += (unsigned)n;
@@ -151,31 +148,38 @@ size_t lds_bytes_of(const RglDev &r)
 {
     const WarpDev w = r.vndf();
     const size_t slices = (size_t)w.n_phi * (size_t)w.n_theta, per_c = (size_t)(w.nx - 1) * (size_t)(w.ny - 1), per_r = (size_t)(w.ny - 1);
-    const size_t cond = (slices * per_c * 8 + 15) / 16 * 16, marg = (slices * per_r * 4 + 15) / 16 * 16;
-    return grid_bytes_of(r) + 2 * (cond + marg);
+    const size_t left = (slices * per_c * 8 + 15) / 16 * 16, total = (slices * per_r * 8 + 15) / 16 * 16, marg = (slices * per_r * 4 + 15) / 16 * 16;
+    return grid_bytes_of(r) + 2 * (left + total + marg);
 }
 
-// one distribution's tables: memory (bracket form) -> LDS (slice form); every thread of the block takes part
+// one distribution's tables: memory (records, bracket-major) -> LDS (slice-major); every thread of the block takes part
 __device__ __forceinline__ SearchLds stage_search(const WarpDev &w, unsigned &at_float4, int block)
 {
     const int per_c = (w.nx - 1) * (w.ny - 1), per_r = w.ny - 1, slices = w.n_phi * w.n_theta;
     const int tb = w.n_theta > 1 ? w.n_theta - 1 : 1, pb = w.n_phi > 1 ? w.n_phi - 1 : 1;
+    const unsigned stride = (unsigned)w.stride, totals_at = (unsigned)(w.phi_nodes() + w.slices());
     SearchLds t;
-    t.cond_at = at_float4 * 2;                                   // in float2
+    t.per_row = (unsigned)(w.nx - 1);
+    t.left_at = at_float4 * 2;                                   // in float2
     at_float4 += (unsigned)((slices * per_c + 1) / 2);
+    t.total_at = at_float4 * 2;                                  // in float2
+    at_float4 += (unsigned)((slices * per_r + 1) / 2);
     t.marg_at = at_float4 * 4;                                   // in float
     at_float4 += (unsigned)((slices * per_r + 3) / 4);
-    float2 *cond = (float2 *)rgl_lds + t.cond_at;
+    float2 *left = (float2 *)rgl_lds + t.left_at, *total = (float2 *)rgl_lds + t.total_at;
     float *marg = (float *)rgl_lds + t.marg_at;
+    // slice (ip, it) is read from a bracket it bounds: phi node ip - ipb of the bracket's pair, .xy / .zw by it - itb
     for (int k = threadIdx.x; k < slices * per_c; k += block) {
         const int sl = k / per_c, cell = k - sl * per_c, ip = sl / w.n_theta, it = sl - ip * w.n_theta;
-        const int itb = it < tb ? it : tb - 1;
-        const float4 v = w.cond2[(unsigned)(ip * tb + itb) * (unsigned)per_c + (unsigned)cell];
-        cond[k] = it > itb ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+        const int itb = it < tb ? it : tb - 1, ipb = ip < pb ? ip : pb - 1;
+        const float4 v = w.cells[((unsigned)(ipb * tb + itb) * (unsigned)per_c + (unsigned)cell) * stride + (unsigned)(ip - ipb)];
+        left[k] = it > itb ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
     }
     for (int k = threadIdx.x; k < slices * per_r; k += block) {
         const int sl = k / per_r, row = k - sl * per_r, ip = sl / w.n_theta, it = sl - ip * w.n_theta;
         const int itb = it < tb ? it : tb - 1, ipb = ip < pb ? ip : pb - 1;
+        const float4 tv = w.cells[((unsigned)(ipb * tb + itb) * (unsigned)per_c + (unsigned)row * t.per_row) * stride + totals_at + (unsigned)(ip - ipb)];
+        total[k] = it > itb ? make_float2(tv.z, tv.w) : make_float2(tv.x, tv.y);
         const float4 v = w.margq[(unsigned)(ipb * tb + itb) * (unsigned)per_r + (unsigned)row];
         const int c = (ip - ipb) + 2 * (it - itb);
         marg[k] = c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
@@ -435,15 +439,17 @@ bool ascending(const float *p, int n)
     return true;
 }
 
-// appends one function's tables to the image (offsets in floats, each a multiple of 4 so that the vectors are 16-B aligned):
-// the corner bricks (normalised if a distribution; per parameter bracket like the search tables) and, for distributions, the running integrals in the BRACKET form the
-// kernels search — `cond2` (along x, node rows row / row + 1, the two theta slices of a bracket side by side) and `margq` (the
-// marginal cdf after the cell row, the four slices of a (phi, theta) bracket side by side) — all rounded to Float once from
-// f64 sums, in the oracle's loop order.  src: [n_phi][n_theta][n_ch][ny][nx].
+// appends one function's tables to the image (offsets in floats; every table on a 128-B boundary), bracket-major — WarpDev in
+// merl_rgl.hpp has the forms: the measured values as corner bricks, a distribution as one RECORD per cell (integrals left of the cell,
+// normalised corner bricks, row totals) plus `margq`; all rounded to Float once from f64 sums, in the oracle's loop order.
+// src: [n_phi][n_theta][n_ch][ny][nx].
 WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, int ny, int n_phi, int n_theta, int n_ch, bool distribution)
 {
     const size_t per = (size_t)nx * ny, cells = (size_t)(nx - 1) * (size_t)(ny - 1), slices = (size_t)n_phi * (size_t)n_theta;
     const size_t per_cond = (size_t)ny * (size_t)(nx - 1), per_marg = (size_t)(ny - 1);
+    const int tb = n_theta > 1 ? n_theta - 1 : 1, pb = n_phi > 1 ? n_phi - 1 : 1;
+    const size_t P = n_phi > 1 ? 2 : 1, S = rgl_bracket_slices(n_phi, n_theta);
+    const size_t stride = distribution ? 2 * P + S : (size_t)n_ch * S;      // float4s per cell
     size_t at = blob.size();
     const WarpOffsets off = plan_warp(at, nx, ny, n_phi, n_theta, n_ch, distribution);
     blob.resize(at, 0.0f);
@@ -471,41 +477,44 @@ WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, 
                 for (size_t k = 0; k < per_marg; ++k) margf[s * per_marg + k] = (float)(marg[k] * norm);
             }
             for (size_t k = 0; k < per; ++k) node[k] = (float)((double)src[k] * norm);
-            // a slice's corner bricks go to every bracket the slice bounds: [bracket][cell][channel][slice of the bracket, phi fastest]
+            // a slice's corner bricks go to every bracket the slice bounds, as the bracket's slice (dp, dt), phi fastest
             const int ip = (int)(s / (size_t)n_theta), it = (int)(s % (size_t)n_theta);
-            const int tb = n_theta > 1 ? n_theta - 1 : 1, pb = n_phi > 1 ? n_phi - 1 : 1;
-            const size_t in_bracket = rgl_bracket_slices(n_phi, n_theta);
             for (int dp = 0; dp < (n_phi > 1 ? 2 : 1); ++dp)
                 for (int dt = 0; dt < (n_theta > 1 ? 2 : 1); ++dt) {
-                    const int ipb = ip - dp, itb = it - dt;          // the bracket in which this slice is the (dp, dt) corner
+                    const int ipb = ip - dp, itb = it - dt;
                     if (ipb < 0 || ipb >= pb || itb < 0 || itb >= tb) continue;
                     const size_t slot = n_phi > 1 ? (size_t)dp + 2 * (size_t)dt : (size_t)dt, first = ((size_t)ipb * tb + itb) * cells;
                     for (int y = 0; y < ny - 1; ++y)
                         for (int x = 0; x < nx - 1; ++x) {
                             const size_t cell = (size_t)y * (size_t)(nx - 1) + (size_t)x;
-                            float *q = &blob[off.cells + (((first + cell) * (size_t)n_ch + (size_t)ch) * in_bracket + slot) * 4];
+                            float *q = &blob[off.cells + ((first + cell) * stride + (distribution ? P : (size_t)ch * S) + slot) * 4];
                             q[0] = node[(size_t)y * nx + x]; q[1] = node[(size_t)y * nx + x + 1];
                             q[2] = node[(size_t)(y + 1) * nx + x]; q[3] = node[(size_t)(y + 1) * nx + x + 1];
                         }
                 }
         }
     if (distribution) {
-        const int tb = n_theta > 1 ? n_theta - 1 : 1, pb = n_phi > 1 ? n_phi - 1 : 1;
-        for (int ip = 0; ip < n_phi; ++ip)
-            for (int it = 0; it < tb; ++it) {
-                const size_t s0 = (size_t)ip * n_theta + it, s1 = n_theta > 1 ? s0 + 1 : s0;
-                float *c = &blob[off.cond2 + ((size_t)ip * tb + it) * cells * 4];
-                for (int y = 0; y < ny - 1; ++y)
-                    for (int x = 0; x < nx - 1; ++x, c += 4) {
-                        const size_t lo = (size_t)y * (size_t)(nx - 1) + (size_t)x, hi = lo + (size_t)(nx - 1);
-                        c[0] = condf[s0 * per_cond + lo]; c[1] = condf[s0 * per_cond + hi];
-                        c[2] = condf[s1 * per_cond + lo]; c[3] = condf[s1 * per_cond + hi];
-                    }
-            }
-        for (int ip = 0; ip < pb; ++ip)
-            for (int it = 0; it < tb; ++it) {
-                const size_t dp = n_phi > 1 ? (size_t)n_theta : 0, dt = n_theta > 1 ? 1 : 0, s0 = (size_t)ip * n_theta + it;
-                float *m = &blob[off.margq + ((size_t)ip * tb + it) * per_marg * 4];
+        for (int ipb = 0; ipb < pb; ++ipb)
+            for (int itb = 0; itb < tb; ++itb) {
+                const size_t first = ((size_t)ipb * tb + itb) * cells;
+                // the record's integrals: per phi node of the bracket one float4 = (slice (ip, it): rows row, row + 1 | slice (ip, it + 1): the same)
+                for (size_t k = 0; k < P; ++k) {
+                    const size_t s0 = (size_t)(ipb + (int)k) * n_theta + itb, s1 = n_theta > 1 ? s0 + 1 : s0;
+                    for (int y = 0; y < ny - 1; ++y)
+                        for (int x = 0; x < nx - 1; ++x) {
+                            const size_t cell = (size_t)y * (size_t)(nx - 1) + (size_t)x;
+                            float *l = &blob[off.cells + ((first + cell) * stride + k) * 4], *t = &blob[off.cells + ((first + cell) * stride + P + S + k) * 4];
+                            const size_t lo = (size_t)y * (size_t)(nx - 1), hi = lo + (size_t)(nx - 1), last = (size_t)(nx - 2);
+                            if (x > 0) {                 // up to node x: what is left of the cell (column 0: zeros)
+                                l[0] = condf[s0 * per_cond + lo + x - 1]; l[1] = condf[s0 * per_cond + hi + x - 1];
+                                l[2] = condf[s1 * per_cond + lo + x - 1]; l[3] = condf[s1 * per_cond + hi + x - 1];
+                            }
+                            t[0] = condf[s0 * per_cond + lo + last]; t[1] = condf[s0 * per_cond + hi + last];
+                            t[2] = condf[s1 * per_cond + lo + last]; t[3] = condf[s1 * per_cond + hi + last];
+                        }
+                }
+                const size_t dp = n_phi > 1 ? (size_t)n_theta : 0, dt = n_theta > 1 ? 1 : 0, s0 = (size_t)ipb * n_theta + itb;
+                float *m = &blob[off.margq + ((size_t)ipb * tb + itb) * per_marg * 4];
                 for (size_t y = 0; y < per_marg; ++y, m += 4) {
                     m[0] = margf[s0 * per_marg + y]; m[1] = margf[(s0 + dp) * per_marg + y];
                     m[2] = margf[(s0 + dt) * per_marg + y]; m[3] = margf[(s0 + dp + dt) * per_marg + y];
@@ -558,7 +567,7 @@ RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob)
     if (f.n_wl > 0) blob.insert(blob.end(), f.wavelengths, f.wavelengths + f.n_wl);
     auto put = [&](int which, const float *src, const int res[2], int n_phi, int n_theta, int n_ch, bool distribution) {
         const WarpOffsets o = append_warp(blob, src, res[0], res[1], n_phi, n_theta, n_ch, distribution);
-        l.cells[which] = o.cells; l.cond2[which] = o.cond2; l.margq[which] = o.margq;
+        l.cells[which] = o.cells; l.margq[which] = o.margq;
     };
     put(0, f.ndf, f.res_ndf, 1, 1, 1, false);
     put(1, f.sigma, f.res_sigma, 1, 1, 1, false);
@@ -568,13 +577,13 @@ RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob)
     return l;
 }
 
-// base: 16-B aligned
+// base: 128-B aligned on the device (the tables then sit on cache-line boundaries); the host copy need not be
 RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base)
 {
     auto at = [&](size_t off) { return (const float4 *)(base + off); };
     RglDev r;
     r.ndf_cells = at(l.cells[0]); r.sigma_cells = at(l.cells[1]); r.vndf_cells = at(l.cells[2]); r.lum_cells = at(l.cells[3]); r.rgb_cells = at(l.cells[4]);
-    r.vndf_cond2 = at(l.cond2[2]); r.vndf_margq = at(l.margq[2]); r.lum_cond2 = at(l.cond2[3]); r.lum_margq = at(l.margq[3]);
+    r.vndf_margq = at(l.margq[2]); r.lum_margq = at(l.margq[3]);
     r.phi = base + l.phi; r.theta = base + l.theta;
     r.ndf_nx = f.res_ndf[0]; r.ndf_ny = f.res_ndf[1]; r.sigma_nx = f.res_sigma[0]; r.sigma_ny = f.res_sigma[1];
     r.nx = f.res[0]; r.ny = f.res[1]; r.n_phi = f.n_phi; r.n_theta = f.n_theta;

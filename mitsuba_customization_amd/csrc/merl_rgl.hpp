@@ -44,25 +44,31 @@
 
 namespace mrl {
 
-// One piecewise-bilinear function.  Slices are row-major in (phi, theta); a slice is (ny - 1) x (nx - 1) cells, x fastest.
+// One piecewise-bilinear function.  A slice is (ny - 1) x (nx - 1) cells, x fastest; everything is stored per parameter BRACKET
+// (tb = max(n_theta - 1, 1), pb = max(n_phi - 1, 1); a bracket has S = 1 / 2 / 4 slices, phi fastest, and P = 1 / 2 phi nodes):
+//   measured values:  cells [pb][tb][cell][n_ch][S]   the cell's four corner values (v00, v10, v01, v11) per slice
+//   distributions:    cells [pb][tb][cell] RECORDS of 2 P + S float4 — everything an inverse warp or a search step needs about the cell
+//                     in one 64-B (isotropic) or 128-B (anisotropic) piece of ONE cache line:
+//                       [0, P)          running integrals along x LEFT of the cell (up to node col) of node rows (row, row + 1): .xy of
+//                                       slice (ip, it), .zw of slice (ip, it + 1); one float4 per phi node; zeros in column 0
+//                       [P, P + S)      the corner values per slice, normalised
+//                       [P + S, 2P + S) the totals of node rows (row, row + 1), same form as the first part
+//                     margq [pb][tb][ny - 1]  marginal cdf after the cell row, of slices (ip, it) (ip+1, it) (ip, it+1) (ip+1, it+1)
 struct WarpDev {
-    // per parameter BRACKET (tb = max(n_theta - 1, 1), pb = max(n_phi - 1, 1); a bracket has 1 / 2 / 4 slices, phi fastest):
-    const float4 *cells;    // [pb][tb][cell][n_ch][slice of the bracket]  the cell's four corner values (v00, v10, v01, v11), normalised if a distribution
-    // distributions only — the search tables:
-    const float4 *cond2;    // [n_phi][tb][cell]   running integrals along x, up to node col + 1, of node rows (row, row + 1):
-                            //                     .xy of slice (ip, it), .zw of slice (ip, it + 1) (of (ip, it) again when n_theta = 1)
-    const float4 *margq;    // [pb][tb][ny - 1]    marginal cdf after the cell row, of slices (ip, it) (ip+1, it) (ip, it+1) (ip+1, it+1)
-    const float *phi, *theta;   // ascending parameter grids (unused when the count is 1)
-    int nx, ny, n_phi, n_theta, n_ch;
-    int normalized;
+    const float4 *cells;
+    const float4 *margq;        // distributions only
+    int nx, ny, n_phi, n_theta;
+    int normalized;             // a distribution: values are densities over the unit square
+    int stride, first;          // float4s per cell; where the corner values (of channel 0) start in a cell's piece
+    MRL_HD int phi_nodes() const { return n_phi > 1 ? 2 : 1; }
+    MRL_HD int slices() const { return (n_phi > 1 ? 2 : 1) * (n_theta > 1 ? 2 : 1); }
 };
 
-// The material's descriptor, compact: it travels to the kernels by value in SGPRs (12 pointers + 13 integers; five full WarpDev
-// records — 90 SGPRs — made the compiler park scalars in VGPR lanes inside the unit loop).  vndf, luminance and the measured values
-// share the parameter grids and the resolution; the five functions are handed out as WarpDev views.
+// The material's descriptor, compact: it travels to the kernels by value in SGPRs.  vndf, luminance and the measured values share the
+// parameter grids and the resolution; the five functions are handed out as WarpDev views.
 struct RglDev {
     const float4 *ndf_cells, *sigma_cells, *vndf_cells, *lum_cells, *rgb_cells;
-    const float4 *vndf_cond2, *vndf_margq, *lum_cond2, *lum_margq;
+    const float4 *vndf_margq, *lum_margq;
     const float *phi, *theta;   // ascending parameter grids of vndf / luminance / rgb
     // spectral files ("spectra" + "wavelengths" instead of "rgb"): `rgb_cells` then holds the spectra, one channel per wavelength
     // node (n_values = n_wl), and a value is interpolated linearly between the nodes around the wavelength asked for
@@ -76,16 +82,18 @@ struct RglDev {
     // the same descriptor over a copy of the image at another address (the host table: merl_materials.hip)
     void rebase(const char *from, const char *to)
     {
-        const float4 **q[9] = { &ndf_cells, &sigma_cells, &vndf_cells, &lum_cells, &rgb_cells, &vndf_cond2, &vndf_margq, &lum_cond2, &lum_margq };
+        const float4 **q[7] = { &ndf_cells, &sigma_cells, &vndf_cells, &lum_cells, &rgb_cells, &vndf_margq, &lum_margq };
         for (const float4 **x : q) *x = (const float4 *)(to + ((const char *)*x - from));
         const float **g[3] = { &phi, &theta, &wavelengths };
         for (const float **x : g) if (*x) *x = (const float *)(to + ((const char *)*x - from));
     }
-    MRL_HD WarpDev ndf() const { return { ndf_cells, nullptr, nullptr, nullptr, nullptr, ndf_nx, ndf_ny, 1, 1, 1, 0 }; }
-    MRL_HD WarpDev sigma() const { return { sigma_cells, nullptr, nullptr, nullptr, nullptr, sigma_nx, sigma_ny, 1, 1, 1, 0 }; }
-    MRL_HD WarpDev vndf() const { return { vndf_cells, vndf_cond2, vndf_margq, phi, theta, nx, ny, n_phi, n_theta, 1, 1 }; }
-    MRL_HD WarpDev luminance() const { return { lum_cells, lum_cond2, lum_margq, phi, theta, nx, ny, n_phi, n_theta, 1, 1 }; }
-    MRL_HD WarpDev rgb() const { return { rgb_cells, nullptr, nullptr, phi, theta, nx, ny, n_phi, n_theta, n_values, 0 }; }
+    MRL_HD int phi_nodes() const { return n_phi > 1 ? 2 : 1; }
+    MRL_HD int slices() const { return (n_phi > 1 ? 2 : 1) * (n_theta > 1 ? 2 : 1); }
+    MRL_HD WarpDev ndf() const { return { ndf_cells, nullptr, ndf_nx, ndf_ny, 1, 1, 0, 1, 0 }; }
+    MRL_HD WarpDev sigma() const { return { sigma_cells, nullptr, sigma_nx, sigma_ny, 1, 1, 0, 1, 0 }; }
+    MRL_HD WarpDev vndf() const { return { vndf_cells, vndf_margq, nx, ny, n_phi, n_theta, 1, 2 * phi_nodes() + slices(), phi_nodes() }; }
+    MRL_HD WarpDev luminance() const { return { lum_cells, lum_margq, nx, ny, n_phi, n_theta, 1, 2 * phi_nodes() + slices(), phi_nodes() }; }
+    MRL_HD WarpDev rgb() const { return { rgb_cells, nullptr, nx, ny, n_phi, n_theta, 0, n_values * slices(), 0 }; }
 };
 
 namespace rgl {
@@ -95,12 +103,12 @@ namespace rgl {
 #endif
 
 // the four parameter slices around (phi_i, theta_i) and their weights, phi fastest (the order the oracle sums in); `mask`
-// says which entries exist (a grid of one node has no upper neighbour) — uniform over a launch, so the tests on it are
-// scalar branches and the arrays stay in registers.  pair[]: the theta bracket's index in cond2 for phi node ip / ip + 1;
-// quad: the (phi, theta) bracket's index in margq.
-// Offsets instead of indices (formed once per unit: a 32-bit multiply costs what an f64 FMA costs): soff[k] = slice k x cells of a
-// slice (into the per-slice tables), roff[k] = slice k x cell rows, pair[] / quad already multiplied by their row lengths.
-struct Slices { unsigned soff[4], roff[4]; double w[4]; int mask; unsigned pair[2], quad; };
+// says which entries exist (a grid of one node has no upper neighbour) — uniform over a launch (a constant in the kernels compiled
+// for a bracket shape), so the tests on it are scalar branches or none and the arrays stay in registers.
+// Offsets instead of indices (formed once per unit: a 32-bit multiply costs what an f64 FMA costs): cell0 = the bracket's first cell
+// in the bracket-major tables, quad = its first row in margq; soff[k] / roff[k] = slice k x cells / cell rows of a slice (the slice-major
+// copies of the search tables in LDS).
+struct Slices { unsigned soff[4], roff[4]; double w[4]; int mask; unsigned cell0, quad; };
 
 // largest i in [0, n - 2] with node(i) <= p, and p's position in that bracket; node(k): the ascending grid's k-th value
 template <class Node>
@@ -144,7 +152,7 @@ MRL_HD Slices find_slices(const WarpDev &w, const Grids &g, double phi_i, double
     for (int k = 0; k < 4; ++k) { out.soff[k] = sl[k] * per_c; out.roff[k] = sl[k] * per_r; }
     out.w[0] = (1.0 - tp) * (1.0 - tt); out.w[1] = tp * (1.0 - tt); out.w[2] = (1.0 - tp) * tt; out.w[3] = tp * tt;
     out.mask = 1 | (w.n_phi > 1 ? 2 : 0) | (w.n_theta > 1 ? 4 : 0) | (w.n_phi > 1 && w.n_theta > 1 ? 8 : 0);
-    out.pair[0] = (unsigned)(ip * tb + it) * per_c; out.pair[1] = (unsigned)(ip1 * tb + it) * per_c;
+    out.cell0 = (unsigned)(ip * tb + it) * per_c;
     out.quad = (unsigned)(ip * tb + it) * per_r;
     return out;
 }
@@ -154,7 +162,7 @@ MRL_HD Slices single_slice()
     Slices out;
     for (int k = 0; k < 4; ++k) { out.soff[k] = out.roff[k] = 0u; out.w[k] = 0.0; }
     out.w[0] = 1.0; out.mask = 1;
-    out.pair[0] = out.pair[1] = out.quad = 0u;
+    out.cell0 = out.quad = 0u;
     return out;
 }
 
@@ -171,10 +179,10 @@ struct D2 { double x, y; };
 //   blend4:    their weighted sum.
 struct Raw4 { float4 q0, q1, q2, q3; };      // q1: the phi neighbour, q2: the theta neighbour, q3: both
 MRL_HD unsigned bracket_slices(const Slices &s) { return (unsigned)((s.mask & 1) + ((s.mask >> 1) & 1) + ((s.mask >> 2) & 1) + ((s.mask >> 3) & 1)); }
-MRL_HD Raw4 fetch_raw(const Slices &s, const float4 *base, int index, int n_ch = 1, int channel = 0)
+MRL_HD Raw4 fetch_raw(const Slices &s, const WarpDev &w, int index, int channel = 0)
 {
-    // the bracket's slices lie side by side (16 / 32 / 64 B per cell and channel), phi fastest
-    const float4 *p = base + ((s.pair[0] + (unsigned)index) * (unsigned)n_ch + (unsigned)channel) * bracket_slices(s);
+    // the bracket's slices lie side by side (16 / 32 / 64 B per cell and channel), phi fastest; a distribution's behind the cell's integrals
+    const float4 *p = w.cells + (s.cell0 + (unsigned)index) * (unsigned)w.stride + (unsigned)w.first + (unsigned)channel * bracket_slices(s);
     Raw4 r;
     // absent slices: zeros (never summed).  Defined values on purpose: left undefined, the compiler merges each conditional read with the
     // conditional sum that uses it — the load next to its use again, one round trip per slice (measured: 1.49 -> 1.97 ms)
@@ -198,13 +206,13 @@ MRL_HD D4 blend4(const Slices &s, const Raw4 &r)
     if (s.mask & 8) add(s.w[3], r.q3);
     return v;
 }
-MRL_HD D4 fetch4(const Slices &s, const float4 *base, int index, int n_ch = 1, int channel = 0)
+MRL_HD D4 fetch4(const Slices &s, const WarpDev &w, int index, int channel = 0)
 {
-    return blend4(s, fetch_raw(s, base, index, n_ch, channel));
+    return blend4(s, fetch_raw(s, w, index, channel));
 }
 
 // the blends of the bracket vectors, in slice order (the same sums, in the same order, as a slice-by-slice read):
-// a / b: cond2 of the theta bracket at phi node ip / ip + 1 (b unused without an upper phi neighbour)
+// a / b: a record's integrals at the bracket's phi node ip / ip + 1 (b unused without an upper phi neighbour)
 MRL_HD D2 blend_pairs(const Slices &s, const float4 &a, const float4 &b)
 {
 #pragma clang fp contract(off)
@@ -224,29 +232,34 @@ MRL_HD double blend_quad(const Slices &s, const float4 &q)
     return v;
 }
 
-// The search tables of one distribution read from memory: one load serves the two theta slices of a bracket (cond2) or all
-// four slices (margq).
+// A distribution's running integrals read from memory — from its cell records (the integrals LEFT of a cell, the totals of its two
+// node rows) and from margq (the marginal after a cell row) — in two steps each: the loads, then the sums (see fetch_raw).
 struct SearchMem {
-    const float4 *cond2, *margq;
-    MRL_HD explicit SearchMem(const WarpDev &w) : cond2(w.cond2), margq(w.margq) {}
-    // the conditional running integrals of node rows (row, row + 1) up to node col + 1, cell = row (nx - 1) + col
-    MRL_HD D2 cond(const Slices &s, int cell) const { return cond_blend(s, cond_raw(s, cell)); }
-    // the marginal cdf after cell row `row`
-    MRL_HD double marg(const Slices &s, int row) const { return marg_blend(s, marg_raw(s, row)); }
-    // the same in two steps (loads, then sums: see fetch_raw)
-    struct CondRaw { float4 a, b; };
+    const float4 *cells, *margq;
+    unsigned stride, totals_at, per_row;        // float4s per record; where a record's totals start; cells per row
+    MRL_HD explicit SearchMem(const WarpDev &w)
+        : cells(w.cells), margq(w.margq), stride((unsigned)w.stride), totals_at((unsigned)(w.phi_nodes() + w.slices())), per_row((unsigned)(w.nx - 1)) {}
+    struct PairRaw { float4 a, b; };
     typedef float4 MargRaw;
-    MRL_HD CondRaw cond_raw(const Slices &s, int cell) const
+    MRL_HD PairRaw pair_at(const Slices &s, const float4 *p) const
     {
-        CondRaw r;
+        PairRaw r;
         r.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        r.a = cond2[s.pair[0] + (unsigned)cell];
-        if (s.mask & 2) r.b = cond2[s.pair[1] + (unsigned)cell];
+        r.a = p[0];
+        if (s.mask & 2) r.b = p[1];
         return r;
     }
-    MRL_HD D2 cond_blend(const Slices &s, const CondRaw &r) const { return blend_pairs(s, r.a, r.b); }
+    // node rows (row, row + 1) of cell `cell` = row (nx - 1) + col: the conditional running integrals up to node col
+    MRL_HD PairRaw left_raw(const Slices &s, int cell) const { return pair_at(s, cells + (s.cell0 + (unsigned)cell) * stride); }
+    // ... and over the whole rows
+    MRL_HD PairRaw total_raw(const Slices &s, int row) const { return pair_at(s, cells + (s.cell0 + (unsigned)row * per_row) * stride + totals_at); }
+    MRL_HD D2 pair_blend(const Slices &s, const PairRaw &r) const { return blend_pairs(s, r.a, r.b); }
+    // the marginal cdf after cell row `row`
     MRL_HD MargRaw marg_raw(const Slices &s, int row) const { return margq[s.quad + (unsigned)row]; }
     MRL_HD double marg_blend(const Slices &s, const MargRaw &q) const { return blend_quad(s, q); }
+    MRL_HD D2 left(const Slices &s, int cell) const { return pair_blend(s, left_raw(s, cell)); }
+    MRL_HD D2 total(const Slices &s, int row) const { return pair_blend(s, total_raw(s, row)); }
+    MRL_HD double marg(const Slices &s, int row) const { return marg_blend(s, marg_raw(s, row)); }
 };
 
 MRL_HD int clamp_cell(double p, int last)
@@ -298,7 +311,7 @@ MRL_HD double warp_eval(const WarpDev &w, const Slices &s, double x_in, double y
     const Cell c = locate(w, x_in, y_in);
     D4 q;
     if (known && known->row == c.oy && known->col == c.ox) q = known->q;
-    else q = fetch4(s, w.cells, c.index, w.n_ch, channel);
+    else q = fetch4(s, w, c.index, channel);
     return cell_value(w, c, q);
 }
 
@@ -331,7 +344,7 @@ MRL_HD double warp_sample(const WarpDev &w, const Search &t, const Slices &s, do
     }
     const int row = lo;
     uy -= before;
-    const D2 tot = t.cond(s, row * (nx - 1) + nx - 2);       // the totals of node rows (row, row + 1)
+    const D2 tot = t.total(s, row);                          // the totals of node rows (row, row + 1)
     const double r0 = tot.x, r1 = tot.y;
     const double y = clamp01(invert_linear(r0, r1, uy));
     ux *= lerp(y, r0, r1);
@@ -339,12 +352,12 @@ MRL_HD double warp_sample(const WarpDev &w, const Search &t, const Slices &s, do
     D2 left = { 0.0, 0.0 };                                  // the conditional integrals left of column lo, likewise
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        const D2 p = t.cond(s, row * (nx - 1) + mid);
+        const D2 p = t.left(s, row * (nx - 1) + mid + 1);   // the integrals up to node mid + 1: left of cell mid + 1
         if (lerp(y, p.x, p.y) < ux) { lo = mid + 1; left = p; } else hi = mid;
     }
     const int col = lo;
     ux -= lerp(y, left.x, left.y);
-    const D4 q = fetch4(s, w.cells, row * (nx - 1) + col);
+    const D4 q = fetch4(s, w, row * (nx - 1) + col);
     const double c0 = lerp(y, q.x, q.z), c1 = lerp(y, q.y, q.w);
     const double x = clamp01(invert_linear(c0, c1, ux));
     x_out = fast::div_fast((double)col + x, (double)(nx - 1));
@@ -370,15 +383,15 @@ MRL_HD double warp_invert(const WarpDev &w, const Search &t, const Slices &s, do
     if (known && known->row == row && known->col == col) {
         q = known->q; left = known->left; before = known->before; r0 = known->r0; r1 = known->r1;
     } else {
-        // everything the cell needs is read before anything is summed: one round trip (the reads left of column 0 / below row 0
-        // are issued at a clamped index and dropped)
-        const Raw4 qr = fetch_raw(s, w.cells, row * (nx - 1) + col);
-        const auto lr = t.cond_raw(s, row * (nx - 1) + (col > 0 ? col - 1 : 0));
-        const auto tr = t.cond_raw(s, row * (nx - 1) + nx - 2);
+        // everything the cell needs is read before anything is summed, and from memory it is ONE record (column 0's holds zeros on its
+        // left) plus the marginal below the row (read at a clamped index and dropped in row 0)
+        const Raw4 qr = fetch_raw(s, w, row * (nx - 1) + col);
+        const auto lr = t.left_raw(s, row * (nx - 1) + col);
+        const auto tr = t.total_raw(s, row);
         const auto br = t.marg_raw(s, row > 0 ? row - 1 : 0);
         q = blend4(s, qr);
-        const D2 l = t.cond_blend(s, lr), tot = t.cond_blend(s, tr);
-        if (col > 0) left = l;
+        left = t.pair_blend(s, lr);
+        const D2 tot = t.pair_blend(s, tr);
         r0 = tot.x; r1 = tot.y;
         const double bf = t.marg_blend(s, br);
         if (row > 0) before = bf;
@@ -521,13 +534,13 @@ MRL_HD void eval_pdf_at(const RglDev &b, const Search &tv, const Incident &in, f
     Raw4 raw[BATCH ? 3 : 1], rawl{};
     const bool have_l = fl && fl->row == c.oy && fl->col == c.ox;
     if constexpr (WANT_RGB && BATCH)
-        for (int k = 0; k < 3; ++k) raw[k] = fetch_raw(in.sv, wr.cells, c.index, wr.n_ch, k);
+        for (int k = 0; k < 3; ++k) raw[k] = fetch_raw(in.sv, wr, c.index, k);
     if constexpr (WANT_PDF)
-        if (!have_l) rawl = fetch_raw(in.sv, wl.cells, c.index);
+        if (!have_l) rawl = fetch_raw(in.sv, wl, c.index);
     if constexpr (WANT_RGB) {
         const double scale = value_scale(b, in, h);
         for (int k = 0; k < 3; ++k) {
-            if constexpr (!BATCH) raw[0] = fetch_raw(in.sv, wr.cells, c.index, wr.n_ch, k);
+            if constexpr (!BATCH) raw[0] = fetch_raw(in.sv, wr, c.index, k);
             double v = cell_value(wr, c, blend4(in.sv, raw[BATCH ? k : 0]));
             v = v < 0.0 ? 0.0 : v;
             rgb[k] = (float)(v * scale);

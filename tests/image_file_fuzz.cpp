@@ -55,22 +55,18 @@ static bool consistent(const ImageHeader &h, unsigned long long file_bytes, cons
     if (p.texel_bytes != h.texel_bytes) return false;
     if (p.is_rgl) {
         const RglFields &f = p.shapes;
-        // the cells are stored per parameter bracket, the bracket's 1 / 2 / 4 slices side by side
+        // everything is stored per parameter bracket: a distribution's cells as records (integrals left of the cell, corner values per
+        // slice, row totals), the measured values as the bracket's 1 / 2 / 4 slices side by side; tables start on 128-B boundaries
         const uint64_t floats = p.texel_bytes / 4;
-        const uint64_t copies = (uint64_t)(f.n_phi > 1 ? f.n_phi - 1 : 1) * (f.n_theta > 1 ? f.n_theta - 1 : 1) * (f.n_phi > 1 ? 2 : 1) * (f.n_theta > 1 ? 2 : 1);
+        const uint64_t brackets = (uint64_t)(f.n_phi > 1 ? f.n_phi - 1 : 1) * (f.n_theta > 1 ? f.n_theta - 1 : 1);
+        const uint64_t in_bracket = (uint64_t)(f.n_phi > 1 ? 2 : 1) * (f.n_theta > 1 ? 2 : 1), record = 2 * (uint64_t)(f.n_phi > 1 ? 2 : 1) + in_bracket;
+        const uint64_t per_c = (uint64_t)(f.res[0] - 1) * (f.res[1] - 1);
         const uint64_t cells[5] = { (uint64_t)(f.res_ndf[0] - 1) * (f.res_ndf[1] - 1), (uint64_t)(f.res_sigma[0] - 1) * (f.res_sigma[1] - 1),
-                                    (uint64_t)(f.res[0] - 1) * (f.res[1] - 1) * copies, (uint64_t)(f.res[0] - 1) * (f.res[1] - 1) * copies,
-                                    (uint64_t)(f.res[0] - 1) * (f.res[1] - 1) * copies * 3 };
+                                    per_c * brackets * record, per_c * brackets * record, per_c * brackets * in_bracket * 3 };
         for (int w = 0; w < 5; ++w) {
-            if (p.layout.cells[w] % 4 != 0 || p.layout.cells[w] + cells[w] * 4 > floats) return false;
-            if (w == 2 || w == 3) {
-                // the search tables are stored per parameter bracket: n_phi x max(n_theta - 1, 1) float4 per cell, and
-                // max(n_phi - 1, 1) x max(n_theta - 1, 1) float4 per cell row
-                const uint64_t tb = f.n_theta > 1 ? f.n_theta - 1 : 1, pb = f.n_phi > 1 ? f.n_phi - 1 : 1;
-                const uint64_t per_c = (uint64_t)(f.res[0] - 1) * (f.res[1] - 1);
-                if (p.layout.cond2[w] % 4 != 0 || p.layout.cond2[w] + per_c * (uint64_t)f.n_phi * tb * 4 > floats) return false;
-                if (p.layout.margq[w] % 4 != 0 || p.layout.margq[w] + (uint64_t)(f.res[1] - 1) * pb * tb * 4 > floats) return false;
-            }
+            if (p.layout.cells[w] % 32 != 0 || p.layout.cells[w] + cells[w] * 4 > floats) return false;
+            if (w == 2 || w == 3)
+                if (p.layout.margq[w] % 32 != 0 || p.layout.margq[w] + (uint64_t)(f.res[1] - 1) * brackets * 4 > floats) return false;
         }
         if (p.layout.theta + (uint64_t)f.n_theta > floats) return false;
     } else {
