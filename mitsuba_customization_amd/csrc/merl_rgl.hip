@@ -46,18 +46,20 @@ extern __shared__ float4 rgl_lds[];
 
 // ---- the parameter grids in LDS (every single-material kernel): phi_i then theta_i at the start of the block's LDS ----
 struct GridLds {
-    unsigned theta_at_;                 // float index of theta_i's first node in rgl_lds (phi_i starts at 0)
+    unsigned theta_at_, wl_at_;         // float index of theta_i's / the wavelengths' first node in rgl_lds (phi_i starts at 0)
     __device__ __forceinline__ float phi_at(int k) const { return ((const float *)rgl_lds)[k]; }
     __device__ __forceinline__ float theta_at(int k) const { return ((const float *)rgl_lds)[theta_at_ + (unsigned)k]; }
+    __device__ __forceinline__ float wavelength_at(int k) const { return ((const float *)rgl_lds)[wl_at_ + (unsigned)k]; }
 };
-size_t grid_bytes_of(const RglDev &r) { return ((size_t)(r.n_phi + r.n_theta) * sizeof(float) + 15) / 16 * 16; }
+size_t grid_bytes_of(const RglDev &r) { return ((size_t)(r.n_phi + r.n_theta + r.n_wl) * sizeof(float) + 15) / 16 * 16; }
 __device__ __forceinline__ GridLds stage_grids(const RglDev &r, unsigned &at_float4, int block)
 {
     float *g = (float *)rgl_lds;
     for (int k = threadIdx.x; k < r.n_phi; k += block) g[k] = r.phi[k];
     for (int k = threadIdx.x; k < r.n_theta; k += block) g[r.n_phi + k] = r.theta[k];
-    at_float4 += (unsigned)((r.n_phi + r.n_theta + 3) / 4);
-    return GridLds{ (unsigned)r.n_phi };
+    for (int k = threadIdx.x; k < r.n_wl; k += block) g[r.n_phi + r.n_theta + k] = r.wavelengths[k];
+    at_float4 += (unsigned)((r.n_phi + r.n_theta + r.n_wl + 3) / 4);
+    return GridLds{ (unsigned)r.n_phi, (unsigned)(r.n_phi + r.n_theta) };
 }
 
 // Slice by slice, taken out of the records while they are copied: left [slices][cell] float2 (node rows row / row + 1, up to node col),
@@ -223,10 +225,11 @@ __device__ __forceinline__ void rgl_unit(const BatchArgs &a, const RglDev &r, co
 // MULTI: a batch with a material id per unit — the lanes whose id names an RGL material evaluate it through the descriptor
 // stored behind that material's image (read on demand: a few more cache-resident loads per lookup) and overwrite the zeros
 // the table / GGX kernel of the same call left there; every other lane skips.  Launched after that kernel, on the same stream.
-// Blocks per CU the compiler is asked to make room for (= waves per SIMD): the kernel waits on memory, a wave more is worth a
-// register or two.  sample() alone sits at 167 VGPRs: 3; eval + pdf at 131: 4 (128 VGPRs, 3 dwords of scratch); the fused unit inside
-// a batch with ids at 172: 3 (168, no spill: 3.75 -> 3.32 ms on the mixed batch of tools/rgl_rates.py) — but the fused
-// single-material kernel spills at 168 and LOSES (7.06 -> 8.14 ms on the anisotropic file): 2, as it was.
+// Blocks per CU the compiler is asked to make room for (= waves per SIMD).  With a lookup's reads in flight together a unit holds
+// 12 - 16 vectors between the reads and the sums, and a spill costs more than a wave: per bracket shape (the kernels compiled for
+// one) the largest bound without scratch — measured side by side with tools/rgl_ab_time.py; the run-time-shape kernels (batches with
+// ids, odd shapes) keep the bounds they had, but for the fused unit inside a batch with ids (25 spilled registers at 3: 3.62 -> 3.32 ms
+// at 2 on the mixed batch of tools/rgl_rates.py).
 #ifndef MRL_RGL_EVALPDF_BLOCKS
 #define MRL_RGL_EVALPDF_BLOCKS 4
 #endif
@@ -235,6 +238,9 @@ __device__ __forceinline__ void rgl_unit(const BatchArgs &a, const RglDev &r, co
 #endif
 #ifndef MRL_RGL_EVAL_BLOCKS
 #define MRL_RGL_EVAL_BLOCKS 4
+#endif
+#ifndef MRL_RGL_MULTI_FUSED_BLOCKS
+#define MRL_RGL_MULTI_FUSED_BLOCKS 2
 #endif
 #ifndef MRL_RGL_BLOCKS15
 #define MRL_RGL_BLOCKS15 3, 4, 2, 2, 3          // eval, pdf, sample, fused, eval + pdf of the anisotropic shape (four slices in flight per lookup)
@@ -247,7 +253,7 @@ constexpr int rgl_min_blocks(int mode, bool multi, int mask)
     constexpr int b15[5] = { MRL_RGL_BLOCKS15 }, b5[5] = { MRL_RGL_BLOCKS5 };
     if (mask == 15) return b15[mode];
     if (mask == 5) return b5[mode];
-    return mode == 3 ? (multi ? 3 : 2) : (mode == 2 ? MRL_RGL_SAMPLE_BLOCKS : (mode == 4 ? MRL_RGL_EVALPDF_BLOCKS : MRL_RGL_EVAL_BLOCKS));
+    return mode == 3 ? (multi ? MRL_RGL_MULTI_FUSED_BLOCKS : 2) : (mode == 2 ? MRL_RGL_SAMPLE_BLOCKS : (mode == 4 ? MRL_RGL_EVALPDF_BLOCKS : MRL_RGL_EVAL_BLOCKS));
 }
 template <int MODE, bool INDEXED, bool MULTI, int MASK = 0>
 __global__ __launch_bounds__(kRglBlock, rgl_min_blocks(MODE, MULTI, MASK)) void k_rgl(BatchArgs a, RglDev r)
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(kRglBlock, rgl_min_blocks(MODE, MULTI, MASK)) void 
     const size_t stride = (size_t)gridDim.x * kRglBlock;
     size_t n_items = a.n;
     if constexpr (INDEXED) { const size_t c = (size_t)*a.idx_count; n_items = c < a.n ? c : a.n; }
-    GridLds grids{ 0u };
+    GridLds grids{ 0u, 0u };
     if constexpr (!MULTI) {
         unsigned at = 0;
         grids = stage_grids(r, at, kRglBlock);
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(kRglBlock, rgl_min_blocks(MODE, MULTI, MASK)) void 
             const MaterialDev &m = a.materials[id];
             if (m.kind != KIND_RGL) continue;
             const RglDev &rm = *(const RglDev *)m.rgl;
-            rgl_unit<MODE, 0>(a, rm, rgl::GridMem{ rm.phi, rm.theta }, rgl::SearchMem(rm.vndf()), rgl::SearchMem(rm.luminance()), i);
+            rgl_unit<MODE, 0>(a, rm, rgl::GridMem{ rm.phi, rm.theta, rm.wavelengths }, rgl::SearchMem(rm.vndf()), rgl::SearchMem(rm.luminance()), i);
         } else {
             rgl_unit<MODE, MASK>(a, r, grids, rgl::SearchMem(r.vndf()), rgl::SearchMem(r.luminance()), i);
         }
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(rgl_lds_block(MODE, MASK)) void k_rgl_lds(BatchArgs
 
 // ---- spectral files: W values per unit at the wavelengths wl[i * W .. ) (nullptr: the file's own nodes) ----
 // a.out_rgb / a.out_weight hold n x W values.  Same structure as rgl_unit: what depends on wi alone is formed once.
-template <int MODE, class Search>
+template <int MODE, int MASK, class Search>
 __device__ __forceinline__ void rgl_unit_spectral(const BatchArgs &a, const RglDev &r, const GridLds &g, const Search &tv, const Search &tl, size_t i, const float *wl_all, int W)
 {
     constexpr bool has_eval = MODE == 0 || MODE == 3 || MODE == 4, has_pdf = MODE == 1 || MODE == 3 || MODE == 4,
@@ -312,25 +318,26 @@ __device__ __forceinline__ void rgl_unit_spectral(const BatchArgs &a, const RglD
     const float *wl = wl_all ? wl_all + i * (size_t)W : nullptr;
     rgl::Incident in;
     const bool up = wiz > 0.0f && rgl::incident<has_eval || has_sample>(r, g, wix, wiy, wiz, in);
+    if constexpr (MASK != 0) in.sv.mask = MASK;
     if constexpr (has_eval || has_pdf) {
         const float wox = a.wo[3 * i], woy = a.wo[3 * i + 1], woz = a.wo[3 * i + 2];
         float *values = has_eval ? a.out_rgb + i * (size_t)W : nullptr;
         float pdf = 0.0f;
-        if (up) rgl::eval_pdf_spectral_at<has_eval, has_pdf>(r, tv, in, wox, woy, woz, wl, W, values, pdf);
+        if (up) rgl::eval_pdf_spectral_at<has_eval, has_pdf>(r, g, tv, in, wox, woy, woz, wl, W, values, pdf);
         else if constexpr (has_eval) for (int k = 0; k < W; ++k) values[k] = 0.0f;
         if constexpr (has_pdf) a.out_pdf[i] = pdf;
     }
     if constexpr (has_sample) {
         float wo2[3] = { 0.0f, 0.0f, 0.0f }, pdf2 = 0.0f;
         float *weight = a.out_weight + i * (size_t)W;
-        if (up) rgl::sample_spectral_at(r, tv, tl, in, a.u[2 * i], a.u[2 * i + 1], wl, W, wo2, pdf2, weight);
+        if (up) rgl::sample_spectral_at(r, g, tv, tl, in, a.u[2 * i], a.u[2 * i + 1], wl, W, wo2, pdf2, weight);
         else for (int k = 0; k < W; ++k) weight[k] = 0.0f;
         a.out_wo[3 * i] = wo2[0]; a.out_wo[3 * i + 1] = wo2[1]; a.out_wo[3 * i + 2] = wo2[2];
         a.out_pdf2[i] = pdf2;
     }
 }
 
-template <int MODE, bool LDS>
+template <int MODE, bool LDS, int MASK = 0>
 __global__ __launch_bounds__(LDS ? rgl_lds_block(MODE) : kRglBlock) void k_rgl_spectral(BatchArgs a, RglDev r, const float *wl, int W)
 {
     constexpr int kBlockThreads = LDS ? rgl_lds_block(MODE) : kRglBlock;
@@ -341,11 +348,11 @@ __global__ __launch_bounds__(LDS ? rgl_lds_block(MODE) : kRglBlock) void k_rgl_s
         const SearchLds tv = stage_search(r.vndf(), at, kBlockThreads);
         const SearchLds tl = stage_search(r.luminance(), at, kBlockThreads);
         __syncthreads();
-        for (size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride) rgl_unit_spectral<MODE>(a, r, grids, tv, tl, i, wl, W);
+        for (size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride) rgl_unit_spectral<MODE, MASK>(a, r, grids, tv, tl, i, wl, W);
     } else {
         __syncthreads();
         for (size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride)
-            rgl_unit_spectral<MODE>(a, r, grids, rgl::SearchMem(r.vndf()), rgl::SearchMem(r.luminance()), i, wl, W);
+            rgl_unit_spectral<MODE, MASK>(a, r, grids, rgl::SearchMem(r.vndf()), rgl::SearchMem(r.luminance()), i, wl, W);
     }
 }
 
@@ -597,8 +604,8 @@ RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base)
 }
 
 namespace {
-template <int MODE>
-hipError_t launch_spectral_mode(const BatchArgs &a, const RglDev &r, const float *wl, int W, int search, int compute_units, hipStream_t stream)
+template <int MODE, int MASK>
+hipError_t launch_spectral_masked(const BatchArgs &a, const RglDev &r, const float *wl, int W, int search, int compute_units, hipStream_t stream)
 {
     if (search == 0 && a.n >= (size_t)1 << 15) {
         const size_t need = lds_bytes_of(r);
@@ -606,8 +613,8 @@ hipError_t launch_spectral_mode(const BatchArgs &a, const RglDev &r, const float
             constexpr int kThreads = rgl_lds_block(MODE);
             size_t blocks = (a.n + kThreads - 1) / kThreads;
             if (blocks > (size_t)compute_units) blocks = (size_t)compute_units;
-            (void)hipFuncSetAttribute((const void *)k_rgl_spectral<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-            hipLaunchKernelGGL((k_rgl_spectral<MODE, true>), dim3((unsigned)blocks), dim3(kThreads), need, stream, a, r, wl, W);
+            (void)hipFuncSetAttribute((const void *)k_rgl_spectral<MODE, true, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            hipLaunchKernelGGL((k_rgl_spectral<MODE, true, MASK>), dim3((unsigned)blocks), dim3(kThreads), need, stream, a, r, wl, W);
             return hipGetLastError();
         }
     }
@@ -615,9 +622,17 @@ hipError_t launch_spectral_mode(const BatchArgs &a, const RglDev &r, const float
     const size_t cap = (size_t)compute_units * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_rgl_spectral<MODE, false>), dim3((unsigned)blocks), dim3(kRglBlock), grid_bytes_of(r), stream, a, r, wl, W);
+    hipLaunchKernelGGL((k_rgl_spectral<MODE, false, MASK>), dim3((unsigned)blocks), dim3(kRglBlock), grid_bytes_of(r), stream, a, r, wl, W);
     return hipGetLastError();
 }
+// (the database's spectral files are isotropic: that shape has its own kernels, every other one tests the shape at run time)
+template <int MODE>
+hipError_t launch_spectral_mode(const BatchArgs &a, const RglDev &r, const float *wl, int W, int search, int compute_units, hipStream_t stream)
+{
+    if (r.n_phi == 1 && r.n_theta > 1) return launch_spectral_masked<MODE, 5>(a, r, wl, W, search, compute_units, stream);
+    return launch_spectral_masked<MODE, 0>(a, r, wl, W, search, compute_units, stream);
+}
+
 } // namespace
 
 hipError_t launch_rgl_spectral(int mode, const BatchArgs &a, const RglDev &r, const float *wl, int W, int search, int compute_units, hipStream_t stream)

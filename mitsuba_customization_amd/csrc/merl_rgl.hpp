@@ -131,9 +131,10 @@ MRL_HD void bracket(const float *grid, int n, double p, int &i, double &t)
 // kernel keeps in LDS (merl_rgl.hip: GridLds) — the bracket search is 3 - 4 dependent reads per grid and unit, a third of an
 // anisotropic eval while each was a round trip through the vector memory pipe.
 struct GridMem {
-    const float *phi, *theta;
+    const float *phi, *theta, *wavelengths;     // (wavelengths: spectral files)
     MRL_HD float phi_at(int k) const { return phi[k]; }
     MRL_HD float theta_at(int k) const { return theta[k]; }
+    MRL_HD float wavelength_at(int k) const { return wavelengths[k]; }
 };
 
 template <class Grids>
@@ -606,25 +607,29 @@ MRL_HD void sample_at(const RglDev &b, const Search &tv, const Search &tl, const
 // ---- spectral files: W values per unit, at the wavelengths wl[0 .. W) (wl == nullptr: at the file's own nodes, W = n_wl) ----
 // the measured spectrum at warp position (sx, sy): linear between the file's wavelength nodes, clamped outside them — the
 // wavelength as the third interpolated parameter, as upstream's spectral variants evaluate `spectra`
-MRL_HD double spectrum_at(const RglDev &b, const Slices &sv, double sx, double sy, const float *wl, int k)
+// c: the cell of the position in the values table (one per unit: every wavelength reads the same cell); g: where the file's
+// wavelength grid is read.  The two nodes' corner values are read together.
+template <class Grids>
+MRL_HD double spectrum_at(const RglDev &b, const Grids &g, const WarpDev &wr, const Slices &sv, const Cell &c, const float *wl, int k)
 {
 #pragma clang fp contract(off)
     double v;
     if (!wl) {
-        v = warp_eval(b.rgb(), sv, sx, sy, k);
+        v = cell_value(wr, c, fetch4(sv, wr, c.index, k));
     } else {
         int c0 = 0;
         double t = 0.0;
-        if (b.n_wl > 1) bracket(b.wavelengths, b.n_wl, (double)wl[k], c0, t);
-        v = warp_eval(b.rgb(), sv, sx, sy, c0);
-        if (b.n_wl > 1) v = lerp(t, v, warp_eval(b.rgb(), sv, sx, sy, c0 + 1));
+        if (b.n_wl > 1) bracket_by([&g](int j) { return g.wavelength_at(j); }, b.n_wl, (double)wl[k], c0, t);
+        const Raw4 r0 = fetch_raw(sv, wr, c.index, c0), r1 = fetch_raw(sv, wr, c.index, b.n_wl > 1 ? c0 + 1 : c0);
+        v = cell_value(wr, c, blend4(sv, r0));
+        if (b.n_wl > 1) v = lerp(t, v, cell_value(wr, c, blend4(sv, r1)));
     }
     return v < 0.0 ? 0.0 : v;
 }
 
 // values[0 .. W) and / or pdf; values is the caller's row (written once per wavelength, no register array)
-template <bool WANT_VALUES, bool WANT_PDF, class Search>
-MRL_HD void eval_pdf_spectral_at(const RglDev &b, const Search &tv, const Incident &in, float wox, float woy, float woz, const float *wl, int W,
+template <bool WANT_VALUES, bool WANT_PDF, class Grids, class Search>
+MRL_HD void eval_pdf_spectral_at(const RglDev &b, const Grids &g, const Search &tv, const Incident &in, float wox, float woy, float woz, const float *wl, int W,
                                  float *values, float &pdf, const Found *fv = nullptr, const Found *fl = nullptr)
 {
 #pragma clang fp contract(off)
@@ -636,13 +641,15 @@ MRL_HD void eval_pdf_spectral_at(const RglDev &b, const Search &tv, const Incide
     }
     if constexpr (WANT_VALUES) {
         const double scale = value_scale(b, in, h);
-        for (int k = 0; k < W; ++k) values[k] = (float)(spectrum_at(b, in.sv, h.sx, h.sy, wl, k) * scale);
+        const WarpDev wr = b.rgb();
+        const Cell c = locate(wr, h.sx, h.sy);
+        for (int k = 0; k < W; ++k) values[k] = (float)(spectrum_at(b, g, wr, in.sv, c, wl, k) * scale);
     }
     if constexpr (WANT_PDF) pdf = pdf_of(b, in, h, fl);
 }
 
-template <class Search>
-MRL_HD void sample_spectral_at(const RglDev &b, const Search &tv, const Search &tl, const Incident &in, float u0, float u1, const float *wl, int W,
+template <class Grids, class Search>
+MRL_HD void sample_spectral_at(const RglDev &b, const Grids &g, const Search &tv, const Search &tl, const Incident &in, float u0, float u1, const float *wl, int W,
                                float wo_out[3], float &pdf_out, float *weight)
 {
 #pragma clang fp contract(off)
@@ -661,8 +668,10 @@ MRL_HD void sample_spectral_at(const RglDev &b, const Search &tv, const Search &
     wo_out[0] = wof[0]; wo_out[1] = wof[1]; wo_out[2] = wof[2];
     pdf_out = p;
     const double scale = value_scale(b, in, h);
+    const WarpDev wr = b.rgb();
+    const Cell c = locate(wr, h.sx, h.sy);
     for (int k = 0; k < W; ++k) {
-        const float f = (float)(spectrum_at(b, in.sv, h.sx, h.sy, wl, k) * scale);
+        const float f = (float)(spectrum_at(b, g, wr, in.sv, c, wl, k) * scale);
         weight[k] = f / p;
     }
 }
@@ -696,7 +705,7 @@ MRL_HD void eval_pdf_spectral(const RglDev &b, float wix, float wiy, float wiz, 
         if constexpr (WANT_VALUES) for (int k = 0; k < W; ++k) values[k] = 0.0f;
         return;
     }
-    eval_pdf_spectral_at<WANT_VALUES, WANT_PDF>(b, SearchMem(b.vndf()), in, wox, woy, woz, wl, W, values, pdf);
+    eval_pdf_spectral_at<WANT_VALUES, WANT_PDF>(b, GridMem{ b.phi, b.theta, b.wavelengths }, SearchMem(b.vndf()), in, wox, woy, woz, wl, W, values, pdf);
 }
 
 MRL_HD void sample_spectral(const RglDev &b, float wix, float wiy, float wiz, float u0, float u1, const float *wl, int W,
@@ -705,7 +714,7 @@ MRL_HD void sample_spectral(const RglDev &b, float wix, float wiy, float wiz, fl
     wo_out[0] = wo_out[1] = wo_out[2] = 0.0f; pdf_out = 0.0f;
     Incident in;
     if (!(wiz > 0.0f) || !incident<true>(b, GridMem{ b.phi, b.theta }, wix, wiy, wiz, in)) { for (int k = 0; k < W; ++k) weight[k] = 0.0f; return; }
-    sample_spectral_at(b, SearchMem(b.vndf()), SearchMem(b.luminance()), in, u0, u1, wl, W, wo_out, pdf_out, weight);
+    sample_spectral_at(b, GridMem{ b.phi, b.theta, b.wavelengths }, SearchMem(b.vndf()), SearchMem(b.luminance()), in, u0, u1, wl, W, wo_out, pdf_out, weight);
 }
 
 } // namespace rgl
