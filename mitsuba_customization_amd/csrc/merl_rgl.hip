@@ -199,11 +199,13 @@ __device__ __forceinline__ void rgl_unit(const BatchArgs &a, const RglDev &r, co
 {
     constexpr bool has_eval = MODE == 0 || MODE == 3 || MODE == 4, has_pdf = MODE == 1 || MODE == 3 || MODE == 4,
                    has_sample = MODE == 2 || MODE == 3;
-    const float wix = a.wi[3 * i], wiy = a.wi[3 * i + 1], wiz = a.wi[3 * i + 2];
+    float wix = a.wi[3 * i], wiy = a.wi[3 * i + 1], wiz = a.wi[3 * i + 2];
     // (the unit's other stream reads are issued before the incident-only work waits for its own)
     float wox = 0.0f, woy = 0.0f, woz = 0.0f, u0 = 0.0f, u1 = 0.0f;
     if constexpr (has_eval || has_pdf) { wox = a.wo[3 * i]; woy = a.wo[3 * i + 1]; woz = a.wo[3 * i + 2]; }
     if constexpr (has_sample) { u0 = a.u[2 * i]; u1 = a.u[2 * i + 1]; }
+    // (all three components of wi are wanted HERE: without this the compiler reads wi.z, tests it, and only then reads wi.xy — a round trip more)
+    asm volatile("" : "+v"(wix), "+v"(wiy), "+v"(wiz));
     rgl::Incident in;
     const bool up = wiz > 0.0f && rgl::incident<has_eval || has_sample>(r, g, wix, wiy, wiz, in);
     if constexpr (MASK != 0) in.sv.mask = MASK;
@@ -274,7 +276,9 @@ __global__ __launch_bounds__(kRglBlock, rgl_min_blocks(MODE, MULTI, MASK)) void 
             if (id < 0 || id >= a.n_materials) continue;
             const MaterialDev &m = a.materials[id];
             if (m.kind != KIND_RGL) continue;
-            const RglDev &rm = *(const RglDev *)m.rgl;
+            // the unit's descriptor into registers, whole (31 dwords read together): through a reference every table read would be
+            // two dependent loads — the pointer, then the data
+            const RglDev rm = *(const RglDev *)m.rgl;
             rgl_unit<MODE, 0>(a, rm, rgl::GridMem{ rm.phi, rm.theta, rm.wavelengths }, rgl::SearchMem(rm.vndf()), rgl::SearchMem(rm.luminance()), i);
         } else {
             rgl_unit<MODE, MASK>(a, r, grids, rgl::SearchMem(r.vndf()), rgl::SearchMem(r.luminance()), i);
