@@ -17,7 +17,8 @@ CASES = [dict(seed=1, n_phi=1, n_theta=6, res=12, res_ndf=16, res_sigma=8),     
          dict(seed=2, n_phi=5, n_theta=4, res=9, res_ndf=8, res_sigma=6),            # anisotropic
          dict(seed=3, n_phi=1, n_theta=1, res=2, res_ndf=2, res_sigma=2),            # the smallest legal file
          dict(seed=4, n_phi=4, n_theta=3, res=7, res_ndf=8, res_sigma=6, reduction=2),   # phi_i in [-pi, 0]: point symmetry
-         dict(seed=5, n_phi=3, n_theta=3, res=6, res_ndf=6, res_sigma=4, reduction=4)]   # phi_i in [-pi, -pi/2]: two mirror planes
+         dict(seed=5, n_phi=3, n_theta=3, res=6, res_ndf=6, res_sigma=4, reduction=4),   # phi_i in [-pi, -pi/2]: two mirror planes
+         dict(seed=6, n_phi=5, n_theta=1, res=8, res_ndf=8, res_sigma=6)]                # one elevation node: brackets of two phi slices (the kernel that tests the shape at run time)
 
 
 def _close(a, b, what, orc=None, wi=None, wo=None, max_ill=0):

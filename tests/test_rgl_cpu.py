@@ -125,7 +125,8 @@ def test_guards():
                                   dict(seed=2, n_phi=5, n_theta=4, res=9, res_ndf=8, res_sigma=6),
                                   dict(seed=3, n_phi=1, n_theta=1, res=2, res_ndf=2, res_sigma=2),
                                   dict(seed=4, n_phi=4, n_theta=3, res=7, res_ndf=8, res_sigma=6, reduction=2),
-                                  dict(seed=5, n_phi=3, n_theta=3, res=6, res_ndf=6, res_sigma=4, reduction=4)],
+                                  dict(seed=5, n_phi=3, n_theta=3, res=6, res_ndf=6, res_sigma=4, reduction=4),
+                                  dict(seed=6, n_phi=5, n_theta=1, res=8, res_ndf=8, res_sigma=6)],      # one elevation node: a bracket of two phi slices
                          ids=lambda c: f"phi{c['n_phi']}_theta{c['n_theta']}_res{c['res']}_red{c.get('reduction', 1)}")
 def test_product_per_unit_functions_on_the_host_match_the_oracle(case, tmp_path_factory):
     """The product's RGL code — image builder (cell bricks, running integrals) and per-unit eval / pdf / sample, the SAME
