@@ -117,10 +117,11 @@ enum mrl_option {
                                   empties.  Settable while no table lives in it; 0 frees it.  The arena is asked for as
                                   physically contiguous memory (plain device memory if the driver refuses).  Measured effect
                                   on the 100-table launch: DESIGN.md §6 (address translation bounds that launch). */
-    MRL_OPT_RGL_SEARCH = 12,   /* where a single-material launch on an RGL material reads the two distributions' search tables
-                                  (conditional / marginal running integrals): 0 (default) a copy in the CU's LDS when they fit
-                                  (125 KB for the database's isotropic 8 x 32 x 32 shape), 1 always memory.  Same results bit
-                                  for bit; the option exists so that both paths can be measured and tested. */
+    MRL_OPT_RGL_SEARCH = 12,   /* where a single-material launch on an RGL material reads the two distributions' running integrals
+                                  (conditional / marginal, what sample()'s searches walk): 0 (default) a copy in the CU's LDS when
+                                  they fit (129 KB for the database's isotropic 8 x 32 x 32 shape; the marginal rows alone for
+                                  sample() on larger files), 1 always the image in memory.  Same results bit for bit; the option
+                                  exists so that both paths can be measured and tested. */
     MRL_OPT_COSINE_FACTOR = 13, /* SURVEY.md Appendix B 4 — does the plugin's eval() multiply the BRDF by cos(theta_o)?  0 (default,
                                   upstream Mitsuba's convention): eval() = f cos(theta_o); 1: eval() = f alone — from eval() and from
                                   the eval() inside sample()'s weight (weight == eval / pdf stays true).  Table materials (MERL,
@@ -244,7 +245,7 @@ int mrl_eval_sample_spectral_batch(mrl_ctx *ctx, const float *wi, const float *w
                                    size_t n, float *out_values, float *out_pdf, float *out_wo, float *out_pdf2, float *out_weight);
 /* On-disk cache of a material's DEVICE image: what is resident for the material — the texels as Float (RGB tables
  * in the compact rows form, 24 MB for a MERL table, whatever the context's layout: a brick context expands them on the device), the
- * sampling marginal, the conditional sampling rows; for an RGL material the cell-brick image with its running integrals — written so that
+ * sampling marginal, the conditional sampling rows; for an RGL material the bracket-major image with its cell records — written so that
  * another process makes the material resident with one read and one copy: no parse, no re-layout of the f64 payload, no quadrature /
  * prefix-scan kernels, no host normalisation.  5.5 ms instead of 12.4 per MERL table.  Table, n-channel and RGL materials;
  * not analytic ones.  An image is tied to this library version and (when it holds conditional sampling rows) to the lookup / node options

@@ -2,11 +2,13 @@
 // the host-side image builder (normalisation + running integrals, f64, in the oracle's loop order) and the kernels.
 // PARITY UNPINNED (see merl_rgl.hpp).  SURVEY.md §8f item 3.
 //
-//   k_rgl<MODE, INDEXED, MULTI>   one lane = one unit, grid-stride; the material's descriptor (five WarpDev) arrives by value in
-//                          SGPRs; every table read is a per-lane gather served by L1/L2 (a material is 0.5 - 50 MB).
-// What bounds it: the number of scattered lane-addresses the CU's texture addresser resolves (93 % of wave cycles wait on
-// memory, VALU is under 10 % busy: profiles/r03_rgl_pmc.json) — hence the image's cell bricks (one 16-B load per cell and
-// slice where the file's node-major layout needs four); measured rates: DESIGN.md §5c.
+//   k_rgl<MODE, INDEXED, MULTI, MASK>          one lane = one unit, grid-stride; the material's descriptor arrives by value in SGPRs
+//                                              (MULTI: read per unit from behind the unit's material); the distributions' running
+//                                              integrals come from the cell records in memory
+//   k_rgl_lds<MODE, INDEXED, MARG_ONLY, MASK>  one workgroup per CU first copies those integrals (or the marginal rows alone) into LDS
+//   k_rgl_spectral<MODE, LDS, MASK>            the same for spectral files, W values per unit
+// MASK: the bracket shape the kernel is compiled for (5 isotropic, 15 anisotropic, 0 tested at run time).  What bounds them — round
+// trips, then L1 line fills, then (isotropic) the vector ALU — and the measured rates: merl_rgl.hpp's header, DESIGN.md §5e.
 #include "merl_kernels.hpp"
 #include "merl_rgl.hpp"
 
@@ -18,8 +20,8 @@ namespace mrl {
 namespace {
 
 constexpr int kRglBlock = 256;
-// the LDS variant: ONE workgroup per CU holds the file's search tables (up to 160 KB) — 4 waves per SIMD for eval and for pdf alone, 3 for the fused modes and the
-// modes with a sample() (which carries two visited cells through its eval: 130 - 170 VGPRs)
+// the LDS variant: ONE workgroup per CU holds the file's running integrals (up to 160 KB) — 4 waves per SIMD for eval and for pdf alone,
+// 3 for the modes with a sample() (which carries two visited cells through its eval: 160 - 170 VGPRs), 2 for the anisotropic shape's
 #ifndef MRL_RGL_LDS_BLOCK_SAMPLE
 #define MRL_RGL_LDS_BLOCK_SAMPLE 768
 #endif
@@ -38,10 +40,9 @@ constexpr int rgl_lds_block(int mode, int mask = 0)
     return mode >= 2 ? (mask == 15 ? MRL_RGL_LDS_BLOCK_SAMPLE15 : MRL_RGL_LDS_BLOCK_SAMPLE) : MRL_RGL_LDS_BLOCK_EVAL;
 }
 
-// ---- the search tables in LDS ----
-// Slice by slice (a bracket's float4 taken apart while it is copied): cond [slices][cell] float2, marg [slices][ny - 1] float, for vndf
-// and then luminance.  A ds_read gather of 64 scattered addresses costs a tenth of the global one (LDS has no tag lookup per line),
-// and these are the reads sample() is made of: 2 x (log2 ny + log2 nx) dependent steps per unit and slice.
+// ---- the running integrals in LDS ----
+// Slice by slice (taken out of the records while they are copied: SearchLds below), for vndf and then luminance.  A ds_read gather of 64
+// scattered addresses costs no line fill, and these are the reads sample() is made of: 2 x (log2 ny + log2 nx) dependent steps per unit.
 extern __shared__ float4 rgl_lds[];
 
 // ---- the parameter grids in LDS (every single-material kernel): phi_i then theta_i at the start of the block's LDS ----
@@ -145,7 +146,7 @@ __device__ __forceinline__ SearchLdsMarg stage_marg(const WarpDev &w, unsigned &
     return t;
 }
 
-// bytes of LDS the two distributions' search tables take, slice by slice (16-B aligned pieces)
+// bytes of LDS the two distributions' running integrals take, slice by slice (16-B aligned pieces)
 size_t lds_bytes_of(const RglDev &r)
 {
     const WarpDev w = r.vndf();
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(kRglBlock, rgl_min_blocks(MODE, MULTI, MASK)) void 
     }
 }
 
-// The single-material launch when the file's search tables fit a CU's LDS: one workgroup per CU copies them in (once: the grid is
+// The single-material launch when the file's running integrals fit a CU's LDS: one workgroup per CU copies them in (once: the grid is
 // persistent) and every search step of every unit is a ds_read.  Same functions, same sums, same bits as k_rgl.
 // MARG_ONLY: the partial form (SearchLdsMarg) for files whose conditional integrals do not fit
 template <int MODE, bool INDEXED, bool MARG_ONLY = false, int MASK = 0>
@@ -376,7 +377,7 @@ hipError_t launch_masked(const BatchArgs &a, const RglDev *r, bool indexed, int 
     // (kernels compiled for a bracket shape: the full LDS form for isotropic files — anisotropic ones rarely fit —, the marginal-rows
     // form for anisotropic ones; the other combinations take the kernel that tests the shape at run time)
     constexpr int kLdsMask = MASK == 5 ? 5 : 0, kMargMask = MASK == 15 ? 15 : 0;
-    // LDS variant: a single-material launch large enough to pay for the copy (one image of the search tables per CU)
+    // LDS variant: a single-material launch large enough to pay for the copy (one image of the running integrals per CU)
     if (search == 0 && a.n >= (size_t)1 << 15) {
         // one workgroup per CU
         auto grid_of = [&](int threads) { size_t blocks = (a.n + (size_t)threads - 1) / (size_t)threads; return dim3((unsigned)(blocks > (size_t)compute_units ? (size_t)compute_units : blocks)); };
@@ -655,11 +656,11 @@ hipError_t launch_rgl_spectral(int mode, const BatchArgs &a, const RglDev &r, co
 hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev *r, bool indexed, int search, int compute_units, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
-    // The fused unit of a file whose search tables do not fit a CU's LDS (an anisotropic file: its lookups blend four slices of a
-    // 14 MB image, the launch waits on L2 / memory): eval + pdf and sample() as TWO launches on the stream.  The fused kernel carries
-    // sample()'s 170 VGPRs through its eval as well (2-3 waves per SIMD); apart, eval + pdf runs at 5 waves per SIMD and sample()
-    // with its marginal rows in LDS — 16M units: 7.03 ms fused, 6.63 ms apart on one box (profiles/r04_rgl_rates.json); the 12 B per unit of wi
-    // read twice do not show.  Same functions, same bits (the separate entry points are bit-compared with the fused one).
+    // The fused unit of a file whose integrals do not fit a CU's LDS (an anisotropic file: its lookups blend four slices of a 45 MB
+    // image, the launch waits on L1 fills): eval + pdf and sample() as TWO launches on the stream.  The fused kernel carries sample()'s
+    // 220 VGPRs through its eval as well (2 waves per SIMD); apart, eval + pdf runs at 3 waves per SIMD and sample() with its marginal
+    // rows in LDS — 16M units: 4.26 ms fused, 4.10 ms apart (profiles/r04_rgl_rates.json); the 12 B per unit of wi read twice do not
+    // show.  Same functions, same bits (the separate entry points are bit-compared with the fused one).
     if (mode == 3 && r && search == 0 && a.n >= (size_t)1 << 15 && lds_bytes_of(*r) > (size_t)lds_limit()) {
         const hipError_t e = launch_mode<4>(a, r, indexed, search, compute_units, stream);
         return e != hipSuccess ? e : launch_mode<2>(a, r, indexed, search, compute_units, stream);

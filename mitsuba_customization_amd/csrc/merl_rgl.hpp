@@ -19,21 +19,25 @@
 // pi/8-rotated atan polynomial, Taylor sin / cos: relative error ~1e-15 each) in place of ocml's correctly rounded
 // division, sqrt, asin, atan2, sin and cos.  One lane per unit.
 //
-// What bounds the kernel and what this file does about it (profiles/r03_rgl_pmc.json, r04_rgl_pmc.json): the
-// cost is the number of SCATTERED lane-addresses the CU's texture addresser resolves (one load instruction of 64 lanes that
-// touch ~50 lines costs ~80 cycles of a CU whatever its width), not bytes and not arithmetic.  Hence
-//   * cell bricks: what a lookup needs about a cell sits in ONE aligned 16-B vector per table and parameter slice, and the
-//     vectors of the 2 / 4 slices of a parameter BRACKET lie side by side (32 / 64 B: one cache line where slice-major tables
-//     cost one line per slice — the L1 hit rate of eval was 16 - 40 %, its miss path the busiest unit);
-//   * the SEARCH tables (conditional and marginal running integrals — ten dependent reads per sample() and slice in the
-//     textbook form) are stored for the BRACKET, not the slice: the two theta_i slices of a bracket side by side in one
-//     float4 (`cond2`), the four slices of a (phi_i, theta_i) bracket's marginal in one float4 (`margq`) — one load where
-//     round 3 issued two / four — and are read through a policy (`Search`): from memory (SearchMem: host images, batches
-//     with material ids, files too large for a CU's LDS) or from a copy in LDS (merl_rgl.hip: a `ds_read` gather costs a
-//     tenth of a scattered global one);
+// What bounds the kernel and what this file does about it (profiles/r04_rgl_pmc.json, r04_rgl_l2.json,
+// r04_gather_quad.json).  Two things, found in this order:
+//   (1) ROUND TRIPS.  A table read that sits next to its use inside a conditional block (`if (slice exists) { q = table[..];
+//       v = fma(w, q, v); }`) cannot be hoisted, so the wave waits for every read on its own — 25 serial round trips per
+//       anisotropic eval, the CU's L1 idling on one outstanding line per wave.  Hence every lookup here comes in two steps,
+//       READS (fetch_raw, Search::*_raw: loads only, issued back to back) and SUMS (blend4, *_blend), and the callers issue
+//       everything a stage needs before they sum anything: an inverse warp its whole cell, eval its three channels and the
+//       luminance cell.  The kernels compiled for one bracket shape (merl_rgl.hip, MASK) make the reads straight-line code.
+//   (2) LINE FILLS.  With the reads in flight together a lane's reads that fall in one 128-B line merge into one L1 fill, and
+//       the cost of a unit is its number of distinct lines (~4-5 CU-cycles each from L2).  Hence the image is stored per
+//       parameter BRACKET — the 2 / 4 slices a lookup blends side by side — and a distribution's cell is ONE RECORD (WarpDev):
+//       the integrals left of the cell, the corner values per slice, the row totals: an inverse warp = one line.
+//   * The running integrals are read through a policy (`Search`): from the records in memory (SearchMem: host images, batches
+//     with material ids, files too large for a CU's LDS) or from slice-major copies in LDS (merl_rgl.hip: every step of
+//     sample()'s two binary searches a ds_read); the parameter grids through `Grids` (memory, or LDS in every
+//     single-material kernel).
 //   * sample() hands the cells its two searches ended in to the eval / pdf it reports at the returned direction
 //     (`Found`): the inverse warp of a point the forward warp has just produced lands in the same cell (but for one unit in
-//     ~10^5, which re-reads), so its three table reads and the luminance lookup are not issued again;
+//     ~10^5, which re-reads), so nothing is read twice;
 //   * what depends on the incident direction alone (angles, parameter bracket, projected area) is formed once per unit.
 // Every blend is spelt with explicit FMAs and contraction is off: which multiply the compiler would fuse depends on the
 // inlining context, and the entry points (separate, fused, queue, batch with ids, LDS or memory) must agree bit for bit.
@@ -107,7 +111,7 @@ namespace rgl {
 // for a bracket shape), so the tests on it are scalar branches or none and the arrays stay in registers.
 // Offsets instead of indices (formed once per unit: a 32-bit multiply costs what an f64 FMA costs): cell0 = the bracket's first cell
 // in the bracket-major tables, quad = its first row in margq; soff[k] / roff[k] = slice k x cells / cell rows of a slice (the slice-major
-// copies of the search tables in LDS).
+// copies of the running integrals in LDS).
 struct Slices { unsigned soff[4], roff[4]; double w[4]; int mask; unsigned cell0, quad; };
 
 // largest i in [0, n - 2] with node(i) <= p, and p's position in that bracket; node(k): the ascending grid's k-th value
@@ -476,7 +480,7 @@ MRL_HD bool incident(const RglDev &b, const Grids &g, float wix, float wiy, floa
 // warp's density there, and the two geometric factors of the pdf.  ok = false: the pair evaluates to zero.
 struct Half { bool ok; double u_m_x, u_m_y, sx, sy, vndf_pdf, sin_theta_m, wi_dot_m; };
 
-// tv: where vndf's search tables are read; fv (may be null): the cell of vndf a sample() has just visited
+// tv: where vndf's running integrals are read; fv (may be null): the cell of vndf a sample() has just visited
 template <class Search>
 MRL_HD Half half_lookup(const RglDev &b, const Search &tv, const Incident &in, float wox, float woy, float woz, const Found *fv)
 {
