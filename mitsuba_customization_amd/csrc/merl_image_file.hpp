@@ -20,7 +20,7 @@ struct RglFields {                   // host arrays, as the file holds them (x f
     int n_wl;                        // 0: an RGB file (rgb [n_phi][n_theta][3][ny][nx]); else a spectral one: `rgb` holds "spectra"
     const float *wavelengths;        // [n_phi][n_theta][n_wl][ny][nx] over this ascending grid
 };
-struct RglLayout { size_t phi, theta, wavelengths, cells[5], margq[5]; };   // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
+struct RglLayout { size_t phi, theta, wavelengths, cells[5], margq[5], rowh[5]; };   // float offsets into the image (ndf, sigma, vndf, luminance, rgb)
 inline int rgl_value_channels(const RglFields &f) { return f.n_wl > 0 ? f.n_wl : 3; }
 
 inline const char *rgl_check_shapes(const RglFields &f)
@@ -39,7 +39,7 @@ inline const char *rgl_check_shapes(const RglFields &f)
     return nullptr;
 }
 
-struct WarpOffsets { size_t cells = 0, margq = 0; };
+struct WarpOffsets { size_t cells = 0, margq = 0, rowh = 0; };
 // Everything is stored per parameter BRACKET (merl_rgl.hpp, WarpDev): brackets along theta / phi, the 1 / 2 / 4 slices of a bracket
 // side by side, one copy of a slice per bracket it bounds
 inline size_t rgl_theta_brackets(int n_theta) { return n_theta > 1 ? (size_t)n_theta - 1 : 1; }
@@ -49,6 +49,9 @@ inline size_t rgl_brackets(int n_phi, int n_theta) { return rgl_phi_brackets(n_p
 // float4s per cell of a DISTRIBUTION's record: the running integrals left of the cell (one float4 per phi node of the bracket), the
 // corner values (one per slice), the totals of the cell's two node rows (per phi node): 64 B isotropic, 128 B — one line — anisotropic
 inline size_t rgl_record_float4s(int n_phi, int n_theta) { return 2 * (size_t)(n_phi > 1 ? 2 : 1) + rgl_bracket_slices(n_phi, n_theta); }
+// float4s per cell row of a distribution's ROW HEADER: the row's totals and the conditional integrals at the three columns the column
+// search's first two halvings test (one float4 per phi node each): 64 B isotropic, 128 B — one line — anisotropic
+inline size_t rgl_row_header_float4s(int n_phi) { return 4 * (size_t)(n_phi > 1 ? 2 : 1); }
 // where one function's tables go: `at` is the running size of the image in floats (every table starts on a 128-byte boundary, a cache
 // line: records and the value vectors of a cell then never straddle one more line than their size asks for)
 inline WarpOffsets plan_warp(size_t &at, int nx, int ny, int n_phi, int n_theta, int n_ch, bool distribution)
@@ -59,6 +62,7 @@ inline WarpOffsets plan_warp(size_t &at, int nx, int ny, int n_phi, int n_theta,
     if (distribution) {
         off.cells = grow(cells * 4 * brackets * rgl_record_float4s(n_phi, n_theta));
         off.margq = grow((size_t)(ny - 1) * 4 * brackets);
+        off.rowh = grow((size_t)(ny - 1) * 4 * brackets * rgl_row_header_float4s(n_phi));
     } else {
         off.cells = grow(cells * 4 * (size_t)n_ch * brackets * rgl_bracket_slices(n_phi, n_theta));
     }
@@ -72,7 +76,7 @@ inline size_t rgl_plan_layout(const RglFields &f, RglLayout &l)
     l.phi = 0; l.theta = (size_t)f.n_phi; l.wavelengths = (size_t)f.n_phi + (size_t)f.n_theta;
     auto put = [&](int which, const int res[2], int n_phi, int n_theta, int n_ch, bool distribution) {
         const WarpOffsets o = plan_warp(at, res[0], res[1], n_phi, n_theta, n_ch, distribution);
-        l.cells[which] = o.cells; l.margq[which] = o.margq;
+        l.cells[which] = o.cells; l.margq[which] = o.margq; l.rowh[which] = o.rowh;
     };
     put(0, f.res_ndf, 1, 1, 1, false);
     put(1, f.res_sigma, 1, 1, 1, false);
@@ -87,7 +91,7 @@ inline size_t nch_brick_float4s(int n_ch) { return n_ch == 1 ? 2 : n_ch == 2 ? 4
 
 // ---- the file ----
 struct ImageHeader {
-    char magic[8];                       // "MRLIMG\4\0" (2: RGL search tables in the bracket form; 3: the cells too; 4: one record per cell of a distribution)
+    char magic[8];                       // "MRLIMG\4\0" (2: RGL search tables in the bracket form; 3: the cells too; 4: one record per cell of a distribution; 5: + row headers)
     uint32_t header_bytes, kind, layout, n_ch, param, lookup, node, n_ti;
     int32_t dims[3];
     int32_t rgl_shape[8];                // n_phi n_theta res_x res_y res_ndf_x res_ndf_y res_sigma_x res_sigma_y
@@ -95,7 +99,7 @@ struct ImageHeader {
     uint32_t negative;                   // MRL_OPT_NEGATIVE the table was built under: 0 = negative values were clamped to 0, 1 / 2 = the image holds them
     uint64_t texel_bytes, sampling_doubles, sampling2d_doubles, checksum;
 };
-constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 4, 0 };
+constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 5, 0 };
 constexpr uint64_t kImageChecksumSeed = 0xCBF29CE484222325ull;
 // the kinds and layouts an image can name (values of mrl::Kind / mrl::Layout / mrl::Param, repeated here so that this header needs no HIP)
 constexpr uint32_t kImgKindMerl = 0, kImgKindTable = 1, kImgKindNch = 4, kImgKindRgl = 5, kImgKindRglSpectral = 6, kImgLayoutRows = 0, kImgLayoutBrick = 1, kImgParamLast = 2;
@@ -196,8 +200,9 @@ inline const char *image_content_check(const ImagePlan &p, const void *payload)
         const size_t cells = (size_t)(s.res[0] - 1) * (size_t)(s.res[1] - 1);
         const size_t brackets = rgl_brackets(s.n_phi, s.n_theta);
         for (int w = 2; w <= 3; ++w) {                       // vndf, luminance: densities and their integrals (the records, the marginals)
-            const size_t spans[2][2] = { { p.layout.cells[w], cells * 4 * brackets * rgl_record_float4s(s.n_phi, s.n_theta) },
-                                         { p.layout.margq[w], (size_t)(s.res[1] - 1) * 4 * brackets } };
+            const size_t spans[3][2] = { { p.layout.cells[w], cells * 4 * brackets * rgl_record_float4s(s.n_phi, s.n_theta) },
+                                         { p.layout.margq[w], (size_t)(s.res[1] - 1) * 4 * brackets },
+                                         { p.layout.rowh[w], (size_t)(s.res[1] - 1) * 4 * brackets * rgl_row_header_float4s(s.n_phi) } };
             for (const auto &sp : spans)
                 for (size_t i = 0; i < sp[1]; ++i) if (f[sp[0] + i] < 0.0f) return "negative value in a distribution of the image";
         }

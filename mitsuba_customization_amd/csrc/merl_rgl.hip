@@ -112,6 +112,16 @@ struct SearchLds {
         if (s.mask & 8) v = __builtin_fma(s.w[3], (double)r.m3, v);
         return v;
     }
+    struct HeadRaw { PairRaw total, p1, p2a, p2b; };
+    // (the memory form's row header, from the slice-major copies: the four reads go out together)
+    __device__ __forceinline__ HeadRaw head_raw(const rgl::Slices &s, int row) const
+    {
+        const rgl::Pivots pv = rgl::pivot_columns((int)per_row + 1);
+        const int first = row * (int)per_row + 1;
+        HeadRaw h;
+        h.total = total_raw(s, row); h.p1 = left_raw(s, first + pv.m1); h.p2a = left_raw(s, first + pv.m2a); h.p2b = left_raw(s, first + pv.m2b);
+        return h;
+    }
     __device__ __forceinline__ rgl::D2 left(const rgl::Slices &s, int cell) const { return pair_blend(s, left_raw(s, cell)); }
     __device__ __forceinline__ rgl::D2 total(const rgl::Slices &s, int row) const { return pair_blend(s, total_raw(s, row)); }
     __device__ __forceinline__ double marg(const rgl::Slices &s, int row) const { return marg_blend(s, marg_raw(s, row)); }
@@ -525,6 +535,20 @@ WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, 
                             t[2] = condf[s1 * per_cond + lo + last]; t[3] = condf[s1 * per_cond + hi + last];
                         }
                 }
+                // the row headers: totals, then the integrals up to the three pivot columns (rgl::pivot_columns), one float4 per phi node each
+                {
+                    const rgl::Pivots pv = rgl::pivot_columns(nx);
+                    const int piv[4] = { nx - 2, pv.m1, pv.m2a, pv.m2b };
+                    for (int y = 0; y < ny - 1; ++y)
+                        for (int g = 0; g < 4; ++g)
+                            for (size_t k = 0; k < P; ++k) {
+                                const size_t s0 = (size_t)(ipb + (int)k) * n_theta + itb, s1 = n_theta > 1 ? s0 + 1 : s0;
+                                const size_t lo = (size_t)y * (size_t)(nx - 1) + (size_t)piv[g], hi = lo + (size_t)(nx - 1);
+                                float *h = &blob[off.rowh + (((((size_t)ipb * tb + itb) * per_marg + (size_t)y) * 4 + (size_t)g) * P + k) * 4];
+                                h[0] = condf[s0 * per_cond + lo]; h[1] = condf[s0 * per_cond + hi];
+                                h[2] = condf[s1 * per_cond + lo]; h[3] = condf[s1 * per_cond + hi];
+                            }
+                }
                 const size_t dp = n_phi > 1 ? (size_t)n_theta : 0, dt = n_theta > 1 ? 1 : 0, s0 = (size_t)ipb * n_theta + itb;
                 float *m = &blob[off.margq + ((size_t)ipb * tb + itb) * per_marg * 4];
                 for (size_t y = 0; y < per_marg; ++y, m += 4) {
@@ -579,7 +603,7 @@ RglLayout rgl_build_image(const RglFields &f, std::vector<float> &blob)
     if (f.n_wl > 0) blob.insert(blob.end(), f.wavelengths, f.wavelengths + f.n_wl);
     auto put = [&](int which, const float *src, const int res[2], int n_phi, int n_theta, int n_ch, bool distribution) {
         const WarpOffsets o = append_warp(blob, src, res[0], res[1], n_phi, n_theta, n_ch, distribution);
-        l.cells[which] = o.cells; l.margq[which] = o.margq;
+        l.cells[which] = o.cells; l.margq[which] = o.margq; l.rowh[which] = o.rowh;
     };
     put(0, f.ndf, f.res_ndf, 1, 1, 1, false);
     put(1, f.sigma, f.res_sigma, 1, 1, 1, false);
@@ -595,7 +619,7 @@ RglDev rgl_descriptor(const RglFields &f, const RglLayout &l, const float *base)
     auto at = [&](size_t off) { return (const float4 *)(base + off); };
     RglDev r;
     r.ndf_cells = at(l.cells[0]); r.sigma_cells = at(l.cells[1]); r.vndf_cells = at(l.cells[2]); r.lum_cells = at(l.cells[3]); r.rgb_cells = at(l.cells[4]);
-    r.vndf_margq = at(l.margq[2]); r.lum_margq = at(l.margq[3]);
+    r.vndf_margq = at(l.margq[2]); r.lum_margq = at(l.margq[3]); r.vndf_rowh = at(l.rowh[2]); r.lum_rowh = at(l.rowh[3]);
     r.phi = base + l.phi; r.theta = base + l.theta;
     r.ndf_nx = f.res_ndf[0]; r.ndf_ny = f.res_ndf[1]; r.sigma_nx = f.res_sigma[0]; r.sigma_ny = f.res_sigma[1];
     r.nx = f.res[0]; r.ny = f.res[1]; r.n_phi = f.n_phi; r.n_theta = f.n_theta;
@@ -659,7 +683,7 @@ hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev *r, bool indexe
     // The fused unit of a file whose integrals do not fit a CU's LDS (an anisotropic file: its lookups blend four slices of a 45 MB
     // image, the launch waits on L1 fills): eval + pdf and sample() as TWO launches on the stream.  The fused kernel carries sample()'s
     // 220 VGPRs through its eval as well (2 waves per SIMD); apart, eval + pdf runs at 3 waves per SIMD and sample() with its marginal
-    // rows in LDS — 16M units: 4.26 ms fused, 4.10 ms apart (profiles/r04_rgl_rates.json); the 12 B per unit of wi read twice do not
+    // rows in LDS — 16M units: 3.89 ms fused, 3.52 ms apart (profiles/r04_rgl_rates.json); the 12 B per unit of wi read twice do not
     // show.  Same functions, same bits (the separate entry points are bit-compared with the fused one).
     if (mode == 3 && r && search == 0 && a.n >= (size_t)1 << 15 && lds_bytes_of(*r) > (size_t)lds_limit()) {
         const hipError_t e = launch_mode<4>(a, r, indexed, search, compute_units, stream);

@@ -58,9 +58,12 @@ namespace mrl {
 //                       [P, P + S)      the corner values per slice, normalised
 //                       [P + S, 2P + S) the totals of node rows (row, row + 1), same form as the first part
 //                     margq [pb][tb][ny - 1]  marginal cdf after the cell row, of slices (ip, it) (ip+1, it) (ip, it+1) (ip+1, it+1)
+//                     rowh  [pb][tb][ny - 1]  ROW HEADERS of 4 P float4: the row's totals, then the integrals up to the three columns the
+//                                             column search's first two halvings test (pivot_columns) — a forward warp reads the totals and
+//                                             decides two of its log2(nx) halvings from ONE line
 struct WarpDev {
     const float4 *cells;
-    const float4 *margq;        // distributions only
+    const float4 *margq, *rowh; // distributions only
     int nx, ny, n_phi, n_theta;
     int normalized;             // a distribution: values are densities over the unit square
     int stride, first;          // float4s per cell; where the corner values (of channel 0) start in a cell's piece
@@ -72,7 +75,7 @@ struct WarpDev {
 // parameter grids and the resolution; the five functions are handed out as WarpDev views.
 struct RglDev {
     const float4 *ndf_cells, *sigma_cells, *vndf_cells, *lum_cells, *rgb_cells;
-    const float4 *vndf_margq, *lum_margq;
+    const float4 *vndf_margq, *lum_margq, *vndf_rowh, *lum_rowh;
     const float *phi, *theta;   // ascending parameter grids of vndf / luminance / rgb
     // spectral files ("spectra" + "wavelengths" instead of "rgb"): `rgb_cells` then holds the spectra, one channel per wavelength
     // node (n_values = n_wl), and a value is interpolated linearly between the nodes around the wavelength asked for
@@ -86,18 +89,18 @@ struct RglDev {
     // the same descriptor over a copy of the image at another address (the host table: merl_materials.hip)
     void rebase(const char *from, const char *to)
     {
-        const float4 **q[7] = { &ndf_cells, &sigma_cells, &vndf_cells, &lum_cells, &rgb_cells, &vndf_margq, &lum_margq };
+        const float4 **q[9] = { &ndf_cells, &sigma_cells, &vndf_cells, &lum_cells, &rgb_cells, &vndf_margq, &lum_margq, &vndf_rowh, &lum_rowh };
         for (const float4 **x : q) *x = (const float4 *)(to + ((const char *)*x - from));
         const float **g[3] = { &phi, &theta, &wavelengths };
         for (const float **x : g) if (*x) *x = (const float *)(to + ((const char *)*x - from));
     }
     MRL_HD int phi_nodes() const { return n_phi > 1 ? 2 : 1; }
     MRL_HD int slices() const { return (n_phi > 1 ? 2 : 1) * (n_theta > 1 ? 2 : 1); }
-    MRL_HD WarpDev ndf() const { return { ndf_cells, nullptr, ndf_nx, ndf_ny, 1, 1, 0, 1, 0 }; }
-    MRL_HD WarpDev sigma() const { return { sigma_cells, nullptr, sigma_nx, sigma_ny, 1, 1, 0, 1, 0 }; }
-    MRL_HD WarpDev vndf() const { return { vndf_cells, vndf_margq, nx, ny, n_phi, n_theta, 1, 2 * phi_nodes() + slices(), phi_nodes() }; }
-    MRL_HD WarpDev luminance() const { return { lum_cells, lum_margq, nx, ny, n_phi, n_theta, 1, 2 * phi_nodes() + slices(), phi_nodes() }; }
-    MRL_HD WarpDev rgb() const { return { rgb_cells, nullptr, nx, ny, n_phi, n_theta, 0, n_values * slices(), 0 }; }
+    MRL_HD WarpDev ndf() const { return { ndf_cells, nullptr, nullptr, ndf_nx, ndf_ny, 1, 1, 0, 1, 0 }; }
+    MRL_HD WarpDev sigma() const { return { sigma_cells, nullptr, nullptr, sigma_nx, sigma_ny, 1, 1, 0, 1, 0 }; }
+    MRL_HD WarpDev vndf() const { return { vndf_cells, vndf_margq, vndf_rowh, nx, ny, n_phi, n_theta, 1, 2 * phi_nodes() + slices(), phi_nodes() }; }
+    MRL_HD WarpDev luminance() const { return { lum_cells, lum_margq, lum_rowh, nx, ny, n_phi, n_theta, 1, 2 * phi_nodes() + slices(), phi_nodes() }; }
+    MRL_HD WarpDev rgb() const { return { rgb_cells, nullptr, nullptr, nx, ny, n_phi, n_theta, 0, n_values * slices(), 0 }; }
 };
 
 namespace rgl {
@@ -240,12 +243,22 @@ MRL_HD double blend_quad(const Slices &s, const float4 &q)
 // A distribution's running integrals read from memory — from its cell records (the integrals LEFT of a cell, the totals of its two
 // node rows) and from margq (the marginal after a cell row) — in two steps each: the loads, then the sums (see fetch_raw).
 struct SearchMem {
-    const float4 *cells, *margq;
-    unsigned stride, totals_at, per_row;        // float4s per record; where a record's totals start; cells per row
+    const float4 *cells, *margq, *rowh;
+    unsigned stride, totals_at, per_row, nodes; // float4s per record; where a record's totals start; cells per row; phi nodes of a bracket
     MRL_HD explicit SearchMem(const WarpDev &w)
-        : cells(w.cells), margq(w.margq), stride((unsigned)w.stride), totals_at((unsigned)(w.phi_nodes() + w.slices())), per_row((unsigned)(w.nx - 1)) {}
+        : cells(w.cells), margq(w.margq), rowh(w.rowh), stride((unsigned)w.stride), totals_at((unsigned)(w.phi_nodes() + w.slices())),
+          per_row((unsigned)(w.nx - 1)), nodes((unsigned)w.phi_nodes()) {}
     struct PairRaw { float4 a, b; };
     typedef float4 MargRaw;
+    struct HeadRaw { PairRaw total, p1, p2a, p2b; };
+    // a cell row's header: its totals and the integrals at the three pivot columns, one line
+    MRL_HD HeadRaw head_raw(const Slices &s, int row) const
+    {
+        const float4 *p = rowh + (s.quad + (unsigned)row) * (4u * nodes);
+        HeadRaw h;
+        h.total = pair_at(s, p); h.p1 = pair_at(s, p + nodes); h.p2a = pair_at(s, p + 2u * nodes); h.p2b = pair_at(s, p + 3u * nodes);
+        return h;
+    }
     MRL_HD PairRaw pair_at(const Slices &s, const float4 *p) const
     {
         PairRaw r;
@@ -333,6 +346,15 @@ MRL_HD double invert_linear(double c0, double c1, double u)
     return den != 0.0 ? fast::div_fast(num, den) : 0.0;
 }
 
+// The columns the column search's first two halvings test — (0 + nx - 2) / 2, then the middle of the half it moved into (where that half
+// still has more than one column; else the first pivot again, unused) — and whose integrals a row's header holds.
+struct Pivots { int m1, m2a, m2b; };
+MRL_HD Pivots pivot_columns(int nx)
+{
+    const int last = nx - 2, m1 = last >> 1;
+    return { m1, m1 > 0 ? m1 >> 1 : m1, m1 + 1 < last ? (m1 + 1 + last) >> 1 : m1 };
+}
+
 // uniform sample -> position; returns the density there and what it found on the way
 template <class Search>
 MRL_HD double warp_sample(const WarpDev &w, const Search &t, const Slices &s, double ux, double uy, double &x_out, double &y_out, Found &f)
@@ -349,12 +371,27 @@ MRL_HD double warp_sample(const WarpDev &w, const Search &t, const Slices &s, do
     }
     const int row = lo;
     uy -= before;
-    const D2 tot = t.total(s, row);                          // the totals of node rows (row, row + 1)
+    // the row's header: the totals of node rows (row, row + 1) and the integrals the first two halvings of the column search test —
+    // the very values the search would read cell by cell (so the same decisions), in one line and one round trip
+    const auto hr = t.head_raw(s, row);
+    const D2 tot = t.pair_blend(s, hr.total);
     const double r0 = tot.x, r1 = tot.y;
     const double y = clamp01(invert_linear(r0, r1, uy));
     ux *= lerp(y, r0, r1);
     lo = 0; hi = nx - 2;
     D2 left = { 0.0, 0.0 };                                  // the conditional integrals left of column lo, likewise
+    bool right = false;
+    if (lo < hi) {
+        const D2 p = t.pair_blend(s, hr.p1);                 // at column (lo + hi) >> 1 = pivot m1
+        right = lerp(y, p.x, p.y) < ux;
+        if (right) { lo = ((lo + hi) >> 1) + 1; left = p; } else hi = (lo + hi) >> 1;
+    }
+    if (lo < hi) {
+        auto pr = hr.p2a;
+        if (right) pr = hr.p2b;
+        const D2 p = t.pair_blend(s, pr);                    // at the middle of the half it moved into
+        if (lerp(y, p.x, p.y) < ux) { lo = ((lo + hi) >> 1) + 1; left = p; } else hi = (lo + hi) >> 1;
+    }
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         const D2 p = t.left(s, row * (nx - 1) + mid + 1);   // the integrals up to node mid + 1: left of cell mid + 1
