@@ -49,9 +49,10 @@ inline size_t rgl_brackets(int n_phi, int n_theta) { return rgl_phi_brackets(n_p
 // float4s per cell of a DISTRIBUTION's record: the running integrals left of the cell (one float4 per phi node of the bracket), the
 // corner values (one per slice), the totals of the cell's two node rows (per phi node): 64 B isotropic, 128 B — one line — anisotropic
 inline size_t rgl_record_float4s(int n_phi, int n_theta) { return 2 * (size_t)(n_phi > 1 ? 2 : 1) + rgl_bracket_slices(n_phi, n_theta); }
-// float4s per cell row of a distribution's ROW HEADER: the row's totals and the conditional integrals at the three columns the column
-// search's first two halvings test (one float4 per phi node each): 64 B isotropic, 128 B — one line — anisotropic
-inline size_t rgl_row_header_float4s(int n_phi) { return 4 * (size_t)(n_phi > 1 ? 2 : 1); }
+// float4s per cell row of a distribution's ROW HEADER: five blocks of four entries (one float4 per phi node each: 64 B isotropic, 128 B —
+// one line — anisotropic per block) — the row's totals with the conditional integrals at the three columns the column search's first two
+// halvings test, then per quarter of the row it can be in by then the three columns of its next two halvings
+inline size_t rgl_row_header_float4s(int n_phi) { return 20 * (size_t)(n_phi > 1 ? 2 : 1); }
 // where one function's tables go: `at` is the running size of the image in floats (every table starts on a 128-byte boundary, a cache
 // line: records and the value vectors of a cell then never straddle one more line than their size asks for)
 inline WarpOffsets plan_warp(size_t &at, int nx, int ny, int n_phi, int n_theta, int n_ch, bool distribution)
@@ -91,7 +92,7 @@ inline size_t nch_brick_float4s(int n_ch) { return n_ch == 1 ? 2 : n_ch == 2 ? 4
 
 // ---- the file ----
 struct ImageHeader {
-    char magic[8];                       // "MRLIMG\4\0" (2: RGL search tables in the bracket form; 3: the cells too; 4: one record per cell of a distribution; 5: + row headers)
+    char magic[8];                       // "MRLIMG\4\0" (2: RGL search tables in the bracket form; 3: the cells too; 4: one record per cell of a distribution; 5: + row headers; 6: with their quarter blocks)
     uint32_t header_bytes, kind, layout, n_ch, param, lookup, node, n_ti;
     int32_t dims[3];
     int32_t rgl_shape[8];                // n_phi n_theta res_x res_y res_ndf_x res_ndf_y res_sigma_x res_sigma_y
@@ -99,7 +100,7 @@ struct ImageHeader {
     uint32_t negative;                   // MRL_OPT_NEGATIVE the table was built under: 0 = negative values were clamped to 0, 1 / 2 = the image holds them
     uint64_t texel_bytes, sampling_doubles, sampling2d_doubles, checksum;
 };
-constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 5, 0 };
+constexpr char kImageMagic[8] = { 'M', 'R', 'L', 'I', 'M', 'G', 6, 0 };
 constexpr uint64_t kImageChecksumSeed = 0xCBF29CE484222325ull;
 // the kinds and layouts an image can name (values of mrl::Kind / mrl::Layout / mrl::Param, repeated here so that this header needs no HIP)
 constexpr uint32_t kImgKindMerl = 0, kImgKindTable = 1, kImgKindNch = 4, kImgKindRgl = 5, kImgKindRglSpectral = 6, kImgLayoutRows = 0, kImgLayoutBrick = 1, kImgParamLast = 2;

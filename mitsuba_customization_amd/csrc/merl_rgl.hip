@@ -116,10 +116,19 @@ struct SearchLds {
     // (the memory form's row header, from the slice-major copies: the four reads go out together)
     __device__ __forceinline__ HeadRaw head_raw(const rgl::Slices &s, int row) const
     {
-        const rgl::Pivots pv = rgl::pivot_columns((int)per_row + 1);
+        const rgl::Pivots pv = rgl::pivots_of(0, (int)per_row - 1);
         const int first = row * (int)per_row + 1;
         HeadRaw h;
         h.total = total_raw(s, row); h.p1 = left_raw(s, first + pv.m1); h.p2a = left_raw(s, first + pv.m2a); h.p2b = left_raw(s, first + pv.m2b);
+        return h;
+    }
+    __device__ __forceinline__ HeadRaw quarter_raw(const rgl::Slices &s, int row, int, int lo, int hi) const
+    {
+        const rgl::Pivots pv = rgl::pivots_of(lo, hi);
+        const int first = row * (int)per_row + 1;
+        HeadRaw h;
+        h.p1 = left_raw(s, first + pv.m1); h.p2a = left_raw(s, first + pv.m2a); h.p2b = left_raw(s, first + pv.m2b);
+        h.total = h.p1;
         return h;
     }
     __device__ __forceinline__ rgl::D2 left(const rgl::Slices &s, int cell) const { return pair_blend(s, left_raw(s, cell)); }
@@ -535,19 +544,24 @@ WarpOffsets append_warp(std::vector<float> &blob, const float *src_all, int nx, 
                             t[2] = condf[s1 * per_cond + lo + last]; t[3] = condf[s1 * per_cond + hi + last];
                         }
                 }
-                // the row headers: totals, then the integrals up to the three pivot columns (rgl::pivot_columns), one float4 per phi node each
+                // the row headers: block 0 = the row's totals + the integrals up to the three pivot columns of [0, nx - 2]; blocks 1..4 = (unused
+                // entry) + the three pivot columns of the quarter's range (rgl::pivots_of / quarter_of); one float4 per phi node each
                 {
-                    const rgl::Pivots pv = rgl::pivot_columns(nx);
-                    const int piv[4] = { nx - 2, pv.m1, pv.m2a, pv.m2b };
+                    const int last = nx - 2;
                     for (int y = 0; y < ny - 1; ++y)
-                        for (int g = 0; g < 4; ++g)
-                            for (size_t k = 0; k < P; ++k) {
-                                const size_t s0 = (size_t)(ipb + (int)k) * n_theta + itb, s1 = n_theta > 1 ? s0 + 1 : s0;
-                                const size_t lo = (size_t)y * (size_t)(nx - 1) + (size_t)piv[g], hi = lo + (size_t)(nx - 1);
-                                float *h = &blob[off.rowh + (((((size_t)ipb * tb + itb) * per_marg + (size_t)y) * 4 + (size_t)g) * P + k) * 4];
-                                h[0] = condf[s0 * per_cond + lo]; h[1] = condf[s0 * per_cond + hi];
-                                h[2] = condf[s1 * per_cond + lo]; h[3] = condf[s1 * per_cond + hi];
-                            }
+                        for (int blk = 0; blk < 5; ++blk) {
+                            const rgl::Range rg = blk == 0 ? rgl::Range{ 0, last } : rgl::quarter_of(0, last, blk - 1);
+                            const rgl::Pivots pv = rgl::pivots_of(rg.lo, rg.hi);
+                            const int piv[4] = { blk == 0 ? last : pv.m1, pv.m1, pv.m2a, pv.m2b };
+                            for (int g = 0; g < 4; ++g)
+                                for (size_t k = 0; k < P; ++k) {
+                                    const size_t s0 = (size_t)(ipb + (int)k) * n_theta + itb, s1 = n_theta > 1 ? s0 + 1 : s0;
+                                    const size_t lo = (size_t)y * (size_t)(nx - 1) + (size_t)piv[g], hi = lo + (size_t)(nx - 1);
+                                    float *h = &blob[off.rowh + ((((((size_t)ipb * tb + itb) * per_marg + (size_t)y) * 5 + (size_t)blk) * 4 + (size_t)g) * P + k) * 4];
+                                    h[0] = condf[s0 * per_cond + lo]; h[1] = condf[s0 * per_cond + hi];
+                                    h[2] = condf[s1 * per_cond + lo]; h[3] = condf[s1 * per_cond + hi];
+                                }
+                        }
                 }
                 const size_t dp = n_phi > 1 ? (size_t)n_theta : 0, dt = n_theta > 1 ? 1 : 0, s0 = (size_t)ipb * n_theta + itb;
                 float *m = &blob[off.margq + ((size_t)ipb * tb + itb) * per_marg * 4];
@@ -683,7 +697,7 @@ hipError_t launch_rgl(int mode, const BatchArgs &a, const RglDev *r, bool indexe
     // The fused unit of a file whose integrals do not fit a CU's LDS (an anisotropic file: its lookups blend four slices of a 45 MB
     // image, the launch waits on L1 fills): eval + pdf and sample() as TWO launches on the stream.  The fused kernel carries sample()'s
     // 220 VGPRs through its eval as well (2 waves per SIMD); apart, eval + pdf runs at 3 waves per SIMD and sample() with its marginal
-    // rows in LDS — 16M units: 3.89 ms fused, 3.52 ms apart (profiles/r04_rgl_rates.json); the 12 B per unit of wi read twice do not
+    // rows in LDS — 16M units: 3.84 ms fused, 3.34 ms apart (profiles/r04_rgl_rates.json); the 12 B per unit of wi read twice do not
     // show.  Same functions, same bits (the separate entry points are bit-compared with the fused one).
     if (mode == 3 && r && search == 0 && a.n >= (size_t)1 << 15 && lds_bytes_of(*r) > (size_t)lds_limit()) {
         const hipError_t e = launch_mode<4>(a, r, indexed, search, compute_units, stream);

@@ -58,9 +58,10 @@ namespace mrl {
 //                       [P, P + S)      the corner values per slice, normalised
 //                       [P + S, 2P + S) the totals of node rows (row, row + 1), same form as the first part
 //                     margq [pb][tb][ny - 1]  marginal cdf after the cell row, of slices (ip, it) (ip+1, it) (ip, it+1) (ip+1, it+1)
-//                     rowh  [pb][tb][ny - 1]  ROW HEADERS of 4 P float4: the row's totals, then the integrals up to the three columns the
-//                                             column search's first two halvings test (pivot_columns) — a forward warp reads the totals and
-//                                             decides two of its log2(nx) halvings from ONE line
+//                     rowh  [pb][tb][ny - 1]  ROW HEADERS of 5 blocks x 4 P float4: the row's totals with the integrals up to the three columns
+//                                             the column search's first two halvings test (pivots_of), then per quarter of the row the three
+//                                             columns of the next two halvings — a forward warp reads the totals and decides four of its
+//                                             log2(nx) halvings from TWO lines
 struct WarpDev {
     const float4 *cells;
     const float4 *margq, *rowh; // distributions only
@@ -254,7 +255,15 @@ struct SearchMem {
     // a cell row's header: its totals and the integrals at the three pivot columns, one line
     MRL_HD HeadRaw head_raw(const Slices &s, int row) const
     {
-        const float4 *p = rowh + (s.quad + (unsigned)row) * (4u * nodes);
+        const float4 *p = rowh + (s.quad + (unsigned)row) * (20u * nodes);
+        HeadRaw h;
+        h.total = pair_at(s, p); h.p1 = pair_at(s, p + nodes); h.p2a = pair_at(s, p + 2u * nodes); h.p2b = pair_at(s, p + 3u * nodes);
+        return h;
+    }
+    // ... and the block of the quarter q = 2 (first halving went right) + (second went right): the pivots of its range [lo, hi], one line
+    MRL_HD HeadRaw quarter_raw(const Slices &s, int row, int q, int, int) const
+    {
+        const float4 *p = rowh + (s.quad + (unsigned)row) * (20u * nodes) + (unsigned)(1 + q) * (4u * nodes);
         HeadRaw h;
         h.total = pair_at(s, p); h.p1 = pair_at(s, p + nodes); h.p2a = pair_at(s, p + 2u * nodes); h.p2b = pair_at(s, p + 3u * nodes);
         return h;
@@ -346,13 +355,24 @@ MRL_HD double invert_linear(double c0, double c1, double u)
     return den != 0.0 ? fast::div_fast(num, den) : 0.0;
 }
 
-// The columns the column search's first two halvings test — (0 + nx - 2) / 2, then the middle of the half it moved into (where that half
-// still has more than one column; else the first pivot again, unused) — and whose integrals a row's header holds.
+// The columns a binary search of [lo, hi] tests first — (lo + hi) / 2 — and next, in the half it moved into (where that half still has
+// more than one column; else the first pivot again, unused): what a header block holds the integrals of.
 struct Pivots { int m1, m2a, m2b; };
-MRL_HD Pivots pivot_columns(int nx)
+MRL_HD Pivots pivots_of(int lo, int hi)
 {
-    const int last = nx - 2, m1 = last >> 1;
-    return { m1, m1 > 0 ? m1 >> 1 : m1, m1 + 1 < last ? (m1 + 1 + last) >> 1 : m1 };
+    const int m1 = (lo + hi) >> 1;
+    return { m1, m1 > lo ? (lo + m1) >> 1 : m1, m1 + 1 < hi ? (m1 + 1 + hi) >> 1 : m1 };
+}
+// the range two halvings of [lo, hi] end in when they went (q & 2: the first, q & 1: the second) right; a halving of a single column does not happen
+struct Range { int lo, hi; };
+MRL_HD Range quarter_of(int lo, int hi, int q)
+{
+    for (int level = 0; level < 2; ++level)
+        if (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (q & (2 >> level)) lo = mid + 1; else hi = mid;
+        }
+    return { lo, hi };
 }
 
 // uniform sample -> position; returns the density there and what it found on the way
@@ -371,8 +391,9 @@ MRL_HD double warp_sample(const WarpDev &w, const Search &t, const Slices &s, do
     }
     const int row = lo;
     uy -= before;
-    // the row's header: the totals of node rows (row, row + 1) and the integrals the first two halvings of the column search test —
-    // the very values the search would read cell by cell (so the same decisions), in one line and one round trip
+    // the row's header: the totals of node rows (row, row + 1) and the integrals the first two halvings of the column search test; then
+    // the header block of the quarter those end in: the next two — the very values the search would read cell by cell (so the same
+    // decisions), two lines and two round trips for four halvings
     const auto hr = t.head_raw(s, row);
     const D2 tot = t.pair_blend(s, hr.total);
     const double r0 = tot.x, r1 = tot.y;
@@ -380,17 +401,25 @@ MRL_HD double warp_sample(const WarpDev &w, const Search &t, const Slices &s, do
     ux *= lerp(y, r0, r1);
     lo = 0; hi = nx - 2;
     D2 left = { 0.0, 0.0 };                                  // the conditional integrals left of column lo, likewise
-    bool right = false;
+    // two halvings from a block's three pivots; returns 2 (the first went right) + 1 (the second did)
+    auto two_halvings = [&](const decltype(hr) &h) {
+        int q = 0;
+        if (lo < hi) {
+            const D2 p = t.pair_blend(s, h.p1);              // at column (lo + hi) >> 1
+            if (lerp(y, p.x, p.y) < ux) { lo = ((lo + hi) >> 1) + 1; left = p; q = 2; } else hi = (lo + hi) >> 1;
+        }
+        if (lo < hi) {
+            auto pr = h.p2a;
+            if (q) pr = h.p2b;
+            const D2 p = t.pair_blend(s, pr);                // at the middle of the half it moved into
+            if (lerp(y, p.x, p.y) < ux) { lo = ((lo + hi) >> 1) + 1; left = p; q |= 1; } else hi = (lo + hi) >> 1;
+        }
+        return q;
+    };
+    const int quarter = two_halvings(hr);
     if (lo < hi) {
-        const D2 p = t.pair_blend(s, hr.p1);                 // at column (lo + hi) >> 1 = pivot m1
-        right = lerp(y, p.x, p.y) < ux;
-        if (right) { lo = ((lo + hi) >> 1) + 1; left = p; } else hi = (lo + hi) >> 1;
-    }
-    if (lo < hi) {
-        auto pr = hr.p2a;
-        if (right) pr = hr.p2b;
-        const D2 p = t.pair_blend(s, pr);                    // at the middle of the half it moved into
-        if (lerp(y, p.x, p.y) < ux) { lo = ((lo + hi) >> 1) + 1; left = p; } else hi = (lo + hi) >> 1;
+        const auto qr = t.quarter_raw(s, row, quarter, lo, hi);
+        (void)two_halvings(qr);
     }
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;

@@ -67,7 +67,7 @@ static bool consistent(const ImageHeader &h, unsigned long long file_bytes, cons
             if (p.layout.cells[w] % 32 != 0 || p.layout.cells[w] + cells[w] * 4 > floats) return false;
             if (w == 2 || w == 3)
                 if (p.layout.margq[w] % 32 != 0 || p.layout.margq[w] + (uint64_t)(f.res[1] - 1) * brackets * 4 > floats ||
-                    p.layout.rowh[w] % 32 != 0 || p.layout.rowh[w] + (uint64_t)(f.res[1] - 1) * brackets * 16 * (f.n_phi > 1 ? 2 : 1) > floats) return false;
+                    p.layout.rowh[w] % 32 != 0 || p.layout.rowh[w] + (uint64_t)(f.res[1] - 1) * brackets * 80 * (f.n_phi > 1 ? 2 : 1) > floats) return false;
         }
         if (p.layout.theta + (uint64_t)f.n_theta > floats) return false;
     } else {

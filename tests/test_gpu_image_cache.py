@@ -89,8 +89,8 @@ def test_altered_truncated_and_mismatched_images_are_refused(tables, tmp_path):
             assert g.material_count() == count and g.memory_info()["table_bytes"] == used
 
         refused(b"", "not a material image")
-        refused(b"MRLIMG\x04\x00" + raw[8:], "not a material image")       # an earlier format (no row headers)
-        refused(b"MRLIMG\x06\x00" + raw[8:], "not a material image")
+        refused(b"MRLIMG\x05\x00" + raw[8:], "not a material image")       # an earlier format (row headers without quarter blocks)
+        refused(b"MRLIMG\x07\x00" + raw[8:], "not a material image")
         refused(raw[:-1], "file length")
         refused(raw + b"\0", "file length")
         flipped = bytearray(raw); flipped[-5] ^= 0x10
